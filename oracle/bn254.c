@@ -1,0 +1,776 @@
+/* TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  See oracle/bn254.h for scope, parity status and citations. */
+#include "bn254.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------------------------------------
+ * Fq : 4 x 64-bit Montgomery, R = 2^256  (the in-memory form halo2curves uses)
+ * ---------------------------------------------------------------------------------------------- */
+static const uint64_t FQ_P[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+static const uint64_t FR_R[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+static const uint64_t FQ_N0 = 0x87d20782e4866389ull; /* -p^-1 mod 2^64 */
+
+static ofq FQ_R1, FQ_R2, FQ_ZERO, FQ_B3; /* R mod p, R^2 mod p, 0, 3*R mod p ; filled by init */
+static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+
+static int ge_p(const uint64_t a[4]) {
+  for (int i = 3; i >= 0; i--) {
+    if (a[i] > FQ_P[i]) return 1;
+    if (a[i] < FQ_P[i]) return 0;
+  }
+  return 1;
+}
+static void sub_p(uint64_t a[4]) {
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 t = (u128)a[i] - FQ_P[i] - br;
+    a[i] = (uint64_t)t;
+    br = (t >> 64) & 1;
+  }
+}
+static void fq_add(ofq* o, const ofq* a, const ofq* b) {
+  u128 c = 0;
+  uint64_t t[4];
+  for (int i = 0; i < 4; i++) {
+    c += (u128)a->l[i] + b->l[i];
+    t[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  /* p < 2^254 so a + b < 2^255: no carry out */
+  if (ge_p(t)) sub_p(t);
+  memcpy(o->l, t, 32);
+}
+static void fq_sub(ofq* o, const ofq* a, const ofq* b) {
+  u128 br = 0;
+  uint64_t t[4];
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)a->l[i] - b->l[i] - br;
+    t[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+  if (br) {
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+      c += (u128)t[i] + FQ_P[i];
+      t[i] = (uint64_t)c;
+      c >>= 64;
+    }
+  }
+  memcpy(o->l, t, 32);
+}
+static void fq_neg(ofq* o, const ofq* a) { fq_sub(o, &FQ_ZERO, a); }
+static void fq_dbl(ofq* o, const ofq* a) { fq_add(o, a, a); }
+static int fq_is_zero(const ofq* a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static int fq_eq(const ofq* a, const ofq* b) { return memcmp(a->l, b->l, 32) == 0; }
+
+/* CIOS Montgomery product */
+static void fq_mul(ofq* o, const ofq* a, const ofq* b) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (u128)a->l[j] * b->l[i] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[4] = (uint64_t)c;
+    t[5] = (uint64_t)(c >> 64);
+    uint64_t m = t[0] * FQ_N0;
+    c = (u128)m * FQ_P[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 4; j++) {
+      c += (u128)m * FQ_P[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[3] = (uint64_t)c;
+    t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  if (t[4] || ge_p(t)) sub_p(t);
+  memcpy(o->l, t, 32);
+}
+static void fq_sqr(ofq* o, const ofq* a) { fq_mul(o, a, a); }
+
+static void fq_pow(ofq* o, const ofq* a, const uint64_t e[4]) {
+  ofq acc = FQ_R1, base = *a;
+  for (int i = 0; i < 256; i++) {
+    if ((e[i >> 6] >> (i & 63)) & 1) fq_mul(&acc, &acc, &base);
+    fq_sqr(&base, &base);
+  }
+  *o = acc;
+}
+static void fq_inv(ofq* o, const ofq* a) {
+  uint64_t e[4] = {FQ_P[0] - 2, FQ_P[1], FQ_P[2], FQ_P[3]};
+  fq_pow(o, a, e);
+}
+/* canonical LE bytes <-> Montgomery */
+static int fq_from_bytes(ofq* o, const uint8_t b[32]) {
+  ofq t;
+  memcpy(t.l, b, 32); /* little-endian host */
+  int canonical = !ge_p(t.l);
+  fq_mul(o, &t, &FQ_R2);
+  return canonical;
+}
+static void fq_to_bytes(uint8_t b[32], const ofq* a) {
+  ofq one = {{1, 0, 0, 0}}, t;
+  fq_mul(&t, a, &one);
+  memcpy(b, t.l, 32);
+}
+
+static void oracle_init(void) {
+  memset(&FQ_ZERO, 0, sizeof FQ_ZERO);
+  /* R mod p by 256 modular doublings of 1; R^2 by 256 more */
+  ofq one = {{1, 0, 0, 0}};
+  ofq t = one;
+  for (int i = 0; i < 256; i++) fq_dbl(&t, &t);
+  FQ_R1 = t;
+  for (int i = 0; i < 256; i++) fq_dbl(&t, &t);
+  FQ_R2 = t;
+  ofq three = FQ_R1;
+  fq_add(&three, &three, &FQ_R1);
+  fq_add(&three, &three, &FQ_R1);
+  FQ_B3 = three;
+}
+static void ensure_init(void) { pthread_once(&g_once, oracle_init); }
+
+/* ------------------------------------------------------------------------------------------------
+ * G1 : y^2 = x^3 + 3, Jacobian coordinates.  Case split as src/cuzk/wgsl/curve/ec.template.wgsl:36-86
+ * (add-2007-bl) and :10-34 (dbl-2009-l).
+ * ---------------------------------------------------------------------------------------------- */
+static void g1_identity(og1* o) {
+  o->x = FQ_ZERO;
+  o->y = FQ_R1;
+  o->z = FQ_ZERO;
+}
+static int g1_is_identity(const og1* a) { return fq_is_zero(&a->z); }
+
+static void g1_double(og1* o, const og1* p) {
+  if (g1_is_identity(p)) {
+    g1_identity(o);
+    return;
+  }
+  ofq A, B, C, D, E, F, t, X3, Y3, Z3;
+  fq_sqr(&A, &p->x);
+  fq_sqr(&B, &p->y);
+  fq_sqr(&C, &B);
+  fq_add(&t, &p->x, &B);
+  fq_sqr(&t, &t);
+  fq_sub(&t, &t, &A);
+  fq_sub(&t, &t, &C);
+  fq_dbl(&D, &t);
+  fq_dbl(&E, &A);
+  fq_add(&E, &E, &A);
+  fq_sqr(&F, &E);
+  fq_dbl(&t, &D);
+  fq_sub(&X3, &F, &t);
+  fq_sub(&t, &D, &X3);
+  fq_mul(&Y3, &E, &t);
+  fq_dbl(&t, &C);
+  fq_dbl(&t, &t);
+  fq_dbl(&t, &t);
+  fq_sub(&Y3, &Y3, &t);
+  fq_mul(&Z3, &p->y, &p->z);
+  fq_dbl(&Z3, &Z3);
+  o->x = X3;
+  o->y = Y3;
+  o->z = Z3;
+}
+
+static void g1_add(og1* o, const og1* p, const og1* q) {
+  if (g1_is_identity(p)) {
+    *o = *q;
+    return;
+  }
+  if (g1_is_identity(q)) {
+    *o = *p;
+    return;
+  }
+  ofq Z1Z1, Z2Z2, U1, U2, S1, S2, H, I, J, r, V, t, X3, Y3, Z3;
+  fq_sqr(&Z1Z1, &p->z);
+  fq_sqr(&Z2Z2, &q->z);
+  fq_mul(&U1, &p->x, &Z2Z2);
+  fq_mul(&U2, &q->x, &Z1Z1);
+  fq_mul(&S1, &p->y, &q->z);
+  fq_mul(&S1, &S1, &Z2Z2);
+  fq_mul(&S2, &q->y, &p->z);
+  fq_mul(&S2, &S2, &Z1Z1);
+  if (fq_eq(&U1, &U2)) {
+    if (fq_eq(&S1, &S2)) {
+      g1_double(o, p);
+    } else {
+      g1_identity(o);
+    }
+    return;
+  }
+  fq_sub(&H, &U2, &U1);
+  fq_dbl(&I, &H);
+  fq_sqr(&I, &I);
+  fq_mul(&J, &H, &I);
+  fq_sub(&r, &S2, &S1);
+  fq_dbl(&r, &r);
+  fq_mul(&V, &U1, &I);
+  fq_sqr(&X3, &r);
+  fq_sub(&X3, &X3, &J);
+  fq_dbl(&t, &V);
+  fq_sub(&X3, &X3, &t);
+  fq_sub(&t, &V, &X3);
+  fq_mul(&Y3, &r, &t);
+  fq_mul(&t, &S1, &J);
+  fq_dbl(&t, &t);
+  fq_sub(&Y3, &Y3, &t);
+  fq_add(&Z3, &p->z, &q->z);
+  fq_sqr(&Z3, &Z3);
+  fq_sub(&Z3, &Z3, &Z1Z1);
+  fq_sub(&Z3, &Z3, &Z2Z2);
+  fq_mul(&Z3, &Z3, &H);
+  o->x = X3;
+  o->y = Y3;
+  o->z = Z3;
+}
+
+/* p (Jacobian) + (ax, ay) affine, optionally negated */
+static void g1_add_affine(og1* o, const og1* p, const ofq* ax, const ofq* ay, int negate) {
+  og1 q;
+  q.x = *ax;
+  if (negate)
+    fq_neg(&q.y, ay);
+  else
+    q.y = *ay;
+  q.z = FQ_R1;
+  g1_add(o, p, &q);
+}
+static void g1_neg(og1* o, const og1* p) {
+  o->x = p->x;
+  fq_neg(&o->y, &p->y);
+  o->z = p->z;
+}
+/* k as 32 LE bytes (any 256-bit integer) */
+static void g1_mul_bytes(og1* o, const og1* p, const uint8_t k[32]) {
+  og1 acc;
+  g1_identity(&acc);
+  for (int i = 255; i >= 0; i--) {
+    g1_double(&acc, &acc);
+    if ((k[i >> 3] >> (i & 7)) & 1) g1_add(&acc, &acc, p);
+  }
+  *o = acc;
+}
+static void g1_mul_u64(og1* o, const og1* p, uint64_t k) {
+  uint8_t b[32] = {0};
+  memcpy(b, &k, 8);
+  g1_mul_bytes(o, p, b);
+}
+static void g1_from_bytes96(og1* o, const uint8_t b[96]) {
+  fq_from_bytes(&o->x, b);
+  fq_from_bytes(&o->y, b + 32);
+  fq_from_bytes(&o->z, b + 64);
+}
+static void g1_to_bytes96(uint8_t b[96], const og1* p) {
+  fq_to_bytes(b, &p->x);
+  fq_to_bytes(b + 32, &p->y);
+  fq_to_bytes(b + 64, &p->z);
+}
+
+/* ------------------------------------------------------------------------------------------------ hooks */
+void oracle_fq_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+  ensure_init();
+  for (size_t i = 0; i < n; i++) {
+    ofq x, y, z;
+    fq_from_bytes(&x, a + 32 * i);
+    if (b)
+      fq_from_bytes(&y, b + 32 * i);
+    else
+      y = FQ_ZERO;
+    switch (op) {
+      case 0: fq_add(&z, &x, &y); break;
+      case 1: fq_sub(&z, &x, &y); break;
+      case 2: fq_mul(&z, &x, &y); break;
+      case 3: fq_sqr(&z, &x); break;
+      case 4: fq_neg(&z, &x); break;
+      default: fq_inv(&z, &x); break;
+    }
+    fq_to_bytes(out + 32 * i, &z);
+  }
+}
+
+void oracle_g1_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+  ensure_init();
+  for (size_t i = 0; i < n; i++) {
+    og1 p, q, r;
+    g1_from_bytes96(&p, a + 96 * i);
+    if (op == 0) {
+      g1_from_bytes96(&q, b + 96 * i);
+      g1_add(&r, &p, &q);
+    } else if (op == 1) {
+      g1_double(&r, &p);
+    } else {
+      g1_neg(&r, &p);
+    }
+    g1_to_bytes96(out + 96 * i, &r);
+  }
+}
+
+void oracle_g1_scalar_mul(const uint8_t* p_xy, const uint8_t* k, uint8_t* out, size_t n) {
+  ensure_init();
+  for (size_t i = 0; i < n; i++) {
+    og1 p, r;
+    fq_from_bytes(&p.x, p_xy + 64 * i);
+    fq_from_bytes(&p.y, p_xy + 64 * i + 32);
+    p.z = FQ_R1;
+    g1_mul_bytes(&r, &p, k + 32 * i);
+    g1_to_bytes96(out + 96 * i, &r);
+  }
+}
+
+int oracle_g1_to_affine64(const uint8_t xyz[96], uint8_t out[64]) {
+  ensure_init();
+  og1 p;
+  g1_from_bytes96(&p, xyz);
+  if (g1_is_identity(&p)) {
+    memset(out, 0, 64);
+    return 1;
+  }
+  ofq zi, zi2, zi3, x, y;
+  fq_inv(&zi, &p.z);
+  fq_sqr(&zi2, &zi);
+  fq_mul(&zi3, &zi2, &zi);
+  fq_mul(&x, &p.x, &zi2);
+  fq_mul(&y, &p.y, &zi3);
+  fq_to_bytes(out, &x);
+  fq_to_bytes(out + 32, &y);
+  return 0;
+}
+
+int oracle_points_on_curve(const uint8_t* xy, size_t n) {
+  ensure_init();
+  for (size_t i = 0; i < n; i++) {
+    ofq x, y, l, r;
+    if (!fq_from_bytes(&x, xy + 64 * i)) return 0;
+    if (!fq_from_bytes(&y, xy + 64 * i + 32)) return 0;
+    fq_sqr(&l, &y);
+    fq_sqr(&r, &x);
+    fq_mul(&r, &r, &x);
+    fq_add(&r, &r, &FQ_B3);
+    if (!fq_eq(&l, &r)) return 0;
+  }
+  return 1;
+}
+
+void oracle_constants(uint8_t p[32], uint8_t r[32], uint8_t r2_mod_p[32], uint8_t one_mont[32], uint64_t* n0inv64) {
+  ensure_init();
+  memcpy(p, FQ_P, 32);
+  memcpy(r, FR_R, 32);
+  memcpy(r2_mod_p, FQ_R2.l, 32);
+  memcpy(one_mont, FQ_R1.l, 32);
+  *n0inv64 = FQ_N0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * MSM : restatement of halo2curves 0.9.0 `msm_serial` / `msm_best` (called at src/lib.rs:45-47).
+ * Booth-recoded windows of c = ceil(ln n) bits (c = 1 for n < 4, 3 for n < 32), 2^(c-1) buckets per
+ * window, summation by parts, windows combined from the top by c doublings.  (msm_best additionally
+ * batches bucket additions in affine form for c >= 10; that changes the cost, not the group element.)
+ * ---------------------------------------------------------------------------------------------- */
+static unsigned scalar_bit(const uint8_t s[32], int bit) {
+  if (bit < 0 || bit >= 256) return 0;
+  return (s[bit >> 3] >> (bit & 7)) & 1u;
+}
+/* signed digit of window `win`: slice of c+1 bits whose lowest bit is bit (win*c - 1), bit -1 := 0 */
+static int32_t booth_digit(int win, int c, const uint8_t s[32]) {
+  uint32_t u = 0;
+  int lo = win * c - 1;
+  for (int k = c; k >= 0; k--) u = (u << 1) | scalar_bit(s, lo + k);
+  int32_t t = (int32_t)((u + 1) >> 1);
+  if (u >> c) t -= (int32_t)1 << c;
+  return t;
+}
+static int msm_window_bits(size_t n) {
+  if (n < 4) return 1;
+  if (n < 32) return 3;
+  return (int)ceil(log((double)n));
+}
+
+static void msm_serial(const ofq* bx, const ofq* by, const uint8_t* scalars, size_t n, og1* acc) {
+  int c = msm_window_bits(n);
+  int nwin = 254 / c + 1; /* Fr::NUM_BITS = 254 */
+  size_t nb = (size_t)1 << (c - 1);
+  og1* buckets = (og1*)malloc(nb * sizeof(og1));
+  g1_identity(acc);
+  for (int w = nwin - 1; w >= 0; w--) {
+    for (int k = 0; k < c; k++) g1_double(acc, acc);
+    for (size_t b = 0; b < nb; b++) g1_identity(&buckets[b]);
+    for (size_t i = 0; i < n; i++) {
+      int32_t d = booth_digit(w, c, scalars + 32 * i);
+      if (d > 0)
+        g1_add_affine(&buckets[d - 1], &buckets[d - 1], &bx[i], &by[i], 0);
+      else if (d < 0)
+        g1_add_affine(&buckets[-d - 1], &buckets[-d - 1], &bx[i], &by[i], 1);
+    }
+    og1 running;
+    g1_identity(&running);
+    for (size_t b = nb; b-- > 0;) {
+      g1_add(&running, &running, &buckets[b]);
+      g1_add(acc, acc, &running);
+    }
+  }
+  free(buckets);
+}
+
+typedef struct {
+  const ofq *bx, *by;
+  const uint8_t* scalars;
+  size_t n;
+  og1 out;
+} msm_job;
+static void* msm_job_run(void* arg) {
+  msm_job* j = (msm_job*)arg;
+  msm_serial(j->bx, j->by, j->scalars, j->n, &j->out);
+  return NULL;
+}
+
+int oracle_msm_bn254_g1_mt(const uint8_t* xy, const uint8_t* scalars, size_t n, int n_threads, uint8_t out_xyz[96]) {
+  ensure_init();
+  og1 acc;
+  g1_identity(&acc);
+  if (n == 0) {
+    g1_to_bytes96(out_xyz, &acc);
+    return 0;
+  }
+  ofq* bx = (ofq*)malloc(n * sizeof(ofq));
+  ofq* by = (ofq*)malloc(n * sizeof(ofq));
+  for (size_t i = 0; i < n; i++) {
+    fq_from_bytes(&bx[i], xy + 64 * i);
+    fq_from_bytes(&by[i], xy + 64 * i + 32);
+  }
+  if (n_threads < 1) n_threads = 1;
+  if ((size_t)n_threads > n) n_threads = (int)n;
+  if (n_threads == 1) {
+    msm_serial(bx, by, scalars, n, &acc);
+  } else {
+    msm_job* jobs = (msm_job*)calloc((size_t)n_threads, sizeof(msm_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+    size_t per = (n + (size_t)n_threads - 1) / (size_t)n_threads;
+    int used = 0;
+    for (int t = 0; t < n_threads; t++) {
+      size_t lo = (size_t)t * per;
+      if (lo >= n) break;
+      size_t hi = lo + per < n ? lo + per : n;
+      jobs[t].bx = bx + lo;
+      jobs[t].by = by + lo;
+      jobs[t].scalars = scalars + 32 * lo;
+      jobs[t].n = hi - lo;
+      pthread_create(&th[t], NULL, msm_job_run, &jobs[t]);
+      used++;
+    }
+    for (int t = 0; t < used; t++) {
+      pthread_join(th[t], NULL);
+      g1_add(&acc, &acc, &jobs[t].out);
+    }
+    free(jobs);
+    free(th);
+  }
+  free(bx);
+  free(by);
+  g1_to_bytes96(out_xyz, &acc);
+  return 0;
+}
+
+int oracle_msm_bn254_g1(const uint8_t* xy, const uint8_t* scalars, size_t n, uint8_t out_xyz[96]) {
+  return oracle_msm_bn254_g1_mt(xy, scalars, n, 1, out_xyz);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * cuZK stage models
+ * ---------------------------------------------------------------------------------------------- */
+int oracle_decompose_scalars_signed(const uint8_t* scalars, size_t n, int num_words, int word_size, int32_t* digits) {
+  const int32_t l = (int32_t)1 << word_size, h = l >> 1;
+  for (size_t i = 0; i < n; i++) {
+    const uint8_t* s = scalars + 32 * i;
+    int32_t carry = 0;
+    for (int w = 0; w < num_words; w++) {
+      int32_t raw = 0;
+      for (int k = word_size - 1; k >= 0; k--) raw = (raw << 1) | (int32_t)scalar_bit(s, w * word_size + k);
+      int32_t d = raw + carry;
+      if (d >= h) {
+        d -= l;
+        carry = 1;
+      } else {
+        carry = 0;
+      }
+      digits[(size_t)w * n + i] = d + h;
+    }
+    if (carry) return -1; /* src/cuzk/test/utils.rs:150-152 panics */
+  }
+  return 0;
+}
+
+void oracle_transpose(const int32_t* digits_w, size_t n, int num_columns, int32_t* col_ptr, int32_t* val_idxs) {
+  memset(col_ptr, 0, sizeof(int32_t) * ((size_t)num_columns + 1));
+  for (size_t i = 0; i < n; i++) col_ptr[digits_w[i] + 1]++;
+  for (int b = 0; b < num_columns; b++) col_ptr[b + 1] += col_ptr[b];
+  int32_t* cur = (int32_t*)calloc((size_t)num_columns, sizeof(int32_t));
+  for (size_t i = 0; i < n; i++) {
+    int32_t d = digits_w[i];
+    val_idxs[col_ptr[d] + cur[d]] = (int32_t)i;
+    cur[d]++;
+  }
+  free(cur);
+}
+
+void oracle_smvp_signed(const int32_t* col_ptr, const int32_t* val_idxs, const uint8_t* xy, size_t n, int num_columns,
+                        uint8_t* buckets_xyz) {
+  ensure_init();
+  (void)n;
+  const int h = num_columns / 2;
+  for (int k = 0; k < h; k++) {
+    og1 bucket;
+    g1_identity(&bucket);
+    for (int j = 0; j < 2; j++) {
+      int row = (j == 0) ? k + h : h - k;
+      if (k == 0 && j == 0) row = 0;
+      og1 sum;
+      g1_identity(&sum);
+      for (int32_t t = col_ptr[row]; t < col_ptr[row + 1]; t++) {
+        ofq x, y;
+        const uint8_t* pt = xy + 64 * (size_t)val_idxs[t];
+        fq_from_bytes(&x, pt);
+        fq_from_bytes(&y, pt + 32);
+        g1_add_affine(&sum, &sum, &x, &y, 0);
+      }
+      int bi;
+      if (h > row) {
+        bi = h - row;
+        g1_neg(&sum, &sum);
+      } else {
+        bi = row - h;
+      }
+      if (bi > 0) g1_add(&bucket, &bucket, &sum);
+    }
+    g1_to_bytes96(buckets_xyz + 96 * (size_t)k, &bucket);
+  }
+}
+
+static og1* load_points96(const uint8_t* b, int n) {
+  og1* p = (og1*)malloc(sizeof(og1) * (size_t)n);
+  for (int i = 0; i < n; i++) g1_from_bytes96(&p[i], b + 96 * (size_t)i);
+  return p;
+}
+
+static void par_reduce_1(const og1* buckets, int nb, int nt, og1* g_out, og1* m_out) {
+  int per = nb / nt;
+  for (int t = 0; t < nt; t++) {
+    int idx = (t == 0) ? 0 : (nt - t) * per;
+    og1 m = buckets[idx], g = m;
+    for (int i = 0; i < per - 1; i++) {
+      g1_add(&m, &m, &buckets[(nt - t) * per - 1 - i]);
+      g1_add(&g, &g, &m);
+    }
+    g_out[t] = g;
+    m_out[t] = m;
+  }
+}
+static void par_reduce_2(const og1* g_in, const og1* m_in, int nb, int nt, og1* out) {
+  int per = nb / nt;
+  for (int t = 0; t < nt; t++) {
+    og1 g = g_in[t];
+    uint64_t s = (uint64_t)per * (uint64_t)(nt - t - 1);
+    if (s > 0) {
+      og1 ms;
+      g1_mul_u64(&ms, &m_in[t], s);
+      g1_add(&g, &g, &ms);
+    }
+    out[t] = g;
+  }
+}
+
+void oracle_bucket_reduction(int kind, const uint8_t* buckets_xyz, int num_buckets, int num_threads, uint8_t out_xyz[96]) {
+  ensure_init();
+  og1* b = load_points96(buckets_xyz, num_buckets);
+  og1 acc;
+  g1_identity(&acc);
+  if (kind == 0) { /* serial_bucket_reduction: indices 1..h-1 then 0 with weights 1..h */
+    for (int i = 1; i <= num_buckets; i++) {
+      int idx = (i < num_buckets) ? i : 0;
+      og1 t;
+      g1_mul_u64(&t, &b[idx], (uint64_t)i);
+      g1_add(&acc, &acc, &t);
+    }
+  } else if (kind == 1) { /* running_sum_bucket_reduction */
+    og1 m = b[0], g = m;
+    for (int i = 0; i < num_buckets - 1; i++) {
+      g1_add(&m, &m, &b[num_buckets - 1 - i]);
+      g1_add(&g, &g, &m);
+    }
+    acc = g;
+  } else {
+    og1* g = (og1*)malloc(sizeof(og1) * (size_t)num_threads);
+    og1* m = (og1*)malloc(sizeof(og1) * (size_t)num_threads);
+    og1* r = (og1*)malloc(sizeof(og1) * (size_t)num_threads);
+    par_reduce_1(b, num_buckets, num_threads, g, m);
+    par_reduce_2(g, m, num_buckets, num_threads, r);
+    for (int t = 0; t < num_threads; t++) g1_add(&acc, &acc, &r[t]);
+    free(g);
+    free(m);
+    free(r);
+  }
+  g1_to_bytes96(out_xyz, &acc);
+  free(b);
+}
+
+void oracle_parallel_bucket_reduction_1(const uint8_t* buckets_xyz, int num_buckets, int num_threads, uint8_t* g_out,
+                                        uint8_t* m_out) {
+  ensure_init();
+  og1* b = load_points96(buckets_xyz, num_buckets);
+  og1* g = (og1*)malloc(sizeof(og1) * (size_t)num_threads);
+  og1* m = (og1*)malloc(sizeof(og1) * (size_t)num_threads);
+  par_reduce_1(b, num_buckets, num_threads, g, m);
+  for (int t = 0; t < num_threads; t++) {
+    g1_to_bytes96(g_out + 96 * (size_t)t, &g[t]);
+    g1_to_bytes96(m_out + 96 * (size_t)t, &m[t]);
+  }
+  free(b);
+  free(g);
+  free(m);
+}
+
+void oracle_parallel_bucket_reduction_2(const uint8_t* g_in, const uint8_t* m_in, int num_buckets, int num_threads,
+                                        uint8_t* out) {
+  ensure_init();
+  og1* g = load_points96(g_in, num_threads);
+  og1* m = load_points96(m_in, num_threads);
+  og1* r = (og1*)malloc(sizeof(og1) * (size_t)num_threads);
+  par_reduce_2(g, m, num_buckets, num_threads, r);
+  for (int t = 0; t < num_threads; t++) g1_to_bytes96(out + 96 * (size_t)t, &r[t]);
+  free(g);
+  free(m);
+  free(r);
+}
+
+void oracle_horner(const uint8_t* window_sums_xyz, int num_words, int word_size, uint8_t out_xyz[96]) {
+  ensure_init();
+  og1* s = load_points96(window_sums_xyz, num_words);
+  og1 acc = s[num_words - 1];
+  for (int w = num_words - 2; w >= 0; w--) {
+    for (int k = 0; k < word_size; k++) g1_double(&acc, &acc);
+    g1_add(&acc, &acc, &s[w]);
+  }
+  g1_to_bytes96(out_xyz, &acc);
+  free(s);
+}
+
+int oracle_msm_cuzk_model(const uint8_t* xy, const uint8_t* scalars, size_t n, int word_size, uint8_t out_xyz[96]) {
+  ensure_init();
+  int num_words = (256 + word_size - 1) / word_size;
+  int num_columns = 1 << word_size;
+  int h = num_columns / 2;
+  int32_t* digits = (int32_t*)malloc(sizeof(int32_t) * (size_t)num_words * (n ? n : 1));
+  if (oracle_decompose_scalars_signed(scalars, n, num_words, word_size, digits) != 0) {
+    free(digits);
+    return -1;
+  }
+  int32_t* col_ptr = (int32_t*)malloc(sizeof(int32_t) * ((size_t)num_columns + 1));
+  int32_t* val = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
+  uint8_t* buckets = (uint8_t*)malloc(96 * (size_t)h);
+  uint8_t* sums = (uint8_t*)malloc(96 * (size_t)num_words);
+  for (int w = 0; w < num_words; w++) {
+    oracle_transpose(digits + (size_t)w * n, n, num_columns, col_ptr, val);
+    oracle_smvp_signed(col_ptr, val, xy, n, num_columns, buckets);
+    oracle_bucket_reduction(1, buckets, h, 1, sums + 96 * (size_t)w);
+  }
+  oracle_horner(sums, num_words, word_size, out_xyz);
+  free(digits);
+  free(col_ptr);
+  free(val);
+  free(buckets);
+  free(sums);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * deterministic synthetic inputs -- identical definition in oracle/bn254_ref.py
+ * ---------------------------------------------------------------------------------------------- */
+static uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static void draw256(uint64_t seed, uint64_t index, uint64_t attempt, uint64_t domain, uint64_t out[4]) {
+  uint64_t base = splitmix64(seed ^ ((domain & 0xFF) << 56)) ^ (index * 0xD1342543DE82EF95ull);
+  base = splitmix64(base ^ (attempt * 0xA0761D6478BD642Full));
+  uint64_t s = base;
+  for (int i = 0; i < 4; i++) {
+    s = splitmix64(s);
+    out[i] = s;
+  }
+  out[3] &= 0x3FFFFFFFFFFFFFFFull; /* 254 bits */
+}
+static int lt4(const uint64_t a[4], const uint64_t m[4]) {
+  for (int i = 3; i >= 0; i--) {
+    if (a[i] < m[i]) return 1;
+    if (a[i] > m[i]) return 0;
+  }
+  return 0;
+}
+
+void oracle_sample_scalars(uint64_t seed, size_t first, size_t n, uint8_t* out32) {
+  for (size_t i = 0; i < n; i++) {
+    uint64_t v[4];
+    for (uint64_t attempt = 0;; attempt++) {
+      draw256(seed, first + i, attempt, 1, v);
+      if (lt4(v, FR_R)) break;
+    }
+    memcpy(out32 + 32 * i, v, 32);
+  }
+}
+
+void oracle_sample_points(uint64_t seed, size_t first, size_t n, uint8_t* out64) {
+  ensure_init();
+  /* (p + 1) / 4 */
+  uint64_t e[4];
+  {
+    u128 c = (u128)FQ_P[0] + 1;
+    uint64_t t[4];
+    t[0] = (uint64_t)c;
+    c >>= 64;
+    for (int i = 1; i < 4; i++) {
+      c += FQ_P[i];
+      t[i] = (uint64_t)c;
+      c >>= 64;
+    }
+    for (int i = 0; i < 4; i++) e[i] = (t[i] >> 2) | (i < 3 ? t[i + 1] << 62 : 0);
+  }
+  for (size_t i = 0; i < n; i++) {
+    for (uint64_t attempt = 0;; attempt++) {
+      uint64_t v[4];
+      draw256(seed, first + i, attempt, 2, v);
+      if (!lt4(v, FQ_P)) continue;
+      ofq x, rhs, y, y2;
+      uint8_t xb[32];
+      memcpy(xb, v, 32);
+      fq_from_bytes(&x, xb);
+      fq_sqr(&rhs, &x);
+      fq_mul(&rhs, &rhs, &x);
+      fq_add(&rhs, &rhs, &FQ_B3);
+      fq_pow(&y, &rhs, e);
+      fq_sqr(&y2, &y);
+      if (!fq_eq(&y2, &rhs)) continue;
+      uint8_t yb[32];
+      fq_to_bytes(yb, &y);
+      if ((unsigned)(yb[0] & 1) != (unsigned)((xb[0] >> 1) & 1)) {
+        fq_neg(&y, &y);
+        fq_to_bytes(yb, &y);
+      }
+      memcpy(out64 + 64 * i, xb, 32);
+      memcpy(out64 + 64 * i + 32, yb, 32);
+      break;
+    }
+  }
+}
