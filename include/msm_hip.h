@@ -1,0 +1,129 @@
+/* libmsm_hip -- C ABI of the MI355X-native BN254 G1 multi-scalar-multiplication engine.
+ *
+ * Drop-in boundary for the hot path of ICME-Lab/msm-webgpu (all reference paths relative to /root/reference):
+ *
+ *     pub async fn run_webgpu_msm<C: CurveAffine>(g: &[C], v: &[C::Scalar]) -> C::Curve      src/lib.rs:76-82
+ *     pub async fn compute_msm<C: CurveAffine>(points: &[C], scalars: &[C::Scalar]) -> C::Curve   src/cuzk/msm.rs:75-417
+ *
+ * The reference has no FFI layer; a Rust maintainer binds these entry points with `extern "C"` and keeps the two
+ * signatures above (INTEGRATION.md shows the shim).  Wire formats are exactly what the reference's own helpers emit:
+ *
+ *     points  : n x 64 B, x || y, each coordinate the canonical (non-Montgomery) integer in [0, p), little-endian
+ *               = points_to_bytes()   src/lib.rs:55-65  (the point at infinity is not representable, lib.rs:58 panics)
+ *     scalars : n x 32 B, canonical integer in [0, r), little-endian
+ *               = scalars_to_bytes()  src/lib.rs:50-52, field_to_bytes src/cuzk/utils.rs:10-14
+ *     result  : 96 B Jacobian x || y || z, canonical little-endian, z = 0 <=> identity
+ *               = what C::Curve::new_jacobian consumes at src/cuzk/msm.rs:394
+ *
+ * Conventions: every function returns MSM_HIP_OK (0) or a negative error; nothing aborts or throws across the ABI
+ * (the reference panics instead: src/cuzk/gpu.rs:22,51, src/lib.rs:58, src/cuzk/msm.rs:399, src/cuzk/utils.rs:20).
+ * The caller owns all host buffers.  A context is used by one host thread at a time.  There is no CPU fallback:
+ * with no usable HIP device every entry point fails with MSM_HIP_ERR_NO_DEVICE.
+ */
+#ifndef MSM_HIP_H
+#define MSM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSM_HIP_OK 0
+#define MSM_HIP_ERR_NO_DEVICE (-1)     /* no HIP device / device init failed            (≙ gpu.rs:22,51 expect) */
+#define MSM_HIP_ERR_INVALID_ARG (-2)   /* null pointer, n mismatch, bad window range                             */
+#define MSM_HIP_ERR_OUT_OF_MEMORY (-3) /* hipMalloc failed                                                       */
+#define MSM_HIP_ERR_NONCANONICAL (-4)  /* a coordinate >= p or a scalar whose recode overflows (≙ utils.rs:20)   */
+#define MSM_HIP_ERR_NOT_ON_CURVE (-5)  /* only with MSM_HIP_CHECK_ON_CURVE                                      */
+#define MSM_HIP_ERR_NO_BASES (-6)      /* run called before set_bases                                            */
+#define MSM_HIP_ERR_HIP (-7)           /* a HIP runtime call failed; msm_hip_last_hip_error() has the code        */
+
+#define MSM_HIP_NUM_WINDOWS 16         /* num_subtasks = ceil(256 / 16)                       src/cuzk/msm.rs:82 */
+#define MSM_HIP_WINDOW_BITS 16         /* chunk_size                                           src/cuzk/msm.rs:79 */
+#define MSM_HIP_BUCKETS_PER_WINDOW 32768 /* 2^(c-1) signed buckets                             src/cuzk/msm.rs:191 */
+
+/* flags for msm_hip_set_bases_* */
+#define MSM_HIP_CHECK_ON_CURVE 1u      /* verify y^2 = x^3 + 3 for every base (one extra square + cube per point) */
+
+typedef struct msm_hip_ctx msm_hip_ctx;
+
+/* ---- context: replaces get_adapter/get_device + per-call buffer/pipeline creation (src/cuzk/gpu.rs:11-54,
+ *      src/cuzk/msm.rs:88-94).  Persistent: one stream, pooled device buffers, resident bases. ---- */
+int msm_hip_ctx_create(msm_hip_ctx** out, int device_id);
+void msm_hip_ctx_destroy(msm_hip_ctx* ctx);
+
+/* ---- bases: upload + convert to the device's Montgomery form once (≙ the point half of the decompose shader,
+ *      src/cuzk/wgsl/cuzk/decompose_scalars.template.wgsl:41-70, launched at src/cuzk/msm.rs:441-524) ---- */
+int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, uint32_t flags);
+/* same, bytes already in device memory (plain device pointer, e.g. a torch tensor's data_ptr) */
+int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t n, uint32_t flags);
+
+/* ---- run: sum_i scalars[i] * bases[i] over the first n bases (n <= number of bases set).
+ *      ≙ compute_msm stages 1-5, src/cuzk/msm.rs:96-416 (decompose, transpose, SMVP, bucket reduce, Horner) ---- */
+int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
+int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]);
+/* asynchronous halves of run_device: `launch` enqueues all device work of one MSM into result slot `slot` (0 or 1)
+ * and returns; `finish` waits for that slot and performs the host finalisation (src/cuzk/msm.rs:391-416).
+ * Lets a caller overlap the host Horner of MSM i with the device work of MSM i+1. */
+int msm_hip_launch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot);
+int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]);
+
+/* ---- window-sharded execution (multi-GPU; Pippenger windows are independent).
+ *      Computes the window sums S_w for w in [w_begin, w_end) and writes (w_end - w_begin) x 96 B Jacobian
+ *      canonical-LE records to `window_sums_dev` (device memory, so that RCCL can gather them in place). ---- */
+int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end,
+                                     void* window_sums_dev);
+/* result = sum_w 2^(16 w) * S_w over num_windows records (host memory): src/cuzk/msm.rs:411-416 */
+int msm_hip_combine_windows_bn254(const uint8_t* window_sums_host, int num_windows, uint8_t out_xyz[96]);
+
+/* ---- one-shot: create context, set bases, run, destroy (≙ compute_msm as the reference calls it) ---- */
+int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
+
+/* ---- synthetic inputs generated in HBM (≙ sample_scalars / sample_points, src/lib.rs:20-42, seeded):
+ *      scalars uniform in [0, r) by rejection; points by try-and-increment on x (Curve::random does the same).
+ *      Output is the wire format above, written to device memory. ---- */
+int msm_hip_sample_scalars_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void* scalars_dev);
+int msm_hip_sample_points_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void* xy_dev);
+
+/* ---- measurement: per-stage device time of the last run, from HIP events on the context's own stream.
+ *      ms[0] decompose+histogram, ms[1] scan, ms[2] scatter, ms[3] SMVP accumulate, ms[4] bucket reduce,
+ *      ms[5] whole device pipeline, ms[6] host finalisation.  Returns the number of entries written. ---- */
+int msm_hip_last_stage_ms(msm_hip_ctx* ctx, float* ms, int cap);
+/* the context's stream as a hipStream_t (for callers that want to order their own work after a run) */
+void* msm_hip_stream(msm_hip_ctx* ctx);
+
+/* ---- stage-level read-back for parity tests (≙ read_from_gpu_test, src/cuzk/gpu.rs:137-171).  Each copies the
+ *      buffer left by the last run to host memory.  Layouts:
+ *      digits    : u16[num_windows_run][n]    code = sign << 15 | (|d| & 0x7fff); 0 = digit 0 (no entry);
+ *                  0x8000 = digit -2^15 (bucket slot 0)        cf. decompose_scalars.template.wgsl:93-112
+ *      col_ptr   : u32[num_windows_run][32769] start of bucket slot k in val_idxs   cf. transpose.template.wgsl:58-61
+ *      val_idxs  : u32[num_windows_run][n]    point index | sign << 31, grouped by slot (order within a slot is
+ *                  unspecified)                                 cf. transpose.template.wgsl:66-73
+ *      buckets   : [num_windows_run][32768] x 96 B Jacobian canonical LE, slot k as smvp.template.wgsl:94
+ *      windows   : [num_windows_run] x 96 B Jacobian canonical LE
+ * ---- */
+int msm_hip_read_digits(msm_hip_ctx* ctx, uint16_t* out, size_t cap_elems);
+int msm_hip_read_col_ptr(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems);
+int msm_hip_read_val_idxs(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems);
+int msm_hip_read_buckets(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes);
+int msm_hip_read_window_sums(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes);
+
+/* ---- device op hooks for parity tests (≙ the single-op shaders src/cuzk/wgsl/test/test_field.wgsl:13-62 and
+ *      test_point.wgsl:18-88 driven by tests/field.rs:68, tests/point.rs:71).  Host buffers, canonical LE.
+ *      fq op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg ; a, b, out: n x 32 B
+ *      g1 op: 0 add, 1 double(a), 2 a + affine(b: n x 64 B) ; a, b, out: n x 96 B Jacobian
+ *      g1_mul_u32: out[i] = k[i] * a[i] (≙ double_and_add) ---- */
+int msm_hip_test_fq_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
+int msm_hip_test_g1_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
+int msm_hip_test_g1_mul_u32(msm_hip_ctx* ctx, const uint8_t* a, const uint32_t* k, uint8_t* out, size_t n);
+
+const char* msm_hip_strerror(int code);
+int msm_hip_last_hip_error(msm_hip_ctx* ctx);
+/* ABI version; bumped on any signature change */
+int msm_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSM_HIP_H */

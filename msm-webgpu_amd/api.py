@@ -1,0 +1,336 @@
+"""ctypes binding of libmsm_hip.so and the Python mirror of the reference's Rust API for the MSM path.
+
+Reference surface mirrored here (paths relative to /root/reference):
+    run_webgpu_msm(g, v) -> C::Curve          src/lib.rs:76-82
+    compute_msm(points, scalars) -> C::Curve  src/cuzk/msm.rs:75-417
+    points_to_bytes / scalars_to_bytes        src/lib.rs:50-65
+    sample_points / sample_scalars            src/lib.rs:20-42   (seeded here; the reference uses thread_rng)
+Error behaviour: the reference panics (gpu.rs:22,51; lib.rs:58; msm.rs:399; utils.rs:20); here every failure raises
+MsmHipError carrying the C-ABI error code.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import build as _build
+
+P = 21888242871839275222246405745257275088696311157297823662689037894645226208583  # src/cuzk/msm.rs:39
+NUM_WINDOWS = 16
+WINDOW_BITS = 16
+BUCKETS_PER_WINDOW = 1 << 15
+
+_lib = None
+
+
+class MsmHipError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().msm_hip_strerror(code).decode() if _lib is not None else "error"
+        super().__init__("%s failed: %s (%d)" % (where, msg, code))
+
+
+def lib():
+    """Load libmsm_hip.so (in-tree).  Raises if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        so = _build.SO
+        if not os.path.exists(so):
+            raise ImportError("libmsm_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % so)
+        L = C.CDLL(so)
+        vp, u8p, sz, i = C.c_void_p, C.c_char_p, C.c_size_t, C.c_int
+        L.msm_hip_strerror.restype = C.c_char_p
+        L.msm_hip_strerror.argtypes = [i]
+        L.msm_hip_abi_version.restype = i
+        L.msm_hip_ctx_create.argtypes = [C.POINTER(vp), i]
+        L.msm_hip_ctx_destroy.argtypes = [vp]
+        L.msm_hip_ctx_destroy.restype = None
+        L.msm_hip_set_bases_bn254.argtypes = [vp, u8p, sz, C.c_uint32]
+        L.msm_hip_set_bases_device_bn254.argtypes = [vp, vp, sz, C.c_uint32]
+        L.msm_hip_run_bn254.argtypes = [vp, u8p, sz, u8p]
+        L.msm_hip_run_device_bn254.argtypes = [vp, vp, sz, u8p]
+        L.msm_hip_launch_device_bn254.argtypes = [vp, vp, sz, i]
+        L.msm_hip_finish_bn254.argtypes = [vp, i, u8p]
+        L.msm_hip_run_windows_device_bn254.argtypes = [vp, vp, sz, i, i, vp]
+        L.msm_hip_combine_windows_bn254.argtypes = [u8p, i, u8p]
+        L.msm_hip_msm_bn254_g1.argtypes = [u8p, u8p, sz, u8p]
+        L.msm_hip_sample_scalars_device.argtypes = [vp, C.c_uint64, sz, vp]
+        L.msm_hip_sample_points_device.argtypes = [vp, C.c_uint64, sz, vp]
+        L.msm_hip_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i]
+        L.msm_hip_stream.argtypes = [vp]
+        L.msm_hip_stream.restype = vp
+        L.msm_hip_read_digits.argtypes = [vp, vp, sz]
+        L.msm_hip_read_col_ptr.argtypes = [vp, vp, sz]
+        L.msm_hip_read_val_idxs.argtypes = [vp, vp, sz]
+        L.msm_hip_read_buckets.argtypes = [vp, vp, sz]
+        L.msm_hip_read_window_sums.argtypes = [vp, vp, sz]
+        L.msm_hip_test_fq_op.argtypes = [vp, i, u8p, u8p, u8p, sz]
+        L.msm_hip_test_g1_op.argtypes = [vp, i, u8p, u8p, u8p, sz]
+        L.msm_hip_test_g1_mul_u32.argtypes = [vp, u8p, vp, u8p, sz]
+        L.msm_hip_last_hip_error.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+def _check(code, where):
+    if code != 0:
+        raise MsmHipError(code, where)
+
+
+# ------------------------------------------------------------------------------------------------ wire format
+def points_to_bytes(points):
+    """[(x, y), ...] canonical integers -> n x 64 B, x || y little-endian (src/lib.rs:55-65).
+    The point at infinity (None) is not representable: the reference panics at lib.rs:58, this raises."""
+    out = bytearray()
+    for pt in points:
+        if pt is None:
+            raise ValueError("point at infinity has no coordinates (src/lib.rs:58)")
+        x, y = pt
+        if not (0 <= x < P and 0 <= y < P):
+            raise ValueError("coordinate out of range")
+        out += int(x).to_bytes(32, "little") + int(y).to_bytes(32, "little")
+    return bytes(out)
+
+
+def scalars_to_bytes(scalars):
+    """[s, ...] integers in [0, r) -> n x 32 B little-endian (src/lib.rs:50-52)."""
+    return b"".join(int(s).to_bytes(32, "little") for s in scalars)
+
+
+class G1:
+    """Result of an MSM: a Jacobian point (x, y, z), canonical integers, z = 0 <=> identity (≙ C::Curve)."""
+
+    __slots__ = ("xyz",)
+
+    def __init__(self, xyz):
+        self.xyz = bytes(xyz)
+        assert len(self.xyz) == 96
+
+    def coords(self):
+        b = self.xyz
+        return tuple(int.from_bytes(b[k:k + 32], "little") for k in (0, 32, 64))
+
+    def is_identity(self):
+        return self.coords()[2] == 0
+
+    def to_affine(self):
+        """(x, y) canonical integers, or None for the identity (≙ Curve::to_affine, tests/cuzk.rs:88-94)."""
+        x, y, z = self.coords()
+        if z == 0:
+            return None
+        zi = pow(z, -1, P)
+        return (x * zi * zi % P, y * zi * zi * zi % P)
+
+    def to_affine_bytes(self):
+        """The 64-byte canonical affine encoding used for bit-exact comparison; 64 zero bytes for the identity."""
+        a = self.to_affine()
+        if a is None:
+            return bytes(64)
+        return a[0].to_bytes(32, "little") + a[1].to_bytes(32, "little")
+
+    def __eq__(self, other):  # projective equality, as G1's PartialEq (src/lib.rs:166)
+        return isinstance(other, G1) and self.to_affine() == other.to_affine()
+
+    def __hash__(self):
+        return hash(self.to_affine())
+
+    def __repr__(self):
+        return "G1(%s)" % (self.to_affine(),)
+
+
+# ------------------------------------------------------------------------------------------------ context
+def _as_device_u8(t, row, what):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise TypeError("%s must be a CUDA(HIP) uint8 tensor" % what)
+    if t.dtype != torch.uint8 or not t.is_contiguous() or t.numel() % row:
+        raise ValueError("%s must be contiguous uint8 with a multiple of %d bytes" % (what, row))
+    return t, t.numel() // row
+
+
+class MsmContext:
+    """Persistent engine on one GPU: stream, pooled buffers, resident bases (include/msm_hip.h)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().msm_hip_ctx_create(C.byref(self._h), int(device)), "msm_hip_ctx_create")
+        self.device = int(device)
+        self.n_bases = 0
+        self._keepalive = None
+
+    def close(self):
+        if self._h:
+            lib().msm_hip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- bases
+    def set_bases(self, points, check_on_curve=False):
+        """points: bytes (host, n x 64 B wire format) or a CUDA uint8 tensor holding the same bytes."""
+        flags = 1 if check_on_curve else 0
+        if isinstance(points, torch.Tensor) and points.is_cuda:
+            t, n = _as_device_u8(points, 64, "points")
+            torch.cuda.current_stream(t.device).synchronize()
+            _check(lib().msm_hip_set_bases_device_bn254(self._h, t.data_ptr(), n, flags), "msm_hip_set_bases_device_bn254")
+        else:
+            b = bytes(points)
+            if len(b) % 64:
+                raise ValueError("points must be n x 64 bytes")
+            n = len(b) // 64
+            _check(lib().msm_hip_set_bases_bn254(self._h, b, n, flags), "msm_hip_set_bases_bn254")
+        self.n_bases = n
+        return n
+
+    # -- whole MSM
+    def msm(self, scalars):
+        """sum_i scalars[i] * bases[i] -> G1.  scalars: bytes (n x 32 B) or CUDA uint8 tensor."""
+        out = C.create_string_buffer(96)
+        if isinstance(scalars, torch.Tensor) and scalars.is_cuda:
+            t, n = _as_device_u8(scalars, 32, "scalars")
+            torch.cuda.current_stream(t.device).synchronize()
+            _check(lib().msm_hip_run_device_bn254(self._h, t.data_ptr(), n, out), "msm_hip_run_device_bn254")
+        else:
+            b = bytes(scalars)
+            if len(b) % 32:
+                raise ValueError("scalars must be n x 32 bytes")
+            _check(lib().msm_hip_run_bn254(self._h, b, len(b) // 32, out), "msm_hip_run_bn254")
+        return G1(out.raw)
+
+    def launch(self, scalars_dev, slot=0):
+        """Enqueue the device work of one MSM into result slot 0/1 and return at once."""
+        t, n = _as_device_u8(scalars_dev, 32, "scalars")
+        self._keepalive = t
+        _check(lib().msm_hip_launch_device_bn254(self._h, t.data_ptr(), n, slot), "msm_hip_launch_device_bn254")
+
+    def finish(self, slot=0):
+        """Wait for the slot's device work, run the host window combine, return G1."""
+        out = C.create_string_buffer(96)
+        _check(lib().msm_hip_finish_bn254(self._h, slot, out), "msm_hip_finish_bn254")
+        return G1(out.raw)
+
+    # -- window shard (multi-GPU)
+    def msm_windows(self, scalars_dev, w_begin, w_end, out_dev=None):
+        """Window sums S_w, w in [w_begin, w_end), as a CUDA uint8 tensor [(w_end - w_begin), 96]."""
+        t, n = _as_device_u8(scalars_dev, 32, "scalars")
+        if out_dev is None:
+            out_dev = torch.empty((w_end - w_begin, 96), dtype=torch.uint8, device=t.device)
+        torch.cuda.current_stream(t.device).synchronize()
+        _check(lib().msm_hip_run_windows_device_bn254(self._h, t.data_ptr(), n, w_begin, w_end, out_dev.data_ptr()),
+               "msm_hip_run_windows_device_bn254")
+        return out_dev
+
+    @staticmethod
+    def combine_windows(window_sums):
+        """Host Horner over all window sums (bytes or uint8 tensor, num_windows x 96 B) -> G1."""
+        if isinstance(window_sums, torch.Tensor):
+            window_sums = window_sums.cpu().contiguous().numpy().tobytes()
+        b = bytes(window_sums)
+        out = C.create_string_buffer(96)
+        _check(lib().msm_hip_combine_windows_bn254(b, len(b) // 96, out), "msm_hip_combine_windows_bn254")
+        return G1(out.raw)
+
+    # -- synthetic inputs in HBM
+    def sample_scalars(self, n, seed):
+        t = torch.empty((n, 32), dtype=torch.uint8, device="cuda:%d" % self.device)
+        _check(lib().msm_hip_sample_scalars_device(self._h, seed, n, t.data_ptr()), "msm_hip_sample_scalars_device")
+        return t
+
+    def sample_points(self, n, seed):
+        t = torch.empty((n, 64), dtype=torch.uint8, device="cuda:%d" % self.device)
+        _check(lib().msm_hip_sample_points_device(self._h, seed, n, t.data_ptr()), "msm_hip_sample_points_device")
+        return t
+
+    # -- measurement
+    def stage_ms(self):
+        buf = (C.c_float * 8)()
+        k = lib().msm_hip_last_stage_ms(self._h, buf, 8)
+        names = ["decompose", "scan", "scatter", "smvp", "bucket_reduce", "device_total", "host_finalise"]
+        return {names[j]: float(buf[j]) for j in range(k)}
+
+    # -- stage read-back (parity tests)
+    def read_digits(self, n, w_count=NUM_WINDOWS):
+        a = np.empty((w_count, n), dtype=np.uint16)
+        _check(lib().msm_hip_read_digits(self._h, a.ctypes.data, a.size), "msm_hip_read_digits")
+        return a
+
+    def read_col_ptr(self, w_count=NUM_WINDOWS):
+        a = np.empty((w_count, BUCKETS_PER_WINDOW + 1), dtype=np.uint32)
+        _check(lib().msm_hip_read_col_ptr(self._h, a.ctypes.data, a.size), "msm_hip_read_col_ptr")
+        return a
+
+    def read_val_idxs(self, n, w_count=NUM_WINDOWS):
+        a = np.empty((w_count, n), dtype=np.uint32)
+        _check(lib().msm_hip_read_val_idxs(self._h, a.ctypes.data, a.size), "msm_hip_read_val_idxs")
+        return a
+
+    def read_buckets(self, w_count=NUM_WINDOWS):
+        a = np.empty((w_count, BUCKETS_PER_WINDOW, 96), dtype=np.uint8)
+        _check(lib().msm_hip_read_buckets(self._h, a.ctypes.data, a.size), "msm_hip_read_buckets")
+        return a
+
+    def read_window_sums(self, w_count=NUM_WINDOWS):
+        a = np.empty((w_count, 96), dtype=np.uint8)
+        _check(lib().msm_hip_read_window_sums(self._h, a.ctypes.data, a.size), "msm_hip_read_window_sums")
+        return a
+
+    # -- single-op hooks (≙ tests/field.rs, tests/point.rs)
+    def fq_op(self, op, a, b=None):
+        code = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "neg": 4}[op]
+        n = len(a) // 32
+        out = C.create_string_buffer(max(32 * n, 1))
+        _check(lib().msm_hip_test_fq_op(self._h, code, a, b, out, n), "msm_hip_test_fq_op")
+        return out.raw[:32 * n]
+
+    def g1_op(self, op, a, b=None):
+        code = {"add": 0, "double": 1, "add_affine": 2}[op]
+        n = len(a) // 96
+        out = C.create_string_buffer(max(96 * n, 1))
+        _check(lib().msm_hip_test_g1_op(self._h, code, a, b, out, n), "msm_hip_test_g1_op")
+        return out.raw[:96 * n]
+
+    def g1_mul_u32(self, a, ks):
+        n = len(a) // 96
+        k = np.ascontiguousarray(ks, dtype=np.uint32)
+        out = C.create_string_buffer(max(96 * n, 1))
+        _check(lib().msm_hip_test_g1_mul_u32(self._h, a, k.ctypes.data, out, n), "msm_hip_test_g1_mul_u32")
+        return out.raw[:96 * n]
+
+
+# ------------------------------------------------------------------------------------------------ reference-shaped functions
+_default_ctx = {}
+
+
+def _ctx(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = MsmContext(device)
+    return _default_ctx[device]
+
+
+def compute_msm(points, scalars, device=0):
+    """≙ compute_msm (src/cuzk/msm.rs:75): one-shot MSM including base upload; returns G1."""
+    ctx = _ctx(device)
+    n = ctx.set_bases(points)
+    ns = (scalars.numel() if isinstance(scalars, torch.Tensor) else len(scalars)) // 32
+    if ns != n:
+        raise ValueError("points and scalars differ in length (%d vs %d)" % (n, ns))
+    return ctx.msm(scalars)
+
+
+def run_webgpu_msm(g, v, device=0):
+    """≙ run_webgpu_msm (src/lib.rs:76-82); the name is the reference's, the device is an MI355X."""
+    return compute_msm(g, v, device)
+
+
+def sample_scalars(n, seed=0, device=0):
+    """≙ sample_scalars (src/lib.rs:20-23), seeded; CUDA uint8 tensor [n, 32] in the wire format."""
+    return _ctx(device).sample_scalars(n, seed)
+
+
+def sample_points(n, seed=0, device=0):
+    """≙ sample_points (src/lib.rs:36-42), seeded; CUDA uint8 tensor [n, 64] in the wire format."""
+    return _ctx(device).sample_points(n, seed)

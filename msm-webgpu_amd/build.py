@@ -1,0 +1,35 @@
+"""Build libmsm_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libmsm_hip.so")
+SOURCES = ["msm_hip.hip", "msm_kernels.h", "g1.h", "fq29.h", "host_g1.h", "bn254_constants.h"]
+HEADER = os.path.join(HERE, "..", "include", "msm_hip.h")
+
+
+def needs_build():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -shared -fPIC csrc/msm_hip.hip -> msm-webgpu_amd/libmsm_hip.so"""
+    if not force and not needs_build():
+        return SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+           os.path.join(CSRC, "msm_hip.hip"), "-o", SO + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(SO + ".tmp", SO)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,251 @@
+// BN254 base-field arithmetic for gfx950: 9 limbs x 29 bits in 32-bit VGPRs, Montgomery radix R = 2^261.
+//
+// Why this shape (measured on MI355X, profiles/r01_ubench_valu_rates.txt): v_mad_u64_u32 issues at ~2.3 ns per
+// wave-instruction per SIMD -- only 1.25x a plain VOP3 op -- while every carry-propagating add
+// (v_add_co_u32 / v_addc_co_u32) costs ~2.0 ns, i.e. nearly a full multiply.  A saturated 8 x 32-bit limb
+// multiplier therefore spends as much on carries as on products.  With 29-bit limbs a 64-bit column
+// accumulator absorbs all 18 partial products of a Montgomery step without any carry instruction
+// (18 * 2^58 < 2^64), additions are 9 independent VOP2 adds with no carry chain ("lazy" limbs up to 2^30),
+// and 2^261 / p = 169 leaves room for values up to ~12p between multiplications, so nothing is reduced
+// mod p until a value is stored.
+//
+// The reference's field library (src/cuzk/wgsl/field/field.template.wgsl:40-135,
+// src/cuzk/wgsl/montgomery/mont_pro_product.template.wgsl:7-53, src/cuzk/wgsl/bigint/bigint.template.wgsl:11-46)
+// uses 20 x 13-bit limbs because WGSL has no 64-bit integers; only its semantics (Montgomery product,
+// add, sub mod p) are kept here.
+//
+// Conventions
+//   value(x)  = sum_i x.v[i] * 2^(29 i)
+//   "normal"  : limbs 0..7 < 2^29 + 8, top limb small       (output of fq_sub / fq_norm)
+//   "exact"   : limbs 0..7 < 2^29 exactly (unique)          (output of fq_mul / fq_sqr; value < 2p)
+//   "lazy"    : limbs < 2^30 + 16                           (fq_add of two normal values)
+//   fq_mul / fq_sqr accept lazy operands with value(a) * value(b) <= 169 p^2 and return exact, < 2p.
+#pragma once
+#include <cstdint>
+
+#include "bn254_constants.h"
+
+#if defined(__HIPCC__)
+#define FQ_HD __host__ __device__ __forceinline__
+#else
+#define FQ_HD inline
+#endif
+
+#if defined(FQ_CHECK)  // host-only bound checking used by tests/test_fq29_host.py
+#include <cstdio>
+#include <cstdlib>
+#define FQ_ASSERT(c, msg)                                      \
+  do {                                                         \
+    if (!(c)) {                                                \
+      fprintf(stderr, "fq29 bound violated: %s\n", msg);       \
+      abort();                                                 \
+    }                                                          \
+  } while (0)
+#else
+#define FQ_ASSERT(c, msg) ((void)0)
+#endif
+
+namespace bn254 {
+
+struct fq {
+  uint32_t v[9];
+};
+
+FQ_HD fq fq_zero() {
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = 0;
+  return r;
+}
+FQ_HD fq fq_one() {  // Montgomery form of 1
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = FQ_ONE29[i];
+  return r;
+}
+
+// One carry-save pass: limbs 0..7 end < 2^29 + (max_in >> 29); value unchanged.
+FQ_HD fq fq_norm(const fq& x) {
+  fq r;
+  r.v[0] = x.v[0] & FQ_MASK;
+#pragma unroll
+  for (int i = 1; i < 8; i++) r.v[i] = (x.v[i] & FQ_MASK) + (x.v[i - 1] >> 29);
+  r.v[8] = x.v[8] + (x.v[7] >> 29);
+  return r;
+}
+
+// Lazy add: no carries, no reduction.
+FQ_HD fq fq_add(const fq& a, const fq& b) {
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+  return r;
+}
+FQ_HD fq fq_dbl(const fq& a) { return fq_add(a, a); }
+
+// a - b + K*p, normal.  Requires value(b) < (K-1)*p and b's limbs 0..7 <= 2^31 - 4, a's <= 2^30 + 2^29.
+template <int K>
+FQ_HD fq fq_sub(const fq& a, const fq& b) {
+  static_assert(K >= 2 && K <= 16, "K*p constant not tabulated");
+  fq t;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    FQ_ASSERT(FQ_KP29[K][i] >= b.v[i] || i == 8, "fq_sub: limb borrow");
+    FQ_ASSERT(i != 8 || FQ_KP29[K][8] + a.v[8] >= b.v[8], "fq_sub: top limb borrow");
+    t.v[i] = a.v[i] + FQ_KP29[K][i] - b.v[i];
+  }
+  return fq_norm(t);
+}
+
+// Montgomery product a*b/R mod p, R = 2^261.  Operand limbs <= 2^30 + 16; value(a)*value(b) <= 169 p^2.
+// Result exact (limbs < 2^29), value < 2p.
+FQ_HD fq fq_mul(const fq& a, const fq& b) {
+  uint64_t c[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) c[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    FQ_ASSERT(a.v[i] <= (1u << 30) + 64 && b.v[i] <= (1u << 30) + 64, "fq_mul: operand limb too large");
+#pragma unroll
+    for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a.v[j] * b.v[i];
+    const uint32_t m = ((uint32_t)c[i] * FQ_N0_29) & FQ_MASK;
+#pragma unroll
+    for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)m * FQ_P29[j];
+    c[i + 1] += c[i] >> 29;
+  }
+  fq r;
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+    r.v[k - 9] = (uint32_t)c[k] & FQ_MASK;
+    c[k + 1] += c[k] >> 29;
+  }
+  r.v[8] = (uint32_t)c[17];
+  FQ_ASSERT((c[17] >> 26) == 0, "fq_mul: result >= 2^258");
+  return r;
+}
+
+// Montgomery square: 45 products instead of 81 (cross terms doubled once).
+FQ_HD fq fq_sqr(const fq& a) {
+  uint64_t c[18];
+  uint32_t a2[9];
+#pragma unroll
+  for (int k = 0; k < 18; k++) c[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    FQ_ASSERT(a.v[i] <= (1u << 30) + 64, "fq_sqr: operand limb too large");
+    a2[i] = a.v[i] << 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    c[2 * i] += (uint64_t)a.v[i] * a.v[i];
+#pragma unroll
+    for (int j = i + 1; j < 9; j++) c[i + j] += (uint64_t)a.v[i] * a2[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const uint32_t m = ((uint32_t)c[i] * FQ_N0_29) & FQ_MASK;
+#pragma unroll
+    for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)m * FQ_P29[j];
+    c[i + 1] += c[i] >> 29;
+  }
+  fq r;
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+    r.v[k - 9] = (uint32_t)c[k] & FQ_MASK;
+    c[k + 1] += c[k] >> 29;
+  }
+  r.v[8] = (uint32_t)c[17];
+  return r;
+}
+
+// x exact and < 2p  ->  true iff x == 0 (mod p)
+FQ_HD bool fq_is_zero_exact(const fq& x) {
+  uint32_t z = 0, e = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    z |= x.v[i];
+    e |= x.v[i] ^ FQ_P29[i];
+  }
+  return z == 0 || e == 0;
+}
+
+// x exact and < 2p  ->  canonical representative in [0, p), exact
+FQ_HD fq fq_canonical(const fq& x) {
+  fq d;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const uint32_t t = x.v[i] - FQ_P29[i] - borrow;
+    borrow = t >> 31;
+    d.v[i] = (i < 8) ? (t & FQ_MASK) : t;
+  }
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = borrow ? x.v[i] : d.v[i];
+  return r;
+}
+
+// any normal/lazy x with value <= 84p (so that x * 2p <= 169 p^2)  ->  exact value mod p in [0, 2p), same Montgomery form
+FQ_HD fq fq_tidy(const fq& x) { return fq_mul(x, fq_one()); }
+
+// 8 x 32-bit packed words (value < 2^256)  <->  9 x 29-bit limbs (exact)
+FQ_HD fq fq_unpack(const uint32_t w[8]) {
+  fq r;
+  uint64_t acc = 0;
+  int bits = 0, k = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    if (bits < 29 && k < 8) {
+      acc |= (uint64_t)w[k++] << bits;
+      bits += 32;
+    }
+    r.v[i] = (uint32_t)acc & FQ_MASK;
+    acc >>= 29;
+    bits -= 29;
+  }
+  return r;
+}
+FQ_HD void fq_pack(uint32_t w[8], const fq& x) {  // x exact, value < 2^256
+  uint64_t acc = 0;
+  int bits = 0, k = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    acc |= (uint64_t)x.v[i] << bits;
+    bits += 29;
+    if (bits >= 32 && k < 8) {
+      w[k++] = (uint32_t)acc;
+      acc >>= 32;
+      bits -= 32;
+    }
+  }
+}
+
+// canonical integer (packed) -> Montgomery form, and back
+FQ_HD fq fq_to_mont(const fq& x_plain) {
+  fq r2;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r2.v[i] = FQ_R2_29[i];
+  return fq_canonical(fq_mul(x_plain, r2));
+}
+FQ_HD fq fq_from_mont(const fq& x) {  // x normal, value <= 84p
+  fq one = fq_zero();
+  one.v[0] = 1;
+  return fq_canonical(fq_mul(x, one));
+}
+
+FQ_HD fq fq_neg_canonical(const fq& y) {  // y canonical in [0,p) -> p - y (or 0)
+  uint32_t z = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) z |= y.v[i];
+  fq t;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const uint32_t d = FQ_P29[i] - y.v[i] - borrow;
+    borrow = d >> 31;
+    t.v[i] = (i < 8) ? (d & FQ_MASK) : d;
+  }
+  return z ? t : y;
+}
+
+}  // namespace bn254

@@ -1,0 +1,189 @@
+// BN254 G1 (y^2 = x^3 + 3) point arithmetic on fq29 limbs, extended-Jacobian "XYZZ" coordinates
+// (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2).
+//
+// The reference adds full Jacobian points with add-2007-bl at 11M + 5S even when the incoming point is affine
+// (src/cuzk/wgsl/curve/ec.template.wgsl:36-86, used by smvp.template.wgsl:70-79).  The bucket accumulator here
+// adds an affine point into an XYZZ accumulator (EFD madd-2008-s, 8M + 2S) and full XYZZ additions
+// (add-2008-s, 12M + 2S) / doublings (dbl-2008-s-1) are used by the bucket reduction.  The case split is the
+// reference's (ec.template.wgsl:36-65): P = inf, Q = inf, P = Q -> double, P = -Q -> inf.
+//
+// Value bounds kept between operations (fq29.h conventions; all coordinates "normal"):
+//     X < 9p,  Y < 5p,  ZZ < 2p (exact),  ZZZ < 2p (exact)
+// Every fq_sub<K> below states the bound of its subtrahend in the trailing comment.
+#pragma once
+#include "fq29.h"
+
+namespace bn254 {
+
+struct g1_affine {  // Montgomery form, canonical
+  fq x, y;
+};
+
+struct g1_xyzz {
+  fq x, y, zz, zzz;
+  bool inf;
+};
+
+FQ_HD g1_xyzz g1_identity() {
+  g1_xyzz r;
+  r.x = fq_zero();
+  r.y = fq_zero();
+  r.zz = fq_zero();
+  r.zzz = fq_zero();
+  r.inf = true;
+  return r;
+}
+
+FQ_HD g1_xyzz g1_from_affine(const fq& px, const fq& py) {
+  g1_xyzz r;
+  r.x = px;
+  r.y = py;
+  r.zz = fq_one();
+  r.zzz = fq_one();
+  r.inf = false;
+  return r;
+}
+
+// 2 * (px, py) for an affine point (EFD mdbl-2008-s-1)
+FQ_HD g1_xyzz g1_double_affine(const fq& px, const fq& py) {
+  g1_xyzz r;
+  const fq U = fq_dbl(py);                              // < 2p, lazy
+  const fq V = fq_sqr(U);                               // < 2p
+  const fq W = fq_mul(U, V);                            // < 2p
+  const fq S = fq_mul(px, V);                           // < 2p
+  const fq XX = fq_sqr(px);                             // < 2p
+  const fq M = fq_norm(fq_add(fq_dbl(XX), XX));         // < 6p
+  const fq MM = fq_sqr(M);                              // 36 p^2
+  r.x = fq_sub<5>(MM, fq_dbl(S));                       // 2S < 4p      -> X < 7p
+  const fq T = fq_sub<8>(S, r.x);                       // X < 7p       -> T < 10p
+  r.y = fq_sub<3>(fq_mul(M, T), fq_mul(W, py));         // < 2p         -> Y < 5p
+  r.zz = V;
+  r.zzz = W;
+  r.inf = false;
+  return r;
+}
+
+// 2 * a  (EFD dbl-2008-s-1, a = 0)
+FQ_HD g1_xyzz g1_double(const g1_xyzz& a) {
+  if (a.inf) return a;
+  g1_xyzz r;
+  const fq U = fq_dbl(a.y);                             // < 10p, lazy
+  const fq V = fq_sqr(U);                               // 100 p^2
+  const fq W = fq_mul(U, V);                            // 20 p^2
+  const fq S = fq_mul(a.x, V);                          // 18 p^2
+  const fq XX = fq_sqr(a.x);                            // 81 p^2
+  const fq M = fq_norm(fq_add(fq_dbl(XX), XX));         // < 6p
+  const fq MM = fq_sqr(M);
+  r.x = fq_sub<5>(MM, fq_dbl(S));                       // 2S < 4p      -> X < 7p
+  const fq T = fq_sub<8>(S, r.x);                       // X < 7p       -> T < 10p
+  r.y = fq_sub<3>(fq_mul(M, T), fq_mul(W, a.y));        // < 2p         -> Y < 5p
+  r.zz = fq_mul(V, a.zz);
+  r.zzz = fq_mul(W, a.zzz);
+  r.inf = false;
+  return r;
+}
+
+// a += (px, py)   mixed addition, the SMVP inner operation (EFD madd-2008-s: 8M + 2S)
+FQ_HD void g1_madd(g1_xyzz& a, const fq& px, const fq& py) {
+  if (a.inf) {
+    a = g1_from_affine(px, py);
+    return;
+  }
+  const fq U2 = fq_mul(px, a.zz);                       // < 2p
+  const fq S2 = fq_mul(py, a.zzz);                      // < 2p
+  const fq P = fq_sub<10>(U2, a.x);                     // X < 9p       -> P < 12p
+  const fq R = fq_sub<6>(S2, a.y);                      // Y < 5p       -> R < 8p
+  const fq PP = fq_sqr(P);                              // 144 p^2
+  if (fq_is_zero_exact(PP)) {                           // same x: P = Q or P = -Q
+    if (fq_is_zero_exact(fq_tidy(R)))
+      a = g1_double_affine(px, py);
+    else
+      a = g1_identity();
+    return;
+  }
+  const fq PPP = fq_mul(P, PP);                         // 24 p^2
+  const fq Q = fq_mul(a.x, PP);                         // 18 p^2
+  const fq RR = fq_sqr(R);                              // 64 p^2
+  const fq X3 = fq_sub<7>(RR, fq_add(PPP, fq_dbl(Q)));  // PPP + 2Q < 6p -> X3 < 9p
+  const fq T = fq_sub<10>(Q, X3);                       // X3 < 9p      -> T < 12p
+  a.y = fq_sub<3>(fq_mul(R, T), fq_mul(a.y, PPP));      // < 2p         -> Y3 < 5p
+  a.x = X3;
+  a.zz = fq_mul(a.zz, PP);
+  a.zzz = fq_mul(a.zzz, PPP);
+}
+
+// a + b   (EFD add-2008-s: 12M + 2S)
+FQ_HD g1_xyzz g1_add(const g1_xyzz& a, const g1_xyzz& b) {
+  if (a.inf) return b;
+  if (b.inf) return a;
+  const fq U1 = fq_mul(a.x, b.zz);                      // 18 p^2
+  const fq U2 = fq_mul(b.x, a.zz);
+  const fq S1 = fq_mul(a.y, b.zzz);                     // 10 p^2
+  const fq S2 = fq_mul(b.y, a.zzz);
+  const fq P = fq_sub<3>(U2, U1);                       // < 2p         -> P < 5p
+  const fq R = fq_sub<3>(S2, S1);                       //              -> R < 5p
+  const fq PP = fq_sqr(P);
+  if (fq_is_zero_exact(PP)) {
+    if (fq_is_zero_exact(fq_tidy(R))) return g1_double(a);
+    return g1_identity();
+  }
+  g1_xyzz r;
+  const fq PPP = fq_mul(P, PP);
+  const fq Q = fq_mul(U1, PP);
+  const fq RR = fq_sqr(R);
+  r.x = fq_sub<7>(RR, fq_add(PPP, fq_dbl(Q)));          // < 6p         -> X3 < 9p
+  const fq T = fq_sub<10>(Q, r.x);                      // X3 < 9p      -> T < 12p
+  r.y = fq_sub<3>(fq_mul(R, T), fq_mul(S1, PPP));       // < 2p         -> Y3 < 5p
+  r.zz = fq_mul(fq_mul(a.zz, b.zz), PP);
+  r.zzz = fq_mul(fq_mul(a.zzz, b.zzz), PPP);
+  r.inf = false;
+  return r;
+}
+
+FQ_HD g1_xyzz g1_neg(const g1_xyzz& a) {
+  g1_xyzz r = a;
+  if (!a.inf) r.y = fq_sub<6>(fq_zero(), a.y);          // Y < 5p       -> < 6p ... re-tidied below
+  if (!a.inf) r.y = fq_tidy(r.y);                       // back under the Y < 5p invariant (exact, < 2p)
+  return r;
+}
+
+// k * a for a small scalar, left-to-right double-and-add (≙ double_and_add, ec.template.wgsl:124-139)
+FQ_HD g1_xyzz g1_mul_u32(const g1_xyzz& a, uint32_t k) {
+  g1_xyzz acc = g1_identity();
+  for (int bit = 31; bit >= 0; bit--) {
+    acc = g1_double(acc);
+    if ((k >> bit) & 1u) acc = g1_add(acc, a);
+  }
+  return acc;
+}
+
+// XYZZ -> Jacobian (X', Y', Z') with Z' = ZZ:  X' = X*ZZ, Y' = Y*ZZZ  (x = X'/Z'^2, y = Y'/Z'^3).
+// Outputs Montgomery-form canonical values; the identity is (0, 0, 0) -- Z = 0 <=> identity, as ec.template.wgsl:4-8.
+FQ_HD void g1_to_jacobian(const g1_xyzz& a, fq& X, fq& Y, fq& Z) {
+  if (a.inf) {
+    X = fq_zero();
+    Y = fq_zero();
+    Z = fq_zero();
+    return;
+  }
+  X = fq_canonical(fq_mul(a.x, a.zz));
+  Y = fq_canonical(fq_mul(a.y, a.zzz));
+  Z = fq_canonical(a.zz);
+}
+
+// Jacobian (Montgomery, canonical) -> XYZZ: ZZ = Z^2, ZZZ = Z^3
+FQ_HD g1_xyzz g1_from_jacobian(const fq& X, const fq& Y, const fq& Z) {
+  uint32_t z = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) z |= Z.v[i];
+  if (z == 0) return g1_identity();
+  g1_xyzz r;
+  r.x = X;
+  r.y = Y;
+  r.zz = fq_sqr(Z);
+  r.zzz = fq_mul(r.zz, Z);
+  r.inf = false;
+  return r;
+}
+
+}  // namespace bn254

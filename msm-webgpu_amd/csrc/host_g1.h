@@ -1,0 +1,195 @@
+// Host finalisation arithmetic: BN254 Fq as 4 x 64-bit Montgomery limbs (R = 2^256) and Jacobian G1.
+//
+// The only host-side group arithmetic in the product: the window combine result = sum_w 2^(16w) S_w
+// (≙ src/cuzk/msm.rs:391-416, which the reference also runs on the host).  It is 240 dependent doublings --
+// a serial chain that one CPU core finishes in ~60 us while a single GPU lane would need milliseconds --
+// so it stays on the host by design (DESIGN.md "Window combine").  Not a fallback for any device stage.
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+#include "bn254_constants.h"
+
+namespace bn254 {
+namespace host {
+
+typedef unsigned __int128 u128;
+
+struct hfq {
+  uint64_t l[4];
+};
+
+inline bool hfq_geq_p(const hfq& a) {
+  for (int i = 3; i >= 0; i--) {
+    if (a.l[i] != FQ_P64[i]) return a.l[i] > FQ_P64[i];
+  }
+  return true;
+}
+inline void hfq_sub_p(hfq& a) {
+  uint64_t borrow = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)a.l[i] - FQ_P64[i] - borrow;
+    a.l[i] = (uint64_t)d;
+    borrow = (uint64_t)(d >> 64) & 1u;
+  }
+}
+inline hfq hfq_add(const hfq& a, const hfq& b) {
+  hfq r;
+  u128 c = 0;
+  for (int i = 0; i < 4; i++) {
+    c += (u128)a.l[i] + b.l[i];
+    r.l[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  if (hfq_geq_p(r)) hfq_sub_p(r);
+  return r;
+}
+inline hfq hfq_sub(const hfq& a, const hfq& b) {
+  hfq r;
+  uint64_t borrow = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)a.l[i] - b.l[i] - borrow;
+    r.l[i] = (uint64_t)d;
+    borrow = (uint64_t)(d >> 64) & 1u;
+  }
+  if (borrow) {
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+      c += (u128)r.l[i] + FQ_P64[i];
+      r.l[i] = (uint64_t)c;
+      c >>= 64;
+    }
+  }
+  return r;
+}
+// Montgomery product, separated operand scanning: full 512-bit product first, then four reduction rounds
+inline hfq hfq_mul(const hfq& a, const hfq& b) {
+  uint64_t t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 carry = 0;
+    for (int j = 0; j < 4; j++) {
+      carry += (u128)a.l[i] * b.l[j] + t[i + j];
+      t[i + j] = (uint64_t)carry;
+      carry >>= 64;
+    }
+    t[i + 4] = (uint64_t)carry;
+  }
+  for (int i = 0; i < 4; i++) {
+    const uint64_t m = t[i] * FQ_N0_64;
+    u128 carry = 0;
+    for (int j = 0; j < 4; j++) {
+      carry += (u128)m * FQ_P64[j] + t[i + j];
+      t[i + j] = (uint64_t)carry;
+      carry >>= 64;
+    }
+    for (int k = i + 4; carry && k < 9; k++) {
+      carry += t[k];
+      t[k] = (uint64_t)carry;
+      carry >>= 64;
+    }
+  }
+  hfq r = {{t[4], t[5], t[6], t[7]}};
+  if (t[8] || hfq_geq_p(r)) hfq_sub_p(r);
+  return r;
+}
+inline hfq hfq_sqr(const hfq& a) { return hfq_mul(a, a); }
+inline bool hfq_is_zero(const hfq& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+inline bool hfq_eq(const hfq& a, const hfq& b) { return memcmp(a.l, b.l, 32) == 0; }
+
+// canonical little-endian bytes <-> Montgomery; returns false when the encoding is >= p
+inline bool hfq_from_bytes(hfq& r, const uint8_t b[32]) {
+  hfq t;
+  memcpy(t.l, b, 32);
+  const bool ok = !hfq_geq_p(t);
+  hfq r2 = {{FQ_R2_64[0], FQ_R2_64[1], FQ_R2_64[2], FQ_R2_64[3]}};
+  r = hfq_mul(t, r2);
+  return ok;
+}
+inline void hfq_to_bytes(uint8_t b[32], const hfq& a) {
+  hfq one = {{1, 0, 0, 0}};
+  hfq t = hfq_mul(a, one);
+  memcpy(b, t.l, 32);
+}
+
+struct hg1 {  // Jacobian, z == 0 <=> identity
+  hfq x, y, z;
+};
+inline hg1 hg1_identity() {
+  hg1 r;
+  memset(&r, 0, sizeof r);
+  return r;
+}
+inline bool hg1_is_identity(const hg1& p) { return hfq_is_zero(p.z); }
+
+inline hg1 hg1_double(const hg1& p) {  // dbl-2009-l, a = 0
+  if (hg1_is_identity(p)) return p;
+  hfq A = hfq_sqr(p.x), B = hfq_sqr(p.y), C = hfq_sqr(B);
+  hfq t = hfq_add(p.x, B);
+  t = hfq_sub(hfq_sub(hfq_sqr(t), A), C);
+  hfq D = hfq_add(t, t);
+  hfq E = hfq_add(hfq_add(A, A), A);
+  hfq F = hfq_sqr(E);
+  hg1 r;
+  r.x = hfq_sub(F, hfq_add(D, D));
+  hfq c8 = hfq_add(C, C);
+  c8 = hfq_add(c8, c8);
+  c8 = hfq_add(c8, c8);
+  r.y = hfq_sub(hfq_mul(E, hfq_sub(D, r.x)), c8);
+  hfq yz = hfq_mul(p.y, p.z);
+  r.z = hfq_add(yz, yz);
+  return r;
+}
+inline hg1 hg1_add(const hg1& p, const hg1& q) {  // add-2007-bl with the usual case split
+  if (hg1_is_identity(p)) return q;
+  if (hg1_is_identity(q)) return p;
+  hfq z1z1 = hfq_sqr(p.z), z2z2 = hfq_sqr(q.z);
+  hfq u1 = hfq_mul(p.x, z2z2), u2 = hfq_mul(q.x, z1z1);
+  hfq s1 = hfq_mul(hfq_mul(p.y, q.z), z2z2), s2 = hfq_mul(hfq_mul(q.y, p.z), z1z1);
+  if (hfq_eq(u1, u2)) return hfq_eq(s1, s2) ? hg1_double(p) : hg1_identity();
+  hfq h = hfq_sub(u2, u1);
+  hfq i = hfq_add(h, h);
+  i = hfq_sqr(i);
+  hfq j = hfq_mul(h, i);
+  hfq rr = hfq_sub(s2, s1);
+  rr = hfq_add(rr, rr);
+  hfq v = hfq_mul(u1, i);
+  hg1 r;
+  r.x = hfq_sub(hfq_sub(hfq_sqr(rr), j), hfq_add(v, v));
+  hfq s1j = hfq_mul(s1, j);
+  r.y = hfq_sub(hfq_mul(rr, hfq_sub(v, r.x)), hfq_add(s1j, s1j));
+  hfq zz = hfq_add(p.z, q.z);
+  r.z = hfq_mul(hfq_sub(hfq_sub(hfq_sqr(zz), z1z1), z2z2), h);
+  return r;
+}
+inline bool hg1_from_bytes96(hg1& r, const uint8_t b[96]) {
+  bool ok = hfq_from_bytes(r.x, b);
+  ok &= hfq_from_bytes(r.y, b + 32);
+  ok &= hfq_from_bytes(r.z, b + 64);
+  return ok;
+}
+inline void hg1_to_bytes96(uint8_t b[96], const hg1& p) {
+  if (hg1_is_identity(p)) {
+    memset(b, 0, 96);
+    return;
+  }
+  hfq_to_bytes(b, p.x);
+  hfq_to_bytes(b + 32, p.y);
+  hfq_to_bytes(b + 64, p.z);
+}
+
+// result = sum_w 2^(window_bits * w) * S_w, from the top window down  (src/cuzk/msm.rs:411-416)
+inline bool combine_windows(const uint8_t* sums96, int num_windows, int window_bits, uint8_t out[96]) {
+  hg1 acc = hg1_identity();
+  bool ok = true;
+  for (int w = num_windows - 1; w >= 0; w--) {
+    for (int k = 0; k < window_bits; k++) acc = hg1_double(acc);
+    hg1 s;
+    ok &= hg1_from_bytes96(s, sums96 + 96 * (size_t)w);
+    acc = hg1_add(acc, s);
+  }
+  hg1_to_bytes96(out, acc);
+  return ok;
+}
+
+}  // namespace host
+}  // namespace bn254

@@ -1,0 +1,514 @@
+// libmsm_hip.so -- host side of the MI355X BN254 MSM engine behind the C ABI of include/msm_hip.h.
+//
+// Replaces, for the hot path only, the reference's orchestrator compute_msm (src/cuzk/msm.rs:75-417) and its wgpu
+// wrappers (src/cuzk/gpu.rs): one persistent context = one HIP stream, pooled device buffers, bases resident in HBM
+// in device Montgomery form; no per-call device creation, shader generation or pipeline compilation
+// (cf. src/cuzk/msm.rs:88-94, src/cuzk/shader_manager.rs:74-100).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/msm_hip.h"
+#include "host_g1.h"
+#include "msm_kernels.h"
+
+using namespace msmk;
+
+namespace {
+
+constexpr int N_EVENTS = 6;
+constexpr size_t WSUM_BYTES = (size_t)NWIN * 96;
+
+struct Slot {
+  uint8_t* h_wsums = nullptr;  // pinned: NWIN x 96 B window sums + 4 B error word
+  uint8_t* d_wsums = nullptr;  // device:  NWIN x 96 B + 4 B error word
+  hipEvent_t done = nullptr;
+  int w_begin = 0, w_count = 0;
+  size_t n = 0;
+  bool pending = false;
+};
+
+}  // namespace
+
+struct msm_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[N_EVENTS] = {};
+  int last_hip_error = 0;
+
+  uint32_t* d_bases = nullptr;  // n_bases x 16 words
+  size_t n_bases = 0, cap_bases = 0;
+
+  size_t cap_n = 0;  // capacity of the per-run work buffers
+  uint32_t* d_scalars = nullptr;
+  uint16_t* d_digits = nullptr;
+  uint32_t* d_hist = nullptr;
+  uint32_t* d_col_ptr = nullptr;
+  uint32_t* d_cursor = nullptr;
+  uint32_t* d_val = nullptr;
+  uint32_t* d_buckets = nullptr;
+  uint32_t* d_partials = nullptr;
+  uint32_t* d_err = nullptr;
+  uint8_t* d_stage = nullptr;  // staging for host byte inputs of set_bases / test hooks
+  size_t cap_stage = 0;
+
+  Slot slot[2];
+  // description of the last launched run (for the stage read-back hooks and timings)
+  size_t last_n = 0;
+  int last_w_count = 0;
+  bool timings_valid = false;
+  float stage_ms[8] = {};
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                         \
+  do {                                             \
+    hipError_t e_ = (expr);                        \
+    if (e_ != hipSuccess) {                        \
+      if (ctx) (ctx)->last_hip_error = (int)e_;    \
+      return e_ == hipErrorOutOfMemory ? MSM_HIP_ERR_OUT_OF_MEMORY : MSM_HIP_ERR_HIP; \
+    }                                              \
+  } while (0)
+
+template <typename T>
+int dev_alloc(msm_hip_ctx* ctx, T*& p, size_t count) {
+  if (p) {
+    (void)hipFree(p);
+    p = nullptr;
+  }
+  HIP_TRY(ctx, hipMalloc((void**)&p, count * sizeof(T)));
+  return MSM_HIP_OK;
+}
+
+int ensure_stage(msm_hip_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->cap_stage) return MSM_HIP_OK;
+  int rc = dev_alloc(ctx, ctx->d_stage, bytes);
+  if (rc) {
+    ctx->cap_stage = 0;
+    return rc;
+  }
+  ctx->cap_stage = bytes;
+  return MSM_HIP_OK;
+}
+
+int ensure_work(msm_hip_ctx* ctx, size_t n) {
+  if (n <= ctx->cap_n) return MSM_HIP_OK;
+  ctx->cap_n = 0;
+  int rc;
+  if ((rc = dev_alloc(ctx, ctx->d_scalars, n * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_digits, n * NWIN))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_val, n * NWIN))) return rc;
+  ctx->cap_n = n;
+  return MSM_HIP_OK;
+}
+
+inline unsigned blocks_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+int err_from_bits(uint32_t bits) {
+  if (bits & ERRBIT_NOT_ON_CURVE) return MSM_HIP_ERR_NOT_ON_CURVE;
+  if (bits & (ERRBIT_NONCANONICAL | ERRBIT_SCALAR_CARRY)) return MSM_HIP_ERR_NONCANONICAL;
+  return MSM_HIP_OK;
+}
+
+// Enqueue stages 1-4 for windows [w_begin, w_begin + w_count) on the context stream; window sums (canonical Jacobian
+// bytes) and the error word land in `s.d_wsums`.
+int enqueue_pipeline(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count, Slot& s) {
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_hist, 0, (size_t)w_count * HALF * sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(s.d_wsums + WSUM_BYTES, 0, 4, st));
+  uint32_t* d_err = reinterpret_cast<uint32_t*>(s.d_wsums + WSUM_BYTES);
+
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+  hipLaunchKernelGGL(k_decompose, dim3(blocks_for(n, 256)), dim3(256), 0, st, d_scalars, n, w_begin, w_count, ctx->d_digits,
+                     ctx->d_hist, d_err);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+  hipLaunchKernelGGL(k_scan, dim3(w_count), dim3(1024), 0, st, ctx->d_hist, ctx->d_col_ptr, ctx->d_cursor);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+  hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n, 256), w_count), dim3(256), 0, st, ctx->d_digits, n, ctx->d_cursor, ctx->d_val);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
+  hipLaunchKernelGGL(k_smvp_bucket, dim3(HALF / 256, w_count), dim3(256), 0, st, ctx->d_bases, ctx->d_col_ptr, ctx->d_val, n,
+                     ctx->d_buckets);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[4], st));
+  hipLaunchKernelGGL(k_bpr_runs, dim3(BPR_BLOCKS, w_count), dim3(BPR_BLOCK), 0, st, ctx->d_buckets, ctx->d_partials);
+  hipLaunchKernelGGL(k_bpr_final, dim3(1), dim3(64), 0, st, ctx->d_partials, w_count, reinterpret_cast<uint32_t*>(s.d_wsums));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[5], st));
+  HIP_TRY(ctx, hipGetLastError());
+
+  s.w_begin = w_begin;
+  s.w_count = w_count;
+  s.n = n;
+  ctx->last_n = n;
+  ctx->last_w_count = w_count;
+  ctx->timings_valid = true;
+  return MSM_HIP_OK;
+}
+
+int collect_timings(msm_hip_ctx* ctx) {
+  if (!ctx->timings_valid) return MSM_HIP_OK;
+  for (int i = 0; i < 5; i++) HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+  HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[5], ctx->ev[0], ctx->ev[5]));
+  return MSM_HIP_OK;
+}
+
+int check_run_args(msm_hip_ctx* ctx, const void* scalars, size_t n) {
+  if (!ctx || (!scalars && n)) return MSM_HIP_ERR_INVALID_ARG;
+  if (ctx->n_bases == 0 && n) return MSM_HIP_ERR_NO_BASES;
+  if (n > ctx->n_bases) return MSM_HIP_ERR_INVALID_ARG;
+  return MSM_HIP_OK;
+}
+
+int set_bases_from_device(msm_hip_ctx* ctx, const uint32_t* d_xy, size_t n, uint32_t flags) {
+  if (n > ctx->cap_bases) {
+    ctx->n_bases = ctx->cap_bases = 0;
+    int rc = dev_alloc(ctx, ctx->d_bases, n * 16);
+    if (rc) return rc;
+    ctx->cap_bases = n;
+  }
+  ctx->n_bases = 0;
+  if (n == 0) return MSM_HIP_OK;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(k_convert_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_xy, ctx->d_bases, n, flags, ctx->d_err);
+  HIP_TRY(ctx, hipGetLastError());
+  uint32_t bits = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&bits, ctx->d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  int rc = err_from_bits(bits);
+  if (rc) return rc;
+  ctx->n_bases = n;
+  return MSM_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msm_hip_abi_version(void) { return 1; }
+
+const char* msm_hip_strerror(int code) {
+  switch (code) {
+    case MSM_HIP_OK: return "ok";
+    case MSM_HIP_ERR_NO_DEVICE: return "no usable HIP device";
+    case MSM_HIP_ERR_INVALID_ARG: return "invalid argument";
+    case MSM_HIP_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case MSM_HIP_ERR_NONCANONICAL: return "non-canonical field element in input";
+    case MSM_HIP_ERR_NOT_ON_CURVE: return "base point not on the curve";
+    case MSM_HIP_ERR_NO_BASES: return "bases not set";
+    case MSM_HIP_ERR_HIP: return "HIP runtime error";
+    default: return "unknown error";
+  }
+}
+
+int msm_hip_last_hip_error(msm_hip_ctx* ctx) { return ctx ? ctx->last_hip_error : 0; }
+void* msm_hip_stream(msm_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
+  if (!out) return MSM_HIP_ERR_INVALID_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MSM_HIP_ERR_NO_DEVICE;
+  if (device_id < 0 || device_id >= count) return MSM_HIP_ERR_INVALID_ARG;
+  if (hipSetDevice(device_id) != hipSuccess) return MSM_HIP_ERR_NO_DEVICE;
+  msm_hip_ctx* ctx = new (std::nothrow) msm_hip_ctx();
+  if (!ctx) return MSM_HIP_ERR_OUT_OF_MEMORY;
+  ctx->device = device_id;
+  int rc = MSM_HIP_OK;
+  auto fail = [&](int code) {
+    msm_hip_ctx_destroy(ctx);
+    return code;
+  };
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(MSM_HIP_ERR_NO_DEVICE);
+  for (int i = 0; i < N_EVENTS; i++)
+    if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
+  if ((rc = dev_alloc(ctx, ctx->d_hist, (size_t)NWIN * HALF))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_col_ptr, (size_t)NWIN * (HALF + 1)))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_cursor, (size_t)NWIN * HALF))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_buckets, (size_t)NWIN * HALF * 24))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_partials, (size_t)NWIN * BPR_BLOCKS * XYZZ_WORDS))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_err, 1))) return fail(rc);
+  for (int s = 0; s < 2; s++) {
+    if (hipHostMalloc((void**)&ctx->slot[s].h_wsums, WSUM_BYTES + 4, hipHostMallocDefault) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
+    if ((rc = dev_alloc(ctx, ctx->slot[s].d_wsums, WSUM_BYTES + 4))) return fail(rc);
+    if (hipEventCreateWithFlags(&ctx->slot[s].done, hipEventDisableTiming) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
+  }
+  *out = ctx;
+  return MSM_HIP_OK;
+}
+
+void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  void* bufs[] = {ctx->d_bases, ctx->d_scalars, ctx->d_digits, ctx->d_hist, ctx->d_col_ptr, ctx->d_cursor,
+                  ctx->d_val,   ctx->d_buckets, ctx->d_partials, ctx->d_err, ctx->d_stage};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  for (int s = 0; s < 2; s++) {
+    if (ctx->slot[s].h_wsums) (void)hipHostFree(ctx->slot[s].h_wsums);
+    if (ctx->slot[s].d_wsums) (void)hipFree(ctx->slot[s].d_wsums);
+    if (ctx->slot[s].done) (void)hipEventDestroy(ctx->slot[s].done);
+  }
+  for (int i = 0; i < N_EVENTS; i++)
+    if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t n, uint32_t flags) {
+  if (!ctx || (!xy_dev && n)) return MSM_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return set_bases_from_device(ctx, static_cast<const uint32_t*>(xy_dev), n, flags);
+}
+
+int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, uint32_t flags) {
+  if (!ctx || (!xy_host && n)) return MSM_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_stage(ctx, n * 64 + 16);
+  if (rc) return rc;
+  if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage, xy_host, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  return set_bases_from_device(ctx, reinterpret_cast<const uint32_t*>(ctx->d_stage), n, flags);
+}
+
+int msm_hip_launch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot) {
+  int rc = check_run_args(ctx, scalars_dev, n);
+  if (rc) return rc;
+  if (slot < 0 || slot > 1) return MSM_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Slot& s = ctx->slot[slot];
+  s.pending = true;
+  s.n = n;
+  s.w_begin = 0;
+  s.w_count = NWIN;
+  if (n == 0) return MSM_HIP_OK;
+  if ((rc = ensure_work(ctx, n))) return rc;
+  if ((rc = enqueue_pipeline(ctx, static_cast<const uint32_t*>(scalars_dev), n, 0, NWIN, s))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, s.d_wsums, WSUM_BYTES + 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(s.done, ctx->stream));
+  return MSM_HIP_OK;
+}
+
+int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]) {
+  if (!ctx || !out_xyz || slot < 0 || slot > 1) return MSM_HIP_ERR_INVALID_ARG;
+  Slot& s = ctx->slot[slot];
+  if (!s.pending) return MSM_HIP_ERR_INVALID_ARG;
+  s.pending = false;
+  if (s.n == 0) {
+    memset(out_xyz, 0, 96);
+    return MSM_HIP_OK;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventSynchronize(s.done));
+  uint32_t bits;
+  memcpy(&bits, s.h_wsums + WSUM_BYTES, 4);
+  int rc = err_from_bits(bits);
+  if (rc) return rc;
+  auto t0 = std::chrono::steady_clock::now();
+  if (!bn254::host::combine_windows(s.h_wsums, NWIN, WBITS, out_xyz)) return MSM_HIP_ERR_HIP;
+  ctx->stage_ms[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return MSM_HIP_OK;
+}
+
+int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]) {
+  if (!out_xyz) return MSM_HIP_ERR_INVALID_ARG;
+  int rc = msm_hip_launch_device_bn254(ctx, scalars_dev, n, 0);
+  if (rc) return rc;
+  rc = msm_hip_finish_bn254(ctx, 0, out_xyz);
+  if (rc) return rc;
+  return n ? collect_timings(ctx) : MSM_HIP_OK;
+}
+
+int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
+  int rc = check_run_args(ctx, scalars_host, n);
+  if (rc) return rc;
+  if (!out_xyz) return MSM_HIP_ERR_INVALID_ARG;
+  if (n == 0) {
+    memset(out_xyz, 0, 96);
+    return MSM_HIP_OK;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if ((rc = ensure_work(ctx, n))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scalars, scalars_host, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  return msm_hip_run_device_bn254(ctx, ctx->d_scalars, n, out_xyz);
+}
+
+int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end,
+                                     void* window_sums_dev) {
+  int rc = check_run_args(ctx, scalars_dev, n);
+  if (rc) return rc;
+  if (!window_sums_dev || w_begin < 0 || w_end > NWIN || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int w_count = w_end - w_begin;
+  Slot& s = ctx->slot[0];
+  if (n == 0) {
+    HIP_TRY(ctx, hipMemsetAsync(window_sums_dev, 0, (size_t)w_count * 96, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSM_HIP_OK;
+  }
+  if ((rc = ensure_work(ctx, n))) return rc;
+  if ((rc = enqueue_pipeline(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, s))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(window_sums_dev, s.d_wsums, (size_t)w_count * 96, hipMemcpyDeviceToDevice, ctx->stream));
+  uint32_t bits = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&bits, s.d_wsums + WSUM_BYTES, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if ((rc = err_from_bits(bits))) return rc;
+  return collect_timings(ctx);
+}
+
+int msm_hip_combine_windows_bn254(const uint8_t* window_sums_host, int num_windows, uint8_t out_xyz[96]) {
+  if (!window_sums_host || !out_xyz || num_windows < 1 || num_windows > NWIN) return MSM_HIP_ERR_INVALID_ARG;
+  if (!bn254::host::combine_windows(window_sums_host, num_windows, WBITS, out_xyz)) return MSM_HIP_ERR_NONCANONICAL;
+  return MSM_HIP_OK;
+}
+
+int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
+  msm_hip_ctx* ctx = nullptr;
+  int rc = msm_hip_ctx_create(&ctx, 0);
+  if (rc) return rc;
+  rc = msm_hip_set_bases_bn254(ctx, xy_host, n, 0);
+  if (!rc) rc = msm_hip_run_bn254(ctx, scalars_host, n, out_xyz);
+  msm_hip_ctx_destroy(ctx);
+  return rc;
+}
+
+int msm_hip_sample_scalars_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void* scalars_dev) {
+  if (!ctx || (!scalars_dev && n)) return MSM_HIP_ERR_INVALID_ARG;
+  if (n == 0) return MSM_HIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_sample_scalars, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, seed, n, static_cast<uint32_t*>(scalars_dev));
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSM_HIP_OK;
+}
+
+int msm_hip_sample_points_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void* xy_dev) {
+  if (!ctx || (!xy_dev && n)) return MSM_HIP_ERR_INVALID_ARG;
+  if (n == 0) return MSM_HIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_sample_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, seed, n, static_cast<uint32_t*>(xy_dev));
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSM_HIP_OK;
+}
+
+int msm_hip_last_stage_ms(msm_hip_ctx* ctx, float* ms, int cap) {
+  if (!ctx || !ms) return MSM_HIP_ERR_INVALID_ARG;
+  int k = cap < 7 ? cap : 7;
+  for (int i = 0; i < k; i++) ms[i] = ctx->stage_ms[i];
+  return k;
+}
+
+// ---- stage read-back ------------------------------------------------------------------------------------------------
+static int read_back(msm_hip_ctx* ctx, void* out, const void* src, size_t bytes, size_t cap_bytes) {
+  if (!ctx || !out) return MSM_HIP_ERR_INVALID_ARG;
+  if (bytes > cap_bytes) return MSM_HIP_ERR_INVALID_ARG;
+  if (bytes == 0) return MSM_HIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSM_HIP_OK;
+}
+
+int msm_hip_read_digits(msm_hip_ctx* ctx, uint16_t* out, size_t cap_elems) {
+  if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  return read_back(ctx, out, ctx->d_digits, ctx->last_n * ctx->last_w_count * 2, cap_elems * 2);
+}
+int msm_hip_read_col_ptr(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
+  if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  return read_back(ctx, out, ctx->d_col_ptr, (size_t)ctx->last_w_count * (HALF + 1) * 4, cap_elems * 4);
+}
+int msm_hip_read_val_idxs(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
+  if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  // windows are laid out with stride n; only the first col_ptr[w][32768] entries of each window are meaningful
+  return read_back(ctx, out, ctx->d_val, ctx->last_n * ctx->last_w_count * 4, cap_elems * 4);
+}
+
+// buckets are kept in device Montgomery form; convert through the test hook path on the way out
+namespace {
+__global__ void __launch_bounds__(256) k_export_buckets(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, size_t count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const fq X = ld_fq(buckets + i * 24), Y = ld_fq(buckets + i * 24 + 8), Z = ld_fq(buckets + i * 24 + 16);
+  st_fq(out + i * 24, fq_from_mont(X));
+  st_fq(out + i * 24 + 8, fq_from_mont(Y));
+  st_fq(out + i * 24 + 16, fq_from_mont(Z));
+}
+}  // namespace
+
+int msm_hip_read_buckets(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
+  if (!ctx || !out) return MSM_HIP_ERR_INVALID_ARG;
+  const size_t count = (size_t)ctx->last_w_count * HALF;
+  if (count * 96 > cap_bytes) return MSM_HIP_ERR_INVALID_ARG;
+  if (count == 0) return MSM_HIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_stage(ctx, count * 96);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_export_buckets, dim3(blocks_for(count, 256)), dim3(256), 0, ctx->stream, ctx->d_buckets,
+                     reinterpret_cast<uint32_t*>(ctx->d_stage), count);
+  HIP_TRY(ctx, hipGetLastError());
+  return read_back(ctx, out, ctx->d_stage, count * 96, cap_bytes);
+}
+
+int msm_hip_read_window_sums(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
+  if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  return read_back(ctx, out, ctx->slot[0].d_wsums, (size_t)ctx->last_w_count * 96, cap_bytes);
+}
+
+// ---- op hooks -------------------------------------------------------------------------------------------------------
+static int run_hook(msm_hip_ctx* ctx, const uint8_t* a, size_t a_bytes, const uint8_t* b, size_t b_bytes, uint8_t* out,
+                    size_t out_bytes, uint8_t*& da, uint8_t*& db, uint8_t*& dout) {
+  if (!ctx || !a || !out) return MSM_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  int rc = ensure_stage(ctx, up16(a_bytes) + up16(b_bytes) + up16(out_bytes) + 16);
+  if (rc) return rc;
+  da = ctx->d_stage;
+  db = da + up16(a_bytes);
+  dout = db + up16(b_bytes);
+  HIP_TRY(ctx, hipMemcpyAsync(da, a, a_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (b && b_bytes) HIP_TRY(ctx, hipMemcpyAsync(db, b, b_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (!b) db = nullptr;
+  return MSM_HIP_OK;
+}
+
+int msm_hip_test_fq_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+  if (n == 0) return MSM_HIP_OK;
+  if (op < 0 || op > 4) return MSM_HIP_ERR_INVALID_ARG;
+  uint8_t *da, *db, *dout;
+  int rc = run_hook(ctx, a, n * 32, b, b ? n * 32 : 0, out, n * 32, da, db, dout);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_test_fq, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, op, (const uint32_t*)da, (const uint32_t*)db,
+                     (uint32_t*)dout, n);
+  HIP_TRY(ctx, hipGetLastError());
+  return read_back(ctx, out, dout, n * 32, n * 32);
+}
+
+int msm_hip_test_g1_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+  if (n == 0) return MSM_HIP_OK;
+  if (op < 0 || op > 2 || (op != 1 && !b)) return MSM_HIP_ERR_INVALID_ARG;
+  const size_t b_bytes = op == 0 ? n * 96 : (op == 2 ? n * 64 : 0);
+  uint8_t *da, *db, *dout;
+  int rc = run_hook(ctx, a, n * 96, op == 1 ? nullptr : b, b_bytes, out, n * 96, da, db, dout);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_test_g1, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, op, (const uint32_t*)da, (const uint32_t*)db,
+                     (uint32_t*)dout, n);
+  HIP_TRY(ctx, hipGetLastError());
+  return read_back(ctx, out, dout, n * 96, n * 96);
+}
+
+int msm_hip_test_g1_mul_u32(msm_hip_ctx* ctx, const uint8_t* a, const uint32_t* k, uint8_t* out, size_t n) {
+  if (n == 0) return MSM_HIP_OK;
+  if (!k) return MSM_HIP_ERR_INVALID_ARG;
+  uint8_t *da, *db, *dout;
+  int rc = run_hook(ctx, a, n * 96, reinterpret_cast<const uint8_t*>(k), n * 4, out, n * 96, da, db, dout);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_test_g1_mul_u32, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)da,
+                     (const uint32_t*)db, (uint32_t*)dout, n);
+  HIP_TRY(ctx, hipGetLastError());
+  return read_back(ctx, out, dout, n * 96, n * 96);
+}
+
+}  // extern "C"

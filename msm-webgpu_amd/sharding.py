@@ -1,0 +1,54 @@
+"""Window sharding across the GPUs of one node (new relative to the reference, which is single-device).
+
+Pippenger windows are independent: rank r computes the window sums S_w for its contiguous
+window range on its own GPU (all bases resident on every GPU, every rank recodes all scalars because the signed-digit
+carry chain runs across windows), then ONE collective -- an all-gather of world_size x W_local x 96 B over RCCL/xGMI --
+brings all 16 window sums to every rank, and the host window combine (src/cuzk/msm.rs:411-416) finishes.  Elliptic-curve
+addition is not an RCCL reduction operator, hence gather + local combine rather than all-reduce.
+"""
+import torch
+import torch.distributed as dist
+
+from .api import NUM_WINDOWS, MsmContext
+
+
+def window_range(rank, world_size, num_windows=NUM_WINDOWS):
+    """Contiguous, balanced partition of [0, num_windows): the first (num_windows % world) ranks get one extra."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, extra = divmod(num_windows, world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def max_windows_per_rank(world_size, num_windows=NUM_WINDOWS):
+    return -(-num_windows // world_size)
+
+
+def gather_window_sums(local_sums, rank, world_size, group=None, num_windows=NUM_WINDOWS):
+    """local_sums: uint8 [W_local, 96] (device tensor under nccl, CPU tensor under gloo).
+    Returns uint8 [num_windows, 96] with every window sum in window order, on every rank."""
+    per = max_windows_per_rank(world_size, num_windows)
+    padded = torch.zeros((per, 96), dtype=torch.uint8, device=local_sums.device)
+    padded[: local_sums.shape[0]] = local_sums
+    if world_size == 1:
+        gathered = padded.unsqueeze(0)
+    else:
+        gathered = torch.empty((world_size, per, 96), dtype=torch.uint8, device=local_sums.device)
+        dist.all_gather_into_tensor(gathered.view(-1), padded.view(-1), group=group)
+    rows = []
+    for r in range(world_size):
+        b, e = window_range(r, world_size, num_windows)
+        rows.append(gathered[r, : e - b])
+    return torch.cat(rows, dim=0)
+
+
+def sharded_msm(ctx, scalars_dev, rank, world_size, group=None):
+    """One MSM with windows sharded over the ranks of `group`; every rank returns the full G1 result."""
+    b, e = window_range(rank, world_size)
+    if e > b:
+        local = ctx.msm_windows(scalars_dev, b, e)
+    else:
+        local = torch.empty((0, 96), dtype=torch.uint8, device=scalars_dev.device)
+    all_sums = gather_window_sums(local, rank, world_size, group)
+    return MsmContext.combine_windows(all_sums)

@@ -1,0 +1,76 @@
+// Host build (g++ -DFQ_CHECK) of the device arithmetic headers, for CPU-side unit tests of the exact code
+// the HIP kernels inline.  Test-only: not part of libmsm_hip.so.
+#include <cstring>
+
+#include "g1.h"
+
+using namespace bn254;
+
+static fq load_fq(const uint8_t* b) {  // canonical LE bytes -> Montgomery fq
+  uint32_t w[8];
+  memcpy(w, b, 32);
+  return fq_to_mont(fq_unpack(w));
+}
+static void store_fq(uint8_t* b, const fq& x) {  // normal Montgomery fq (value <= 84p) -> canonical LE bytes
+  uint32_t w[8];
+  fq_pack(w, fq_from_mont(x));
+  memcpy(b, w, 32);
+}
+static g1_xyzz load_jac(const uint8_t* b) { return g1_from_jacobian(load_fq(b), load_fq(b + 32), load_fq(b + 64)); }
+static void store_jac(uint8_t* b, const g1_xyzz& p) {
+  fq X, Y, Z;
+  g1_to_jacobian(p, X, Y, Z);
+  store_fq(b, X);
+  store_fq(b + 32, Y);
+  store_fq(b + 64, Z);
+}
+
+extern "C" {
+// op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg
+void h_fq_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    fq x = load_fq(a + 32 * i), y = b ? load_fq(b + 32 * i) : fq_zero(), z;
+    switch (op) {
+      case 0: z = fq_add(x, y); break;
+      case 1: z = fq_sub<2>(x, y); break;
+      case 2: z = fq_mul(x, y); break;
+      case 3: z = fq_sqr(x); break;
+      default: z = fq_neg_canonical(x); break;
+    }
+    store_fq(out + 32 * i, z);
+  }
+}
+// pack/unpack round trip of raw 256-bit values
+void h_fq_roundtrip(const uint8_t* a, uint8_t* out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    uint32_t w[8], w2[8];
+    memcpy(w, a + 32 * i, 32);
+    fq_pack(w2, fq_unpack(w));
+    memcpy(out + 32 * i, w2, 32);
+  }
+}
+// acc (96 B Jacobian canonical) += chain of `m` affine points (64 B each); exercises the lazy bounds over long chains
+void h_g1_madd_chain(const uint8_t* acc, const uint8_t* pts, size_t m, uint8_t* out) {
+  g1_xyzz a = load_jac(acc);
+  for (size_t i = 0; i < m; i++) g1_madd(a, load_fq(pts + 64 * i), load_fq(pts + 64 * i + 32));
+  store_jac(out, a);
+}
+// op: 0 add, 1 double(a)
+void h_g1_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    g1_xyzz p = load_jac(a + 96 * i);
+    g1_xyzz r = op == 0 ? g1_add(p, load_jac(b + 96 * i)) : g1_double(p);
+    store_jac(out + 96 * i, r);
+  }
+}
+void h_g1_mul_u32(const uint8_t* a, uint32_t k, uint8_t* out) { store_jac(out, g1_mul_u32(load_jac(a), k)); }
+// running-sum chain: feeds outputs of g1_add back into g1_add many times (bound stability)
+void h_g1_running_sum(const uint8_t* pts96, size_t n, uint8_t* out) {
+  g1_xyzz m = g1_identity(), g = g1_identity();
+  for (size_t i = 0; i < n; i++) {
+    m = g1_add(m, load_jac(pts96 + 96 * i));
+    g = g1_add(g, m);
+  }
+  store_jac(out, g);
+}
+}

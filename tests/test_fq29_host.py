@@ -1,0 +1,99 @@
+"""CPU build (g++ -DFQ_CHECK) of the exact arithmetic headers the HIP kernels inline -- fq29.h (9 x 29-bit lazy limbs)
+and g1.h (XYZZ formulas) -- checked against the oracle, with every limb/value bound asserted.  Host logic only."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+from oracle import bn254_ref as ref
+from oracle import cpu
+from tests.util import P, b32, jacobian_bytes, rng
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def H(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("fq29") / "fq29_harness.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFQ_CHECK", "-fPIC", "-shared", "-I", os.path.join(ROOT, "msm-webgpu_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host_harness", "fq29_harness.cpp"), "-o", so])
+    return C.CDLL(so)
+
+
+def test_field_ops(H):
+    r = rng(1)
+    edge = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, 1 << 253, (1 << 253) - 1, 1 << 232, (1 << 232) - 1, (1 << 29) - 1, 1 << 29,
+            0x1FFFFFFF << 29]
+    vals = edge + [r.randrange(P) for _ in range(3000)]
+    n = len(vals)
+    A = b"".join(b32(x) for x in vals)
+    B = b"".join(b32(vals[(i * 7 + 3) % n]) for i in range(n))
+    for op, name in enumerate(["add", "sub", "mul", "sqr", "neg"]):
+        out = C.create_string_buffer(32 * n)
+        H.h_fq_op(op, A, B, out, n)
+        assert out.raw == cpu.fq_op(name, A, B), name
+
+
+def test_pack_unpack_roundtrip(H):
+    r = rng(2)
+    raw = b"".join(r.randrange(1 << 256).to_bytes(32, "little") for _ in range(200)) + b"\xff" * 32 + bytes(32)
+    out = C.create_string_buffer(len(raw))
+    H.h_fq_roundtrip(raw, out, len(raw) // 32)
+    assert out.raw == raw
+
+
+def test_mixed_add_chain_and_special_cases(H):
+    r = rng(3)
+    pts = ref.sample_points(5, 40)
+    out = C.create_string_buffer(96)
+    chain = [pts[0], pts[0], pts[1], ref.neg(pts[1]), pts[2], pts[2], pts[2], pts[3]] + pts[4:30]
+    want = None
+    for q in chain:
+        want = ref.add(want, q)
+    H.h_g1_madd_chain(bytes(96), ref.points_to_bytes(chain), len(chain), out)
+    assert cpu.to_affine64(out.raw) == ref.affine_to_bytes64(want)
+    H.h_g1_madd_chain(jacobian_bytes(ref.neg(pts[7]), r), ref.points_to_bytes([pts[7]]), 1, out)
+    assert cpu.to_affine64(out.raw) == bytes(64)
+    H.h_g1_madd_chain(jacobian_bytes(ref.neg(pts[7]), r), ref.points_to_bytes([pts[7], pts[8]]), 2, out)
+    assert cpu.to_affine64(out.raw) == ref.affine_to_bytes64(pts[8])
+    H.h_g1_madd_chain(jacobian_bytes(pts[9], r), ref.points_to_bytes([pts[9]]), 1, out)
+    assert cpu.to_affine64(out.raw) == ref.affine_to_bytes64(ref.add(pts[9], pts[9]))
+
+
+def test_long_accumulation_keeps_bounds(H):
+    lp = cpu.sample_points(77, 5000)
+    out = C.create_string_buffer(96)
+    H.h_g1_madd_chain(bytes(96), lp, 5000, out)
+    assert cpu.to_affine64(out.raw) == cpu.to_affine64(cpu.cpu_msm(lp, b32(1) * 5000))
+
+
+def test_full_add_double_scalar(H):
+    r = rng(4)
+    pts = ref.sample_points(6, 24)
+    a = pts[:10] + [None, pts[3], pts[4], pts[5], None]
+    b = pts[10:20] + [pts[2], None, pts[4], ref.neg(pts[5]), None]
+    A = b"".join(jacobian_bytes(x, r) for x in a)
+    B = b"".join(jacobian_bytes(x, r) for x in b)
+    o = C.create_string_buffer(96 * len(a))
+    H.h_g1_op(0, A, B, o, len(a))
+    for i in range(len(a)):
+        assert cpu.to_affine64(o.raw[96 * i:96 * i + 96]) == ref.affine_to_bytes64(ref.add(a[i], b[i])), i
+    H.h_g1_op(1, A, None, o, len(a))
+    for i in range(len(a)):
+        assert cpu.to_affine64(o.raw[96 * i:96 * i + 96]) == ref.affine_to_bytes64(ref.add(a[i], a[i])), i
+    out = C.create_string_buffer(96)
+    for k in [0, 1, 2, 3, 255, 256, 32767, 0xFFFFFFFF, 123456789]:
+        H.h_g1_mul_u32(jacobian_bytes(pts[11], r), k, out)
+        assert cpu.to_affine64(out.raw) == ref.affine_to_bytes64(ref.mul(k, pts[11])), k
+
+
+def test_running_sum_feedback(H):
+    r = rng(5)
+    bk = ref.sample_points(8, 40)
+    out = C.create_string_buffer(96)
+    H.h_g1_running_sum(b"".join(jacobian_bytes(x, r) for x in bk), len(bk), out)
+    want = None
+    for i, q in enumerate(bk):
+        want = ref.add(want, ref.mul(len(bk) - i, q))
+    assert cpu.to_affine64(out.raw) == ref.affine_to_bytes64(want)

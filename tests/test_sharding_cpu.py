@@ -1,0 +1,74 @@
+"""The multi-GPU path on CPU: window partition + one all-gather (gloo, world_size 2) + host combine.
+Per-rank window sums come from the oracle's stage models here (no GPU); the collective and the combine are the
+product's (msm-webgpu_amd/sharding.py, msm_hip_combine_windows_bn254)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import cpu
+
+
+def test_window_range_partitions():
+    from msm_webgpu_amd.sharding import max_windows_per_rank, window_range
+
+    for world in (1, 2, 3, 4, 5, 8, 16):
+        ranges = [window_range(r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == 16
+        assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+        assert max(e - b for b, e in ranges) == max_windows_per_rank(world)
+        assert max(e - b for b, e in ranges) - min(e - b for b, e in ranges) <= 1
+    with pytest.raises(ValueError):
+        window_range(2, 2)
+
+
+def _window_sums(points, scalars, b, e):
+    digits = cpu.decompose_scalars_signed(scalars)
+    out = []
+    for w in range(b, e):
+        cp, vi = cpu.transpose(digits[w], 1 << 16)
+        out.append(cpu.bucket_reduction("running_sum", cpu.smvp_signed(cp, vi, points, 1 << 16)))
+    return b"".join(out)
+
+
+def _worker(rank, world, port, n, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import msm_webgpu_amd as m
+    from msm_webgpu_amd.sharding import gather_window_sums, window_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    points, scalars = cpu.sample_points(91, n), cpu.sample_scalars(92, n)
+    b, e = window_range(rank, world)
+    local = torch.from_numpy(np.frombuffer(_window_sums(points, scalars, b, e), dtype=np.uint8).copy()).view(e - b, 96)
+    all_sums = gather_window_sums(local, rank, world)
+    result = m.MsmContext.combine_windows(all_sums)
+    q.put((rank, result.to_affine_bytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gather_and_combine_gloo(built, world):
+    n = 600
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = cpu.to_affine64(cpu.cpu_msm(cpu.sample_points(91, n), cpu.sample_scalars(92, n)))
+    assert all(g[1] == want for g in got)
