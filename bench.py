@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: BN254 G1 MSM at 2^20 points, 16-bit signed-bucket windows (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--logn 20] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one whole MSM (decompose, sort, SMVP accumulate, bucket reduce on the GPU; window combine on the host) over
+synthetic inputs that are already resident in HBM when the timed region starts.  N = 1: one GPU does all 16 windows.
+N > 1: the 16 Pippenger windows are sharded over the ranks (one process per GPU), one RCCL all-gather of the window
+sums per MSM, host combine -- total work is fixed, so "scaling" is "strong".  Rank 0 prints ONE JSON line.
+
+roofline: the SMVP accumulate kernel.  achieved = ALGORITHMIC bytes per launch (N * W_local * 68 B read +
+W_local * 2^15 * 96 B written) / its average duration measured with HIP events on the engine's own stream over the
+timed steps; peak = 8000 GB/s (HBM3E).  traffic (PMC-measured HBM bytes per launch) is read from
+profiles/smvp_pmc_traffic.json when that file matches the workload, else null.
+cpu_baseline: the CPU oracle's restatement of halo2curves' serial msm (kind "port", not halo2curves itself) timed on
+this host on the same inputs, rank 0, N = 1 only; it is also the bit-exact check of the GPU result.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+NUM_WINDOWS = 16
+BUCKETS = 1 << 15
+
+
+def smvp_algorithmic_bytes(n, w_local):
+    return n * w_local * (64 + 4) + w_local * BUCKETS * 96
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--logn", type=int, default=20, help="log2 of the MSM size (20 = the config the metric is quoted on)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-logn", type=int, default=None, help="bounded CPU sample size (default: min(logn, 20))")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    import msm_webgpu_amd as m  # fails loudly if libmsm_hip.so is missing
+    from msm_webgpu_amd.sharding import gather_window_sums, window_range
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n = 1 << args.logn
+    ctx = m.MsmContext(local_rank)
+    # identical synthetic inputs on every rank (deterministic device sampler), resident in HBM
+    points = ctx.sample_points(n, 0x6D736D5F0000 + args.logn)
+    scalar_sets = [ctx.sample_scalars(n, 0x6D736D5F1000 + args.logn + 7 * i) for i in range(2)]
+    ctx.set_bases(points)
+    w_begin, w_end = window_range(rank, world)
+    w_local = w_end - w_begin
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    smvp_ms, stage_acc = [], {}
+
+    def note_stages():
+        st = ctx.stage_ms()
+        smvp_ms.append(st["smvp"])
+        for k, v in st.items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+
+    def run_steps(count, record):
+        """`count` MSMs; returns the last result.  N = 1 pipelines the host combine of MSM i with the device work of i+1."""
+        result = None
+        if world == 1:
+            ctx.launch(scalar_sets[0], 0)
+            for i in range(1, count):
+                ctx.launch(scalar_sets[i & 1], i & 1)
+                result = ctx.finish((i - 1) & 1)
+                if record:
+                    note_stages()
+            result = ctx.finish((count - 1) & 1)
+            if record:
+                note_stages()
+        else:
+            for i in range(count):
+                local = ctx.msm_windows(scalar_sets[i & 1], w_begin, w_end)
+                if record:
+                    note_stages()
+                sums = gather_window_sums(local, rank, world)
+                result = m.MsmContext.combine_windows(sums)
+        return result
+
+    run_steps(max(args.warmup, 1), False)
+    sync_all()
+    t0 = time.perf_counter()
+    last = run_steps(args.steps, True)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    smvp_avg_ms = sum(smvp_ms) / len(smvp_ms)
+    alg_bytes = smvp_algorithmic_bytes(n, w_local)
+    achieved = alg_bytes / (smvp_avg_ms * 1e-3) / 1e9
+
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "smvp_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("logn") == args.logn and pmc.get("w_local") == w_local:
+            traffic = pmc.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+
+    out = {
+        "metric": "BN254 MSM/s at 2^%d points" % args.logn,
+        "value": args.steps / elapsed,
+        "unit": "MSM/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": "2^%d BN254 G1 MSM, 16-bit signed-bucket windows, inputs resident in HBM" % args.logn,
+                   "windows_per_gpu": w_local, "parallelism": "windows/%d" % world if world > 1 else "single GPU",
+                   "host_combine": "pipelined" if world == 1 else "per step"},
+        "roofline": {"bound": "hbm", "kernel": "k_smvp_bucket", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
+                     "kernel_ms": smvp_avg_ms},
+        "stage_ms": {k: v / len(smvp_ms) for k, v in stage_acc.items()},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu as oracle_cpu  # the checker + the timed CPU baseline; never on the product path
+
+        logs = args.cpu_sample_logn if args.cpu_sample_logn is not None else min(args.logn, 20)
+        ns = 1 << logs
+        pb = points[:ns].cpu().numpy().tobytes()
+        last_set = scalar_sets[(args.steps - 1) & 1]
+        sb = last_set[:ns].cpu().numpy().tobytes()
+        t1 = time.perf_counter()
+        want = oracle_cpu.cpu_msm(pb, sb, 1)
+        cpu_s = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": (ns / n) / cpu_s, "unit": "MSM/s", "cores": 1, "kind": "port",
+                               "sample": "one 2^%d MSM on 1 thread (oracle/bn254.c restatement of halo2curves msm_serial; "
+                                         "scaled by 2^%d/2^%d)" % (logs, logs, args.logn),
+                               "seconds": cpu_s}
+        if ns == n:
+            out["verified_bit_exact_vs_cpu"] = bool(last.to_affine_bytes() == oracle_cpu.to_affine64(want))
+        threads = min(os.cpu_count() or 1, 64)
+        t1 = time.perf_counter()
+        want_mt = oracle_cpu.cpu_msm(pb, sb, threads)
+        cpu_mt = time.perf_counter() - t1
+        out["cpu_baseline_mt"] = {"value": (ns / n) / cpu_mt, "unit": "MSM/s", "cores": threads, "kind": "port", "seconds": cpu_mt,
+                                  "agrees": bool(oracle_cpu.to_affine64(want_mt) == oracle_cpu.to_affine64(want))}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,8 @@ struct Slot {
   uint8_t* h_wsums = nullptr;  // pinned: NWIN x 96 B window sums + 4 B error word
   uint8_t* d_wsums = nullptr;  // device:  NWIN x 96 B + 4 B error word
   hipEvent_t done = nullptr;
+  hipEvent_t ev[N_EVENTS] = {};  // stage boundaries of the run that used this slot
+  bool timed = false;
   int w_begin = 0, w_count = 0;
   size_t n = 0;
   bool pending = false;
@@ -37,7 +39,6 @@ struct Slot {
 struct msm_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[N_EVENTS] = {};
   int last_hip_error = 0;
 
   uint32_t* d_bases = nullptr;  // n_bases x 16 words
@@ -60,7 +61,6 @@ struct msm_hip_ctx {
   // description of the last launched run (for the stage read-back hooks and timings)
   size_t last_n = 0;
   int last_w_count = 0;
-  bool timings_valid = false;
   float stage_ms[8] = {};
 };
 
@@ -123,20 +123,20 @@ int enqueue_pipeline(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int 
   HIP_TRY(ctx, hipMemsetAsync(s.d_wsums + WSUM_BYTES, 0, 4, st));
   uint32_t* d_err = reinterpret_cast<uint32_t*>(s.d_wsums + WSUM_BYTES);
 
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+  HIP_TRY(ctx, hipEventRecord(s.ev[0], st));
   hipLaunchKernelGGL(k_decompose, dim3(blocks_for(n, 256)), dim3(256), 0, st, d_scalars, n, w_begin, w_count, ctx->d_digits,
                      ctx->d_hist, d_err);
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+  HIP_TRY(ctx, hipEventRecord(s.ev[1], st));
   hipLaunchKernelGGL(k_scan, dim3(w_count), dim3(1024), 0, st, ctx->d_hist, ctx->d_col_ptr, ctx->d_cursor);
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+  HIP_TRY(ctx, hipEventRecord(s.ev[2], st));
   hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n, 256), w_count), dim3(256), 0, st, ctx->d_digits, n, ctx->d_cursor, ctx->d_val);
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
+  HIP_TRY(ctx, hipEventRecord(s.ev[3], st));
   hipLaunchKernelGGL(k_smvp_bucket, dim3(HALF / 256, w_count), dim3(256), 0, st, ctx->d_bases, ctx->d_col_ptr, ctx->d_val, n,
                      ctx->d_buckets);
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[4], st));
+  HIP_TRY(ctx, hipEventRecord(s.ev[4], st));
   hipLaunchKernelGGL(k_bpr_runs, dim3(BPR_BLOCKS, w_count), dim3(BPR_BLOCK), 0, st, ctx->d_buckets, ctx->d_partials);
   hipLaunchKernelGGL(k_bpr_final, dim3(1), dim3(64), 0, st, ctx->d_partials, w_count, reinterpret_cast<uint32_t*>(s.d_wsums));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[5], st));
+  HIP_TRY(ctx, hipEventRecord(s.ev[5], st));
   HIP_TRY(ctx, hipGetLastError());
 
   s.w_begin = w_begin;
@@ -144,14 +144,16 @@ int enqueue_pipeline(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int 
   s.n = n;
   ctx->last_n = n;
   ctx->last_w_count = w_count;
-  ctx->timings_valid = true;
+  s.timed = true;
   return MSM_HIP_OK;
 }
 
-int collect_timings(msm_hip_ctx* ctx) {
-  if (!ctx->timings_valid) return MSM_HIP_OK;
-  for (int i = 0; i < 5; i++) HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[i], ctx->ev[i], ctx->ev[i + 1]));
-  HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[5], ctx->ev[0], ctx->ev[5]));
+// stage times of the run that used slot `s` (its events must have completed)
+int collect_timings(msm_hip_ctx* ctx, Slot& s) {
+  if (!s.timed) return MSM_HIP_OK;
+  s.timed = false;
+  for (int i = 0; i < 5; i++) HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[i], s.ev[i], s.ev[i + 1]));
+  HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[5], s.ev[0], s.ev[5]));
   return MSM_HIP_OK;
 }
 
@@ -222,8 +224,6 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
     return code;
   };
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(MSM_HIP_ERR_NO_DEVICE);
-  for (int i = 0; i < N_EVENTS; i++)
-    if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
   if ((rc = dev_alloc(ctx, ctx->d_hist, (size_t)NWIN * HALF))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_col_ptr, (size_t)NWIN * (HALF + 1)))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_cursor, (size_t)NWIN * HALF))) return fail(rc);
@@ -234,6 +234,8 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
     if (hipHostMalloc((void**)&ctx->slot[s].h_wsums, WSUM_BYTES + 4, hipHostMallocDefault) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
     if ((rc = dev_alloc(ctx, ctx->slot[s].d_wsums, WSUM_BYTES + 4))) return fail(rc);
     if (hipEventCreateWithFlags(&ctx->slot[s].done, hipEventDisableTiming) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
+    for (int i = 0; i < N_EVENTS; i++)
+      if (hipEventCreate(&ctx->slot[s].ev[i]) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
   }
   *out = ctx;
   return MSM_HIP_OK;
@@ -251,9 +253,9 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
     if (ctx->slot[s].h_wsums) (void)hipHostFree(ctx->slot[s].h_wsums);
     if (ctx->slot[s].d_wsums) (void)hipFree(ctx->slot[s].d_wsums);
     if (ctx->slot[s].done) (void)hipEventDestroy(ctx->slot[s].done);
+    for (int i = 0; i < N_EVENTS; i++)
+      if (ctx->slot[s].ev[i]) (void)hipEventDestroy(ctx->slot[s].ev[i]);
   }
-  for (int i = 0; i < N_EVENTS; i++)
-    if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -309,16 +311,14 @@ int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]) {
   auto t0 = std::chrono::steady_clock::now();
   if (!bn254::host::combine_windows(s.h_wsums, NWIN, WBITS, out_xyz)) return MSM_HIP_ERR_HIP;
   ctx->stage_ms[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  return MSM_HIP_OK;
+  return collect_timings(ctx, s);
 }
 
 int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]) {
   if (!out_xyz) return MSM_HIP_ERR_INVALID_ARG;
   int rc = msm_hip_launch_device_bn254(ctx, scalars_dev, n, 0);
   if (rc) return rc;
-  rc = msm_hip_finish_bn254(ctx, 0, out_xyz);
-  if (rc) return rc;
-  return n ? collect_timings(ctx) : MSM_HIP_OK;
+  return msm_hip_finish_bn254(ctx, 0, out_xyz);
 }
 
 int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
@@ -355,7 +355,7 @@ int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, 
   HIP_TRY(ctx, hipMemcpyAsync(&bits, s.d_wsums + WSUM_BYTES, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if ((rc = err_from_bits(bits))) return rc;
-  return collect_timings(ctx);
+  return collect_timings(ctx, s);
 }
 
 int msm_hip_combine_windows_bn254(const uint8_t* window_sums_host, int num_windows, uint8_t out_xyz[96]) {
