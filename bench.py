@@ -150,7 +150,7 @@ def main():
         "config": {"workload": "2^%d BN254 G1 MSM, 16-bit signed-bucket windows, inputs resident in HBM" % args.logn,
                    "windows_per_gpu": w_local, "parallelism": "windows/%d" % world if world > 1 else "single GPU",
                    "host_combine": "pipelined" if world == 1 else "per step"},
-        "roofline": {"bound": "hbm", "kernel": "k_smvp_bucket", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "k_smvp_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                      "kernel_ms": smvp_avg_ms},
         "stage_ms": {k: v / len(smvp_ms) for k, v in stage_acc.items()},

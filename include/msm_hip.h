@@ -86,9 +86,10 @@ int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, si
 int msm_hip_sample_scalars_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void* scalars_dev);
 int msm_hip_sample_points_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void* xy_dev);
 
-/* ---- measurement: per-stage device time of the last run, from HIP events on the context's own stream.
- *      ms[0] decompose+histogram, ms[1] scan, ms[2] scatter, ms[3] SMVP accumulate, ms[4] bucket reduce,
- *      ms[5] whole device pipeline, ms[6] host finalisation.  Returns the number of entries written. ---- */
+/* ---- measurement: per-stage device time of the last finished run, from HIP events on the context's own stream.
+ *      ms[0] recode + coarse histogram, ms[1] coarse scan, ms[2] coarse scatter, ms[3] fine sort,
+ *      ms[4] SMVP accumulate (k_smvp_chunks), ms[5] SMVP stitch, ms[6] bucket reduce,
+ *      ms[7] whole device pipeline, ms[8] host finalisation.  Returns the number of entries written. ---- */
 int msm_hip_last_stage_ms(msm_hip_ctx* ctx, float* ms, int cap);
 /* the context's stream as a hipStream_t (for callers that want to order their own work after a run) */
 void* msm_hip_stream(msm_hip_ctx* ctx);
@@ -103,6 +104,8 @@ void* msm_hip_stream(msm_hip_ctx* ctx);
  *      buckets   : [num_windows_run][32768] x 96 B Jacobian canonical LE, slot k as smvp.template.wgsl:94
  *      windows   : [num_windows_run] x 96 B Jacobian canonical LE
  * ---- */
+/* digit-code planes are only materialised for read-back when enabled here (the sort recomputes digits on the fly) */
+int msm_hip_set_debug(msm_hip_ctx* ctx, int keep_digit_planes);
 int msm_hip_read_digits(msm_hip_ctx* ctx, uint16_t* out, size_t cap_elems);
 int msm_hip_read_col_ptr(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems);
 int msm_hip_read_val_idxs(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems);

@@ -60,6 +60,7 @@ def lib():
         L.msm_hip_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i]
         L.msm_hip_stream.argtypes = [vp]
         L.msm_hip_stream.restype = vp
+        L.msm_hip_set_debug.argtypes = [vp, i]
         L.msm_hip_read_digits.argtypes = [vp, vp, sz]
         L.msm_hip_read_col_ptr.argtypes = [vp, vp, sz]
         L.msm_hip_read_val_idxs.argtypes = [vp, vp, sz]
@@ -247,12 +248,16 @@ class MsmContext:
 
     # -- measurement
     def stage_ms(self):
-        buf = (C.c_float * 8)()
-        k = lib().msm_hip_last_stage_ms(self._h, buf, 8)
-        names = ["decompose", "scan", "scatter", "smvp", "bucket_reduce", "device_total", "host_finalise"]
+        buf = (C.c_float * 10)()
+        k = lib().msm_hip_last_stage_ms(self._h, buf, 10)
+        names = ["recode_count", "coarse_scan", "coarse_scatter", "fine_sort", "smvp", "smvp_stitch", "bucket_reduce",
+                 "device_total", "host_finalise"]
         return {names[j]: float(buf[j]) for j in range(k)}
 
     # -- stage read-back (parity tests)
+    def set_debug(self, keep_digit_planes=True):
+        _check(lib().msm_hip_set_debug(self._h, 1 if keep_digit_planes else 0), "msm_hip_set_debug")
+
     def read_digits(self, n, w_count=NUM_WINDOWS):
         a = np.empty((w_count, n), dtype=np.uint16)
         _check(lib().msm_hip_read_digits(self._h, a.ctypes.data, a.size), "msm_hip_read_digits")

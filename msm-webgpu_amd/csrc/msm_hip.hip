@@ -20,7 +20,8 @@ using namespace msmk;
 
 namespace {
 
-constexpr int N_EVENTS = 6;
+constexpr int N_EVENTS = 8;  // boundaries of the 7 timed device stages
+constexpr uint32_t MAX_TILES = 1024;
 constexpr size_t WSUM_BYTES = (size_t)NWIN * 96;
 
 struct Slot {
@@ -44,14 +45,22 @@ struct msm_hip_ctx {
   uint32_t* d_bases = nullptr;  // n_bases x 16 words
   size_t n_bases = 0, cap_bases = 0;
 
-  size_t cap_n = 0;  // capacity of the per-run work buffers
+  size_t cap_n = 0;   // capacity of the per-run work buffers (entries per window)
+  size_t stride = 0;  // per-window stride of the entry arrays: cap_n rounded up to a multiple of 4
+  uint32_t cap_chunks = 0;
   uint32_t* d_scalars = nullptr;
-  uint16_t* d_digits = nullptr;
-  uint32_t* d_hist = nullptr;
-  uint32_t* d_col_ptr = nullptr;
-  uint32_t* d_cursor = nullptr;
-  uint32_t* d_val = nullptr;
-  uint32_t* d_buckets = nullptr;
+  uint16_t* d_digits = nullptr;  // digit-code planes, only written when debug read-back is enabled
+  bool debug = false;
+  uint32_t* d_counts = nullptr;      // [W][tiles][128]
+  uint32_t* d_coarse_ptr = nullptr;  // [W][129]
+  uint32_t* d_col_ptr = nullptr;     // [W][32769]
+  uint32_t* d_tmp_val = nullptr;     // [W][stride] coarse-bin order
+  uint8_t* d_tmp_fine = nullptr;     // [W][stride]
+  uint32_t* d_val = nullptr;         // [W][stride] slot order
+  uint32_t* d_buckets = nullptr;     // [W][32768] XYZZ records
+  uint32_t* d_heads = nullptr;       // [W][chunks] XYZZ records
+  uint32_t* d_tails = nullptr;       // [W][chunks] XYZZ records
+  uint32_t* d_tail_slot = nullptr;   // [W][chunks]
   uint32_t* d_partials = nullptr;
   uint32_t* d_err = nullptr;
   uint8_t* d_stage = nullptr;  // staging for host byte inputs of set_bases / test hooks
@@ -61,7 +70,8 @@ struct msm_hip_ctx {
   // description of the last launched run (for the stage read-back hooks and timings)
   size_t last_n = 0;
   int last_w_count = 0;
-  float stage_ms[8] = {};
+  bool last_has_digits = false;
+  float stage_ms[10] = {};
 };
 
 namespace {
@@ -96,14 +106,26 @@ int ensure_stage(msm_hip_ctx* ctx, size_t bytes) {
   return MSM_HIP_OK;
 }
 
+inline uint32_t chunks_for(size_t n) { return (uint32_t)((n + SMVP_CHUNK - 1) / SMVP_CHUNK); }
+
 int ensure_work(msm_hip_ctx* ctx, size_t n) {
-  if (n <= ctx->cap_n) return MSM_HIP_OK;
+  if (n <= ctx->cap_n && (!ctx->debug || ctx->d_digits)) return MSM_HIP_OK;
+  const size_t cap = n > ctx->cap_n ? n : ctx->cap_n;
   ctx->cap_n = 0;
+  const size_t stride = (cap + 3) & ~(size_t)3;
+  const uint32_t chunks = chunks_for(cap);
   int rc;
-  if ((rc = dev_alloc(ctx, ctx->d_scalars, n * 8))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_digits, n * NWIN))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_val, n * NWIN))) return rc;
-  ctx->cap_n = n;
+  if ((rc = dev_alloc(ctx, ctx->d_scalars, cap * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_tmp_val, stride * NWIN))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_tmp_fine, stride * NWIN))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_val, stride * NWIN))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_heads, (size_t)chunks * NWIN * REC_WORDS))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_tails, (size_t)chunks * NWIN * REC_WORDS))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_tail_slot, (size_t)chunks * NWIN))) return rc;
+  if (ctx->debug && (rc = dev_alloc(ctx, ctx->d_digits, cap * NWIN))) return rc;
+  ctx->cap_n = cap;
+  ctx->stride = stride;
+  ctx->cap_chunks = chunks;
   return MSM_HIP_OK;
 }
 
@@ -119,24 +141,40 @@ int err_from_bits(uint32_t bits) {
 // bytes) and the error word land in `s.d_wsums`.
 int enqueue_pipeline(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count, Slot& s) {
   hipStream_t st = ctx->stream;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_hist, 0, (size_t)w_count * HALF * sizeof(uint32_t), st));
+  // tiles of scalars for the two global sort passes: >= 2048 scalars each, at most MAX_TILES of them
+  uint32_t tile_len = 2048;
+  if ((n + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n + MAX_TILES - 1) / MAX_TILES) + 255) / 256 * 256);
+  const uint32_t tiles = (uint32_t)((n + tile_len - 1) / tile_len);
+  const uint32_t chunks = chunks_for(n);
+  const size_t stride = ctx->stride;
+  uint16_t* digits = ctx->debug ? ctx->d_digits : nullptr;
+  ctx->last_has_digits = digits != nullptr;
+
   HIP_TRY(ctx, hipMemsetAsync(s.d_wsums + WSUM_BYTES, 0, 4, st));
   uint32_t* d_err = reinterpret_cast<uint32_t*>(s.d_wsums + WSUM_BYTES);
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_buckets, 0, (size_t)w_count * HALF * REC_WORDS * 4, st));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_tail_slot, 0xFF, (size_t)w_count * chunks * 4, st));
 
   HIP_TRY(ctx, hipEventRecord(s.ev[0], st));
-  hipLaunchKernelGGL(k_decompose, dim3(blocks_for(n, 256)), dim3(256), 0, st, d_scalars, n, w_begin, w_count, ctx->d_digits,
-                     ctx->d_hist, d_err);
+  hipLaunchKernelGGL(k_count, dim3(tiles), dim3(256), 0, st, d_scalars, n, tile_len, tiles, w_begin, w_count, ctx->d_counts, digits, d_err);
   HIP_TRY(ctx, hipEventRecord(s.ev[1], st));
-  hipLaunchKernelGGL(k_scan, dim3(w_count), dim3(1024), 0, st, ctx->d_hist, ctx->d_col_ptr, ctx->d_cursor);
+  hipLaunchKernelGGL(k_scan_coarse, dim3(w_count), dim3(1024), 0, st, ctx->d_counts, tiles, ctx->d_coarse_ptr);
   HIP_TRY(ctx, hipEventRecord(s.ev[2], st));
-  hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n, 256), w_count), dim3(256), 0, st, ctx->d_digits, n, ctx->d_cursor, ctx->d_val);
+  hipLaunchKernelGGL(k_scatter_coarse, dim3(tiles), dim3(256), 0, st, d_scalars, n, stride, tile_len, tiles, w_begin, w_count,
+                     ctx->d_counts, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine);
   HIP_TRY(ctx, hipEventRecord(s.ev[3], st));
-  hipLaunchKernelGGL(k_smvp_bucket, dim3(HALF / 256, w_count), dim3(256), 0, st, ctx->d_bases, ctx->d_col_ptr, ctx->d_val, n,
-                     ctx->d_buckets);
+  hipLaunchKernelGGL(k_sort_fine, dim3(NCOARSE, w_count), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
+                     ctx->d_col_ptr, ctx->d_val);
   HIP_TRY(ctx, hipEventRecord(s.ev[4], st));
+  hipLaunchKernelGGL(k_smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, ctx->d_col_ptr, ctx->d_val, stride,
+                     chunks, ctx->d_buckets, ctx->d_heads, ctx->d_tails, ctx->d_tail_slot);
+  HIP_TRY(ctx, hipEventRecord(s.ev[5], st));
+  hipLaunchKernelGGL(k_smvp_stitch, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_col_ptr, chunks, ctx->d_heads, ctx->d_tails,
+                     ctx->d_tail_slot, ctx->d_buckets);
+  HIP_TRY(ctx, hipEventRecord(s.ev[6], st));
   hipLaunchKernelGGL(k_bpr_runs, dim3(BPR_BLOCKS, w_count), dim3(BPR_BLOCK), 0, st, ctx->d_buckets, ctx->d_partials);
   hipLaunchKernelGGL(k_bpr_final, dim3(1), dim3(64), 0, st, ctx->d_partials, w_count, reinterpret_cast<uint32_t*>(s.d_wsums));
-  HIP_TRY(ctx, hipEventRecord(s.ev[5], st));
+  HIP_TRY(ctx, hipEventRecord(s.ev[7], st));
   HIP_TRY(ctx, hipGetLastError());
 
   s.w_begin = w_begin;
@@ -152,8 +190,8 @@ int enqueue_pipeline(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int 
 int collect_timings(msm_hip_ctx* ctx, Slot& s) {
   if (!s.timed) return MSM_HIP_OK;
   s.timed = false;
-  for (int i = 0; i < 5; i++) HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[i], s.ev[i], s.ev[i + 1]));
-  HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[5], s.ev[0], s.ev[5]));
+  for (int i = 0; i < 7; i++) HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[i], s.ev[i], s.ev[i + 1]));
+  HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[7], s.ev[0], s.ev[7]));
   return MSM_HIP_OK;
 }
 
@@ -224,10 +262,10 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
     return code;
   };
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(MSM_HIP_ERR_NO_DEVICE);
-  if ((rc = dev_alloc(ctx, ctx->d_hist, (size_t)NWIN * HALF))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_counts, (size_t)NWIN * MAX_TILES * NCOARSE))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_coarse_ptr, (size_t)NWIN * (NCOARSE + 1)))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_col_ptr, (size_t)NWIN * (HALF + 1)))) return fail(rc);
-  if ((rc = dev_alloc(ctx, ctx->d_cursor, (size_t)NWIN * HALF))) return fail(rc);
-  if ((rc = dev_alloc(ctx, ctx->d_buckets, (size_t)NWIN * HALF * 24))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_buckets, (size_t)NWIN * HALF * REC_WORDS))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_partials, (size_t)NWIN * BPR_BLOCKS * XYZZ_WORDS))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_err, 1))) return fail(rc);
   for (int s = 0; s < 2; s++) {
@@ -245,8 +283,9 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  void* bufs[] = {ctx->d_bases, ctx->d_scalars, ctx->d_digits, ctx->d_hist, ctx->d_col_ptr, ctx->d_cursor,
-                  ctx->d_val,   ctx->d_buckets, ctx->d_partials, ctx->d_err, ctx->d_stage};
+  void* bufs[] = {ctx->d_bases,   ctx->d_scalars,  ctx->d_digits, ctx->d_counts, ctx->d_coarse_ptr, ctx->d_col_ptr,
+                  ctx->d_tmp_val, ctx->d_tmp_fine, ctx->d_val,    ctx->d_buckets, ctx->d_heads,     ctx->d_tails,
+                  ctx->d_tail_slot, ctx->d_partials, ctx->d_err,  ctx->d_stage};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int s = 0; s < 2; s++) {
@@ -310,7 +349,7 @@ int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]) {
   if (rc) return rc;
   auto t0 = std::chrono::steady_clock::now();
   if (!bn254::host::combine_windows(s.h_wsums, NWIN, WBITS, out_xyz)) return MSM_HIP_ERR_HIP;
-  ctx->stage_ms[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ctx->stage_ms[8] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return collect_timings(ctx, s);
 }
 
@@ -396,7 +435,7 @@ int msm_hip_sample_points_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void
 
 int msm_hip_last_stage_ms(msm_hip_ctx* ctx, float* ms, int cap) {
   if (!ctx || !ms) return MSM_HIP_ERR_INVALID_ARG;
-  int k = cap < 7 ? cap : 7;
+  int k = cap < 9 ? cap : 9;
   for (int i = 0; i < k; i++) ms[i] = ctx->stage_ms[i];
   return k;
 }
@@ -412,8 +451,14 @@ static int read_back(msm_hip_ctx* ctx, void* out, const void* src, size_t bytes,
   return MSM_HIP_OK;
 }
 
-int msm_hip_read_digits(msm_hip_ctx* ctx, uint16_t* out, size_t cap_elems) {
+int msm_hip_set_debug(msm_hip_ctx* ctx, int keep_digit_planes) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  ctx->debug = keep_digit_planes != 0;
+  return MSM_HIP_OK;
+}
+
+int msm_hip_read_digits(msm_hip_ctx* ctx, uint16_t* out, size_t cap_elems) {
+  if (!ctx || !ctx->last_has_digits) return MSM_HIP_ERR_INVALID_ARG;
   return read_back(ctx, out, ctx->d_digits, ctx->last_n * ctx->last_w_count * 2, cap_elems * 2);
 }
 int msm_hip_read_col_ptr(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
@@ -422,19 +467,22 @@ int msm_hip_read_col_ptr(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
 }
 int msm_hip_read_val_idxs(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
-  // windows are laid out with stride n; only the first col_ptr[w][32768] entries of each window are meaningful
-  return read_back(ctx, out, ctx->d_val, ctx->last_n * ctx->last_w_count * 4, cap_elems * 4);
+  // out[w][n]; only the first col_ptr[w][32768] entries of each window are meaningful
+  const size_t n = ctx->last_n;
+  if (!out || n * ctx->last_w_count > cap_elems) return MSM_HIP_ERR_INVALID_ARG;
+  if (n == 0) return MSM_HIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpy2DAsync(out, n * 4, ctx->d_val, ctx->stride * 4, n * 4, (size_t)ctx->last_w_count, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSM_HIP_OK;
 }
 
-// buckets are kept in device Montgomery form; convert through the test hook path on the way out
+// buckets are kept as raw XYZZ records in device Montgomery form; exported as canonical Jacobian bytes
 namespace {
 __global__ void __launch_bounds__(256) k_export_buckets(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, size_t count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  const fq X = ld_fq(buckets + i * 24), Y = ld_fq(buckets + i * 24 + 8), Z = ld_fq(buckets + i * 24 + 16);
-  st_fq(out + i * 24, fq_from_mont(X));
-  st_fq(out + i * 24 + 8, fq_from_mont(Y));
-  st_fq(out + i * 24 + 16, fq_from_mont(Z));
+  st_jacobian_plain(out + i * 24, ld_rec(buckets + i * REC_WORDS));
 }
 }  // namespace
 

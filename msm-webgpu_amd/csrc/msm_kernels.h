@@ -151,111 +151,279 @@ __global__ void __launch_bounds__(256) k_convert_points(const uint32_t* __restri
   st_fq(out + i * 16 + 8, y);
 }
 
-// ------------------------------------------------------------------------------------------------ stage 1: decompose
-// 32-byte scalar -> 16 signed 16-bit digits (≙ decompose_scalars.template.wgsl:83-112, CPU model test/utils.rs:121-161):
-//   d = raw + carry; if d >= 2^15 { d -= 2^16; carry = 1 }.  Stored as a signed-magnitude code
-//   code = sign << 15 | (|d| & 0x7fff):  0 = digit 0 (contributes nothing), 0x8000 = digit -2^15 (bucket slot 0).
-// Also builds the per-window bucket histogram (the first loop of transpose.template.wgsl:53-55).
-__global__ void __launch_bounds__(256) k_decompose(const uint32_t* __restrict__ scalars, size_t n, int w_begin, int w_count,
-                                                   uint16_t* __restrict__ digits, uint32_t* __restrict__ hist,
-                                                   uint32_t* __restrict__ err) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t s[8];
-  ld8(scalars + i * 8, s);
-  uint32_t carry = 0;
-#pragma unroll
-  for (int w = 0; w < NWIN; w++) {
-    const uint32_t raw = (s[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
-    uint32_t d = raw + carry;  // 0 .. 65536
-    uint32_t code;
-    if (d >= (uint32_t)HALF) {
-      const uint32_t mag = 65536u - d;  // 0 .. 32768  (0 only when d == 65536, i.e. digit 0 with carry)
-      carry = 1;
-      code = mag == 0 ? 0u : (0x8000u | (mag & 0x7fffu));
-    } else {
-      carry = 0;
-      code = d;
-    }
-    const int lw = w - w_begin;
-    if (lw >= 0 && lw < w_count) {
-      digits[(size_t)lw * n + i] = (uint16_t)code;
-      if (code != 0) atomicAdd(&hist[(size_t)lw * HALF + (code & 0x7fffu)], 1u);
-    }
+
+// ------------------------------------------------------------------------------------------------ stage 1+2: recode + sort
+// Signed 16-bit digit recode (≙ decompose_scalars.template.wgsl:83-112, CPU model test/utils.rs:121-161):
+//   d = raw + carry; if d >= 2^15 { d -= 2^16; carry = 1 }.  Signed-magnitude code = sign << 15 | (|d| & 0x7fff):
+//   0 = digit 0 (contributes nothing), 0x8000 = digit -2^15 (bucket slot 0).
+//
+// The reference's transpose (transpose.template.wgsl:32-76) is a counting sort run by 16 threads.  Here it is a
+// two-level LDS counting sort over the 15-bit bucket slot, and the recode is fused into both of its global passes
+// (scalars are re-read instead of materialising 16 digit planes: 32 B per scalar either way):
+//   k_count          per tile of scalars: LDS histogram of the 128 coarse bins (slot >> 8) of every window
+//   k_scan_coarse    per window: prefix over (coarse bin, tile) -> start of each (bin, tile) run
+//   k_scatter_coarse per tile: LDS-ranked scatter of (index | sign << 31, slot & 255) into coarse-bin order
+//   k_sort_fine      per (window, coarse bin): LDS counting sort over its 256 slots -> val_idxs + col_ptr
+// Order inside a slot is the arrival order of LDS atomics; the group sum does not depend on it.
+constexpr int NCOARSE = 128;       // coarse bins per window
+constexpr int FINE = HALF / NCOARSE;  // 256 slots per coarse bin
+
+__device__ __forceinline__ uint32_t recode_step(uint32_t raw, uint32_t& carry) {
+  const uint32_t d = raw + carry;  // 0 .. 65536
+  if (d >= (uint32_t)HALF) {
+    const uint32_t mag = 65536u - d;  // 0 .. 32768 (0 only for d == 65536: digit 0 with carry out)
+    carry = 1;
+    return mag == 0 ? 0u : (0x8000u | (mag & 0x7fffu));
   }
-  if (carry) atomicOr(err, ERRBIT_SCALAR_CARRY);  // "final carry is 1", test/utils.rs:150-152
+  carry = 0;
+  return d;
 }
 
-// ------------------------------------------------------------------------------------------------ stage 2a: scan
-// exclusive prefix sum of the histogram of one window per block (≙ transpose.template.wgsl:58-61)
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ col_ptr,
-                                               uint32_t* __restrict__ cursor) {
-  __shared__ uint32_t part[1024];
-  const int w = blockIdx.x, t = threadIdx.x;
-  constexpr int PER = HALF / 1024;  // 32
-  const uint32_t* h = hist + (size_t)w * HALF + t * PER;
-  uint32_t local[PER];
-  uint32_t sum = 0;
-#pragma unroll
-  for (int k = 0; k < PER; k += 4) {
-    const uint4 v = *reinterpret_cast<const uint4*>(h + k);
-    local[k] = v.x; local[k + 1] = v.y; local[k + 2] = v.z; local[k + 3] = v.w;
-    sum += v.x + v.y + v.z + v.w;
-  }
-  part[t] = sum;
+__global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles,
+                                               int w_begin, int w_count, uint32_t* __restrict__ counts,
+                                               uint16_t* __restrict__ digits_dbg, uint32_t* __restrict__ err) {
+  __shared__ uint32_t cnt[NWIN * NCOARSE];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NWIN * NCOARSE; i += 256) cnt[i] = 0;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    uint32_t v = (t >= off) ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[t] - sum;  // exclusive
-  uint32_t* cp = col_ptr + (size_t)w * (HALF + 1) + t * PER;
-  uint32_t* cu = cursor + (size_t)w * HALF + t * PER;
+  const size_t base = (size_t)blockIdx.x * tile_len;
+  const size_t end = base + tile_len < n ? base + tile_len : n;
+  uint32_t bad = 0;
+  for (size_t i = base + tid; i < end; i += 256) {
+    uint32_t s[8];
+    ld8(scalars + i * 8, s);
+    uint32_t carry = 0;
 #pragma unroll
-  for (int k = 0; k < PER; k++) {
-    cp[k] = run;
-    cu[k] = run;
-    run += local[k];
+    for (int w = 0; w < NWIN; w++) {
+      const uint32_t code = recode_step((s[w >> 1] >> ((w & 1) * 16)) & 0xffffu, carry);
+      const int lw = w - w_begin;
+      if (lw >= 0 && lw < w_count) {
+        if (code != 0) atomicAdd(&cnt[lw * NCOARSE + ((code & 0x7fffu) >> 8)], 1u);
+        if (digits_dbg) digits_dbg[(size_t)lw * n + i] = (uint16_t)code;
+      }
+    }
+    bad |= carry;  // "final carry is 1", test/utils.rs:150-152
   }
-  if (t == 1023) col_ptr[(size_t)w * (HALF + 1) + HALF] = run;
+  if (bad) atomicOr(err, ERRBIT_SCALAR_CARRY);
+  __syncthreads();
+  // counts[lw][tile][bin]
+  for (int i = tid; i < w_count * NCOARSE; i += 256)
+    counts[((size_t)(i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[i];
 }
 
-// ------------------------------------------------------------------------------------------------ stage 2b: scatter
-// (≙ transpose.template.wgsl:66-73; order inside a slot is arrival order of the atomics, which the group sum ignores)
-__global__ void __launch_bounds__(256) k_scatter(const uint16_t* __restrict__ digits, size_t n, uint32_t* __restrict__ cursor,
-                                                 uint32_t* __restrict__ val_idxs) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int w = blockIdx.y;
-  if (i >= n) return;
-  const uint32_t code = digits[(size_t)w * n + i];
-  if (code == 0) return;
-  const uint32_t pos = atomicAdd(&cursor[(size_t)w * HALF + (code & 0x7fffu)], 1u);
-  val_idxs[(size_t)w * n + pos] = (uint32_t)i | ((code >> 15) << 31);
+// One block per window, 1024 threads = 8 tile groups x 128 bins.  In place: counts[lw][tile][bin] becomes the number of
+// entries of that bin in earlier tiles; coarse_ptr[lw][0..128] = start of every coarse bin, [128] = entries in the window.
+__global__ void __launch_bounds__(1024) k_scan_coarse(uint32_t* __restrict__ counts, uint32_t tiles, uint32_t* __restrict__ coarse_ptr) {
+  __shared__ uint32_t gsum[8][NCOARSE];
+  __shared__ uint32_t binstart[NCOARSE + 1];
+  const int lw = blockIdx.x, bin = threadIdx.x & (NCOARSE - 1), grp = threadIdx.x >> 7;
+  uint32_t* c = counts + (size_t)lw * tiles * NCOARSE;
+  const uint32_t per = (tiles + 7) / 8;
+  const uint32_t t0 = grp * per, t1 = (t0 + per < tiles) ? t0 + per : tiles;
+  uint32_t sum = 0;
+  for (uint32_t t = t0; t < t1; t++) sum += c[(size_t)t * NCOARSE + bin];
+  gsum[grp][bin] = sum;
+  __syncthreads();
+  if (grp == 0) {
+    uint32_t total = 0;
+    for (int g = 0; g < 8; g++) {
+      const uint32_t v = gsum[g][bin];
+      gsum[g][bin] = total;  // entries of this bin in earlier tile groups
+      total += v;
+    }
+    binstart[bin + 1] = total;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    binstart[0] = 0;
+    for (int b = 0; b < NCOARSE; b++) binstart[b + 1] += binstart[b];
+  }
+  __syncthreads();
+  uint32_t run = gsum[grp][bin];
+  for (uint32_t t = t0; t < t1; t++) {
+    const uint32_t v = c[(size_t)t * NCOARSE + bin];
+    c[(size_t)t * NCOARSE + bin] = run;
+    run += v;
+  }
+  if (threadIdx.x <= NCOARSE) coarse_ptr[(size_t)lw * (NCOARSE + 1) + threadIdx.x] = binstart[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
+                                                        uint32_t tiles, int w_begin, int w_count, const uint32_t* __restrict__ counts,
+                                                        const uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ tmp_val,
+                                                        uint8_t* __restrict__ tmp_fine) {
+  __shared__ uint32_t pos[NWIN * NCOARSE];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < w_count * NCOARSE; i += 256) {
+    const int lw = i / NCOARSE, bin = i % NCOARSE;
+    pos[i] = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin] + counts[((size_t)lw * tiles + blockIdx.x) * NCOARSE + bin];
+  }
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * tile_len;
+  const size_t end = base + tile_len < n ? base + tile_len : n;
+  for (size_t i = base + tid; i < end; i += 256) {
+    uint32_t s[8];
+    ld8(scalars + i * 8, s);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < NWIN; w++) {
+      const uint32_t code = recode_step((s[w >> 1] >> ((w & 1) * 16)) & 0xffffu, carry);
+      const int lw = w - w_begin;
+      if (lw >= 0 && lw < w_count && code != 0) {
+        const uint32_t slot = code & 0x7fffu;
+        const uint32_t p = atomicAdd(&pos[lw * NCOARSE + (slot >> 8)], 1u);
+        tmp_val[(size_t)lw * stride + p] = (uint32_t)i | ((code >> 15) << 31);
+        tmp_fine[(size_t)lw * stride + p] = (uint8_t)(slot & 0xffu);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ tmp_val, const uint8_t* __restrict__ tmp_fine, size_t stride,
+                                                   const uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ col_ptr,
+                                                   uint32_t* __restrict__ val_idxs) {
+  __shared__ uint32_t cnt[FINE];
+  __shared__ uint32_t scan[FINE];
+  const int bin = blockIdx.x, lw = blockIdx.y, tid = threadIdx.x;
+  const uint32_t begin = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin], end = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin + 1];
+  const uint32_t* tv = tmp_val + (size_t)lw * stride;
+  const uint8_t* tf = tmp_fine + (size_t)lw * stride;
+  cnt[tid] = 0;
+  __syncthreads();
+  for (uint32_t i = begin + tid; i < end; i += 256) atomicAdd(&cnt[tf[i]], 1u);
+  __syncthreads();
+  const uint32_t mine = cnt[tid];
+  scan[tid] = mine;
+  __syncthreads();
+  for (int off = 1; off < FINE; off <<= 1) {
+    const uint32_t v = tid >= off ? scan[tid - off] : 0;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  const uint32_t excl = scan[tid] - mine;
+  col_ptr[(size_t)lw * (HALF + 1) + bin * FINE + tid] = begin + excl;
+  if (bin == NCOARSE - 1 && tid == FINE - 1) col_ptr[(size_t)lw * (HALF + 1) + HALF] = end;
+  __syncthreads();
+  cnt[tid] = begin + excl;  // running write position of every slot
+  __syncthreads();
+  uint32_t* out = val_idxs + (size_t)lw * stride;
+  for (uint32_t i = begin + tid; i < end; i += 256) {
+    const uint32_t p = atomicAdd(&cnt[tf[i]], 1u);
+    out[p] = tv[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ stage 3: SMVP
-// bucket accumulate, one lane per bucket slot (≙ smvp.template.wgsl:31-117, CPU model test/utils.rs:166-219):
+// Bucket accumulate (≙ smvp.template.wgsl:31-117, CPU model test/utils.rs:166-219):
 //   B[w][k] = sum_{d=+k} P - sum_{d=-k} P  (k >= 1),   B[w][0] = -sum_{d=-2^15} P
-__global__ void __launch_bounds__(256) k_smvp_bucket(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ col_ptr,
-                                                     const uint32_t* __restrict__ val_idxs, size_t n,
-                                                     uint32_t* __restrict__ buckets) {
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;  // < HALF by grid construction
-  const int w = blockIdx.y;
-  const uint32_t* cp = col_ptr + (size_t)w * (HALF + 1);
-  const uint32_t begin = cp[slot], end = cp[slot + 1];
-  const uint32_t* vi = val_idxs + (size_t)w * n;
+// The reference gives one thread one bucket, so a wave runs as long as its fullest bucket.  Here every lane owns a
+// fixed-length chunk of SMVP_CHUNK consecutive entries of the slot-sorted list -- equal work per lane whatever the bucket
+// sizes -- and flushes its accumulator whenever the slot changes.  Runs that cross a chunk boundary leave a "tail" piece
+// (in the chunk where the run starts) and "head" pieces (in the chunks it continues into); k_smvp_stitch adds them.
+// Buckets and pieces are stored as raw XYZZ records (no multiplication on the flush path).
+constexpr int SMVP_CHUNK = 64;
+constexpr int REC_WORDS = 40;  // 160 B record: 36 limbs, valid flag, 3 pad words; 16-byte aligned
+
+__device__ __forceinline__ void st_rec(uint32_t* p, const g1_xyzz& a) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(a.x.v[0], a.x.v[1], a.x.v[2], a.x.v[3]);
+  q[1] = make_uint4(a.x.v[4], a.x.v[5], a.x.v[6], a.x.v[7]);
+  q[2] = make_uint4(a.x.v[8], a.y.v[0], a.y.v[1], a.y.v[2]);
+  q[3] = make_uint4(a.y.v[3], a.y.v[4], a.y.v[5], a.y.v[6]);
+  q[4] = make_uint4(a.y.v[7], a.y.v[8], a.zz.v[0], a.zz.v[1]);
+  q[5] = make_uint4(a.zz.v[2], a.zz.v[3], a.zz.v[4], a.zz.v[5]);
+  q[6] = make_uint4(a.zz.v[6], a.zz.v[7], a.zz.v[8], a.zzz.v[0]);
+  q[7] = make_uint4(a.zzz.v[1], a.zzz.v[2], a.zzz.v[3], a.zzz.v[4]);
+  q[8] = make_uint4(a.zzz.v[5], a.zzz.v[6], a.zzz.v[7], a.zzz.v[8]);
+  q[9] = make_uint4(a.inf ? 0u : 1u, 0u, 0u, 0u);
+}
+__device__ __forceinline__ g1_xyzz ld_rec(const uint32_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 f = q[9];
+  if (f.x == 0) return g1_identity();
+  const uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5], a6 = q[6], a7 = q[7], a8 = q[8];
+  g1_xyzz a;
+  a.x.v[0] = a0.x; a.x.v[1] = a0.y; a.x.v[2] = a0.z; a.x.v[3] = a0.w;
+  a.x.v[4] = a1.x; a.x.v[5] = a1.y; a.x.v[6] = a1.z; a.x.v[7] = a1.w;
+  a.x.v[8] = a2.x; a.y.v[0] = a2.y; a.y.v[1] = a2.z; a.y.v[2] = a2.w;
+  a.y.v[3] = a3.x; a.y.v[4] = a3.y; a.y.v[5] = a3.z; a.y.v[6] = a3.w;
+  a.y.v[7] = a4.x; a.y.v[8] = a4.y; a.zz.v[0] = a4.z; a.zz.v[1] = a4.w;
+  a.zz.v[2] = a5.x; a.zz.v[3] = a5.y; a.zz.v[4] = a5.z; a.zz.v[5] = a5.w;
+  a.zz.v[6] = a6.x; a.zz.v[7] = a6.y; a.zz.v[8] = a6.z; a.zzz.v[0] = a6.w;
+  a.zzz.v[1] = a7.x; a.zzz.v[2] = a7.y; a.zzz.v[3] = a7.z; a.zzz.v[4] = a7.w;
+  a.zzz.v[5] = a8.x; a.zzz.v[6] = a8.y; a.zzz.v[7] = a8.z; a.zzz.v[8] = a8.w;
+  a.inf = false;
+  return a;
+}
+
+__global__ void __launch_bounds__(256, 4) k_smvp_chunks(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ col_ptr,
+                                                     const uint32_t* __restrict__ val_idxs, size_t stride, uint32_t chunks,
+                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
+                                                     uint32_t* __restrict__ tails, uint32_t* __restrict__ tail_slot) {
+  const int lw = blockIdx.y;
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t* cp = col_ptr + (size_t)lw * (HALF + 1);
+  const uint32_t nw = cp[HALF];
+  const uint64_t begin64 = (uint64_t)c * SMVP_CHUNK;
+  if (c >= chunks || begin64 >= nw) return;
+  const uint32_t begin = (uint32_t)begin64;
+  const uint32_t end = (nw - begin > (uint32_t)SMVP_CHUNK) ? begin + SMVP_CHUNK : nw;
+  // slot containing entry `begin`: largest s with cp[s] <= begin  (cp[0] = 0 <= begin < nw = cp[HALF])
+  uint32_t lo = 0, hi = HALF;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (cp[mid] <= begin) lo = mid; else hi = mid;
+  }
+  uint32_t s = lo, run_begin = cp[s], run_end = cp[s + 1];
+  const uint32_t* vi = val_idxs + (size_t)lw * stride;
+  const size_t rec = ((size_t)lw * chunks + c) * REC_WORDS;
   g1_xyzz acc = g1_identity();
+  uint4 quad = make_uint4(0, 0, 0, 0);
   for (uint32_t t = begin; t < end; t++) {
-    const uint32_t v = vi[t];
+    if (t == run_end) {  // the run of slot s ended inside this chunk
+      if (run_begin >= begin) st_rec(buckets + ((size_t)lw * HALF + s) * REC_WORDS, acc);
+      else st_rec(heads + rec, acc);
+      acc = g1_identity();
+      run_begin = run_end;
+      do { s++; run_end = cp[s + 1]; } while (run_end == run_begin);  // next non-empty slot (exists: t < nw)
+    }
+    if (((t - begin) & 3u) == 0) quad = *reinterpret_cast<const uint4*>(vi + t);
+    const uint32_t k = (t - begin) & 3u;
+    const uint32_t v = k == 0 ? quad.x : (k == 1 ? quad.y : (k == 2 ? quad.z : quad.w));
     const uint32_t* pt = bases + (size_t)(v & 0x7fffffffu) * 16;
     const fq px = ld_fq(pt);
     fq py = ld_fq(pt + 8);
     if (v >> 31) py = fq_neg_canonical(py);
     g1_madd(acc, px, py);
   }
-  st_jacobian(buckets + ((size_t)w * HALF + slot) * 24, acc);
+  // last run of the chunk: complete only if it started here and ends exactly at or before `end`
+  if (run_begin >= begin && run_end <= end) {
+    st_rec(buckets + ((size_t)lw * HALF + s) * REC_WORDS, acc);
+  } else if (run_begin < begin) {
+    st_rec(heads + rec, acc);  // continuation of a run from an earlier chunk (it may continue further)
+  } else {
+    st_rec(tails + rec, acc);  // run starts here and continues into the next chunk(s)
+    tail_slot[(size_t)lw * chunks + c] = s;
+  }
+}
+
+// one lane per chunk that owns an open tail: bucket = tail + every head piece until the run ends
+__global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict__ col_ptr, uint32_t chunks,
+                                                     const uint32_t* __restrict__ heads, const uint32_t* __restrict__ tails,
+                                                     const uint32_t* __restrict__ tail_slot, uint32_t* __restrict__ buckets) {
+  const int lw = blockIdx.y;
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= chunks) return;
+  const uint32_t s = tail_slot[(size_t)lw * chunks + c];
+  if (s == 0xffffffffu) return;
+  const uint32_t run_end = col_ptr[(size_t)lw * (HALF + 1) + s + 1];
+  g1_xyzz acc = ld_rec(tails + ((size_t)lw * chunks + c) * REC_WORDS);
+  for (uint32_t c2 = c + 1; c2 < chunks; c2++) {
+    acc = g1_add(acc, ld_rec(heads + ((size_t)lw * chunks + c2) * REC_WORDS));
+    if ((uint64_t)run_end <= ((uint64_t)c2 + 1) * SMVP_CHUNK) break;
+  }
+  st_rec(buckets + ((size_t)lw * HALF + s) * REC_WORDS, acc);
 }
 
 // ------------------------------------------------------------------------------------------------ stage 4: bucket reduce
@@ -273,10 +441,10 @@ __global__ void __launch_bounds__(BPR_BLOCK) k_bpr_runs(const uint32_t* __restri
   const int w = blockIdx.y;
   const int t = threadIdx.x;
   const int j = blockIdx.x * BPR_BLOCK + t;  // run index, 0 .. 2047
-  const uint32_t* bw = buckets + (size_t)w * HALF * 24;
+  const uint32_t* bw = buckets + (size_t)w * HALF * REC_WORDS;
   g1_xyzz m = g1_identity(), g = g1_identity();
   for (int q = (j + 1) * BPR_RUN; q > j * BPR_RUN; q--) {
-    const g1_xyzz b = ld_jacobian(bw + (size_t)(q & (HALF - 1)) * 24);
+    const g1_xyzz b = ld_rec(bw + (size_t)(q & (HALF - 1)) * REC_WORDS);
     m = g1_add(m, b);
     g = g1_add(g, m);
   }

@@ -27,7 +27,9 @@ def run(ctx):
     pt[64 * 2:64 * 3] = pt[64 * 3:64 * 4]
     points, scalars = bytes(pt), bytes(sc)
     ctx.set_bases(points)
+    ctx.set_debug(True)
     result = ctx.msm(scalars)
+    ctx.set_debug(False)
     return {"points": points, "scalars": scalars, "result": result, "digits": ctx.read_digits(N), "col_ptr": ctx.read_col_ptr(),
             "val": ctx.read_val_idxs(N), "buckets": ctx.read_buckets(), "wsums": ctx.read_window_sums(),
             "model_digits": cpu.decompose_scalars_signed(scalars)}
