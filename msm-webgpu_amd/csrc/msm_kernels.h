@@ -248,69 +248,167 @@ __global__ void __launch_bounds__(1024) k_scan_coarse(uint32_t* __restrict__ cou
   if (threadIdx.x <= NCOARSE) coarse_ptr[(size_t)lw * (NCOARSE + 1) + threadIdx.x] = binstart[threadIdx.x];
 }
 
+// Exclusive prefix sum of one value per thread over a 256-thread block (4 waves); `wave_tot` is 4 words of LDS.
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* wave_tot) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wave_tot[wid] = x;
+  __syncthreads();
+  uint32_t add = 0;
+  for (int k = 0; k < wid; k++) add += wave_tot[k];
+  __syncthreads();
+  return x - v + add;
+}
+
+// Both scatter kernels stage their output through LDS: the block ranks its items per destination bin with LDS atomics,
+// lays them out bin-major in LDS, and writes them out in LDS order, so consecutive lanes store to consecutive global
+// addresses inside each (tile, bin) run instead of 64 unrelated 4-byte stores per wave instruction.
+constexpr int SCAT_SUB = 2048;  // scalars staged per block iteration (8 per thread)
+
 __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
                                                         uint32_t tiles, int w_begin, int w_count, const uint32_t* __restrict__ counts,
                                                         const uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ tmp_val,
                                                         uint8_t* __restrict__ tmp_fine) {
-  __shared__ uint32_t pos[NWIN * NCOARSE];
+  __shared__ uint32_t gpos[NWIN * NCOARSE];  // global write cursor of every (window, coarse bin) run of this tile
+  __shared__ uint32_t hist[NCOARSE];
+  __shared__ uint32_t lstart[NCOARSE];
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t st_val[SCAT_SUB];
+  __shared__ uint32_t st_dst[SCAT_SUB];
+  __shared__ uint8_t st_fine[SCAT_SUB];
   const int tid = threadIdx.x;
   for (int i = tid; i < w_count * NCOARSE; i += 256) {
     const int lw = i / NCOARSE, bin = i % NCOARSE;
-    pos[i] = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin] + counts[((size_t)lw * tiles + blockIdx.x) * NCOARSE + bin];
+    gpos[i] = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin] + counts[((size_t)lw * tiles + blockIdx.x) * NCOARSE + bin];
   }
-  __syncthreads();
-  const size_t base = (size_t)blockIdx.x * tile_len;
-  const size_t end = base + tile_len < n ? base + tile_len : n;
-  for (size_t i = base + tid; i < end; i += 256) {
-    uint32_t s[8];
-    ld8(scalars + i * 8, s);
-    uint32_t carry = 0;
+  const size_t tile_base = (size_t)blockIdx.x * tile_len;
+  const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
+  for (size_t sub = tile_base; sub < tile_end; sub += SCAT_SUB) {
+    // recode this thread's 8 scalars; codes packed two per register: code[j][w] = (pk[j][w >> 1] >> 16 (w & 1)) & 0xffff
+    uint32_t pk[8][8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const size_t i = sub + (size_t)j * 256 + tid;
+      uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (i < tile_end) ld8(scalars + i * 8, s);  // an all-zero scalar recodes to all-zero codes: no entries
+      uint32_t carry = 0;
+#pragma unroll
+      for (int h = 0; h < 8; h++) {
+        const uint32_t c0 = recode_step(s[h] & 0xffffu, carry);
+        const uint32_t c1 = recode_step(s[h] >> 16, carry);
+        pk[j][h] = c0 | (c1 << 16);
+      }
+    }
 #pragma unroll
     for (int w = 0; w < NWIN; w++) {
-      const uint32_t code = recode_step((s[w >> 1] >> ((w & 1) * 16)) & 0xffffu, carry);
       const int lw = w - w_begin;
-      if (lw >= 0 && lw < w_count && code != 0) {
-        const uint32_t slot = code & 0x7fffu;
-        const uint32_t p = atomicAdd(&pos[lw * NCOARSE + (slot >> 8)], 1u);
-        tmp_val[(size_t)lw * stride + p] = (uint32_t)i | ((code >> 15) << 31);
-        tmp_fine[(size_t)lw * stride + p] = (uint8_t)(slot & 0xffu);
+      if (lw < 0 || lw >= w_count) continue;  // block-uniform
+      if (tid < NCOARSE) hist[tid] = 0;
+      __syncthreads();
+      uint32_t rank[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t code = (pk[j][w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+        rank[j] = code ? atomicAdd(&hist[(code & 0x7fffu) >> 8], 1u) : 0u;
       }
+      __syncthreads();
+      const uint32_t mine = tid < NCOARSE ? hist[tid] : 0u;
+      const uint32_t excl = block_excl_scan_256(mine, wave_tot);
+      if (tid < NCOARSE) lstart[tid] = excl;
+      __syncthreads();
+      const uint32_t total = lstart[NCOARSE - 1] + hist[NCOARSE - 1];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t code = (pk[j][w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+        if (code) {
+          const uint32_t slot = code & 0x7fffu, bin = slot >> 8;
+          const uint32_t e = lstart[bin] + rank[j];
+          st_val[e] = (uint32_t)(sub + (size_t)j * 256 + tid) | ((code >> 15) << 31);
+          st_fine[e] = (uint8_t)(slot & 0xffu);
+          st_dst[e] = gpos[lw * NCOARSE + bin] + rank[j];
+        }
+      }
+      __syncthreads();
+      uint32_t* ov = tmp_val + (size_t)lw * stride;
+      uint8_t* of = tmp_fine + (size_t)lw * stride;
+      for (uint32_t e = tid; e < total; e += 256) {
+        const uint32_t d = st_dst[e];
+        ov[d] = st_val[e];
+        of[d] = st_fine[e];
+      }
+      if (tid < NCOARSE) gpos[lw * NCOARSE + tid] += hist[tid];
+      __syncthreads();
     }
   }
 }
 
+constexpr int FINE_CHUNK = 4096;  // entries staged per block iteration (16 per thread)
+
 __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ tmp_val, const uint8_t* __restrict__ tmp_fine, size_t stride,
                                                    const uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ col_ptr,
                                                    uint32_t* __restrict__ val_idxs) {
-  __shared__ uint32_t cnt[FINE];
-  __shared__ uint32_t scan[FINE];
+  __shared__ uint32_t hist[FINE];
+  __shared__ uint32_t lstart[FINE];
+  __shared__ uint32_t gpos[FINE];
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t st_val[FINE_CHUNK];
+  __shared__ uint32_t st_dst[FINE_CHUNK];
   const int bin = blockIdx.x, lw = blockIdx.y, tid = threadIdx.x;
   const uint32_t begin = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin], end = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin + 1];
   const uint32_t* tv = tmp_val + (size_t)lw * stride;
   const uint8_t* tf = tmp_fine + (size_t)lw * stride;
-  cnt[tid] = 0;
-  __syncthreads();
-  for (uint32_t i = begin + tid; i < end; i += 256) atomicAdd(&cnt[tf[i]], 1u);
-  __syncthreads();
-  const uint32_t mine = cnt[tid];
-  scan[tid] = mine;
-  __syncthreads();
-  for (int off = 1; off < FINE; off <<= 1) {
-    const uint32_t v = tid >= off ? scan[tid - off] : 0;
-    __syncthreads();
-    scan[tid] += v;
-    __syncthreads();
-  }
-  const uint32_t excl = scan[tid] - mine;
-  col_ptr[(size_t)lw * (HALF + 1) + bin * FINE + tid] = begin + excl;
-  if (bin == NCOARSE - 1 && tid == FINE - 1) col_ptr[(size_t)lw * (HALF + 1) + HALF] = end;
-  __syncthreads();
-  cnt[tid] = begin + excl;  // running write position of every slot
-  __syncthreads();
   uint32_t* out = val_idxs + (size_t)lw * stride;
-  for (uint32_t i = begin + tid; i < end; i += 256) {
-    const uint32_t p = atomicAdd(&cnt[tf[i]], 1u);
-    out[p] = tv[i];
+  // pass 1: slot histogram of the whole coarse bin -> col_ptr and the global cursor of every slot
+  hist[tid] = 0;
+  __syncthreads();
+  for (uint32_t i = begin + tid; i < end; i += 256) atomicAdd(&hist[tf[i]], 1u);
+  __syncthreads();
+  {
+    const uint32_t excl = block_excl_scan_256(hist[tid], wave_tot);
+    gpos[tid] = begin + excl;
+    col_ptr[(size_t)lw * (HALF + 1) + bin * FINE + tid] = begin + excl;
+    if (bin == NCOARSE - 1 && tid == FINE - 1) col_ptr[(size_t)lw * (HALF + 1) + HALF] = end;
+  }
+  __syncthreads();
+  // pass 2: LDS-staged scatter, FINE_CHUNK entries at a time
+  for (uint32_t base = begin; base < end; base += FINE_CHUNK) {
+    hist[tid] = 0;
+    __syncthreads();
+    uint32_t v[16], fr[16];  // value; slot | rank << 8
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t i = base + j * 256 + tid;
+      if (i < end) {
+        const uint32_t f = tf[i];
+        v[j] = tv[i];
+        fr[j] = f | (atomicAdd(&hist[f], 1u) << 8);
+      } else {
+        fr[j] = 0xffffffffu;
+      }
+    }
+    __syncthreads();
+    const uint32_t excl = block_excl_scan_256(hist[tid], wave_tot);
+    lstart[tid] = excl;
+    __syncthreads();
+    const uint32_t total = (end - base) < (uint32_t)FINE_CHUNK ? (end - base) : (uint32_t)FINE_CHUNK;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      if (fr[j] != 0xffffffffu) {
+        const uint32_t f = fr[j] & 0xffu, r = fr[j] >> 8;
+        const uint32_t e = lstart[f] + r;
+        st_val[e] = v[j];
+        st_dst[e] = gpos[f] + r;
+      }
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < total; e += 256) out[st_dst[e]] = st_val[e];
+    gpos[tid] += hist[tid];
+    __syncthreads();
   }
 }
 
