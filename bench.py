@@ -56,11 +56,15 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     import msm_webgpu_amd as m  # fails loudly if libmsm_hip.so is missing
-    from msm_webgpu_amd.sharding import gather_window_sums, window_range
+    from msm_webgpu_amd.sharding import ShardedMsmPipeline, window_range
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BENCH_FORCE_SHARDED=1 drives the multi-GPU code path (RCCL process group + sharded pipeline) even with one rank,
+    # so that it can be exercised on a single-GPU box under torch.distributed.run --nproc-per-node 1
+    force_sharded = os.environ.get("BENCH_FORCE_SHARDED") == "1"
+    use_dist = world > 1 or (force_sharded and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -75,11 +79,13 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     smvp_ms, stage_acc = [], {}
+    sharded = world > 1 or force_sharded
+    pipe = ShardedMsmPipeline(ctx, rank, world) if sharded else None
 
     def note_stages():
         st = ctx.stage_ms()
@@ -90,7 +96,7 @@ def main():
     def run_steps(count, record):
         """`count` MSMs; returns the last result.  N = 1 pipelines the host combine of MSM i with the device work of i+1."""
         result = None
-        if world == 1:
+        if not sharded:
             ctx.launch(scalar_sets[0], 0)
             for i in range(1, count):
                 ctx.launch(scalar_sets[i & 1], i & 1)
@@ -101,12 +107,21 @@ def main():
             if record:
                 note_stages()
         else:
+            # windows sharded over the ranks; device work, RCCL all-gather, D2H and host combine all pipelined
+            inflight = 0
             for i in range(count):
-                local = ctx.msm_windows(scalar_sets[i & 1], w_begin, w_end)
+                pipe.issue(scalar_sets[i & 1])
+                inflight += 1
+                if inflight == pipe.depth:
+                    result = pipe.complete()
+                    inflight -= 1
+                    if record:
+                        note_stages()
+            while inflight:
+                result = pipe.complete()
+                inflight -= 1
                 if record:
                     note_stages()
-                sums = gather_window_sums(local, rank, world)
-                result = m.MsmContext.combine_windows(sums)
         return result
 
     run_steps(max(args.warmup, 1), False)
@@ -115,10 +130,22 @@ def main():
     last = run_steps(args.steps, True)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # single-MSM latency (no pipelining, stages not overlapped) -- reported beside the throughput figure
+    latency_ms, isolated = None, None
+    if world == 1:
+        lat = []
+        for i in range(5):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ctx.msm(scalar_sets[i & 1])
+            lat.append((time.perf_counter() - t1) * 1e3)
+            isolated = ctx.stage_ms()
+        latency_ms = sorted(lat)[len(lat) // 2]
 
     ms_per_step = elapsed * 1e3 / args.steps
     smvp_avg_ms = sum(smvp_ms) / len(smvp_ms)
@@ -148,12 +175,14 @@ def main():
         "dtype": "u32",
         "data": "synthetic",
         "config": {"workload": "2^%d BN254 G1 MSM, 16-bit signed-bucket windows, inputs resident in HBM" % args.logn,
-                   "windows_per_gpu": w_local, "parallelism": "windows/%d" % world if world > 1 else "single GPU",
-                   "host_combine": "pipelined" if world == 1 else "per step"},
+                   "windows_per_gpu": w_local, "parallelism": "windows/%d + RCCL all-gather" % world if sharded else "single GPU",
+                   "host_combine": "pipelined one MSM behind"},
         "roofline": {"bound": "hbm", "kernel": "k_smvp_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                      "kernel_ms": smvp_avg_ms},
         "stage_ms": {k: v / len(smvp_ms) for k, v in stage_acc.items()},
+        "latency_ms_single_msm": latency_ms,
+        "stage_ms_single_msm": isolated,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -182,7 +211,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

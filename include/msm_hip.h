@@ -41,6 +41,7 @@ extern "C" {
 
 #define MSM_HIP_NUM_WINDOWS 16         /* num_subtasks = ceil(256 / 16)                       src/cuzk/msm.rs:82 */
 #define MSM_HIP_WINDOW_BITS 16         /* chunk_size                                           src/cuzk/msm.rs:79 */
+#define MSM_HIP_NUM_SLOTS 4            /* asynchronous result slots per context                                 */
 #define MSM_HIP_BUCKETS_PER_WINDOW 32768 /* 2^(c-1) signed buckets                             src/cuzk/msm.rs:191 */
 
 /* flags for msm_hip_set_bases_* */
@@ -63,7 +64,7 @@ int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t 
  *      ≙ compute_msm stages 1-5, src/cuzk/msm.rs:96-416 (decompose, transpose, SMVP, bucket reduce, Horner) ---- */
 int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
 int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]);
-/* asynchronous halves of run_device: `launch` enqueues all device work of one MSM into result slot `slot` (0 or 1)
+/* asynchronous halves of run_device: `launch` enqueues all device work of one MSM into result slot `slot` (0 .. MSM_HIP_NUM_SLOTS-1)
  * and returns; `finish` waits for that slot and performs the host finalisation (src/cuzk/msm.rs:391-416).
  * Lets a caller overlap the host Horner of MSM i with the device work of MSM i+1. */
 int msm_hip_launch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot);
@@ -74,6 +75,15 @@ int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]);
  *      canonical-LE records to `window_sums_dev` (device memory, so that RCCL can gather them in place). ---- */
 int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end,
                                      void* window_sums_dev);
+/* asynchronous form: enqueue into a result slot and return.  window_sums_dev == NULL keeps the sums in the slot and
+ * copies them to the host (then msm_hip_finish_bn254 applies when all 16 windows were run).  Afterwards:
+ *   msm_hip_slot_wait_stream  makes a foreign HIP stream (e.g. the one RCCL runs on) wait for the slot on the device,
+ *                             without blocking the host;
+ *   msm_hip_slot_sync         blocks the host until the slot is complete and returns its error status. */
+int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot,
+                                        void* window_sums_dev);
+int msm_hip_slot_wait_stream(msm_hip_ctx* ctx, int slot, void* hip_stream);
+int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot);
 /* result = sum_w 2^(16 w) * S_w over num_windows records (host memory): src/cuzk/msm.rs:411-416 */
 int msm_hip_combine_windows_bn254(const uint8_t* window_sums_host, int num_windows, uint8_t out_xyz[96]);
 
@@ -91,7 +101,7 @@ int msm_hip_sample_points_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void
  *      ms[4] SMVP accumulate (k_smvp_chunks), ms[5] SMVP stitch, ms[6] bucket reduce,
  *      ms[7] whole device pipeline, ms[8] host finalisation.  Returns the number of entries written. ---- */
 int msm_hip_last_stage_ms(msm_hip_ctx* ctx, float* ms, int cap);
-/* the context's stream as a hipStream_t (for callers that want to order their own work after a run) */
+/* the context's main stream as a hipStream_t */
 void* msm_hip_stream(msm_hip_ctx* ctx);
 
 /* ---- stage-level read-back for parity tests (≙ read_from_gpu_test, src/cuzk/gpu.rs:137-171).  Each copies the

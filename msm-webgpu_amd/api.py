@@ -53,6 +53,9 @@ def lib():
         L.msm_hip_launch_device_bn254.argtypes = [vp, vp, sz, i]
         L.msm_hip_finish_bn254.argtypes = [vp, i, u8p]
         L.msm_hip_run_windows_device_bn254.argtypes = [vp, vp, sz, i, i, vp]
+        L.msm_hip_launch_windows_device_bn254.argtypes = [vp, vp, sz, i, i, i, vp]
+        L.msm_hip_slot_wait_stream.argtypes = [vp, i, vp]
+        L.msm_hip_slot_sync.argtypes = [vp, i]
         L.msm_hip_combine_windows_bn254.argtypes = [u8p, i, u8p]
         L.msm_hip_msm_bn254_g1.argtypes = [u8p, u8p, sz, u8p]
         L.msm_hip_sample_scalars_device.argtypes = [vp, C.c_uint64, sz, vp]
@@ -203,7 +206,7 @@ class MsmContext:
         return G1(out.raw)
 
     def launch(self, scalars_dev, slot=0):
-        """Enqueue the device work of one MSM into result slot 0/1 and return at once."""
+        """Enqueue the device work of one MSM into a result slot (0..3) and return at once."""
         t, n = _as_device_u8(scalars_dev, 32, "scalars")
         self._keepalive = t
         _check(lib().msm_hip_launch_device_bn254(self._h, t.data_ptr(), n, slot), "msm_hip_launch_device_bn254")
@@ -224,6 +227,23 @@ class MsmContext:
         _check(lib().msm_hip_run_windows_device_bn254(self._h, t.data_ptr(), n, w_begin, w_end, out_dev.data_ptr()),
                "msm_hip_run_windows_device_bn254")
         return out_dev
+
+    def launch_windows(self, scalars_dev, w_begin, w_end, slot, out_dev):
+        """Asynchronous msm_windows into a result slot (0..3); `out_dev` (CUDA uint8 [w_end - w_begin, 96]) receives the sums."""
+        t, n = _as_device_u8(scalars_dev, 32, "scalars")
+        self._keepalive = (t, out_dev)
+        _check(lib().msm_hip_launch_windows_device_bn254(self._h, t.data_ptr(), n, w_begin, w_end, slot, out_dev.data_ptr()),
+               "msm_hip_launch_windows_device_bn254")
+
+    def slot_wait_stream(self, slot, stream=None):
+        """Make a torch CUDA stream (default: the current one) wait, on the device, for the slot's results."""
+        if stream is None:
+            stream = torch.cuda.current_stream()
+        _check(lib().msm_hip_slot_wait_stream(self._h, slot, stream.cuda_stream), "msm_hip_slot_wait_stream")
+
+    def slot_sync(self, slot):
+        """Block until the slot is complete; raises on a device-side input error."""
+        _check(lib().msm_hip_slot_sync(self._h, slot), "msm_hip_slot_sync")
 
     @staticmethod
     def combine_windows(window_sums):

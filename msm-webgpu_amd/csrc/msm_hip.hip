@@ -1,9 +1,16 @@
 // libmsm_hip.so -- host side of the MI355X BN254 MSM engine behind the C ABI of include/msm_hip.h.
 //
 // Replaces, for the hot path only, the reference's orchestrator compute_msm (src/cuzk/msm.rs:75-417) and its wgpu
-// wrappers (src/cuzk/gpu.rs): one persistent context = one HIP stream, pooled device buffers, bases resident in HBM
+// wrappers (src/cuzk/gpu.rs): one persistent context = two HIP streams, pooled device buffers, bases resident in HBM
 // in device Montgomery form; no per-call device creation, shader generation or pipeline compilation
 // (cf. src/cuzk/msm.rs:88-94, src/cuzk/shader_manager.rs:74-100).
+//
+// Execution model.  Every MSM runs in one of MSM_HIP_NUM_SLOTS result slots (own bucket and window-sum buffers):
+//   stream "main"   : recode + sort + SMVP accumulate + stitch                  -> event smvp_done[slot]
+//   stream "reduce" : (waits smvp_done) bucket reduce -> window sums -> D2H     -> event done[slot]   (two of them)
+// The bucket reduce is bound by the depth of dependent group additions and occupies few waves; putting it on its own
+// stream lets the sort + SMVP of the NEXT MSM (other slot, own bucket buffer) start while it runs.  The host window
+// combine of a slot (src/cuzk/msm.rs:411-416) runs in the caller's thread inside msm_hip_finish_bn254.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -20,26 +27,31 @@ using namespace msmk;
 
 namespace {
 
-constexpr int N_EVENTS = 8;  // boundaries of the 7 timed device stages
+constexpr int N_MAIN_EVENTS = 7;  // boundaries of the 6 timed stages on the main stream
 constexpr uint32_t MAX_TILES = 1024;
 constexpr size_t WSUM_BYTES = (size_t)NWIN * 96;
+constexpr int NSLOT = MSM_HIP_NUM_SLOTS;  // result slots; slot k reduces on reduce stream k & 1
 
 struct Slot {
-  uint8_t* h_wsums = nullptr;  // pinned: NWIN x 96 B window sums + 4 B error word
-  uint8_t* d_wsums = nullptr;  // device:  NWIN x 96 B + 4 B error word
-  hipEvent_t done = nullptr;
-  hipEvent_t ev[N_EVENTS] = {};  // stage boundaries of the run that used this slot
-  bool timed = false;
+  uint8_t* h_wsums = nullptr;      // pinned: NWIN x 96 B window sums + 4 B error word
+  uint8_t* d_wsums = nullptr;      // device: NWIN x 96 B window sums + 4 B error word
+  uint32_t* d_buckets = nullptr;   // [W][32768] XYZZ records
+  uint32_t* d_partials = nullptr;  // [W][BPR_BLOCKS] XYZZ
+  hipEvent_t ev[N_MAIN_EVENTS] = {};
+  hipEvent_t red0 = nullptr, red1 = nullptr;  // bucket reduce begin / end on the reduce stream
+  hipEvent_t smvp_done = nullptr;             // main -> reduce hand-off
+  hipEvent_t done = nullptr;                  // everything of this slot finished (recorded on the reduce stream)
+  bool timed = false, pending = false, to_host = false;
   int w_begin = 0, w_count = 0;
   size_t n = 0;
-  bool pending = false;
 };
 
 }  // namespace
 
 struct msm_hip_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;         // main
+  hipStream_t reduce_stream[2] = {nullptr, nullptr};  // bucket reduce + result copies (slot k uses stream k & 1)
   int last_hip_error = 0;
 
   uint32_t* d_bases = nullptr;  // n_bases x 16 words
@@ -47,7 +59,6 @@ struct msm_hip_ctx {
 
   size_t cap_n = 0;   // capacity of the per-run work buffers (entries per window)
   size_t stride = 0;  // per-window stride of the entry arrays: cap_n rounded up to a multiple of 4
-  uint32_t cap_chunks = 0;
   uint32_t* d_scalars = nullptr;
   uint16_t* d_digits = nullptr;  // digit-code planes, only written when debug read-back is enabled
   bool debug = false;
@@ -57,32 +68,30 @@ struct msm_hip_ctx {
   uint32_t* d_tmp_val = nullptr;     // [W][stride] coarse-bin order
   uint8_t* d_tmp_fine = nullptr;     // [W][stride]
   uint32_t* d_val = nullptr;         // [W][stride] slot order
-  uint32_t* d_buckets = nullptr;     // [W][32768] XYZZ records
   uint32_t* d_heads = nullptr;       // [W][chunks] XYZZ records
   uint32_t* d_tails = nullptr;       // [W][chunks] XYZZ records
   uint32_t* d_tail_slot = nullptr;   // [W][chunks]
-  uint32_t* d_partials = nullptr;
   uint32_t* d_err = nullptr;
   uint8_t* d_stage = nullptr;  // staging for host byte inputs of set_bases / test hooks
   size_t cap_stage = 0;
 
-  Slot slot[2];
-  // description of the last launched run (for the stage read-back hooks and timings)
+  Slot slot[NSLOT];
+  // description of the last launched run (for the stage read-back hooks)
   size_t last_n = 0;
-  int last_w_count = 0;
+  int last_w_count = 0, last_slot = 0;
   bool last_has_digits = false;
   float stage_ms[10] = {};
 };
 
 namespace {
 
-#define HIP_TRY(ctx, expr)                         \
-  do {                                             \
-    hipError_t e_ = (expr);                        \
-    if (e_ != hipSuccess) {                        \
-      if (ctx) (ctx)->last_hip_error = (int)e_;    \
+#define HIP_TRY(ctx, expr)                                                             \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      if (ctx) (ctx)->last_hip_error = (int)e_;                                        \
       return e_ == hipErrorOutOfMemory ? MSM_HIP_ERR_OUT_OF_MEMORY : MSM_HIP_ERR_HIP; \
-    }                                              \
+    }                                                                                  \
   } while (0)
 
 template <typename T>
@@ -110,6 +119,9 @@ inline uint32_t chunks_for(size_t n) { return (uint32_t)((n + SMVP_CHUNK - 1) / 
 
 int ensure_work(msm_hip_ctx* ctx, size_t n) {
   if (n <= ctx->cap_n && (!ctx->debug || ctx->d_digits)) return MSM_HIP_OK;
+  // growing the pools: nothing may still be running on them
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (hipStream_t r : ctx->reduce_stream) HIP_TRY(ctx, hipStreamSynchronize(r));
   const size_t cap = n > ctx->cap_n ? n : ctx->cap_n;
   ctx->cap_n = 0;
   const size_t stride = (cap + 3) & ~(size_t)3;
@@ -125,7 +137,6 @@ int ensure_work(msm_hip_ctx* ctx, size_t n) {
   if (ctx->debug && (rc = dev_alloc(ctx, ctx->d_digits, cap * NWIN))) return rc;
   ctx->cap_n = cap;
   ctx->stride = stride;
-  ctx->cap_chunks = chunks;
   return MSM_HIP_OK;
 }
 
@@ -137,10 +148,12 @@ int err_from_bits(uint32_t bits) {
   return MSM_HIP_OK;
 }
 
-// Enqueue stages 1-4 for windows [w_begin, w_begin + w_count) on the context stream; window sums (canonical Jacobian
-// bytes) and the error word land in `s.d_wsums`.
-int enqueue_pipeline(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count, Slot& s) {
-  hipStream_t st = ctx->stream;
+// Enqueue one MSM (windows [w_begin, w_begin + w_count)) into slot `s`.  Window sums (canonical Jacobian bytes) go to
+// `wsums_out` (device memory; the slot's own buffer when null); the error word and, if `to_host`, the window sums are
+// copied to the slot's pinned buffer.  Returns without waiting.
+int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count, Slot& s, uint32_t* wsums_out,
+            bool to_host) {
+  hipStream_t st = ctx->stream, rs = ctx->reduce_stream[(&s - ctx->slot) & 1];
   // tiles of scalars for the two global sort passes: >= 2048 scalars each, at most MAX_TILES of them
   uint32_t tile_len = 2048;
   if ((n + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n + MAX_TILES - 1) / MAX_TILES) + 255) / 256 * 256);
@@ -148,11 +161,13 @@ int enqueue_pipeline(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int 
   const uint32_t chunks = chunks_for(n);
   const size_t stride = ctx->stride;
   uint16_t* digits = ctx->debug ? ctx->d_digits : nullptr;
-  ctx->last_has_digits = digits != nullptr;
-
-  HIP_TRY(ctx, hipMemsetAsync(s.d_wsums + WSUM_BYTES, 0, 4, st));
   uint32_t* d_err = reinterpret_cast<uint32_t*>(s.d_wsums + WSUM_BYTES);
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_buckets, 0, (size_t)w_count * HALF * REC_WORDS * 4, st));
+  if (!wsums_out) wsums_out = reinterpret_cast<uint32_t*>(s.d_wsums);
+
+  // the slot's previous occupant (bucket reduce + copies on the reduce stream) must have drained
+  HIP_TRY(ctx, hipStreamWaitEvent(st, s.done, 0));
+  HIP_TRY(ctx, hipMemsetAsync(d_err, 0, 4, st));
+  HIP_TRY(ctx, hipMemsetAsync(s.d_buckets, 0, (size_t)w_count * HALF * REC_WORDS * 4, st));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_tail_slot, 0xFF, (size_t)w_count * chunks * 4, st));
 
   HIP_TRY(ctx, hipEventRecord(s.ev[0], st));
@@ -167,32 +182,49 @@ int enqueue_pipeline(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int 
                      ctx->d_col_ptr, ctx->d_val);
   HIP_TRY(ctx, hipEventRecord(s.ev[4], st));
   hipLaunchKernelGGL(k_smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, ctx->d_col_ptr, ctx->d_val, stride,
-                     chunks, ctx->d_buckets, ctx->d_heads, ctx->d_tails, ctx->d_tail_slot);
+                     chunks, s.d_buckets, ctx->d_heads, ctx->d_tails, ctx->d_tail_slot);
   HIP_TRY(ctx, hipEventRecord(s.ev[5], st));
   hipLaunchKernelGGL(k_smvp_stitch, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_col_ptr, chunks, ctx->d_heads, ctx->d_tails,
-                     ctx->d_tail_slot, ctx->d_buckets);
+                     ctx->d_tail_slot, s.d_buckets);
   HIP_TRY(ctx, hipEventRecord(s.ev[6], st));
-  hipLaunchKernelGGL(k_bpr_runs, dim3(BPR_BLOCKS, w_count), dim3(BPR_BLOCK), 0, st, ctx->d_buckets, ctx->d_partials);
-  hipLaunchKernelGGL(k_bpr_final, dim3(1), dim3(64), 0, st, ctx->d_partials, w_count, reinterpret_cast<uint32_t*>(s.d_wsums));
-  HIP_TRY(ctx, hipEventRecord(s.ev[7], st));
+  HIP_TRY(ctx, hipEventRecord(s.smvp_done, st));
+
+  HIP_TRY(ctx, hipStreamWaitEvent(rs, s.smvp_done, 0));
+  HIP_TRY(ctx, hipEventRecord(s.red0, rs));
+  hipLaunchKernelGGL(k_bpr_runs, dim3(BPR_BLOCKS, w_count), dim3(BPR_BLOCK), 0, rs, s.d_buckets, s.d_partials);
+  hipLaunchKernelGGL(k_bpr_final, dim3(w_count), dim3(64), 0, rs, s.d_partials, wsums_out);
+  HIP_TRY(ctx, hipEventRecord(s.red1, rs));
+  if (to_host) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * 96, hipMemcpyDeviceToHost, rs));
+  HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums + WSUM_BYTES, d_err, 4, hipMemcpyDeviceToHost, rs));
+  HIP_TRY(ctx, hipEventRecord(s.done, rs));
   HIP_TRY(ctx, hipGetLastError());
 
   s.w_begin = w_begin;
   s.w_count = w_count;
   s.n = n;
+  s.timed = true;
+  s.pending = true;
+  s.to_host = to_host;
   ctx->last_n = n;
   ctx->last_w_count = w_count;
-  s.timed = true;
+  ctx->last_slot = (int)(&s - ctx->slot);
+  ctx->last_has_digits = digits != nullptr;
   return MSM_HIP_OK;
 }
 
-// stage times of the run that used slot `s` (its events must have completed)
-int collect_timings(msm_hip_ctx* ctx, Slot& s) {
-  if (!s.timed) return MSM_HIP_OK;
-  s.timed = false;
-  for (int i = 0; i < 7; i++) HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[i], s.ev[i], s.ev[i + 1]));
-  HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[7], s.ev[0], s.ev[7]));
-  return MSM_HIP_OK;
+// wait for slot `s`, fetch its error word and stage times
+int wait_slot(msm_hip_ctx* ctx, Slot& s) {
+  HIP_TRY(ctx, hipEventSynchronize(s.done));
+  s.pending = false;
+  if (s.timed) {
+    s.timed = false;
+    for (int i = 0; i < 6; i++) HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[i], s.ev[i], s.ev[i + 1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[6], s.red0, s.red1));
+    HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[7], s.ev[0], s.red1));
+  }
+  uint32_t bits;
+  memcpy(&bits, s.h_wsums + WSUM_BYTES, 4);
+  return err_from_bits(bits);
 }
 
 int check_run_args(msm_hip_ctx* ctx, const void* scalars, size_t n) {
@@ -203,6 +235,8 @@ int check_run_args(msm_hip_ctx* ctx, const void* scalars, size_t n) {
 }
 
 int set_bases_from_device(msm_hip_ctx* ctx, const uint32_t* d_xy, size_t n, uint32_t flags) {
+  // no run may still be reading the old bases
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (n > ctx->cap_bases) {
     ctx->n_bases = ctx->cap_bases = 0;
     int rc = dev_alloc(ctx, ctx->d_bases, n * 16);
@@ -223,11 +257,17 @@ int set_bases_from_device(msm_hip_ctx* ctx, const uint32_t* d_xy, size_t n, uint
   return MSM_HIP_OK;
 }
 
+__global__ void __launch_bounds__(256) k_export_buckets(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, size_t count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  st_jacobian_plain(out + i * 24, ld_rec(buckets + i * REC_WORDS));
+}
+
 }  // namespace
 
 extern "C" {
 
-int msm_hip_abi_version(void) { return 1; }
+int msm_hip_abi_version(void) { return 2; }
 
 const char* msm_hip_strerror(int code) {
   switch (code) {
@@ -262,18 +302,24 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
     return code;
   };
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(MSM_HIP_ERR_NO_DEVICE);
+  for (int k = 0; k < 2; k++)
+    if (hipStreamCreateWithFlags(&ctx->reduce_stream[k], hipStreamNonBlocking) != hipSuccess) return fail(MSM_HIP_ERR_NO_DEVICE);
   if ((rc = dev_alloc(ctx, ctx->d_counts, (size_t)NWIN * MAX_TILES * NCOARSE))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_coarse_ptr, (size_t)NWIN * (NCOARSE + 1)))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_col_ptr, (size_t)NWIN * (HALF + 1)))) return fail(rc);
-  if ((rc = dev_alloc(ctx, ctx->d_buckets, (size_t)NWIN * HALF * REC_WORDS))) return fail(rc);
-  if ((rc = dev_alloc(ctx, ctx->d_partials, (size_t)NWIN * BPR_BLOCKS * XYZZ_WORDS))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_err, 1))) return fail(rc);
-  for (int s = 0; s < 2; s++) {
-    if (hipHostMalloc((void**)&ctx->slot[s].h_wsums, WSUM_BYTES + 4, hipHostMallocDefault) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
-    if ((rc = dev_alloc(ctx, ctx->slot[s].d_wsums, WSUM_BYTES + 4))) return fail(rc);
-    if (hipEventCreateWithFlags(&ctx->slot[s].done, hipEventDisableTiming) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
-    for (int i = 0; i < N_EVENTS; i++)
-      if (hipEventCreate(&ctx->slot[s].ev[i]) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
+  for (int k = 0; k < NSLOT; k++) {
+    Slot& s = ctx->slot[k];
+    if (hipHostMalloc((void**)&s.h_wsums, WSUM_BYTES + 4, hipHostMallocDefault) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
+    memset(s.h_wsums, 0, WSUM_BYTES + 4);
+    if ((rc = dev_alloc(ctx, s.d_wsums, WSUM_BYTES + 4))) return fail(rc);
+    if ((rc = dev_alloc(ctx, s.d_buckets, (size_t)NWIN * HALF * REC_WORDS))) return fail(rc);
+    if ((rc = dev_alloc(ctx, s.d_partials, (size_t)NWIN * BPR_BLOCKS * XYZZ_WORDS))) return fail(rc);
+    if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
+    if (hipEventCreateWithFlags(&s.smvp_done, hipEventDisableTiming) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
+    if (hipEventCreate(&s.red0) != hipSuccess || hipEventCreate(&s.red1) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
+    for (int i = 0; i < N_MAIN_EVENTS; i++)
+      if (hipEventCreate(&s.ev[i]) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
   }
   *out = ctx;
   return MSM_HIP_OK;
@@ -283,19 +329,27 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  void* bufs[] = {ctx->d_bases,   ctx->d_scalars,  ctx->d_digits, ctx->d_counts, ctx->d_coarse_ptr, ctx->d_col_ptr,
-                  ctx->d_tmp_val, ctx->d_tmp_fine, ctx->d_val,    ctx->d_buckets, ctx->d_heads,     ctx->d_tails,
-                  ctx->d_tail_slot, ctx->d_partials, ctx->d_err,  ctx->d_stage};
+  for (hipStream_t r : ctx->reduce_stream)
+    if (r) (void)hipStreamSynchronize(r);
+  void* bufs[] = {ctx->d_bases,    ctx->d_scalars, ctx->d_digits, ctx->d_counts, ctx->d_coarse_ptr, ctx->d_col_ptr, ctx->d_tmp_val,
+                  ctx->d_tmp_fine, ctx->d_val,     ctx->d_heads,  ctx->d_tails,  ctx->d_tail_slot,  ctx->d_err,     ctx->d_stage};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
-  for (int s = 0; s < 2; s++) {
-    if (ctx->slot[s].h_wsums) (void)hipHostFree(ctx->slot[s].h_wsums);
-    if (ctx->slot[s].d_wsums) (void)hipFree(ctx->slot[s].d_wsums);
-    if (ctx->slot[s].done) (void)hipEventDestroy(ctx->slot[s].done);
-    for (int i = 0; i < N_EVENTS; i++)
-      if (ctx->slot[s].ev[i]) (void)hipEventDestroy(ctx->slot[s].ev[i]);
+  for (int k = 0; k < NSLOT; k++) {
+    Slot& s = ctx->slot[k];
+    if (s.h_wsums) (void)hipHostFree(s.h_wsums);
+    if (s.d_wsums) (void)hipFree(s.d_wsums);
+    if (s.d_buckets) (void)hipFree(s.d_buckets);
+    if (s.d_partials) (void)hipFree(s.d_partials);
+    hipEvent_t evs[] = {s.done, s.smvp_done, s.red0, s.red1};
+    for (hipEvent_t e : evs)
+      if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < N_MAIN_EVENTS; i++)
+      if (s.ev[i]) (void)hipEventDestroy(s.ev[i]);
   }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  for (hipStream_t r : ctx->reduce_stream)
+    if (r) (void)hipStreamDestroy(r);
   delete ctx;
 }
 
@@ -308,49 +362,70 @@ int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t 
 int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, uint32_t flags) {
   if (!ctx || (!xy_host && n)) return MSM_HIP_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   int rc = ensure_stage(ctx, n * 64 + 16);
   if (rc) return rc;
   if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage, xy_host, n * 64, hipMemcpyHostToDevice, ctx->stream));
   return set_bases_from_device(ctx, reinterpret_cast<const uint32_t*>(ctx->d_stage), n, flags);
 }
 
-int msm_hip_launch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot) {
+int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot,
+                                        void* window_sums_dev) {
   int rc = check_run_args(ctx, scalars_dev, n);
   if (rc) return rc;
-  if (slot < 0 || slot > 1) return MSM_HIP_ERR_INVALID_ARG;
+  if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > NWIN || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   Slot& s = ctx->slot[slot];
-  s.pending = true;
+  const int w_count = w_end - w_begin;
   s.n = n;
-  s.w_begin = 0;
-  s.w_count = NWIN;
-  if (n == 0) return MSM_HIP_OK;
+  s.w_begin = w_begin;
+  s.w_count = w_count;
+  s.to_host = window_sums_dev == nullptr;
+  if (n == 0) {  // identity window sums, nothing to compute
+    s.pending = true;
+    s.timed = false;
+    memset(s.h_wsums, 0, WSUM_BYTES + 4);
+    if (window_sums_dev) {
+      HIP_TRY(ctx, hipMemsetAsync(window_sums_dev, 0, (size_t)w_count * 96, ctx->reduce_stream[slot & 1]));
+      HIP_TRY(ctx, hipEventRecord(s.done, ctx->reduce_stream[slot & 1]));
+    }
+    return MSM_HIP_OK;
+  }
   if ((rc = ensure_work(ctx, n))) return rc;
-  if ((rc = enqueue_pipeline(ctx, static_cast<const uint32_t*>(scalars_dev), n, 0, NWIN, s))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, s.d_wsums, WSUM_BYTES + 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipEventRecord(s.done, ctx->stream));
+  return enqueue(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, s, static_cast<uint32_t*>(window_sums_dev),
+                 window_sums_dev == nullptr);
+}
+
+int msm_hip_launch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot) {
+  return msm_hip_launch_windows_device_bn254(ctx, scalars_dev, n, 0, NWIN, slot, nullptr);
+}
+
+int msm_hip_slot_wait_stream(msm_hip_ctx* ctx, int slot, void* foreign_stream) {
+  if (!ctx || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamWaitEvent(static_cast<hipStream_t>(foreign_stream), ctx->slot[slot].done, 0));
   return MSM_HIP_OK;
 }
 
-int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]) {
-  if (!ctx || !out_xyz || slot < 0 || slot > 1) return MSM_HIP_ERR_INVALID_ARG;
+int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot) {
+  if (!ctx || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   Slot& s = ctx->slot[slot];
   if (!s.pending) return MSM_HIP_ERR_INVALID_ARG;
-  s.pending = false;
-  if (s.n == 0) {
-    memset(out_xyz, 0, 96);
-    return MSM_HIP_OK;
-  }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipEventSynchronize(s.done));
-  uint32_t bits;
-  memcpy(&bits, s.h_wsums + WSUM_BYTES, 4);
-  int rc = err_from_bits(bits);
+  return wait_slot(ctx, s);
+}
+
+int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]) {
+  if (!ctx || !out_xyz || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
+  Slot& s = ctx->slot[slot];
+  if (!s.pending || !s.to_host || s.w_count != NWIN) return MSM_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = wait_slot(ctx, s);
   if (rc) return rc;
   auto t0 = std::chrono::steady_clock::now();
   if (!bn254::host::combine_windows(s.h_wsums, NWIN, WBITS, out_xyz)) return MSM_HIP_ERR_HIP;
   ctx->stage_ms[8] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  return collect_timings(ctx, s);
+  return MSM_HIP_OK;
 }
 
 int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]) {
@@ -370,31 +445,17 @@ int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, u
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if ((rc = ensure_work(ctx, n))) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer may still feed an earlier launch
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scalars, scalars_host, n * 32, hipMemcpyHostToDevice, ctx->stream));
   return msm_hip_run_device_bn254(ctx, ctx->d_scalars, n, out_xyz);
 }
 
 int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end,
                                      void* window_sums_dev) {
-  int rc = check_run_args(ctx, scalars_dev, n);
+  if (!window_sums_dev) return MSM_HIP_ERR_INVALID_ARG;
+  int rc = msm_hip_launch_windows_device_bn254(ctx, scalars_dev, n, w_begin, w_end, 0, window_sums_dev);
   if (rc) return rc;
-  if (!window_sums_dev || w_begin < 0 || w_end > NWIN || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const int w_count = w_end - w_begin;
-  Slot& s = ctx->slot[0];
-  if (n == 0) {
-    HIP_TRY(ctx, hipMemsetAsync(window_sums_dev, 0, (size_t)w_count * 96, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return MSM_HIP_OK;
-  }
-  if ((rc = ensure_work(ctx, n))) return rc;
-  if ((rc = enqueue_pipeline(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, s))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(window_sums_dev, s.d_wsums, (size_t)w_count * 96, hipMemcpyDeviceToDevice, ctx->stream));
-  uint32_t bits = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(&bits, s.d_wsums + WSUM_BYTES, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if ((rc = err_from_bits(bits))) return rc;
-  return collect_timings(ctx, s);
+  return msm_hip_slot_sync(ctx, 0);
 }
 
 int msm_hip_combine_windows_bn254(const uint8_t* window_sums_host, int num_windows, uint8_t out_xyz[96]) {
@@ -446,6 +507,7 @@ static int read_back(msm_hip_ctx* ctx, void* out, const void* src, size_t bytes,
   if (bytes > cap_bytes) return MSM_HIP_ERR_INVALID_ARG;
   if (bytes == 0) return MSM_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (hipStream_t r : ctx->reduce_stream) HIP_TRY(ctx, hipStreamSynchronize(r));
   HIP_TRY(ctx, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MSM_HIP_OK;
@@ -477,24 +539,16 @@ int msm_hip_read_val_idxs(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
   return MSM_HIP_OK;
 }
 
-// buckets are kept as raw XYZZ records in device Montgomery form; exported as canonical Jacobian bytes
-namespace {
-__global__ void __launch_bounds__(256) k_export_buckets(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, size_t count) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  st_jacobian_plain(out + i * 24, ld_rec(buckets + i * REC_WORDS));
-}
-}  // namespace
-
 int msm_hip_read_buckets(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
   if (!ctx || !out) return MSM_HIP_ERR_INVALID_ARG;
   const size_t count = (size_t)ctx->last_w_count * HALF;
   if (count * 96 > cap_bytes) return MSM_HIP_ERR_INVALID_ARG;
   if (count == 0) return MSM_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (hipStream_t r : ctx->reduce_stream) HIP_TRY(ctx, hipStreamSynchronize(r));
   int rc = ensure_stage(ctx, count * 96);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_export_buckets, dim3(blocks_for(count, 256)), dim3(256), 0, ctx->stream, ctx->d_buckets,
+  hipLaunchKernelGGL(k_export_buckets, dim3(blocks_for(count, 256)), dim3(256), 0, ctx->stream, ctx->slot[ctx->last_slot].d_buckets,
                      reinterpret_cast<uint32_t*>(ctx->d_stage), count);
   HIP_TRY(ctx, hipGetLastError());
   return read_back(ctx, out, ctx->d_stage, count * 96, cap_bytes);
@@ -502,7 +556,7 @@ int msm_hip_read_buckets(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
 
 int msm_hip_read_window_sums(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
-  return read_back(ctx, out, ctx->slot[0].d_wsums, (size_t)ctx->last_w_count * 96, cap_bytes);
+  return read_back(ctx, out, ctx->slot[ctx->last_slot].d_wsums, (size_t)ctx->last_w_count * 96, cap_bytes);
 }
 
 // ---- op hooks -------------------------------------------------------------------------------------------------------
@@ -510,6 +564,7 @@ static int run_hook(msm_hip_ctx* ctx, const uint8_t* a, size_t a_bytes, const ui
                     size_t out_bytes, uint8_t*& da, uint8_t*& db, uint8_t*& dout) {
   if (!ctx || !a || !out) return MSM_HIP_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
   int rc = ensure_stage(ctx, up16(a_bytes) + up16(b_bytes) + up16(out_bytes) + 16);
   if (rc) return rc;

@@ -529,6 +529,9 @@ __global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict_
 // Slot 0 carries weight h = 2^15, so it is treated as position 2^15: run j of length BPR_RUN covers positions
 // j*RUN+1 .. (j+1)*RUN (position q reads slot q & 32767).  Per run: descending running sum (m, g), then
 // g += (j*RUN) * m by double-and-add (stage_2 of the reference), then a workgroup tree reduction in LDS.
+// This stage is bound by the DEPTH of dependent group additions (a lone wave needs ~8 us per addition), not by work:
+// the reference's 128-bucket runs (256 threads per window) would be ~270 additions deep; 16-bucket runs on 2048 lanes
+// per window are 32 + 15 doublings/7 additions + 11 tree levels deep and cost a third of the work of 4-bucket runs.
 constexpr int BPR_RUN = 16;
 constexpr int BPR_THREADS = HALF / BPR_RUN;  // 2048 runs per window
 constexpr int BPR_BLOCK = 256;
@@ -538,7 +541,7 @@ __global__ void __launch_bounds__(BPR_BLOCK) k_bpr_runs(const uint32_t* __restri
   __shared__ uint32_t lds[BPR_BLOCK * XYZZ_WORDS];
   const int w = blockIdx.y;
   const int t = threadIdx.x;
-  const int j = blockIdx.x * BPR_BLOCK + t;  // run index, 0 .. 2047
+  const int j = blockIdx.x * BPR_BLOCK + t;  // run index
   const uint32_t* bw = buckets + (size_t)w * HALF * REC_WORDS;
   g1_xyzz m = g1_identity(), g = g1_identity();
   for (int q = (j + 1) * BPR_RUN; q > j * BPR_RUN; q--) {
@@ -571,13 +574,25 @@ __global__ void __launch_bounds__(BPR_BLOCK) k_bpr_runs(const uint32_t* __restri
   }
 }
 
-// one lane per window: add the BPR_BLOCKS partial sums, emit the window sum as canonical Jacobian bytes
-__global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ partials, int w_count, uint32_t* __restrict__ wsums) {
-  const int w = threadIdx.x;
-  if (w >= w_count) return;
-  g1_xyzz acc = g1_identity();
-  for (int b = 0; b < BPR_BLOCKS; b++) acc = g1_add(acc, ld_xyzz(partials + ((size_t)w * BPR_BLOCKS + b) * XYZZ_WORDS));
-  st_jacobian_plain(wsums + (size_t)w * 24, acc);
+// one 64-lane block per window: tree-add the BPR_BLOCKS partial sums, emit the window sum as canonical Jacobian bytes
+__global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ partials, uint32_t* __restrict__ wsums) {
+  static_assert(BPR_BLOCKS <= 64 && (BPR_BLOCKS & (BPR_BLOCKS - 1)) == 0, "one wave reduces the block partials");
+  __shared__ uint32_t lds[BPR_BLOCKS * XYZZ_WORDS];
+  const int w = blockIdx.x, t = threadIdx.x;
+  if (t < BPR_BLOCKS) {
+    const uint32_t* in = partials + ((size_t)w * BPR_BLOCKS + t) * XYZZ_WORDS;
+    for (int i = 0; i < XYZZ_WORDS; i++) lds[t * XYZZ_WORDS + i] = in[i];
+  }
+  __syncthreads();
+  for (int stride = BPR_BLOCKS / 2; stride >= 1; stride >>= 1) {
+    if (t < stride) {
+      const g1_xyzz a = ld_xyzz(lds + t * XYZZ_WORDS);
+      const g1_xyzz b = ld_xyzz(lds + (t + stride) * XYZZ_WORDS);
+      st_xyzz(lds + t * XYZZ_WORDS, g1_add(a, b));
+    }
+    __syncthreads();
+  }
+  if (t == 0) st_jacobian_plain(wsums + (size_t)w * 24, ld_xyzz(lds));
 }
 
 // ------------------------------------------------------------------------------------------------ samplers

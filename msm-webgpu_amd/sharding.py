@@ -52,3 +52,56 @@ def sharded_msm(ctx, scalars_dev, rank, world_size, group=None):
         local = torch.empty((0, 96), dtype=torch.uint8, device=scalars_dev.device)
     all_sums = gather_window_sums(local, rank, world_size, group)
     return MsmContext.combine_windows(all_sums)
+
+
+class ShardedMsmPipeline:
+    """Back-to-back window-sharded MSMs with everything asynchronous: rank-local device work (result slots and
+    main/reduce HIP streams inside the engine), the RCCL all-gather on the torch stream (ordered after the slot by a device-side
+    event wait, no host sync), the D2H copy into pinned memory, and the host window combine one step behind.
+
+        pipe = ShardedMsmPipeline(ctx, rank, world_size, group)
+        pipe.issue(scalars_0); pipe.issue(scalars_1); r0 = pipe.complete(); pipe.issue(scalars_2); r1 = pipe.complete(); ...
+    At most `depth` (<= 3) MSMs may be in flight; each uses one of the engine's four result slots.
+    """
+
+    SLOTS = 4
+
+    def __init__(self, ctx, rank, world_size, group=None, num_windows=NUM_WINDOWS, depth=3):
+        assert 1 <= depth < self.SLOTS
+        self.depth = depth
+        self.ctx, self.rank, self.world, self.group, self.num_windows = ctx, rank, world_size, group, num_windows
+        self.w_begin, self.w_end = window_range(rank, world_size, num_windows)
+        self.per = max_windows_per_rank(world_size, num_windows)
+        dev = torch.device("cuda", ctx.device)
+        self.padded = [torch.zeros((self.per, 96), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
+        self.gathered = [torch.empty((world_size, self.per, 96), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
+        self.host = [torch.empty((world_size, self.per, 96), dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
+        self.copied = [torch.cuda.Event() for _ in range(self.SLOTS)]
+        self.issued = 0
+        self.completed = 0
+
+    def issue(self, scalars_dev):
+        assert self.issued - self.completed < self.depth, "pipeline full: call complete() first"
+        slot = self.issued % self.SLOTS
+        w_local = self.w_end - self.w_begin
+        self.ctx.launch_windows(scalars_dev, self.w_begin, self.w_end, slot, self.padded[slot][:w_local])
+        self.ctx.slot_wait_stream(slot)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.gathered[slot].view(-1), self.padded[slot].view(-1), group=self.group)
+        else:
+            self.gathered[slot].copy_(self.padded[slot].unsqueeze(0))
+        self.host[slot].copy_(self.gathered[slot], non_blocking=True)
+        self.copied[slot].record()
+        self.issued += 1
+
+    def complete(self):
+        assert self.completed < self.issued
+        slot = self.completed % self.SLOTS
+        self.copied[slot].synchronize()
+        self.ctx.slot_sync(slot)
+        rows = []
+        for r in range(self.world):
+            b, e = window_range(r, self.world, self.num_windows)
+            rows.append(self.host[slot][r, : e - b])
+        self.completed += 1
+        return MsmContext.combine_windows(torch.cat(rows, dim=0))

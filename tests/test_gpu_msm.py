@@ -107,3 +107,36 @@ def test_linearity_property(ctx):
     rb = ctx.msm(ref.scalars_to_bytes(b)).to_affine()
     rab = ctx.msm(ref.scalars_to_bytes([(x + y) % R for x, y in zip(a, b)])).to_affine()
     assert ref.add(ra, rb) == rab
+
+
+def test_sharded_pipeline_single_rank(ctx):
+    # the asynchronous multi-GPU pipeline degenerates to one rank: same results, two MSMs in flight
+    from msm_webgpu_amd.sharding import ShardedMsmPipeline
+
+    n = 6000
+    pts = ctx.sample_points(n, 90)
+    sets = [ctx.sample_scalars(n, 91 + i) for i in range(3)]
+    ctx.set_bases(pts)
+    want = [ctx.msm(s) for s in sets]
+    pipe = ShardedMsmPipeline(ctx, 0, 1)
+    pipe.issue(sets[0])
+    pipe.issue(sets[1])
+    pipe.issue(sets[2])
+    got = [pipe.complete()]
+    pipe.issue(sets[0])
+    got += [pipe.complete(), pipe.complete(), pipe.complete()]
+    assert got == want + [want[0]]
+
+
+def test_back_to_back_slots_overlap_is_safe(ctx):
+    # bucket reduce of MSM i (reduce stream) overlaps sort + SMVP of MSM i+1 (main stream): results must not interfere
+    n = 50000
+    pts = ctx.sample_points(n, 95)
+    sets = [ctx.sample_scalars(n, 96 + i) for i in range(2)]
+    ctx.set_bases(pts)
+    want = [ctx.msm(s) for s in sets]
+    ctx.launch(sets[0], 0)
+    for i in range(1, 8):
+        ctx.launch(sets[i & 1], i & 1)
+        assert ctx.finish((i - 1) & 1) == want[(i - 1) & 1]
+    assert ctx.finish(7 & 1) == want[7 & 1]
