@@ -59,6 +59,7 @@ struct msm_hip_ctx {
 
   size_t cap_n = 0;   // capacity of the per-run work buffers (entries per window)
   size_t stride = 0;  // per-window stride of the entry arrays: cap_n rounded up to a multiple of 4
+  size_t cap_recs = 0;  // capacity (records) of the head / tail piece arrays
   uint32_t* d_scalars = nullptr;
   uint16_t* d_digits = nullptr;  // digit-code planes, only written when debug read-back is enabled
   bool debug = false;
@@ -115,28 +116,50 @@ int ensure_stage(msm_hip_ctx* ctx, size_t bytes) {
   return MSM_HIP_OK;
 }
 
-inline uint32_t chunks_for(size_t n) { return (uint32_t)((n + SMVP_CHUNK - 1) / SMVP_CHUNK); }
+// entries per SMVP lane: about SMVP_TARGET_LANES lanes over all windows of the run, a multiple of 4 within the kernel's limits
+inline uint32_t chunk_len_for(size_t n, int w_count) {
+  size_t len = (n * (size_t)w_count + SMVP_TARGET_LANES - 1) / SMVP_TARGET_LANES;
+  len = (len + 3) & ~(size_t)3;
+  if (len < (size_t)SMVP_CHUNK_MIN) len = SMVP_CHUNK_MIN;
+  if (len > (size_t)SMVP_CHUNK_MAX) len = SMVP_CHUNK_MAX;
+  return (uint32_t)len;
+}
+inline uint32_t chunks_for(size_t n, uint32_t chunk_len) { return (uint32_t)((n + chunk_len - 1) / chunk_len); }
+// head/tail piece records needed for any run over at most n points: w_count * chunks is largest at w_count = NWIN
+inline size_t piece_records_for(size_t n) {
+  size_t worst = 0;
+  for (int w = 1; w <= NWIN; w++) {
+    const size_t r = (size_t)w * chunks_for(n, chunk_len_for(n, w));
+    if (r > worst) worst = r;
+  }
+  return worst;
+}
 
-int ensure_work(msm_hip_ctx* ctx, size_t n) {
-  if (n <= ctx->cap_n && (!ctx->debug || ctx->d_digits)) return MSM_HIP_OK;
+int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count) {
+  const size_t need_recs = (size_t)w_count * chunks_for(n, chunk_len_for(n, w_count));
+  if (n <= ctx->cap_n && need_recs <= ctx->cap_recs && (!ctx->debug || ctx->d_digits)) return MSM_HIP_OK;
   // growing the pools: nothing may still be running on them
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (hipStream_t r : ctx->reduce_stream) HIP_TRY(ctx, hipStreamSynchronize(r));
   const size_t cap = n > ctx->cap_n ? n : ctx->cap_n;
   ctx->cap_n = 0;
   const size_t stride = (cap + 3) & ~(size_t)3;
-  const uint32_t chunks = chunks_for(cap);
+  size_t recs = piece_records_for(cap);
+  if (recs < need_recs) recs = need_recs;
+  if (recs < ctx->cap_recs) recs = ctx->cap_recs;
+  ctx->cap_recs = 0;
   int rc;
   if ((rc = dev_alloc(ctx, ctx->d_scalars, cap * 8))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_tmp_val, stride * NWIN))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_tmp_fine, stride * NWIN))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_val, stride * NWIN))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_heads, (size_t)chunks * NWIN * REC_WORDS))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_tails, (size_t)chunks * NWIN * REC_WORDS))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_tail_slot, (size_t)chunks * NWIN))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_heads, recs * REC_WORDS))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_tails, recs * REC_WORDS))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_tail_slot, recs))) return rc;
   if (ctx->debug && (rc = dev_alloc(ctx, ctx->d_digits, cap * NWIN))) return rc;
   ctx->cap_n = cap;
   ctx->stride = stride;
+  ctx->cap_recs = recs;
   return MSM_HIP_OK;
 }
 
@@ -158,7 +181,8 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   uint32_t tile_len = 2048;
   if ((n + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n + MAX_TILES - 1) / MAX_TILES) + 255) / 256 * 256);
   const uint32_t tiles = (uint32_t)((n + tile_len - 1) / tile_len);
-  const uint32_t chunks = chunks_for(n);
+  const uint32_t chunk_len = chunk_len_for(n, w_count);
+  const uint32_t chunks = chunks_for(n, chunk_len);
   const size_t stride = ctx->stride;
   uint16_t* digits = ctx->debug ? ctx->d_digits : nullptr;
   uint32_t* d_err = reinterpret_cast<uint32_t*>(s.d_wsums + WSUM_BYTES);
@@ -182,10 +206,10 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
                      ctx->d_col_ptr, ctx->d_val);
   HIP_TRY(ctx, hipEventRecord(s.ev[4], st));
   hipLaunchKernelGGL(k_smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, ctx->d_col_ptr, ctx->d_val, stride,
-                     chunks, s.d_buckets, ctx->d_heads, ctx->d_tails, ctx->d_tail_slot);
+                     chunks, chunk_len, s.d_buckets, ctx->d_heads, ctx->d_tails, ctx->d_tail_slot);
   HIP_TRY(ctx, hipEventRecord(s.ev[5], st));
-  hipLaunchKernelGGL(k_smvp_stitch, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_col_ptr, chunks, ctx->d_heads, ctx->d_tails,
-                     ctx->d_tail_slot, s.d_buckets);
+  hipLaunchKernelGGL(k_smvp_stitch, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_col_ptr, chunks, chunk_len, ctx->d_heads,
+                     ctx->d_tails, ctx->d_tail_slot, s.d_buckets);
   HIP_TRY(ctx, hipEventRecord(s.ev[6], st));
   HIP_TRY(ctx, hipEventRecord(s.smvp_done, st));
 
@@ -391,7 +415,7 @@ int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_de
     }
     return MSM_HIP_OK;
   }
-  if ((rc = ensure_work(ctx, n))) return rc;
+  if ((rc = ensure_work(ctx, n, w_count))) return rc;
   return enqueue(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, s, static_cast<uint32_t*>(window_sums_dev),
                  window_sums_dev == nullptr);
 }
@@ -444,7 +468,7 @@ int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, u
     return MSM_HIP_OK;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if ((rc = ensure_work(ctx, n))) return rc;
+  if ((rc = ensure_work(ctx, n, NWIN))) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer may still feed an earlier launch
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scalars, scalars_host, n * 32, hipMemcpyHostToDevice, ctx->stream));
   return msm_hip_run_device_bn254(ctx, ctx->d_scalars, n, out_xyz);

@@ -416,11 +416,14 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
 // Bucket accumulate (≙ smvp.template.wgsl:31-117, CPU model test/utils.rs:166-219):
 //   B[w][k] = sum_{d=+k} P - sum_{d=-k} P  (k >= 1),   B[w][0] = -sum_{d=-2^15} P
 // The reference gives one thread one bucket, so a wave runs as long as its fullest bucket.  Here every lane owns a
-// fixed-length chunk of SMVP_CHUNK consecutive entries of the slot-sorted list -- equal work per lane whatever the bucket
-// sizes -- and flushes its accumulator whenever the slot changes.  Runs that cross a chunk boundary leave a "tail" piece
+// fixed-length chunk of `chunk_len` consecutive entries of the slot-sorted list -- equal work per lane whatever the bucket
+// sizes -- and flushes its accumulator whenever the slot changes.  The host picks chunk_len (a multiple of 4 in
+// [SMVP_CHUNK_MIN, SMVP_CHUNK_MAX]) so that about SMVP_TARGET_LANES lanes exist: 4 waves per SIMD in one balanced round.  Runs that cross a chunk boundary leave a "tail" piece
 // (in the chunk where the run starts) and "head" pieces (in the chunks it continues into); k_smvp_stitch adds them.
 // Buckets and pieces are stored as raw XYZZ records (no multiplication on the flush path).
-constexpr int SMVP_CHUNK = 64;
+constexpr int SMVP_CHUNK_MIN = 8;
+constexpr int SMVP_CHUNK_MAX = 1024;
+constexpr int SMVP_TARGET_LANES = 1 << 18;  // 256 CUs x 4 SIMDs x 4 waves x 64 lanes
 constexpr int REC_WORDS = 40;  // 160 B record: 36 limbs, valid flag, 3 pad words; 16-byte aligned
 
 __device__ __forceinline__ void st_rec(uint32_t* p, const g1_xyzz& a) {
@@ -457,16 +460,16 @@ __device__ __forceinline__ g1_xyzz ld_rec(const uint32_t* p) {
 
 __global__ void __launch_bounds__(256, 4) k_smvp_chunks(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ col_ptr,
                                                      const uint32_t* __restrict__ val_idxs, size_t stride, uint32_t chunks,
-                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
+                                                     uint32_t chunk_len, uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
                                                      uint32_t* __restrict__ tails, uint32_t* __restrict__ tail_slot) {
   const int lw = blockIdx.y;
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;
   const uint32_t* cp = col_ptr + (size_t)lw * (HALF + 1);
   const uint32_t nw = cp[HALF];
-  const uint64_t begin64 = (uint64_t)c * SMVP_CHUNK;
+  const uint64_t begin64 = (uint64_t)c * chunk_len;
   if (c >= chunks || begin64 >= nw) return;
   const uint32_t begin = (uint32_t)begin64;
-  const uint32_t end = (nw - begin > (uint32_t)SMVP_CHUNK) ? begin + SMVP_CHUNK : nw;
+  const uint32_t end = (nw - begin > chunk_len) ? begin + chunk_len : nw;
   // slot containing entry `begin`: largest s with cp[s] <= begin  (cp[0] = 0 <= begin < nw = cp[HALF])
   uint32_t lo = 0, hi = HALF;
   while (hi - lo > 1) {
@@ -507,7 +510,7 @@ __global__ void __launch_bounds__(256, 4) k_smvp_chunks(const uint32_t* __restri
 }
 
 // one lane per chunk that owns an open tail: bucket = tail + every head piece until the run ends
-__global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict__ col_ptr, uint32_t chunks,
+__global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict__ col_ptr, uint32_t chunks, uint32_t chunk_len,
                                                      const uint32_t* __restrict__ heads, const uint32_t* __restrict__ tails,
                                                      const uint32_t* __restrict__ tail_slot, uint32_t* __restrict__ buckets) {
   const int lw = blockIdx.y;
@@ -519,7 +522,7 @@ __global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict_
   g1_xyzz acc = ld_rec(tails + ((size_t)lw * chunks + c) * REC_WORDS);
   for (uint32_t c2 = c + 1; c2 < chunks; c2++) {
     acc = g1_add(acc, ld_rec(heads + ((size_t)lw * chunks + c2) * REC_WORDS));
-    if ((uint64_t)run_end <= ((uint64_t)c2 + 1) * SMVP_CHUNK) break;
+    if ((uint64_t)run_end <= ((uint64_t)c2 + 1) * chunk_len) break;
   }
   st_rec(buckets + ((size_t)lw * HALF + s) * REC_WORDS, acc);
 }

@@ -140,3 +140,37 @@ def test_back_to_back_slots_overlap_is_safe(ctx):
         ctx.launch(sets[i & 1], i & 1)
         assert ctx.finish((i - 1) & 1) == want[(i - 1) & 1]
     assert ctx.finish(7 & 1) == want[7 & 1]
+
+
+def test_large_split_consistency(ctx):
+    # BASELINE sizes beyond what the oracle finishes in seconds: MSM(P, s) == MSM(P[:h], s[:h]) + MSM(P[h:], s[h:])
+    n = 1 << 22
+    h = n // 2 + 12345
+    pts, sc = ctx.sample_points(n, 120), ctx.sample_scalars(n, 121)
+    ctx.set_bases(pts)
+    whole = ctx.msm(sc).to_affine()
+    first = ctx.msm(sc[:h].contiguous()).to_affine()
+    ctx.set_bases(pts[h:].contiguous())
+    second = ctx.msm(sc[h:].contiguous()).to_affine()
+    assert ref.add(first, second) == whole
+    # and against the oracle on a 2^15 slice of the same inputs
+    k = 1 << 15
+    ctx.set_bases(pts[:k].contiguous())
+    pb, sb = pts[:k].cpu().numpy().tobytes(), sc[:k].cpu().numpy().tobytes()
+    assert ctx.msm(sc[:k].contiguous()).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb, sb))
+
+
+def test_skewed_scalars_many_equal(ctx):
+    # every scalar equal: one bucket per window holds all n entries (the stitch walks thousands of chunks)
+    n = 1 << 17
+    pts = ctx.sample_points(n, 130)
+    s = 0x1234_5678_9ABC_DEF0_1357_9BDF_2468_ACE0_FEDC_BA98_7654_3210 % R
+    sb = s.to_bytes(32, "little") * n
+    ctx.set_bases(pts)
+    got = ctx.msm(sb).to_affine()
+    ones = (1).to_bytes(32, "little") * n
+    total = ctx.msm(ones).to_affine()          # sum of all points (also a single-bucket case)
+    assert got == ref.mul(s, total)
+    pb = pts[:4096].cpu().numpy().tobytes()
+    ctx.set_bases(pb)
+    assert ctx.msm(ones[: 32 * 4096]).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb, ones[: 32 * 4096]))
