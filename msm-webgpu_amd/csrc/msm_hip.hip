@@ -36,7 +36,7 @@ struct Slot {
   uint8_t* h_wsums = nullptr;      // pinned: NWIN x 96 B window sums + 4 B error word
   uint8_t* d_wsums = nullptr;      // device: NWIN x 96 B window sums + 4 B error word
   uint32_t* d_buckets = nullptr;   // [W][32768] XYZZ records
-  uint32_t* d_partials = nullptr;  // [W][BPR_BLOCKS] XYZZ
+  uint32_t* d_partials = nullptr;  // bucket-reduce scratch: [W][256] row sums, [W][256] column sums, [W][3] parts (XYZZ)
   hipEvent_t ev[N_MAIN_EVENTS] = {};
   hipEvent_t red0 = nullptr, red1 = nullptr;  // bucket reduce begin / end on the reduce stream
   hipEvent_t smvp_done = nullptr;             // main -> reduce hand-off
@@ -215,8 +215,15 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
 
   HIP_TRY(ctx, hipStreamWaitEvent(rs, s.smvp_done, 0));
   HIP_TRY(ctx, hipEventRecord(s.red0, rs));
-  hipLaunchKernelGGL(k_bpr_runs, dim3(BPR_BLOCKS, w_count), dim3(BPR_BLOCK), 0, rs, s.d_buckets, s.d_partials);
-  hipLaunchKernelGGL(k_bpr_final, dim3(w_count), dim3(64), 0, rs, s.d_partials, wsums_out);
+  uint32_t* d_rows = s.d_partials;
+  uint32_t* d_cols = d_rows + (size_t)NWIN * 256 * XYZZ_WORDS;
+  uint32_t* d_parts = d_cols + (size_t)NWIN * 256 * XYZZ_WORDS;
+  if (w_count >= 8)
+    hipLaunchKernelGGL(k_bpr_rowcol<3>, dim3(bpr_rowcol_blocks<3>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols);
+  else
+    hipLaunchKernelGGL(k_bpr_rowcol<2>, dim3(bpr_rowcol_blocks<2>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols);
+  hipLaunchKernelGGL(k_bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts);
+  hipLaunchKernelGGL(k_bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out);
   HIP_TRY(ctx, hipEventRecord(s.red1, rs));
   if (to_host) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * 96, hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums + WSUM_BYTES, d_err, 4, hipMemcpyDeviceToHost, rs));
@@ -338,7 +345,7 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
     memset(s.h_wsums, 0, WSUM_BYTES + 4);
     if ((rc = dev_alloc(ctx, s.d_wsums, WSUM_BYTES + 4))) return fail(rc);
     if ((rc = dev_alloc(ctx, s.d_buckets, (size_t)NWIN * HALF * REC_WORDS))) return fail(rc);
-    if ((rc = dev_alloc(ctx, s.d_partials, (size_t)NWIN * BPR_BLOCKS * XYZZ_WORDS))) return fail(rc);
+    if ((rc = dev_alloc(ctx, s.d_partials, (size_t)NWIN * (256 + 256 + 3) * XYZZ_WORDS))) return fail(rc);
     if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
     if (hipEventCreateWithFlags(&s.smvp_done, hipEventDisableTiming) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
     if (hipEventCreate(&s.red0) != hipSuccess || hipEventCreate(&s.red1) != hipSuccess) return fail(MSM_HIP_ERR_HIP);

@@ -529,73 +529,177 @@ __global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict_
 
 // ------------------------------------------------------------------------------------------------ stage 4: bucket reduce
 // S_w = sum_{k=1}^{h-1} k * B[k] + h * B[0]   (≙ bpr.template.wgsl:38-132, CPU models test/utils.rs:222-338).
-// Slot 0 carries weight h = 2^15, so it is treated as position 2^15: run j of length BPR_RUN covers positions
-// j*RUN+1 .. (j+1)*RUN (position q reads slot q & 32767).  Per run: descending running sum (m, g), then
-// g += (j*RUN) * m by double-and-add (stage_2 of the reference), then a workgroup tree reduction in LDS.
-// This stage is bound by the DEPTH of dependent group additions (a lone wave needs ~8 us per addition), not by work:
-// the reference's 128-bucket runs (256 threads per window) would be ~270 additions deep; 16-bucket runs on 2048 lanes
-// per window are 32 + 15 doublings/7 additions + 11 tree levels deep and cost a third of the work of 4-bucket runs.
-constexpr int BPR_RUN = 16;
-constexpr int BPR_THREADS = HALF / BPR_RUN;  // 2048 runs per window
-constexpr int BPR_BLOCK = 256;
-constexpr int BPR_BLOCKS = BPR_THREADS / BPR_BLOCK;  // 8 partial sums per window
+//
+// This stage is bound by the DEPTH of dependent group additions (a lone wave needs ~7.5 us per addition), not by bytes
+// or work.  The reference's running sums (128 buckets per thread, then a 15-bit double-and-add, bpr.template.wgsl:66-75,
+// 124-125) are ~270 additions deep; shortening the runs only trades depth for double-and-add work.  Instead the weighted
+// sum is decomposed into PLAIN sums, which are shallow trees.  Slot 0 carries weight h = 2^15, so bucket position q
+// (1..32768) reads slot q & 32767; write q - 1 = 128 * hi + lo:
+//     S = sum_q q B_q = 128 * sum_hi hi * R_hi  +  sum_lo (lo + 1) * C_lo,   R_hi = sum_lo B[hi][lo],  C_lo = sum_hi B[hi][lo]
+//   k_bpr_rowcol  the 256 row sums and 128 column sums of every window: 3 serial additions + a 5- or 6-level LDS tree
+//   k_bpr_w256    W(X) = sum_{i<256} i * X_i by the same split applied twice more (16 x 16, then 4 x 4): ~16 additions deep
+//   k_bpr_final   S = 128 * W(R) + W(C) + sum(C): 7 doublings + 2 additions, emits the window sum as canonical bytes
+// Work: 2 additions per bucket (the minimum of the running-sum scheme) + O(1) per window; depth ~33 additions.
+constexpr int BPR_ROWS = 256, BPR_COLS = 128;
 
-__global__ void __launch_bounds__(BPR_BLOCK) k_bpr_runs(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ partials) {
-  __shared__ uint32_t lds[BPR_BLOCK * XYZZ_WORDS];
-  const int w = blockIdx.y;
-  const int t = threadIdx.x;
-  const int j = blockIdx.x * BPR_BLOCK + t;  // run index
+// tree-add `count` (power of two) records spaced `stride` records apart starting at x[base]; every thread of the block
+// must call it (it contains barriers); on return x[base] holds the sum.  `id` enumerates jobs block-wide.
+__device__ __forceinline__ void lds_add_pair(uint32_t* x, int dst, int src) {
+  st_xyzz(x + dst * XYZZ_WORDS, g1_add(ld_xyzz(x + dst * XYZZ_WORDS), ld_xyzz(x + src * XYZZ_WORDS)));
+}
+
+// LOG_R = log2 of the buckets each thread adds serially before the LDS tree.  The host picks 3 (8 buckets) when many
+// windows are in flight -- fewer, better-filled wave-additions: the stage is then bound by the ~7 us a SIMD needs per
+// wave-addition -- and 2 for few windows, where only the depth counts.
+template <int LOG_R>
+__global__ void __launch_bounds__(256) k_bpr_rowcol(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ rows,
+                                                    uint32_t* __restrict__ cols) {
+  constexpr int R = 1 << LOG_R;
+  constexpr int ROW_LANES = BPR_COLS / R, COL_LANES = BPR_ROWS / R;  // threads per row / per column
+  constexpr int ROWS_PER_BLOCK = 256 / ROW_LANES, COLS_PER_BLOCK = 256 / COL_LANES;
+  constexpr int ROW_BLOCKS = BPR_ROWS / ROWS_PER_BLOCK;
+  __shared__ uint32_t x[256 * XYZZ_WORDS];
+  const int w = blockIdx.y, t = threadIdx.x;
   const uint32_t* bw = buckets + (size_t)w * HALF * REC_WORDS;
-  g1_xyzz m = g1_identity(), g = g1_identity();
-  for (int q = (j + 1) * BPR_RUN; q > j * BPR_RUN; q--) {
-    const g1_xyzz b = ld_rec(bw + (size_t)(q & (HALF - 1)) * REC_WORDS);
-    m = g1_add(m, b);
-    g = g1_add(g, m);
+  const bool row_block = (int)blockIdx.x < ROW_BLOCKS;
+  // element e = q - 1 = 128 * hi + lo  ->  slot (e + 1) & 32767
+  int e0, estep, group, lanes_per_group, out_index;
+  if (row_block) {  // R consecutive lo per thread
+    group = t / ROW_LANES;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + group, seg = t % ROW_LANES;
+    e0 = row * BPR_COLS + seg * R;
+    estep = 1;
+    lanes_per_group = ROW_LANES;
+    out_index = row;
+  } else {  // R consecutive hi per thread
+    group = t / COL_LANES;
+    const int col = ((int)blockIdx.x - ROW_BLOCKS) * COLS_PER_BLOCK + group, part = t % COL_LANES;
+    e0 = part * R * BPR_COLS + col;
+    estep = BPR_COLS;
+    lanes_per_group = COL_LANES;
+    out_index = col;
   }
-  const uint32_t s = (uint32_t)j * BPR_RUN;  // < 2^15
-  if (s != 0 && !m.inf) {
-    g1_xyzz sm = g1_identity();
-    for (int bit = 14; bit >= 0; bit--) {
-      sm = g1_double(sm);
-      if ((s >> bit) & 1u) sm = g1_add(sm, m);
-    }
-    g = g1_add(g, sm);
-  }
-  st_xyzz(lds + t * XYZZ_WORDS, g);
+  g1_xyzz acc = ld_rec(bw + (size_t)((e0 + 1) & (HALF - 1)) * REC_WORDS);
+#pragma unroll 1
+  for (int i = 1; i < R; i++) acc = g1_add(acc, ld_rec(bw + (size_t)((e0 + i * estep + 1) & (HALF - 1)) * REC_WORDS));
+  st_xyzz(x + t * XYZZ_WORDS, acc);
   __syncthreads();
-  for (int stride = BPR_BLOCK / 2; stride >= 1; stride >>= 1) {
-    if (t < stride) {
-      const g1_xyzz a = ld_xyzz(lds + t * XYZZ_WORDS);
-      const g1_xyzz b = ld_xyzz(lds + (t + stride) * XYZZ_WORDS);
-      st_xyzz(lds + t * XYZZ_WORDS, g1_add(a, b));
+  const int k = t & (lanes_per_group - 1);
+  for (int sft = lanes_per_group >> 1; sft >= 1; sft >>= 1) {
+    if (k < sft) lds_add_pair(x, t, t + sft);
+    __syncthreads();
+  }
+  if (k == 0) {
+    uint32_t* out = (row_block ? rows + (size_t)w * BPR_ROWS * XYZZ_WORDS : cols + (size_t)w * 256 * XYZZ_WORDS) + (size_t)out_index * XYZZ_WORDS;
+    for (int i = 0; i < XYZZ_WORDS; i++) out[i] = x[t * XYZZ_WORDS + i];
+  }
+}
+template <int LOG_R>
+constexpr int bpr_rowcol_blocks() {
+  return BPR_ROWS / (256 / (BPR_COLS >> LOG_R)) + BPR_COLS / (256 / (BPR_ROWS >> LOG_R));
+}
+
+// W(X) = sum_{i<256} i * X_i for X = rows (blockIdx.x == 0) or the columns padded to 256 with identities (blockIdx.x == 1);
+// out[w][blockIdx.x] = W(X); for the columns additionally out[w][2] = sum(X).
+__global__ void __launch_bounds__(256) k_bpr_w256(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ cols,
+                                                  uint32_t* __restrict__ out) {
+  __shared__ uint32_t x[256 * XYZZ_WORDS];  // X, then overlaid by the level-1 row / column partial sums
+  __shared__ uint32_t y[64 * XYZZ_WORDS];   // 4 x 4 stage, level 1
+  __shared__ uint32_t z[16 * XYZZ_WORDS];   // 4 x 4 stage, level 2: z[v*8 + which*4 + i]
+  __shared__ uint32_t u[8 * XYZZ_WORDS];    // u[0..3] W4 results (v*2 + which), u[4..5] W16 results
+  __shared__ uint32_t tot[8 * XYZZ_WORDS];  // running total of the 16 row sums
+  const int w = blockIdx.y, which_in = blockIdx.x, t = threadIdx.x;
+  const int a = t >> 4, b = t & 15;
+  g1_xyzz xi;
+  if (which_in == 0) xi = ld_xyzz(rows + ((size_t)w * BPR_ROWS + t) * XYZZ_WORDS);
+  else xi = t < BPR_COLS ? ld_xyzz(cols + ((size_t)w * 256 + t) * XYZZ_WORDS) : g1_identity();
+  st_xyzz(x + t * XYZZ_WORDS, xi);
+  __syncthreads();
+  // 16 x 16 split, level 1: threads with b < 8 add row pairs (own element + partner), the others add column pairs
+  g1_xyzz l1;
+  int l1_dst;
+  if (b < 8) {
+    l1 = g1_add(xi, ld_xyzz(x + (16 * a + b + 8) * XYZZ_WORDS));
+    l1_dst = a * 8 + b;  // row partials: [0, 128)
+  } else {
+    const int job = a * 8 + (b - 8), c = job & 15, pr = job >> 4;
+    l1 = g1_add(ld_xyzz(x + (16 * pr + c) * XYZZ_WORDS), ld_xyzz(x + (16 * (pr + 8) + c) * XYZZ_WORDS));
+    l1_dst = 128 + c * 8 + pr;  // column partials: [128, 256)
+  }
+  __syncthreads();
+  st_xyzz(x + l1_dst * XYZZ_WORDS, l1);
+  __syncthreads();
+  for (int sft = 4; sft >= 1; sft >>= 1) {  // 32 groups of 8 -> 1
+    if (t < 32 * sft) {
+      const int g = t / sft, k = t % sft;
+      lds_add_pair(x, g * 8 + k, g * 8 + k + sft);
     }
     __syncthreads();
   }
+  // now V0[i] = x[8 i] (16 row sums RR), V1[i] = x[128 + 8 i] (16 column sums CC)
+  // 4 x 4 split of both 16-vectors, level 1 (32 jobs) + first level of the total of V0 (8 jobs)
+  if (t < 32) {
+    const int v = t >> 4, job = t & 15;
+    const uint32_t* V = x + (v * 128) * XYZZ_WORDS;
+    g1_xyzz r;
+    if (job < 8) {  // row pair: i = job >> 1, j = job & 1 : V[4i + j] + V[4i + j + 2]
+      const int i = job >> 1, j = job & 1;
+      r = g1_add(ld_xyzz(V + (8 * (4 * i + j)) * XYZZ_WORDS), ld_xyzz(V + (8 * (4 * i + j + 2)) * XYZZ_WORDS));
+    } else {  // column pair: j = (job - 8) >> 1, pr = job & 1 : V[4 pr + j] + V[4 (pr + 2) + j]
+      const int j = (job - 8) >> 1, pr = job & 1;
+      r = g1_add(ld_xyzz(V + (8 * (4 * pr + j)) * XYZZ_WORDS), ld_xyzz(V + (8 * (4 * (pr + 2) + j)) * XYZZ_WORDS));
+    }
+    st_xyzz(y + (v * 16 + job) * XYZZ_WORDS, r);  // y[v][0..7] row pairs (i*2+j), y[v][8..15] column pairs (j*2+pr)
+  } else if (t >= 64 && t < 72) {
+    const int k = t - 64;
+    st_xyzz(tot + k * XYZZ_WORDS, g1_add(ld_xyzz(x + (8 * k) * XYZZ_WORDS), ld_xyzz(x + (8 * (k + 8)) * XYZZ_WORDS)));
+  }
+  __syncthreads();
+  // level 2: r_i, c_j (16 jobs) ; total 8 -> 4
+  if (t < 16) {
+    const int v = t >> 3, q = t & 7;  // q < 4: r_q ; q >= 4: c_{q-4}
+    const int base = v * 16 + (q < 4 ? 2 * q : 8 + 2 * (q - 4));
+    st_xyzz(z + (v * 8 + q) * XYZZ_WORDS, g1_add(ld_xyzz(y + base * XYZZ_WORDS), ld_xyzz(y + (base + 1) * XYZZ_WORDS)));
+  } else if (t >= 64 && t < 68) {
+    lds_add_pair(tot, t - 64, t - 64 + 4);
+  }
+  __syncthreads();
+  // W4(u) = u1 + 2 u2 + 3 u3 = (u1 + u3) + 2 (u2 + u3): 4 jobs (v, which) ; total 4 -> 2
+  if (t < 4) {
+    const uint32_t* q4 = z + (t * 4) * XYZZ_WORDS;  // t = v*2 + which  ->  z[v*8 + which*4 ..]
+    const g1_xyzz u1 = ld_xyzz(q4 + 1 * XYZZ_WORDS), u2 = ld_xyzz(q4 + 2 * XYZZ_WORDS), u3 = ld_xyzz(q4 + 3 * XYZZ_WORDS);
+    st_xyzz(u + t * XYZZ_WORDS, g1_add(g1_add(u1, u3), g1_double(g1_add(u2, u3))));  // 3 additions + 1 doubling deep
+  } else if (t >= 64 && t < 66) {
+    lds_add_pair(tot, t - 64, t - 64 + 2);
+  }
+  __syncthreads();
+  // W16(V) = 4 * W4(r) + W4(c): 2 jobs ; total 2 -> 1
+  if (t < 2) {
+    const g1_xyzz wr = ld_xyzz(u + (t * 2) * XYZZ_WORDS), wc = ld_xyzz(u + (t * 2 + 1) * XYZZ_WORDS);
+    st_xyzz(u + (4 + t) * XYZZ_WORDS, g1_add(g1_double(g1_double(wr)), wc));
+  } else if (t == 64) {
+    lds_add_pair(tot, 0, 1);
+  }
+  __syncthreads();
+  // W256(X) = 16 * W16(RR) + W16(CC)
   if (t == 0) {
-    uint32_t* out = partials + ((size_t)w * BPR_BLOCKS + blockIdx.x) * XYZZ_WORDS;
-    for (int i = 0; i < XYZZ_WORDS; i++) out[i] = lds[i];
+    g1_xyzz hi = ld_xyzz(u + 4 * XYZZ_WORDS);
+    for (int i = 0; i < 4; i++) hi = g1_double(hi);
+    st_xyzz(out + ((size_t)w * 3 + which_in) * XYZZ_WORDS, g1_add(hi, ld_xyzz(u + 5 * XYZZ_WORDS)));
+  } else if (t == 64 && which_in == 1) {
+    uint32_t* o = out + ((size_t)w * 3 + 2) * XYZZ_WORDS;
+    for (int i = 0; i < XYZZ_WORDS; i++) o[i] = tot[i];
   }
 }
 
-// one 64-lane block per window: tree-add the BPR_BLOCKS partial sums, emit the window sum as canonical Jacobian bytes
-__global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ partials, uint32_t* __restrict__ wsums) {
-  static_assert(BPR_BLOCKS <= 64 && (BPR_BLOCKS & (BPR_BLOCKS - 1)) == 0, "one wave reduces the block partials");
-  __shared__ uint32_t lds[BPR_BLOCKS * XYZZ_WORDS];
-  const int w = blockIdx.x, t = threadIdx.x;
-  if (t < BPR_BLOCKS) {
-    const uint32_t* in = partials + ((size_t)w * BPR_BLOCKS + t) * XYZZ_WORDS;
-    for (int i = 0; i < XYZZ_WORDS; i++) lds[t * XYZZ_WORDS + i] = in[i];
-  }
-  __syncthreads();
-  for (int stride = BPR_BLOCKS / 2; stride >= 1; stride >>= 1) {
-    if (t < stride) {
-      const g1_xyzz a = ld_xyzz(lds + t * XYZZ_WORDS);
-      const g1_xyzz b = ld_xyzz(lds + (t + stride) * XYZZ_WORDS);
-      st_xyzz(lds + t * XYZZ_WORDS, g1_add(a, b));
-    }
-    __syncthreads();
-  }
-  if (t == 0) st_jacobian_plain(wsums + (size_t)w * 24, ld_xyzz(lds));
+// one lane per window: S = 128 * W(R) + W(C) + sum(C), emitted as canonical Jacobian bytes
+__global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ parts, int w_count, uint32_t* __restrict__ wsums) {
+  const int w = threadIdx.x;
+  if (w >= w_count) return;
+  g1_xyzz acc = ld_xyzz(parts + ((size_t)w * 3 + 0) * XYZZ_WORDS);
+  for (int i = 0; i < 7; i++) acc = g1_double(acc);
+  acc = g1_add(acc, g1_add(ld_xyzz(parts + ((size_t)w * 3 + 1) * XYZZ_WORDS), ld_xyzz(parts + ((size_t)w * 3 + 2) * XYZZ_WORDS)));
+  st_jacobian_plain(wsums + (size_t)w * 24, acc);
 }
 
 // ------------------------------------------------------------------------------------------------ samplers
