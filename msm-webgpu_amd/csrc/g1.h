@@ -106,7 +106,8 @@ FQ_HD void g1_madd(g1_xyzz& a, const fq& px, const fq& py) {
   const fq RR = fq_sqr(R);                              // 64 p^2
   const fq X3 = fq_sub<7>(RR, fq_add(PPP, fq_dbl(Q)));  // PPP + 2Q < 6p -> X3 < 9p
   const fq T = fq_sub<10>(Q, X3);                       // X3 < 9p      -> T < 12p
-  a.y = fq_sub<3>(fq_mul(R, T), fq_mul(a.y, PPP));      // < 2p         -> Y3 < 5p
+  const fq nY = fq_sub<6>(fq_zero(), a.y);              // Y < 5p       -> -Y < 6p
+  a.y = fq_mul2(R, T, nY, PPP);                         // 96 + 12 p^2, one reduction -> Y3 < 2p
   a.x = X3;
   a.zz = fq_mul(a.zz, PP);
   a.zzz = fq_mul(a.zzz, PPP);
@@ -133,7 +134,8 @@ FQ_HD g1_xyzz g1_add(const g1_xyzz& a, const g1_xyzz& b) {
   const fq RR = fq_sqr(R);
   r.x = fq_sub<7>(RR, fq_add(PPP, fq_dbl(Q)));          // < 6p         -> X3 < 9p
   const fq T = fq_sub<10>(Q, r.x);                      // X3 < 9p      -> T < 12p
-  r.y = fq_sub<3>(fq_mul(R, T), fq_mul(S1, PPP));       // < 2p         -> Y3 < 5p
+  const fq nS1 = fq_sub<3>(fq_zero(), S1);              // S1 < 2p      -> -S1 < 3p
+  r.y = fq_mul2(R, T, nS1, PPP);                        // 60 + 6 p^2, one reduction -> Y3 < 2p
   r.zz = fq_mul(fq_mul(a.zz, b.zz), PP);
   r.zzz = fq_mul(fq_mul(a.zzz, b.zzz), PPP);
   r.inf = false;
