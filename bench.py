@@ -76,6 +76,9 @@ def main():
     ctx.set_bases(points)
     w_begin, w_end = window_range(rank, world)
     w_local = w_end - w_begin
+    # tuning aid (never a reported result): BENCH_EMULATE_WORLD=8 makes this single rank do the per-rank share of an
+    # 8-rank run (2 windows) through the sharded pipeline; the MSM value is then NOT a whole-job figure
+    emulate = int(os.environ.get("BENCH_EMULATE_WORLD", "0"))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -84,8 +87,11 @@ def main():
         torch.cuda.synchronize()
 
     smvp_ms, stage_acc = [], {}
-    sharded = world > 1 or force_sharded
+    sharded = world > 1 or force_sharded or emulate > 1
     pipe = ShardedMsmPipeline(ctx, rank, world) if sharded else None
+    if emulate > 1:
+        pipe.w_begin, pipe.w_end = window_range(0, emulate)
+        w_local = pipe.w_end - pipe.w_begin
 
     def note_stages():
         st = ctx.stage_ms()
@@ -137,7 +143,7 @@ def main():
 
     # single-MSM latency (no pipelining, stages not overlapped) -- reported beside the throughput figure
     latency_ms, isolated = None, None
-    if world == 1:
+    if world == 1 and emulate <= 1:
         lat = []
         for i in range(5):
             torch.cuda.synchronize()
@@ -181,6 +187,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                      "kernel_ms": smvp_avg_ms},
         "stage_ms": {k: v / len(smvp_ms) for k, v in stage_acc.items()},
+        "emulated_world": emulate if emulate > 1 else None,
         "latency_ms_single_msm": latency_ms,
         "stage_ms_single_msm": isolated,
     }

@@ -64,6 +64,7 @@ struct msm_hip_ctx {
   uint16_t* d_digits = nullptr;  // digit-code planes, only written when debug read-back is enabled
   bool debug = false;
   uint32_t* d_counts = nullptr;      // [W][tiles][128]
+  uint32_t* d_bin_total = nullptr;   // [W][128]
   uint32_t* d_coarse_ptr = nullptr;  // [W][129]
   uint32_t* d_col_ptr = nullptr;     // [W][32769]
   uint32_t* d_tmp_val = nullptr;     // [W][stride] coarse-bin order
@@ -71,7 +72,7 @@ struct msm_hip_ctx {
   uint32_t* d_val = nullptr;         // [W][stride] slot order
   uint32_t* d_heads = nullptr;       // [W][chunks] XYZZ records
   uint32_t* d_tails = nullptr;       // [W][chunks] XYZZ records
-  uint32_t* d_tail_slot = nullptr;   // [W][chunks]
+  uint32_t* d_chunk_slot = nullptr;  // [W][chunks] bucket slot of every SMVP chunk's first entry
   uint32_t* d_err = nullptr;
   uint8_t* d_stage = nullptr;  // staging for host byte inputs of set_bases / test hooks
   size_t cap_stage = 0;
@@ -117,8 +118,16 @@ int ensure_stage(msm_hip_ctx* ctx, size_t bytes) {
 }
 
 // entries per SMVP lane: about SMVP_TARGET_LANES lanes over all windows of the run, a multiple of 4 within the kernel's limits
+inline size_t target_lanes() {  // MSM_HIP_TARGET_LANES overrides the default for tuning experiments
+  static const size_t v = [] {
+    const char* e = getenv("MSM_HIP_TARGET_LANES");
+    const long x = e ? atol(e) : 0;
+    return x >= 1024 ? (size_t)x : (size_t)SMVP_TARGET_LANES;
+  }();
+  return v;
+}
 inline uint32_t chunk_len_for(size_t n, int w_count) {
-  size_t len = (n * (size_t)w_count + SMVP_TARGET_LANES - 1) / SMVP_TARGET_LANES;
+  size_t len = (n * (size_t)w_count + target_lanes() - 1) / target_lanes();
   len = (len + 3) & ~(size_t)3;
   if (len < (size_t)SMVP_CHUNK_MIN) len = SMVP_CHUNK_MIN;
   if (len > (size_t)SMVP_CHUNK_MAX) len = SMVP_CHUNK_MAX;
@@ -155,7 +164,7 @@ int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count) {
   if ((rc = dev_alloc(ctx, ctx->d_val, stride * NWIN))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_heads, recs * REC_WORDS))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_tails, recs * REC_WORDS))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_tail_slot, recs))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_chunk_slot, recs))) return rc;
   if (ctx->debug && (rc = dev_alloc(ctx, ctx->d_digits, cap * NWIN))) return rc;
   ctx->cap_n = cap;
   ctx->stride = stride;
@@ -191,25 +200,24 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   // the slot's previous occupant (bucket reduce + copies on the reduce stream) must have drained
   HIP_TRY(ctx, hipStreamWaitEvent(st, s.done, 0));
   HIP_TRY(ctx, hipMemsetAsync(d_err, 0, 4, st));
-  HIP_TRY(ctx, hipMemsetAsync(s.d_buckets, 0, (size_t)w_count * HALF * REC_WORDS * 4, st));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_tail_slot, 0xFF, (size_t)w_count * chunks * 4, st));
 
   HIP_TRY(ctx, hipEventRecord(s.ev[0], st));
   hipLaunchKernelGGL(k_count, dim3(tiles), dim3(256), 0, st, d_scalars, n, tile_len, tiles, w_begin, w_count, ctx->d_counts, digits, d_err);
   HIP_TRY(ctx, hipEventRecord(s.ev[1], st));
-  hipLaunchKernelGGL(k_scan_coarse, dim3(w_count), dim3(1024), 0, st, ctx->d_counts, tiles, ctx->d_coarse_ptr);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total);
+  hipLaunchKernelGGL(k_bin_starts, dim3(w_count), dim3(128), 0, st, ctx->d_bin_total, ctx->d_coarse_ptr);
   HIP_TRY(ctx, hipEventRecord(s.ev[2], st));
   hipLaunchKernelGGL(k_scatter_coarse, dim3(tiles), dim3(256), 0, st, d_scalars, n, stride, tile_len, tiles, w_begin, w_count,
                      ctx->d_counts, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine);
   HIP_TRY(ctx, hipEventRecord(s.ev[3], st));
   hipLaunchKernelGGL(k_sort_fine, dim3(NCOARSE, w_count), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
-                     ctx->d_col_ptr, ctx->d_val);
+                     ctx->d_col_ptr, ctx->d_val, chunks, chunk_len, ctx->d_chunk_slot);
   HIP_TRY(ctx, hipEventRecord(s.ev[4], st));
   hipLaunchKernelGGL(k_smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, ctx->d_col_ptr, ctx->d_val, stride,
-                     chunks, chunk_len, s.d_buckets, ctx->d_heads, ctx->d_tails, ctx->d_tail_slot);
+                     chunks, chunk_len, ctx->d_chunk_slot, s.d_buckets, ctx->d_heads, ctx->d_tails);
   HIP_TRY(ctx, hipEventRecord(s.ev[5], st));
-  hipLaunchKernelGGL(k_smvp_stitch, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_col_ptr, chunks, chunk_len, ctx->d_heads,
-                     ctx->d_tails, ctx->d_tail_slot, s.d_buckets);
+  hipLaunchKernelGGL(k_smvp_stitch, dim3(HALF / 256, w_count), dim3(256), 0, st, ctx->d_col_ptr, chunks, chunk_len, ctx->d_heads,
+                     ctx->d_tails, s.d_buckets);
   HIP_TRY(ctx, hipEventRecord(s.ev[6], st));
   HIP_TRY(ctx, hipEventRecord(s.smvp_done, st));
 
@@ -336,6 +344,7 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
   for (int k = 0; k < 2; k++)
     if (hipStreamCreateWithFlags(&ctx->reduce_stream[k], hipStreamNonBlocking) != hipSuccess) return fail(MSM_HIP_ERR_NO_DEVICE);
   if ((rc = dev_alloc(ctx, ctx->d_counts, (size_t)NWIN * MAX_TILES * NCOARSE))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_bin_total, (size_t)NWIN * NCOARSE))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_coarse_ptr, (size_t)NWIN * (NCOARSE + 1)))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_col_ptr, (size_t)NWIN * (HALF + 1)))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_err, 1))) return fail(rc);
@@ -362,8 +371,8 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipStream_t r : ctx->reduce_stream)
     if (r) (void)hipStreamSynchronize(r);
-  void* bufs[] = {ctx->d_bases,    ctx->d_scalars, ctx->d_digits, ctx->d_counts, ctx->d_coarse_ptr, ctx->d_col_ptr, ctx->d_tmp_val,
-                  ctx->d_tmp_fine, ctx->d_val,     ctx->d_heads,  ctx->d_tails,  ctx->d_tail_slot,  ctx->d_err,     ctx->d_stage};
+  void* bufs[] = {ctx->d_bases,    ctx->d_scalars, ctx->d_digits, ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_col_ptr, ctx->d_tmp_val,
+                  ctx->d_tmp_fine, ctx->d_val,     ctx->d_heads,  ctx->d_tails,  ctx->d_chunk_slot,  ctx->d_err,     ctx->d_stage};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int k = 0; k < NSLOT; k++) {

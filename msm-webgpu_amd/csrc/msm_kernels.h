@@ -154,29 +154,38 @@ __global__ void __launch_bounds__(256) k_convert_points(const uint32_t* __restri
 
 // ------------------------------------------------------------------------------------------------ stage 1+2: recode + sort
 // Signed 16-bit digit recode (≙ decompose_scalars.template.wgsl:83-112, CPU model test/utils.rs:121-161):
-//   d = raw + carry; if d >= 2^15 { d -= 2^16; carry = 1 }.  Signed-magnitude code = sign << 15 | (|d| & 0x7fff):
+//   d = raw + carry; if d >= 2^15 { d -= 2^16; carry = 1 }  -- computed per window without the serial carry chain.  Signed-magnitude code = sign << 15 | (|d| & 0x7fff):
 //   0 = digit 0 (contributes nothing), 0x8000 = digit -2^15 (bucket slot 0).
 //
 // The reference's transpose (transpose.template.wgsl:32-76) is a counting sort run by 16 threads.  Here it is a
 // two-level LDS counting sort over the 15-bit bucket slot, and the recode is fused into both of its global passes
 // (scalars are re-read instead of materialising 16 digit planes: 32 B per scalar either way):
 //   k_count          per tile of scalars: LDS histogram of the 128 coarse bins (slot >> 8) of every window
-//   k_scan_coarse    per window: prefix over (coarse bin, tile) -> start of each (bin, tile) run
+//   k_scan_tiles, k_bin_starts   per (window, coarse bin): prefix over tiles; per window: start of every coarse bin
 //   k_scatter_coarse per tile: LDS-ranked scatter of (index | sign << 31, slot & 255) into coarse-bin order
 //   k_sort_fine      per (window, coarse bin): LDS counting sort over its 256 slots -> val_idxs + col_ptr
 // Order inside a slot is the arrival order of LDS atomics; the group sum does not depend on it.
 constexpr int NCOARSE = 128;       // coarse bins per window
 constexpr int FINE = HALF / NCOARSE;  // 256 slots per coarse bin
 
-__device__ __forceinline__ uint32_t recode_step(uint32_t raw, uint32_t& carry) {
-  const uint32_t d = raw + carry;  // 0 .. 65536
-  if (d >= (uint32_t)HALF) {
-    const uint32_t mag = 65536u - d;  // 0 .. 32768 (0 only for d == 65536: digit 0 with carry out)
-    carry = 1;
-    return mag == 0 ? 0u : (0x8000u | (mag & 0x7fffu));
+// Adding 0x8000 to every 16-bit halfword of the 256-bit scalar (one multiword addition) performs the whole carry chain
+// at once: halfword w of t = s + 0x8000...8000 is the reference's biased digit d_w + 2^15 (decompose_scalars.template.wgsl:
+// 105-112), and the carry out of bit 255 is its "final carry".  Each window's digit is then read independently.
+__device__ __forceinline__ uint32_t bias_scalar(const uint32_t s[8], uint32_t t[8]) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (uint64_t)s[i] + 0x80008000u;
+    t[i] = (uint32_t)c;
+    c >>= 32;
   }
-  carry = 0;
-  return d;
+  return (uint32_t)c;  // 1: the recode does not fit 16 windows ("final carry is 1", test/utils.rs:150-152)
+}
+// biased digit b = d + 2^15 of window w  ->  signed-magnitude code
+__device__ __forceinline__ uint32_t code_of_window(const uint32_t t[8], int w) {
+  const uint32_t b = (t[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+  if (b >= (uint32_t)HALF) return b - (uint32_t)HALF;        // d = 0 .. 2^15 - 1 (0: no entry)
+  return 0x8000u | (((uint32_t)HALF - b) & 0x7fffu);          // d = -(2^15 - b), magnitude 1 .. 2^15 (2^15 -> slot 0)
 }
 
 __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles,
@@ -190,19 +199,18 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
   const size_t end = base + tile_len < n ? base + tile_len : n;
   uint32_t bad = 0;
   for (size_t i = base + tid; i < end; i += 256) {
-    uint32_t s[8];
+    uint32_t s[8], tb[8];
     ld8(scalars + i * 8, s);
-    uint32_t carry = 0;
+    bad |= bias_scalar(s, tb);
 #pragma unroll
     for (int w = 0; w < NWIN; w++) {
-      const uint32_t code = recode_step((s[w >> 1] >> ((w & 1) * 16)) & 0xffffu, carry);
       const int lw = w - w_begin;
       if (lw >= 0 && lw < w_count) {
+        const uint32_t code = code_of_window(tb, w);
         if (code != 0) atomicAdd(&cnt[lw * NCOARSE + ((code & 0x7fffu) >> 8)], 1u);
         if (digits_dbg) digits_dbg[(size_t)lw * n + i] = (uint16_t)code;
       }
     }
-    bad |= carry;  // "final carry is 1", test/utils.rs:150-152
   }
   if (bad) atomicOr(err, ERRBIT_SCALAR_CARRY);
   __syncthreads();
@@ -211,41 +219,44 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
     counts[((size_t)(i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[i];
 }
 
-// One block per window, 1024 threads = 8 tile groups x 128 bins.  In place: counts[lw][tile][bin] becomes the number of
-// entries of that bin in earlier tiles; coarse_ptr[lw][0..128] = start of every coarse bin, [128] = entries in the window.
-__global__ void __launch_bounds__(1024) k_scan_coarse(uint32_t* __restrict__ counts, uint32_t tiles, uint32_t* __restrict__ coarse_ptr) {
-  __shared__ uint32_t gsum[8][NCOARSE];
-  __shared__ uint32_t binstart[NCOARSE + 1];
-  const int lw = blockIdx.x, bin = threadIdx.x & (NCOARSE - 1), grp = threadIdx.x >> 7;
-  uint32_t* c = counts + (size_t)lw * tiles * NCOARSE;
-  const uint32_t per = (tiles + 7) / 8;
-  const uint32_t t0 = grp * per, t1 = (t0 + per < tiles) ? t0 + per : tiles;
-  uint32_t sum = 0;
-  for (uint32_t t = t0; t < t1; t++) sum += c[(size_t)t * NCOARSE + bin];
-  gsum[grp][bin] = sum;
-  __syncthreads();
-  if (grp == 0) {
-    uint32_t total = 0;
-    for (int g = 0; g < 8; g++) {
-      const uint32_t v = gsum[g][bin];
-      gsum[g][bin] = total;  // entries of this bin in earlier tile groups
-      total += v;
+// One wave per (window, coarse bin): in place, counts[lw][tile][bin] becomes the number of entries of that bin in earlier
+// tiles; bin_total[lw][bin] receives the bin's size.  k_bin_starts then turns the totals into coarse_ptr[lw][0..128]
+// (start of every coarse bin; [128] = entries in the window).
+__global__ void __launch_bounds__(256) k_scan_tiles(uint32_t* __restrict__ counts, uint32_t tiles, uint32_t* __restrict__ bin_total) {
+  const int lw = blockIdx.y, lane = threadIdx.x & 63;
+  const int bin = blockIdx.x * 4 + (threadIdx.x >> 6);
+  uint32_t* c = counts + (size_t)lw * tiles * NCOARSE + bin;
+  uint32_t run = 0;
+  for (uint32_t t0 = 0; t0 < tiles; t0 += 64) {
+    const uint32_t t = t0 + lane;
+    const uint32_t v = t < tiles ? c[(size_t)t * NCOARSE] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off);
+      if (lane >= off) x += y;
     }
-    binstart[bin + 1] = total;
+    if (t < tiles) c[(size_t)t * NCOARSE] = run + x - v;
+    run += __shfl(x, 63);
   }
+  if (lane == 0) bin_total[lw * NCOARSE + bin] = run;
+}
+
+__global__ void __launch_bounds__(128) k_bin_starts(const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr) {
+  __shared__ uint32_t wave_tot[2];
+  const int lw = blockIdx.x, t = threadIdx.x, lane = t & 63;
+  const uint32_t v = bin_total[lw * NCOARSE + t];
+  uint32_t x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wave_tot[t >> 6] = x;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    binstart[0] = 0;
-    for (int b = 0; b < NCOARSE; b++) binstart[b + 1] += binstart[b];
-  }
-  __syncthreads();
-  uint32_t run = gsum[grp][bin];
-  for (uint32_t t = t0; t < t1; t++) {
-    const uint32_t v = c[(size_t)t * NCOARSE + bin];
-    c[(size_t)t * NCOARSE + bin] = run;
-    run += v;
-  }
-  if (threadIdx.x <= NCOARSE) coarse_ptr[(size_t)lw * (NCOARSE + 1) + threadIdx.x] = binstart[threadIdx.x];
+  const uint32_t incl = x + (t >= 64 ? wave_tot[0] : 0u);
+  coarse_ptr[(size_t)lw * (NCOARSE + 1) + t] = incl - v;
+  if (t == NCOARSE - 1) coarse_ptr[(size_t)lw * (NCOARSE + 1) + NCOARSE] = incl;
 }
 
 // Exclusive prefix sum of one value per thread over a 256-thread block (4 waves); `wave_tot` is 4 words of LDS.
@@ -289,20 +300,14 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
   const size_t tile_base = (size_t)blockIdx.x * tile_len;
   const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
   for (size_t sub = tile_base; sub < tile_end; sub += SCAT_SUB) {
-    // recode this thread's 8 scalars; codes packed two per register: code[j][w] = (pk[j][w >> 1] >> 16 (w & 1)) & 0xffff
-    uint32_t pk[8][8];
+    // this thread's 8 biased scalars stay in registers; every window's digit code is read from them
+    uint32_t sc[8][8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const size_t i = sub + (size_t)j * 256 + tid;
-      uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (i < tile_end) ld8(scalars + i * 8, s);  // an all-zero scalar recodes to all-zero codes: no entries
-      uint32_t carry = 0;
-#pragma unroll
-      for (int h = 0; h < 8; h++) {
-        const uint32_t c0 = recode_step(s[h] & 0xffffu, carry);
-        const uint32_t c1 = recode_step(s[h] >> 16, carry);
-        pk[j][h] = c0 | (c1 << 16);
-      }
+      uint32_t raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // an all-zero scalar recodes to all-zero digits: no entries
+      if (i < tile_end) ld8(scalars + i * 8, raw);
+      (void)bias_scalar(raw, sc[j]);
     }
 #pragma unroll
     for (int w = 0; w < NWIN; w++) {
@@ -313,7 +318,7 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
       uint32_t rank[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const uint32_t code = (pk[j][w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+        const uint32_t code = code_of_window(sc[j], w);
         rank[j] = code ? atomicAdd(&hist[(code & 0x7fffu) >> 8], 1u) : 0u;
       }
       __syncthreads();
@@ -324,7 +329,7 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
       const uint32_t total = lstart[NCOARSE - 1] + hist[NCOARSE - 1];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const uint32_t code = (pk[j][w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+        const uint32_t code = code_of_window(sc[j], w);
         if (code) {
           const uint32_t slot = code & 0x7fffu, bin = slot >> 8;
           const uint32_t e = lstart[bin] + rank[j];
@@ -351,7 +356,8 @@ constexpr int FINE_CHUNK = 4096;  // entries staged per block iteration (16 per 
 
 __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ tmp_val, const uint8_t* __restrict__ tmp_fine, size_t stride,
                                                    const uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ col_ptr,
-                                                   uint32_t* __restrict__ val_idxs) {
+                                                   uint32_t* __restrict__ val_idxs, uint32_t chunks, uint32_t chunk_len,
+                                                   uint32_t* __restrict__ chunk_slot) {
   __shared__ uint32_t hist[FINE];
   __shared__ uint32_t lstart[FINE];
   __shared__ uint32_t gpos[FINE];
@@ -373,6 +379,10 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
     gpos[tid] = begin + excl;
     col_ptr[(size_t)lw * (HALF + 1) + bin * FINE + tid] = begin + excl;
     if (bin == NCOARSE - 1 && tid == FINE - 1) col_ptr[(size_t)lw * (HALF + 1) + HALF] = end;
+    // SMVP chunks whose first entry lies in this slot's run [first, last)
+    const uint32_t first = begin + excl, last = first + hist[tid];
+    for (uint32_t c = (first + chunk_len - 1) / chunk_len; c < chunks && (uint64_t)c * chunk_len < last; c++)
+      chunk_slot[(size_t)lw * chunks + c] = (uint32_t)(bin * FINE + tid);
   }
   __syncthreads();
   // pass 2: LDS-staged scatter, FINE_CHUNK entries at a time
@@ -418,12 +428,12 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
 // The reference gives one thread one bucket, so a wave runs as long as its fullest bucket.  Here every lane owns a
 // fixed-length chunk of `chunk_len` consecutive entries of the slot-sorted list -- equal work per lane whatever the bucket
 // sizes -- and flushes its accumulator whenever the slot changes.  The host picks chunk_len (a multiple of 4 in
-// [SMVP_CHUNK_MIN, SMVP_CHUNK_MAX]) so that about SMVP_TARGET_LANES lanes exist: 4 waves per SIMD in one balanced round.  Runs that cross a chunk boundary leave a "tail" piece
+// [SMVP_CHUNK_MIN, SMVP_CHUNK_MAX]) so that about SMVP_TARGET_LANES lanes exist (one and a half rounds of 4 waves per SIMD).  Runs that cross a chunk boundary leave a "tail" piece
 // (in the chunk where the run starts) and "head" pieces (in the chunks it continues into); k_smvp_stitch adds them.
 // Buckets and pieces are stored as raw XYZZ records (no multiplication on the flush path).
 constexpr int SMVP_CHUNK_MIN = 8;
 constexpr int SMVP_CHUNK_MAX = 1024;
-constexpr int SMVP_TARGET_LANES = 1 << 18;  // 256 CUs x 4 SIMDs x 4 waves x 64 lanes
+constexpr int SMVP_TARGET_LANES = 3 << 17;  // 1.5 x (256 CUs x 4 SIMDs x 4 waves x 64 lanes): measured optimum of SMVP + stitch
 constexpr int REC_WORDS = 40;  // 160 B record: 36 limbs, valid flag, 3 pad words; 16-byte aligned
 
 __device__ __forceinline__ void st_rec(uint32_t* p, const g1_xyzz& a) {
@@ -460,8 +470,9 @@ __device__ __forceinline__ g1_xyzz ld_rec(const uint32_t* p) {
 
 __global__ void __launch_bounds__(256, 4) k_smvp_chunks(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ col_ptr,
                                                      const uint32_t* __restrict__ val_idxs, size_t stride, uint32_t chunks,
-                                                     uint32_t chunk_len, uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
-                                                     uint32_t* __restrict__ tails, uint32_t* __restrict__ tail_slot) {
+                                                     uint32_t chunk_len, const uint32_t* __restrict__ chunk_slot,
+                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
+                                                     uint32_t* __restrict__ tails) {
   const int lw = blockIdx.y;
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;
   const uint32_t* cp = col_ptr + (size_t)lw * (HALF + 1);
@@ -470,13 +481,8 @@ __global__ void __launch_bounds__(256, 4) k_smvp_chunks(const uint32_t* __restri
   if (c >= chunks || begin64 >= nw) return;
   const uint32_t begin = (uint32_t)begin64;
   const uint32_t end = (nw - begin > chunk_len) ? begin + chunk_len : nw;
-  // slot containing entry `begin`: largest s with cp[s] <= begin  (cp[0] = 0 <= begin < nw = cp[HALF])
-  uint32_t lo = 0, hi = HALF;
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (cp[mid] <= begin) lo = mid; else hi = mid;
-  }
-  uint32_t s = lo, run_begin = cp[s], run_end = cp[s + 1];
+  // slot containing entry `begin` (cp[s] <= begin < cp[s + 1]), tabulated by k_sort_fine
+  uint32_t s = chunk_slot[(size_t)lw * chunks + c], run_begin = cp[s], run_end = cp[s + 1];
   const uint32_t* vi = val_idxs + (size_t)lw * stride;
   const size_t rec = ((size_t)lw * chunks + c) * REC_WORDS;
   g1_xyzz acc = g1_identity();
@@ -505,26 +511,29 @@ __global__ void __launch_bounds__(256, 4) k_smvp_chunks(const uint32_t* __restri
     st_rec(heads + rec, acc);  // continuation of a run from an earlier chunk (it may continue further)
   } else {
     st_rec(tails + rec, acc);  // run starts here and continues into the next chunk(s)
-    tail_slot[(size_t)lw * chunks + c] = s;
   }
 }
 
-// one lane per chunk that owns an open tail: bucket = tail + every head piece until the run ends
+// One lane per bucket slot: empty slots get the identity record (no memset of the bucket array is needed), runs that lie
+// inside one chunk were already written by k_smvp_chunks, and a run that spans chunks c0 < ... < c1 is the tail piece of
+// c0 plus the head pieces of c0+1 .. c1.
 __global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict__ col_ptr, uint32_t chunks, uint32_t chunk_len,
                                                      const uint32_t* __restrict__ heads, const uint32_t* __restrict__ tails,
-                                                     const uint32_t* __restrict__ tail_slot, uint32_t* __restrict__ buckets) {
+                                                     uint32_t* __restrict__ buckets) {
   const int lw = blockIdx.y;
-  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= chunks) return;
-  const uint32_t s = tail_slot[(size_t)lw * chunks + c];
-  if (s == 0xffffffffu) return;
-  const uint32_t run_end = col_ptr[(size_t)lw * (HALF + 1) + s + 1];
-  g1_xyzz acc = ld_rec(tails + ((size_t)lw * chunks + c) * REC_WORDS);
-  for (uint32_t c2 = c + 1; c2 < chunks; c2++) {
-    acc = g1_add(acc, ld_rec(heads + ((size_t)lw * chunks + c2) * REC_WORDS));
-    if ((uint64_t)run_end <= ((uint64_t)c2 + 1) * chunk_len) break;
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;  // < HALF by grid construction
+  const uint32_t* cp = col_ptr + (size_t)lw * (HALF + 1);
+  const uint32_t b = cp[s], e = cp[s + 1];
+  uint32_t* out = buckets + ((size_t)lw * HALF + s) * REC_WORDS;
+  if (b == e) {
+    st_rec(out, g1_identity());
+    return;
   }
-  st_rec(buckets + ((size_t)lw * HALF + s) * REC_WORDS, acc);
+  const uint32_t c0 = b / chunk_len, c1 = (e - 1) / chunk_len;
+  if (c0 == c1) return;
+  g1_xyzz acc = ld_rec(tails + ((size_t)lw * chunks + c0) * REC_WORDS);
+  for (uint32_t c = c0 + 1; c <= c1; c++) acc = g1_add(acc, ld_rec(heads + ((size_t)lw * chunks + c) * REC_WORDS));
+  st_rec(out, acc);
 }
 
 // ------------------------------------------------------------------------------------------------ stage 4: bucket reduce

@@ -102,6 +102,6 @@ class ShardedMsmPipeline:
         rows = []
         for r in range(self.world):
             b, e = window_range(r, self.world, self.num_windows)
-            rows.append(self.host[slot][r, : e - b])
+            rows.append(self.host[slot][r, : min(e - b, self.per)])
         self.completed += 1
         return MsmContext.combine_windows(torch.cat(rows, dim=0))
