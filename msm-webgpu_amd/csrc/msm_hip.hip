@@ -226,10 +226,15 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   uint32_t* d_rows = s.d_partials;
   uint32_t* d_cols = d_rows + (size_t)NWIN * 256 * XYZZ_WORDS;
   uint32_t* d_parts = d_cols + (size_t)NWIN * 256 * XYZZ_WORDS;
-  if (w_count >= 8)
-    hipLaunchKernelGGL(k_bpr_rowcol<3>, dim3(bpr_rowcol_blocks<3>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols);
-  else
+  static const int force_logr = [] { const char* e = getenv("MSM_HIP_BPR_LOGR"); return e ? atoi(e) : 0; }();  // tuning aid
+  // serial run per thread before the LDS tree: 16 buckets when many windows are reduced at once (fewest wave-additions),
+  // 4 for a few windows (shallowest); measured optimum for 16 and for 2 windows respectively
+  if (force_logr == 4 || (force_logr == 0 && w_count >= 8))
+    hipLaunchKernelGGL(k_bpr_rowcol<4>, dim3(bpr_rowcol_blocks<4>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols);
+  else if (force_logr == 2 || force_logr == 0)
     hipLaunchKernelGGL(k_bpr_rowcol<2>, dim3(bpr_rowcol_blocks<2>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols);
+  else
+    hipLaunchKernelGGL(k_bpr_rowcol<3>, dim3(bpr_rowcol_blocks<3>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols);
   hipLaunchKernelGGL(k_bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts);
   hipLaunchKernelGGL(k_bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out);
   HIP_TRY(ctx, hipEventRecord(s.red1, rs));

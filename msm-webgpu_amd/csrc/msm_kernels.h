@@ -557,9 +557,9 @@ __device__ __forceinline__ void lds_add_pair(uint32_t* x, int dst, int src) {
   st_xyzz(x + dst * XYZZ_WORDS, g1_add(ld_xyzz(x + dst * XYZZ_WORDS), ld_xyzz(x + src * XYZZ_WORDS)));
 }
 
-// LOG_R = log2 of the buckets each thread adds serially before the LDS tree.  The host picks 3 (8 buckets) when many
-// windows are in flight -- fewer, better-filled wave-additions: the stage is then bound by the ~7 us a SIMD needs per
-// wave-addition -- and 2 for few windows, where only the depth counts.
+// LOG_R = log2 of the buckets each thread adds serially before the LDS tree.  The host picks 4 (16 buckets) when many
+// windows are reduced at once -- fewer, better-filled wave-additions: the stage is then bound by the ~7 us a SIMD needs
+// per wave-addition -- and 2 for few windows, where only the depth counts.
 template <int LOG_R>
 __global__ void __launch_bounds__(256) k_bpr_rowcol(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ rows,
                                                     uint32_t* __restrict__ cols) {
@@ -608,100 +608,300 @@ constexpr int bpr_rowcol_blocks() {
   return BPR_ROWS / (256 / (BPR_COLS >> LOG_R)) + BPR_COLS / (256 / (BPR_ROWS >> LOG_R));
 }
 
+// ---- cooperative group operations: 8 lanes share ONE addition / doubling -------------------------------------------
+// In the narrow tail of the reduction only a few additions are independent, so most lanes of a wave idle while a lone wave
+// needs ~12 us per XYZZ addition (14 dependent field multiplications).  The multiplications of one addition are mostly
+// independent of each other (critical path 4), so an octet of lanes computes them side by side: lane role r = lane & 7
+// takes one product per stage, operands and intermediate results travel through LDS, stages are separated by block
+// barriers.  An addition then costs 4 multiplication latencies + 5 barriers, a doubling 3 + 4.
+// Every thread of the block must call these functions (they contain __syncthreads); octet o = threadIdx.x >> 3 works on
+// its own operands `pa`, `pb` -> `pout` (LDS pointers to XYZZ_WORDS records; pout may alias pa or pb) when `active`.
+constexpr int COOP_WORDS = 16 * 9;  // scratch words per octet
+
+__device__ __forceinline__ fq ldf(const uint32_t* p) {
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = p[i];
+  return r;
+}
+__device__ __forceinline__ void stf(uint32_t* p, const fq& a) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) p[i] = a.v[i];
+}
+__device__ __forceinline__ void coop_copy(uint32_t* dst, const uint32_t* src, int r) {  // 8 lanes copy one record
+  if (dst != src)
+    for (int i = r; i < XYZZ_WORDS; i += 8) dst[i] = src[i];
+}
+
+__device__ __noinline__ void coop_add(uint32_t* sc_all, const uint32_t* pa, const uint32_t* pb, uint32_t* pout, bool active) {
+  const int r = threadIdx.x & 7;
+  uint32_t* sc = sc_all + (threadIdx.x >> 3) * COOP_WORDS;
+  // mode 0: full addition; 1: result = a (b is the identity); 2: result = b; 3: inactive
+  int mode = 3;
+  if (active) mode = pa[36] != 0 ? 2 : (pb[36] != 0 ? 1 : 0);
+  fq keep = fq_zero();  // r0 keeps P, r1 keeps R across stages
+  // stage 1: U1 = ax*bzz, U2 = bx*azz, S1 = ay*bzzz, S2 = by*azzz, ZZ12 = azz*bzz, ZZZ12 = azzz*bzzz  -> sc[0..5]
+  if (mode == 0 && r < 6) {
+    const uint32_t *fa, *fb;
+    if (r < 4) {
+      const uint32_t* first = (r & 1) ? pb : pa;
+      const uint32_t* second = (r & 1) ? pa : pb;
+      fa = first + ((r & 2) ? 9 : 0);
+      fb = second + ((r & 2) ? 27 : 18);
+    } else {
+      fa = pa + (r == 4 ? 18 : 27);
+      fb = pb + (r == 4 ? 18 : 27);
+    }
+    stf(sc + r * 9, fq_mul(ldf(fa), ldf(fb)));
+  }
+  __syncthreads();
+  // stage 2: r0: P = U2 - U1, PP = P^2 -> sc[6] ; r1: R = S2 - S1 -> sc[9], RR = R^2 -> sc[7]
+  if (mode == 0 && r < 2) {
+    keep = fq_sub<3>(ldf(sc + (r == 0 ? 1 : 3) * 9), ldf(sc + (r == 0 ? 0 : 2) * 9));
+    stf(sc + (6 + r) * 9, fq_sqr(keep));
+    if (r == 1) stf(sc + 9 * 9, keep);
+  }
+  __syncthreads();
+  bool special = false;  // equal x coordinates: doubling or cancellation, done serially by lane 0 at the end
+  if (mode == 0) special = fq_is_zero_exact(ldf(sc + 6 * 9));
+  // stage 3: PPP = P*PP -> sc[10], Q = U1*PP -> sc[11], ZZ3 = ZZ12*PP -> sc[12]
+  if (mode == 0 && !special && r < 3) {
+    const fq PP = ldf(sc + 6 * 9);
+    const fq other = r == 0 ? keep : ldf(sc + (r == 1 ? 0 : 4) * 9);
+    stf(sc + (10 + r) * 9, fq_mul(other, PP));
+  }
+  __syncthreads();
+  // stage 4: r0: X3 = RR - PPP - 2Q -> sc[13], Y3 = R*(Q - X3) - S1*PPP -> sc[14] ; r1: ZZZ3 = ZZZ12*PPP -> sc[15]
+  if (mode == 0 && !special && r < 2) {
+    const fq PPP = ldf(sc + 10 * 9);
+    if (r == 0) {
+      const fq Q = ldf(sc + 11 * 9);
+      const fq X3 = fq_sub<7>(ldf(sc + 7 * 9), fq_add(PPP, fq_dbl(Q)));
+      const fq T = fq_sub<10>(Q, X3);
+      const fq nS1 = fq_sub<3>(fq_zero(), ldf(sc + 2 * 9));
+      stf(sc + 13 * 9, X3);
+      stf(sc + 14 * 9, fq_mul2(ldf(sc + 9 * 9), T, nS1, PPP));
+    } else {
+      stf(sc + 15 * 9, fq_mul(ldf(sc + 5 * 9), PPP));
+    }
+  }
+  __syncthreads();
+  if (mode == 0) {
+    if (special) {
+      if (r == 0) st_xyzz(pout, g1_add(ld_xyzz(pa), ld_xyzz(pb)));
+    } else if (r < 4) {
+      const int src = r == 0 ? 13 : (r == 1 ? 14 : (r == 2 ? 12 : 15));
+      stf(pout + r * 9, ldf(sc + src * 9));
+    } else if (r == 4) {
+      pout[36] = 0;
+    }
+  } else if (mode == 1) {
+    coop_copy(pout, pa, r);
+  } else if (mode == 2) {
+    coop_copy(pout, pb, r);
+  }
+  __syncthreads();
+}
+
+__device__ __noinline__ void coop_double(uint32_t* sc_all, const uint32_t* pa, uint32_t* pout, bool active) {
+  const int r = threadIdx.x & 7;
+  uint32_t* sc = sc_all + (threadIdx.x >> 3) * COOP_WORDS;
+  const bool work = active && pa[36] == 0;  // doubling the identity leaves it unchanged
+  fq keep = fq_zero();                      // r0 keeps U = 2Y
+  // stage 1: r0: V = U^2 -> sc[0] ; r1: XX = X^2 -> sc[1]
+  if (work && r < 2) {
+    if (r == 0) {
+      keep = fq_dbl(ldf(pa + 9));
+      stf(sc + 0 * 9, fq_sqr(keep));
+    } else {
+      stf(sc + 1 * 9, fq_sqr(ldf(pa)));
+    }
+  }
+  __syncthreads();
+  // stage 2: r0: W = U*V -> sc[2] ; r1: S = X*V -> sc[3] ; r2: M = 3*XX -> sc[5], MM = M^2 -> sc[4] ; r3: ZZ3 = V*ZZ -> sc[6]
+  if (work && r < 4) {
+    if (r == 2) {
+      const fq XX = ldf(sc + 1 * 9);
+      const fq M = fq_norm(fq_add(fq_dbl(XX), XX));
+      stf(sc + 5 * 9, M);
+      stf(sc + 4 * 9, fq_sqr(M));
+    } else {
+      const fq V = ldf(sc + 0 * 9);
+      const fq other = r == 0 ? keep : ldf(pa + (r == 1 ? 0 : 18));
+      stf(sc + (r == 0 ? 2 : (r == 1 ? 3 : 6)) * 9, fq_mul(other, V));
+    }
+  }
+  __syncthreads();
+  // stage 3: r0: X3 = MM - 2S -> sc[7], Y3 = M*(S - X3) - W*Y -> sc[8] ; r1: ZZZ3 = W*ZZZ -> sc[9]
+  if (work && r < 2) {
+    const fq W = ldf(sc + 2 * 9);
+    if (r == 0) {
+      const fq S = ldf(sc + 3 * 9);
+      const fq X3 = fq_sub<5>(ldf(sc + 4 * 9), fq_dbl(S));
+      const fq T = fq_sub<8>(S, X3);
+      const fq nY = fq_sub<6>(fq_zero(), ldf(pa + 9));
+      stf(sc + 7 * 9, X3);
+      stf(sc + 8 * 9, fq_mul2(ldf(sc + 5 * 9), T, nY, W));
+    } else {
+      stf(sc + 9 * 9, fq_mul(W, ldf(pa + 27)));
+    }
+  }
+  __syncthreads();
+  if (work) {
+    if (r < 4) {
+      const int src = r == 0 ? 7 : (r == 1 ? 8 : (r == 2 ? 6 : 9));
+      stf(pout + r * 9, ldf(sc + src * 9));
+    } else if (r == 4) {
+      pout[36] = 0;
+    }
+  } else if (active) {
+    coop_copy(pout, pa, r);
+  }
+  __syncthreads();
+}
+
 // W(X) = sum_{i<256} i * X_i for X = rows (blockIdx.x == 0) or the columns padded to 256 with identities (blockIdx.x == 1);
 // out[w][blockIdx.x] = W(X); for the columns additionally out[w][2] = sum(X).
+// 16 x 16 split (RR_a = row sums, CC_b = column sums of the 16 x 16 arrangement of X): W = 16 * W16(RR) + W16(CC);
+// W16(V) by a 4 x 4 split: W16 = 4 * W4(r) + W4(c); W4(u) = u1 + 2 u2 + 3 u3 = (u1 + u3) + 2 (u2 + u3).
+// Levels with at most 32 independent operations use the cooperative octet operations above.
 __global__ void __launch_bounds__(256) k_bpr_w256(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ cols,
                                                   uint32_t* __restrict__ out) {
-  __shared__ uint32_t x[256 * XYZZ_WORDS];  // X, then overlaid by the level-1 row / column partial sums
-  __shared__ uint32_t y[64 * XYZZ_WORDS];   // 4 x 4 stage, level 1
-  __shared__ uint32_t z[16 * XYZZ_WORDS];   // 4 x 4 stage, level 2: z[v*8 + which*4 + i]
-  __shared__ uint32_t u[8 * XYZZ_WORDS];    // u[0..3] W4 results (v*2 + which), u[4..5] W16 results
-  __shared__ uint32_t tot[8 * XYZZ_WORDS];  // running total of the 16 row sums
+  __shared__ uint32_t x[256 * XYZZ_WORDS];
+  __shared__ uint32_t sc[32 * COOP_WORDS];
   const int w = blockIdx.y, which_in = blockIdx.x, t = threadIdx.x;
-  const int a = t >> 4, b = t & 15;
+  const int a = t >> 4, b = t & 15, o = t >> 3;  // o: octet index, 0..31
+  auto X = [&](int i) { return x + i * XYZZ_WORDS; };
+  // after the trees only records 8g of x stay live; the free ones hold the small intermediate vectors
+  auto Y = [&](int j) { return x + (8 * (j >> 1) + 1 + (j & 1)) * XYZZ_WORDS; };  // j < 64
+  auto Z = [&](int j) { return x + (8 * j + 3) * XYZZ_WORDS; };                   // j < 16
+  auto U = [&](int j) { return x + (8 * j + 4) * XYZZ_WORDS; };                   // j < 8
+  auto T = [&](int j) { return x + (8 * j + 5) * XYZZ_WORDS; };                   // j < 8 (total of the row sums)
+  auto Q = [&](int j) { return x + (8 * j + 6) * XYZZ_WORDS; };                   // j < 8 (W4 temporaries)
   g1_xyzz xi;
   if (which_in == 0) xi = ld_xyzz(rows + ((size_t)w * BPR_ROWS + t) * XYZZ_WORDS);
   else xi = t < BPR_COLS ? ld_xyzz(cols + ((size_t)w * 256 + t) * XYZZ_WORDS) : g1_identity();
-  st_xyzz(x + t * XYZZ_WORDS, xi);
+  st_xyzz(X(t), xi);
   __syncthreads();
-  // 16 x 16 split, level 1: threads with b < 8 add row pairs (own element + partner), the others add column pairs
+  // level 1 (256 additions, all lanes busy): threads with b < 8 add row pairs, the others add column pairs
   g1_xyzz l1;
   int l1_dst;
   if (b < 8) {
-    l1 = g1_add(xi, ld_xyzz(x + (16 * a + b + 8) * XYZZ_WORDS));
+    l1 = g1_add(xi, ld_xyzz(X(16 * a + b + 8)));
     l1_dst = a * 8 + b;  // row partials: [0, 128)
   } else {
     const int job = a * 8 + (b - 8), c = job & 15, pr = job >> 4;
-    l1 = g1_add(ld_xyzz(x + (16 * pr + c) * XYZZ_WORDS), ld_xyzz(x + (16 * (pr + 8) + c) * XYZZ_WORDS));
+    l1 = g1_add(ld_xyzz(X(16 * pr + c)), ld_xyzz(X(16 * (pr + 8) + c)));
     l1_dst = 128 + c * 8 + pr;  // column partials: [128, 256)
   }
   __syncthreads();
-  st_xyzz(x + l1_dst * XYZZ_WORDS, l1);
+  st_xyzz(X(l1_dst), l1);
   __syncthreads();
-  for (int sft = 4; sft >= 1; sft >>= 1) {  // 32 groups of 8 -> 1
+  for (int sft = 4; sft >= 2; sft >>= 1) {  // 32 groups of 8 -> 2 (128 and 64 additions)
     if (t < 32 * sft) {
       const int g = t / sft, k = t % sft;
       lds_add_pair(x, g * 8 + k, g * 8 + k + sft);
     }
     __syncthreads();
   }
-  // now V0[i] = x[8 i] (16 row sums RR), V1[i] = x[128 + 8 i] (16 column sums CC)
-  // 4 x 4 split of both 16-vectors, level 1 (32 jobs) + first level of the total of V0 (8 jobs)
-  if (t < 32) {
-    const int v = t >> 4, job = t & 15;
-    const uint32_t* V = x + (v * 128) * XYZZ_WORDS;
-    g1_xyzz r;
-    if (job < 8) {  // row pair: i = job >> 1, j = job & 1 : V[4i + j] + V[4i + j + 2]
+  coop_add(sc, X(o * 8), X(o * 8 + 1), X(o * 8), true);  // 32 groups: 2 -> 1
+  // V0[i] = X(8 i) (16 row sums RR), V1[i] = X(128 + 8 i) (16 column sums CC)
+  auto V = [&](int v, int i) { return X(v * 128 + 8 * i); };
+  {  // 4 x 4 split, level 1: 32 jobs -> Y(v*16 + job)
+    const int v = o >> 4, job = o & 15;
+    const uint32_t *pa, *pb;
+    if (job < 8) {  // row pair (i, j): V[4i + j] + V[4i + j + 2]
       const int i = job >> 1, j = job & 1;
-      r = g1_add(ld_xyzz(V + (8 * (4 * i + j)) * XYZZ_WORDS), ld_xyzz(V + (8 * (4 * i + j + 2)) * XYZZ_WORDS));
-    } else {  // column pair: j = (job - 8) >> 1, pr = job & 1 : V[4 pr + j] + V[4 (pr + 2) + j]
+      pa = V(v, 4 * i + j);
+      pb = V(v, 4 * i + j + 2);
+    } else {  // column pair (j, pr): V[4 pr + j] + V[4 (pr + 2) + j]
       const int j = (job - 8) >> 1, pr = job & 1;
-      r = g1_add(ld_xyzz(V + (8 * (4 * pr + j)) * XYZZ_WORDS), ld_xyzz(V + (8 * (4 * (pr + 2) + j)) * XYZZ_WORDS));
+      pa = V(v, 4 * pr + j);
+      pb = V(v, 4 * (pr + 2) + j);
     }
-    st_xyzz(y + (v * 16 + job) * XYZZ_WORDS, r);  // y[v][0..7] row pairs (i*2+j), y[v][8..15] column pairs (j*2+pr)
-  } else if (t >= 64 && t < 72) {
-    const int k = t - 64;
-    st_xyzz(tot + k * XYZZ_WORDS, g1_add(ld_xyzz(x + (8 * k) * XYZZ_WORDS), ld_xyzz(x + (8 * (k + 8)) * XYZZ_WORDS)));
+    coop_add(sc, pa, pb, Y(v * 16 + job), true);
   }
-  __syncthreads();
-  // level 2: r_i, c_j (16 jobs) ; total 8 -> 4
-  if (t < 16) {
-    const int v = t >> 3, q = t & 7;  // q < 4: r_q ; q >= 4: c_{q-4}
-    const int base = v * 16 + (q < 4 ? 2 * q : 8 + 2 * (q - 4));
-    st_xyzz(z + (v * 8 + q) * XYZZ_WORDS, g1_add(ld_xyzz(y + base * XYZZ_WORDS), ld_xyzz(y + (base + 1) * XYZZ_WORDS)));
-  } else if (t >= 64 && t < 68) {
-    lds_add_pair(tot, t - 64, t - 64 + 4);
+  {  // level 2: r_i, c_j (16 jobs) -> Z(v*8 + q) ; total of V0, level 1 (8 jobs) -> T(k)
+    const uint32_t *pa = x, *pb = x;
+    uint32_t* po = x;
+    const bool act = o < 24;
+    if (o < 16) {
+      const int v = o >> 3, q = o & 7;  // q < 4: r_q ; q >= 4: c_{q-4}
+      const int base = v * 16 + (q < 4 ? 2 * q : 8 + 2 * (q - 4));
+      pa = Y(base);
+      pb = Y(base + 1);
+      po = Z(v * 8 + q);
+    } else if (o < 24) {
+      const int k = o - 16;
+      pa = V(0, k);
+      pb = V(0, k + 8);
+      po = T(k);
+    }
+    coop_add(sc, pa, pb, po, act);
   }
-  __syncthreads();
-  // W4(u) = u1 + 2 u2 + 3 u3 = (u1 + u3) + 2 (u2 + u3): 4 jobs (v, which) ; total 4 -> 2
-  if (t < 4) {
-    const uint32_t* q4 = z + (t * 4) * XYZZ_WORDS;  // t = v*2 + which  ->  z[v*8 + which*4 ..]
-    const g1_xyzz u1 = ld_xyzz(q4 + 1 * XYZZ_WORDS), u2 = ld_xyzz(q4 + 2 * XYZZ_WORDS), u3 = ld_xyzz(q4 + 3 * XYZZ_WORDS);
-    st_xyzz(u + t * XYZZ_WORDS, g1_add(g1_add(u1, u3), g1_double(g1_add(u2, u3))));  // 3 additions + 1 doubling deep
-  } else if (t >= 64 && t < 66) {
-    lds_add_pair(tot, t - 64, t - 64 + 2);
+  {  // W4 step A: p = u1 + u3 -> U(j), q = u2 + u3 -> Q(j) for the 4 vectors j = v*2 + which ; total 8 -> 4
+    const uint32_t *pa = x, *pb = x;
+    uint32_t* po = x;
+    const bool act = o < 12;
+    if (o < 8) {
+      const int j = o >> 1;
+      const uint32_t* q4 = Z(j * 4) - 0;  // u_i = Z(j*4 + i)
+      (void)q4;
+      pa = Z(j * 4 + ((o & 1) ? 2 : 1));
+      pb = Z(j * 4 + 3);
+      po = (o & 1) ? Q(j) : U(j);
+    } else if (o < 12) {
+      const int k = o - 8;
+      pa = T(k);
+      pb = T(k + 4);
+      po = T(k);
+    }
+    coop_add(sc, pa, pb, po, act);
   }
-  __syncthreads();
-  // W16(V) = 4 * W4(r) + W4(c): 2 jobs ; total 2 -> 1
-  if (t < 2) {
-    const g1_xyzz wr = ld_xyzz(u + (t * 2) * XYZZ_WORDS), wc = ld_xyzz(u + (t * 2 + 1) * XYZZ_WORDS);
-    st_xyzz(u + (4 + t) * XYZZ_WORDS, g1_add(g1_double(g1_double(wr)), wc));
-  } else if (t == 64) {
-    lds_add_pair(tot, 0, 1);
+  coop_double(sc, Q(o & 3), Q(o & 3), o < 4);  // W4 step B: q <- 2 q
+  {  // W4 step C: W4 = p + 2q -> U(j) ; total 4 -> 2
+    const uint32_t *pa = x, *pb = x;
+    uint32_t* po = x;
+    const bool act = o < 6;
+    if (o < 4) {
+      pa = U(o);
+      pb = Q(o);
+      po = U(o);
+    } else if (o < 6) {
+      const int k = o - 4;
+      pa = T(k);
+      pb = T(k + 2);
+      po = T(k);
+    }
+    coop_add(sc, pa, pb, po, act);
   }
-  __syncthreads();
-  // W256(X) = 16 * W16(RR) + W16(CC)
-  if (t == 0) {
-    g1_xyzz hi = ld_xyzz(u + 4 * XYZZ_WORDS);
-    for (int i = 0; i < 4; i++) hi = g1_double(hi);
-    st_xyzz(out + ((size_t)w * 3 + which_in) * XYZZ_WORDS, g1_add(hi, ld_xyzz(u + 5 * XYZZ_WORDS)));
-  } else if (t == 64 && which_in == 1) {
-    uint32_t* o = out + ((size_t)w * 3 + 2) * XYZZ_WORDS;
-    for (int i = 0; i < XYZZ_WORDS; i++) o[i] = tot[i];
+  // W16(v) = 4 * W4(r_v) + W4(c_v): U(2v) <- 4 U(2v), then U(4 + v) = U(2v) + U(2v + 1) ; total 2 -> 1
+  coop_double(sc, U(2 * (o & 1)), U(2 * (o & 1)), o < 2);
+  coop_double(sc, U(2 * (o & 1)), U(2 * (o & 1)), o < 2);
+  {
+    const uint32_t *pa = x, *pb = x;
+    uint32_t* po = x;
+    const bool act = o < 3;
+    if (o < 2) {
+      pa = U(2 * o);
+      pb = U(2 * o + 1);
+      po = U(4 + o);
+    } else if (o == 2) {
+      pa = T(0);
+      pb = T(1);
+      po = T(0);
+    }
+    coop_add(sc, pa, pb, po, act);
   }
+  // W256 = 16 * W16(RR) + W16(CC)
+  for (int i = 0; i < 4; i++) coop_double(sc, U(4), U(4), o == 0);
+  coop_add(sc, U(4), U(5), U(4), o == 0);
+  if (t < XYZZ_WORDS) out[((size_t)w * 3 + which_in) * XYZZ_WORDS + t] = U(4)[t];
+  if (which_in == 1 && t >= 64 && t < 64 + XYZZ_WORDS) out[((size_t)w * 3 + 2) * XYZZ_WORDS + (t - 64)] = T(0)[t - 64];
 }
 
-// one lane per window: S = 128 * W(R) + W(C) + sum(C), emitted as canonical Jacobian bytes
+// one lane per window: S = 128 * W(R) + W(C) + sum(C), emitted as canonical Jacobian bytes.  (Operands stay in registers
+// here, which measured faster than the cooperative LDS form: 52 vs 71 us.)
 __global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ parts, int w_count, uint32_t* __restrict__ wsums) {
   const int w = threadIdx.x;
   if (w >= w_count) return;
