@@ -1,14 +1,19 @@
 // Device kernels of the cuZK-style BN254 MSM pipeline for gfx950 (MI355X).  Included once by msm_hip.hip.
 //
-// Pipeline (reference: compute_msm, src/cuzk/msm.rs:75-417) and the HBM layout each stage reads/writes:
+// Pipeline (reference: compute_msm, src/cuzk/msm.rs:75-417) and the HBM layout each stage reads/writes
+// (W = windows handled by this GPU, stride = n rounded up to 4):
 //
-//   bases     u32[n][16]            packed affine, Montgomery (R = 2^261), x || y, 64 B per point, resident
-//   scalars   u32[n][8]             canonical little-endian (wire format)
-//   digits    u16[W][n]             signed-magnitude digit codes, window-major planes
-//   col_ptr   u32[W][32769]         start of every bucket slot in val_idxs (exclusive scan of the histogram)
-//   val_idxs  u32[W][n]             point index | sign << 31, grouped by bucket slot
-//   buckets   u32[W][32768][24]     Jacobian, Montgomery, 96 B per bucket
-//   wsums     u8 [W][96]            window sums, Jacobian, canonical little-endian (leaves the device)
+//   bases      u32[n][16]            packed affine, Montgomery (R = 2^261), x || y, 64 B per point, resident
+//   scalars    u32[n][8]             canonical little-endian (wire format)
+//   counts     u32[W][tiles][128]    per-tile coarse-bin histogram, then prefix over tiles
+//   tmp_val    u32[W][stride]        point index | sign << 31, in coarse-bin order ; tmp_fine u8[W][stride] = slot & 255
+//   val_idxs   u32[W][stride]        point index | sign << 31, grouped by bucket slot
+//   col_ptr    u32[W][32769]         start of every bucket slot in val_idxs
+//   chunk_slot u32[W][chunks]        bucket slot of the first entry of every SMVP chunk
+//   buckets    u32[W][32768][40]     XYZZ records (160 B: 36 limbs + valid flag), Montgomery
+//   heads/tails  [W][chunks][40]     partial sums of bucket runs that cross SMVP chunk boundaries
+//   rows/cols/parts                  bucket-reduce scratch: 256 row sums, 128 column sums, 3 partial results per window
+//   wsums      u8 [W][96]            window sums, Jacobian, canonical little-endian (the only data that leaves the device)
 //
 // The reference keys its CSC rows by the biased digit (65536 rows per window, transpose.template.wgsl:47-73) and lets
 // the SMVP thread visit rows h+k and h-k (smvp.template.wgsl:55-92).  Here the sort key is the bucket slot itself
