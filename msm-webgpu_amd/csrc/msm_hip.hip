@@ -73,6 +73,8 @@ struct msm_hip_ctx {
   uint32_t* d_heads = nullptr;       // [W][chunks] XYZZ records
   uint32_t* d_tails = nullptr;       // [W][chunks] XYZZ records
   uint32_t* d_chunk_slot = nullptr;  // [W][chunks] bucket slot of every SMVP chunk's first entry
+  uint32_t* d_big_queue = nullptr;   // [1 + STITCH_BIG_CAP] buckets with many pieces (skewed scalars), [0] = count
+  uint32_t* d_done_blocks = nullptr;  // block counter of k_smvp_stitch_big
   uint32_t* d_err = nullptr;
   uint8_t* d_stage = nullptr;  // staging for host byte inputs of set_bases / test hooks
   size_t cap_stage = 0;
@@ -217,7 +219,9 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
                      chunks, chunk_len, ctx->d_chunk_slot, s.d_buckets, ctx->d_heads, ctx->d_tails);
   HIP_TRY(ctx, hipEventRecord(s.ev[5], st));
   hipLaunchKernelGGL(k_smvp_stitch, dim3(HALF / 256, w_count), dim3(256), 0, st, ctx->d_col_ptr, chunks, chunk_len, ctx->d_heads,
-                     ctx->d_tails, s.d_buckets);
+                     ctx->d_tails, s.d_buckets, ctx->d_big_queue);
+  hipLaunchKernelGGL(k_smvp_stitch_big, dim3(256), dim3(256), 0, st, ctx->d_col_ptr, chunks, chunk_len, ctx->d_heads, ctx->d_tails,
+                     s.d_buckets, ctx->d_big_queue, ctx->d_done_blocks);
   HIP_TRY(ctx, hipEventRecord(s.ev[6], st));
   HIP_TRY(ctx, hipEventRecord(s.smvp_done, st));
 
@@ -353,6 +357,9 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
   if ((rc = dev_alloc(ctx, ctx->d_coarse_ptr, (size_t)NWIN * (NCOARSE + 1)))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_col_ptr, (size_t)NWIN * (HALF + 1)))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_err, 1))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_big_queue, (size_t)STITCH_BIG_CAP + 1))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_done_blocks, 1))) return fail(rc);
+  if (hipMemset(ctx->d_big_queue, 0, 4) != hipSuccess || hipMemset(ctx->d_done_blocks, 0, 4) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
   for (int k = 0; k < NSLOT; k++) {
     Slot& s = ctx->slot[k];
     if (hipHostMalloc((void**)&s.h_wsums, WSUM_BYTES + 4, hipHostMallocDefault) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
@@ -377,7 +384,8 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   for (hipStream_t r : ctx->reduce_stream)
     if (r) (void)hipStreamSynchronize(r);
   void* bufs[] = {ctx->d_bases,    ctx->d_scalars, ctx->d_digits, ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_col_ptr, ctx->d_tmp_val,
-                  ctx->d_tmp_fine, ctx->d_val,     ctx->d_heads,  ctx->d_tails,  ctx->d_chunk_slot,  ctx->d_err,     ctx->d_stage};
+                  ctx->d_tmp_fine, ctx->d_val,     ctx->d_heads,  ctx->d_tails,  ctx->d_chunk_slot,  ctx->d_err,     ctx->d_stage,
+                  ctx->d_big_queue, ctx->d_done_blocks};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int k = 0; k < NSLOT; k++) {

@@ -359,6 +359,26 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
 
 constexpr int FINE_CHUNK = 4096;  // entries staged per block iteration (16 per thread)
 
+// counter[key] += 1 for every active lane, returning the lane's rank (old value).  All lanes that share the key of the
+// wave's first active lane are served by ONE LDS atomic (ballot + popcount): with heavily skewed scalars (many equal
+// digits) nearly the whole wave shares a key and a plain ds_add would serialise 64-fold; with uniform digits this costs
+// one ballot.  Must be called with the same `valid` pattern by whole waves (inactive lanes pass valid = false).
+__device__ __forceinline__ uint32_t lds_count_rank(uint32_t* counter, uint32_t key, bool valid) {
+  const unsigned long long vm = __ballot(valid);
+  if (vm == 0) return 0;
+  const int first = __ffsll((long long)vm) - 1;
+  const uint32_t k0 = (uint32_t)__shfl((int)key, first);
+  const bool same = valid && key == k0;
+  const unsigned long long sm = __ballot(same);
+  const int lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == first) base = atomicAdd(&counter[k0], (uint32_t)__popcll(sm));
+  base = (uint32_t)__shfl((int)base, first);
+  uint32_t rank = base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+  if (valid && !same) rank = atomicAdd(&counter[key], 1u);
+  return rank;
+}
+
 __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ tmp_val, const uint8_t* __restrict__ tmp_fine, size_t stride,
                                                    const uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ col_ptr,
                                                    uint32_t* __restrict__ val_idxs, uint32_t chunks, uint32_t chunk_len,
@@ -379,6 +399,11 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
   __syncthreads();
   for (uint32_t i = begin + tid; i < end; i += 256) atomicAdd(&hist[tf[i]], 1u);
   __syncthreads();
+  // a slot holding more than a quarter of the bin means skewed scalars: pass 2 then ranks with wave-aggregated atomics
+  __shared__ uint32_t skew_flag;
+  if (tid == 0) skew_flag = 0;
+  __syncthreads();
+  if (hist[tid] > (end - begin) / 4 && end - begin > (uint32_t)FINE_CHUNK) skew_flag = 1;
   {
     const uint32_t excl = block_excl_scan_256(hist[tid], wave_tot);
     gpos[tid] = begin + excl;
@@ -391,6 +416,7 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
   }
   __syncthreads();
   // pass 2: LDS-staged scatter, FINE_CHUNK entries at a time
+  const bool skewed = skew_flag != 0;  // block-uniform (read after the barriers of the scan above)
   for (uint32_t base = begin; base < end; base += FINE_CHUNK) {
     hist[tid] = 0;
     __syncthreads();
@@ -398,10 +424,12 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const uint32_t i = base + j * 256 + tid;
-      if (i < end) {
-        const uint32_t f = tf[i];
+      const bool valid = i < end;
+      const uint32_t f = valid ? tf[i] : 0u;
+      const uint32_t rank = skewed ? lds_count_rank(hist, f, valid) : (valid ? atomicAdd(&hist[f], 1u) : 0u);
+      if (valid) {
         v[j] = tv[i];
-        fr[j] = f | (atomicAdd(&hist[f], 1u) << 8);
+        fr[j] = f | (rank << 8);
       } else {
         fr[j] = 0xffffffffu;
       }
@@ -519,12 +547,21 @@ __global__ void __launch_bounds__(256, 4) k_smvp_chunks(const uint32_t* __restri
   }
 }
 
+// x[dst] += x[src] for XYZZ records held in LDS
+__device__ __forceinline__ void lds_add_pair(uint32_t* x, int dst, int src) {
+  st_xyzz(x + dst * XYZZ_WORDS, g1_add(ld_xyzz(x + dst * XYZZ_WORDS), ld_xyzz(x + src * XYZZ_WORDS)));
+}
+
 // One lane per bucket slot: empty slots get the identity record (no memset of the bucket array is needed), runs that lie
 // inside one chunk were already written by k_smvp_chunks, and a run that spans chunks c0 < ... < c1 is the tail piece of
-// c0 plus the head pieces of c0+1 .. c1.
+// c0 plus the head pieces of c0+1 .. c1.  Buckets with more than STITCH_BIG pieces (heavily skewed scalars: one bucket
+// may hold every entry of a window) are queued for k_smvp_stitch_big instead of being walked by one lane.
+constexpr uint32_t STITCH_BIG = 32;
+constexpr uint32_t STITCH_BIG_CAP = 1 << 15;  // queue capacity; more big buckets than this fall back to the serial walk
+
 __global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict__ col_ptr, uint32_t chunks, uint32_t chunk_len,
                                                      const uint32_t* __restrict__ heads, const uint32_t* __restrict__ tails,
-                                                     uint32_t* __restrict__ buckets) {
+                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ big_queue) {
   const int lw = blockIdx.y;
   const uint32_t s = blockIdx.x * 256 + threadIdx.x;  // < HALF by grid construction
   const uint32_t* cp = col_ptr + (size_t)lw * (HALF + 1);
@@ -536,9 +573,55 @@ __global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict_
   }
   const uint32_t c0 = b / chunk_len, c1 = (e - 1) / chunk_len;
   if (c0 == c1) return;
+  if (c1 - c0 >= STITCH_BIG) {
+    const uint32_t at = atomicAdd(&big_queue[0], 1u);
+    if (at < STITCH_BIG_CAP) {
+      big_queue[1 + at] = ((uint32_t)lw << 16) | s;
+      return;
+    }
+  }
   g1_xyzz acc = ld_rec(tails + ((size_t)lw * chunks + c0) * REC_WORDS);
   for (uint32_t c = c0 + 1; c <= c1; c++) acc = g1_add(acc, ld_rec(heads + ((size_t)lw * chunks + c) * REC_WORDS));
   st_rec(out, acc);
+}
+
+// Queued big buckets: one block per bucket (blocks stride over the queue); every thread adds a strided subset of the
+// pieces, then an LDS tree.  Block 0 resets the queue counter for the next MSM once every block has read it.
+__global__ void __launch_bounds__(256) k_smvp_stitch_big(const uint32_t* __restrict__ col_ptr, uint32_t chunks, uint32_t chunk_len,
+                                                         const uint32_t* __restrict__ heads, const uint32_t* __restrict__ tails,
+                                                         uint32_t* __restrict__ buckets, uint32_t* __restrict__ big_queue,
+                                                         uint32_t* __restrict__ done_blocks) {
+  __shared__ uint32_t x[256 * XYZZ_WORDS];
+  const int t = threadIdx.x;
+  uint32_t count = big_queue[0];
+  if (count > STITCH_BIG_CAP) count = STITCH_BIG_CAP;
+  for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+    const uint32_t code = big_queue[1 + item];
+    const uint32_t lw = code >> 16, s = code & 0xffffu;
+    const uint32_t* cp = col_ptr + (size_t)lw * (HALF + 1);
+    const uint32_t c0 = cp[s] / chunk_len, c1 = (cp[s + 1] - 1) / chunk_len;
+    g1_xyzz acc = g1_identity();
+    for (uint32_t c = c0 + t; c <= c1; c += 256) {
+      const uint32_t* piece = (c == c0 ? tails : heads) + ((size_t)lw * chunks + c) * REC_WORDS;
+      acc = g1_add(acc, ld_rec(piece));
+    }
+    st_xyzz(x + t * XYZZ_WORDS, acc);
+    __syncthreads();
+    for (int sft = 128; sft >= 1; sft >>= 1) {
+      if (t < sft) lds_add_pair(x, t, t + sft);
+      __syncthreads();
+    }
+    if (t == 0) st_rec(buckets + ((size_t)lw * HALF + s) * REC_WORDS, ld_xyzz(x));
+    __syncthreads();
+  }
+  // last block out resets the queue for the next run
+  if (t == 0) {
+    __threadfence();
+    if (atomicAdd(done_blocks, 1u) == gridDim.x - 1) {
+      big_queue[0] = 0;
+      *done_blocks = 0;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ stage 4: bucket reduce
@@ -558,9 +641,6 @@ constexpr int BPR_ROWS = 256, BPR_COLS = 128;
 
 // tree-add `count` (power of two) records spaced `stride` records apart starting at x[base]; every thread of the block
 // must call it (it contains barriers); on return x[base] holds the sum.  `id` enumerates jobs block-wide.
-__device__ __forceinline__ void lds_add_pair(uint32_t* x, int dst, int src) {
-  st_xyzz(x + dst * XYZZ_WORDS, g1_add(ld_xyzz(x + dst * XYZZ_WORDS), ld_xyzz(x + src * XYZZ_WORDS)));
-}
 
 // LOG_R = log2 of the buckets each thread adds serially before the LDS tree.  The host picks 4 (16 buckets) when many
 // windows are reduced at once -- fewer, better-filled wave-additions: the stage is then bound by the ~7 us a SIMD needs

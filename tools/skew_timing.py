@@ -1,0 +1,19 @@
+"""How the engine behaves on heavily skewed scalars (all equal -> one bucket per window holds every entry)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import msm_webgpu_amd as m
+logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+n = 1 << logn
+ctx = m.MsmContext(0)
+pts = ctx.sample_points(n, 1)
+ctx.set_bases(pts)
+uni = ctx.sample_scalars(n, 2)
+ctx.msm(uni)
+s = 0x123456789ABCDEF013579BDF2468ACE0FEDCBA9876543210
+eq = torch.tensor(list(s.to_bytes(32, "little")), dtype=torch.uint8, device="cuda").repeat(n, 1).contiguous()
+half = uni.clone(); half[: n // 2] = eq[: n // 2]
+small = torch.zeros((n, 32), dtype=torch.uint8, device="cuda"); small[:, 0] = torch.randint(0, 4, (n,), dtype=torch.uint8, device="cuda")
+for name, sc in (("uniform", uni), ("all equal", eq), ("half equal", half), ("2-bit scalars", small)):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); r = ctx.msm(sc); dt = time.perf_counter() - t0
+    print("%-14s %8.2f ms  %s" % (name, dt * 1e3, {k: round(v, 3) for k, v in ctx.stage_ms().items()}))
