@@ -70,6 +70,11 @@ int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n
 int msm_hip_launch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot);
 int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]);
 
+/* ---- batch: `batch` independent scalar vectors (batch x n x 32 B, contiguous, device memory) over the resident bases;
+ *      out: batch x 96 B.  Internally a software pipeline over the result slots (BASELINE.json config 5: many MSMs over
+ *      one shared base). ---- */
+int msm_hip_run_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, size_t batch, uint8_t* out_xyz);
+
 /* ---- window-sharded execution (multi-GPU; Pippenger windows are independent).
  *      Computes the window sums S_w for w in [w_begin, w_end) and writes (w_end - w_begin) x 96 B Jacobian
  *      canonical-LE records to `window_sums_dev` (device memory, so that RCCL can gather them in place). ---- */

@@ -50,6 +50,7 @@ def lib():
         L.msm_hip_set_bases_device_bn254.argtypes = [vp, vp, sz, C.c_uint32]
         L.msm_hip_run_bn254.argtypes = [vp, u8p, sz, u8p]
         L.msm_hip_run_device_bn254.argtypes = [vp, vp, sz, u8p]
+        L.msm_hip_run_batch_device_bn254.argtypes = [vp, vp, sz, sz, u8p]
         L.msm_hip_launch_device_bn254.argtypes = [vp, vp, sz, i]
         L.msm_hip_finish_bn254.argtypes = [vp, i, u8p]
         L.msm_hip_run_windows_device_bn254.argtypes = [vp, vp, sz, i, i, vp]
@@ -204,6 +205,17 @@ class MsmContext:
                 raise ValueError("scalars must be n x 32 bytes")
             _check(lib().msm_hip_run_bn254(self._h, b, len(b) // 32, out), "msm_hip_run_bn254")
         return G1(out.raw)
+
+    def msm_batch(self, scalars_dev, n):
+        """`batch` MSMs over the resident bases: scalars_dev is a CUDA uint8 tensor of batch x n x 32 bytes -> [G1, ...]."""
+        t, rows = _as_device_u8(scalars_dev, 32, "scalars")
+        if n <= 0 or rows % n:
+            raise ValueError("scalars must hold a whole number of n-element vectors")
+        batch = rows // n
+        out = C.create_string_buffer(96 * batch)
+        torch.cuda.current_stream(t.device).synchronize()
+        _check(lib().msm_hip_run_batch_device_bn254(self._h, t.data_ptr(), n, batch, out), "msm_hip_run_batch_device_bn254")
+        return [G1(out.raw[96 * k:96 * k + 96]) for k in range(batch)]
 
     def launch(self, scalars_dev, slot=0):
         """Enqueue the device work of one MSM into a result slot (0..3) and return at once."""

@@ -275,8 +275,10 @@ int wait_slot(msm_hip_ctx* ctx, Slot& s) {
   return err_from_bits(bits);
 }
 
+constexpr size_t MAX_POINTS = (size_t)1 << 28;  // point indices carry the digit sign in bit 31; 2^28 keeps every per-window offset in u32
+
 int check_run_args(msm_hip_ctx* ctx, const void* scalars, size_t n) {
-  if (!ctx || (!scalars && n)) return MSM_HIP_ERR_INVALID_ARG;
+  if (!ctx || (!scalars && n) || n > MAX_POINTS) return MSM_HIP_ERR_INVALID_ARG;
   if (ctx->n_bases == 0 && n) return MSM_HIP_ERR_NO_BASES;
   if (n > ctx->n_bases) return MSM_HIP_ERR_INVALID_ARG;
   return MSM_HIP_OK;
@@ -285,6 +287,7 @@ int check_run_args(msm_hip_ctx* ctx, const void* scalars, size_t n) {
 int set_bases_from_device(msm_hip_ctx* ctx, const uint32_t* d_xy, size_t n, uint32_t flags) {
   // no run may still be reading the old bases
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (n > MAX_POINTS) return MSM_HIP_ERR_INVALID_ARG;
   if (n > ctx->cap_bases) {
     ctx->n_bases = ctx->cap_bases = 0;
     int rc = dev_alloc(ctx, ctx->d_bases, n * 16);
@@ -501,6 +504,23 @@ int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, u
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer may still feed an earlier launch
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scalars, scalars_host, n * 32, hipMemcpyHostToDevice, ctx->stream));
   return msm_hip_run_device_bn254(ctx, ctx->d_scalars, n, out_xyz);
+}
+
+int msm_hip_run_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, size_t batch, uint8_t* out_xyz) {
+  if (!out_xyz && batch) return MSM_HIP_ERR_INVALID_ARG;
+  int rc = check_run_args(ctx, scalars_dev, n);
+  if (rc) return rc;
+  // software pipeline over the result slots: the host combine of MSM i overlaps the device work of MSM i+1 .. i+2
+  const uint8_t* sc = static_cast<const uint8_t*>(scalars_dev);
+  constexpr size_t DEPTH = NSLOT - 1;
+  for (size_t i = 0; i < batch + DEPTH; i++) {
+    if (i >= DEPTH) {
+      const size_t j = i - DEPTH;
+      if ((rc = msm_hip_finish_bn254(ctx, (int)(j % NSLOT), out_xyz + 96 * j))) return rc;
+    }
+    if (i < batch && (rc = msm_hip_launch_device_bn254(ctx, sc + i * n * 32, n, (int)(i % NSLOT)))) return rc;
+  }
+  return MSM_HIP_OK;
 }
 
 int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end,

@@ -194,3 +194,17 @@ def test_skewed_distributions_match_oracle(ctx, kind):
     sb = ref.scalars_to_bytes(sc)
     ctx.set_bases(points)
     assert ctx.msm(sb).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points, sb))
+
+
+def test_batch_over_shared_base(ctx):
+    # BASELINE config 5 in miniature: many scalar vectors over one resident base, pipelined inside the library
+    n, batch = 3000, 7
+    pts = ctx.sample_points(n, 150)
+    sc = ctx.sample_scalars(n * batch, 151)
+    ctx.set_bases(pts)
+    got = ctx.msm_batch(sc, n)
+    assert len(got) == batch
+    pb = pts.cpu().numpy().tobytes()
+    for k in range(batch):
+        sb = sc[k * n:(k + 1) * n].cpu().numpy().tobytes()
+        assert got[k].to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb, sb)), k
