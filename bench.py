@@ -153,6 +153,12 @@ def main():
             isolated = ctx.stage_ms()
         latency_ms = sorted(lat)[len(lat) // 2]
 
+    # sharded runs: check the gathered + combined result against this rank's own whole 16-window MSM (outside the timed region)
+    sharded_ok = None
+    if sharded and emulate <= 1:
+        whole = ctx.msm(scalar_sets[(args.steps - 1) & 1])
+        sharded_ok = bool(whole == last)
+
     ms_per_step = elapsed * 1e3 / args.steps
     smvp_avg_ms = sum(smvp_ms) / len(smvp_ms)
     alg_bytes = smvp_algorithmic_bytes(n, w_local)
@@ -188,6 +194,7 @@ def main():
                      "kernel_ms": smvp_avg_ms},
         "stage_ms": {k: v / len(smvp_ms) for k, v in stage_acc.items()},
         "emulated_world": emulate if emulate > 1 else None,
+        "sharded_result_equals_single_gpu": sharded_ok,
         "latency_ms_single_msm": latency_ms,
         "stage_ms_single_msm": isolated,
     }
