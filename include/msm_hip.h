@@ -106,6 +106,9 @@ int msm_hip_sample_points_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void
  *      ms[4] SMVP accumulate (k_smvp_chunks), ms[5] SMVP stitch, ms[6] bucket reduce,
  *      ms[7] whole device pipeline, ms[8] host finalisation.  Returns the number of entries written. ---- */
 int msm_hip_last_stage_ms(msm_hip_ctx* ctx, float* ms, int cap);
+/* which stage boundaries get HIP events (each costs a few microseconds of queue time between kernels):
+ * 0 none, 1 only around the SMVP accumulate kernel (ms[4]; everything else reads 0), 2 every stage (default) */
+int msm_hip_set_stage_timing(msm_hip_ctx* ctx, int level);
 /* the context's main stream as a hipStream_t */
 void* msm_hip_stream(msm_hip_ctx* ctx);
 

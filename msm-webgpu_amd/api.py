@@ -65,6 +65,7 @@ def lib():
         L.msm_hip_stream.argtypes = [vp]
         L.msm_hip_stream.restype = vp
         L.msm_hip_set_debug.argtypes = [vp, i]
+        L.msm_hip_set_stage_timing.argtypes = [vp, i]
         L.msm_hip_read_digits.argtypes = [vp, vp, sz]
         L.msm_hip_read_col_ptr.argtypes = [vp, vp, sz]
         L.msm_hip_read_val_idxs.argtypes = [vp, vp, sz]
@@ -279,6 +280,10 @@ class MsmContext:
         return t
 
     # -- measurement
+    def set_stage_timing(self, level):
+        """0: no stage events; 1: only around the SMVP accumulate kernel; 2: every stage boundary (default)."""
+        _check(lib().msm_hip_set_stage_timing(self._h, int(level)), "msm_hip_set_stage_timing")
+
     def stage_ms(self):
         buf = (C.c_float * 10)()
         k = lib().msm_hip_last_stage_ms(self._h, buf, 10)

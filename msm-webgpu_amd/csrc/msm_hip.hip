@@ -42,6 +42,7 @@ struct Slot {
   hipEvent_t smvp_done = nullptr;             // main -> reduce hand-off
   hipEvent_t done = nullptr;                  // everything of this slot finished (recorded on the reduce stream)
   bool timed = false, pending = false, to_host = false;
+  int timing_level = 0;
   int w_begin = 0, w_count = 0;
   size_t n = 0;
 };
@@ -63,6 +64,7 @@ struct msm_hip_ctx {
   uint32_t* d_scalars = nullptr;
   uint16_t* d_digits = nullptr;  // digit-code planes, only written when debug read-back is enabled
   bool debug = false;
+  int timing_level = 2;  // 0: no stage events, 1: only around the SMVP kernel, 2: every stage boundary
   uint32_t* d_counts = nullptr;      // [W][tiles][128]
   uint32_t* d_bin_total = nullptr;   // [W][128]
   uint32_t* d_coarse_ptr = nullptr;  // [W][129]
@@ -199,34 +201,39 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   uint32_t* d_err = reinterpret_cast<uint32_t*>(s.d_wsums + WSUM_BYTES);
   if (!wsums_out) wsums_out = reinterpret_cast<uint32_t*>(s.d_wsums);
 
-  // the slot's previous occupant (bucket reduce + copies on the reduce stream) must have drained
+  // the slot's previous occupant (bucket reduce + copies on the reduce stream) must have drained; its error word was
+  // re-zeroed at the end of that chain.  Stage events cost a few microseconds of queue time each, so only the ones the
+  // current timing level asks for are recorded.
+  const int tl = ctx->timing_level;
+  auto mark = [&](int i, bool smvp_edge) -> hipError_t {
+    if (tl >= 2 || (tl == 1 && smvp_edge)) return hipEventRecord(s.ev[i], st);
+    return hipSuccess;
+  };
   HIP_TRY(ctx, hipStreamWaitEvent(st, s.done, 0));
-  HIP_TRY(ctx, hipMemsetAsync(d_err, 0, 4, st));
-
-  HIP_TRY(ctx, hipEventRecord(s.ev[0], st));
+  HIP_TRY(ctx, mark(0, false));
   hipLaunchKernelGGL(k_count, dim3(tiles), dim3(256), 0, st, d_scalars, n, tile_len, tiles, w_begin, w_count, ctx->d_counts, digits, d_err);
-  HIP_TRY(ctx, hipEventRecord(s.ev[1], st));
+  HIP_TRY(ctx, mark(1, false));
   hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total);
   hipLaunchKernelGGL(k_bin_starts, dim3(w_count), dim3(128), 0, st, ctx->d_bin_total, ctx->d_coarse_ptr);
-  HIP_TRY(ctx, hipEventRecord(s.ev[2], st));
+  HIP_TRY(ctx, mark(2, false));
   hipLaunchKernelGGL(k_scatter_coarse, dim3(tiles), dim3(256), 0, st, d_scalars, n, stride, tile_len, tiles, w_begin, w_count,
                      ctx->d_counts, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine);
-  HIP_TRY(ctx, hipEventRecord(s.ev[3], st));
+  HIP_TRY(ctx, mark(3, false));
   hipLaunchKernelGGL(k_sort_fine, dim3(NCOARSE, w_count), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
                      ctx->d_col_ptr, ctx->d_val, chunks, chunk_len, ctx->d_chunk_slot);
-  HIP_TRY(ctx, hipEventRecord(s.ev[4], st));
+  HIP_TRY(ctx, mark(4, true));
   hipLaunchKernelGGL(k_smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, ctx->d_col_ptr, ctx->d_val, stride,
                      chunks, chunk_len, ctx->d_chunk_slot, s.d_buckets, ctx->d_heads, ctx->d_tails);
-  HIP_TRY(ctx, hipEventRecord(s.ev[5], st));
+  HIP_TRY(ctx, mark(5, true));
   hipLaunchKernelGGL(k_smvp_stitch, dim3(HALF / 256, w_count), dim3(256), 0, st, ctx->d_col_ptr, chunks, chunk_len, ctx->d_heads,
                      ctx->d_tails, s.d_buckets, ctx->d_big_queue);
   hipLaunchKernelGGL(k_smvp_stitch_big, dim3(256), dim3(256), 0, st, ctx->d_col_ptr, chunks, chunk_len, ctx->d_heads, ctx->d_tails,
                      s.d_buckets, ctx->d_big_queue, ctx->d_done_blocks);
-  HIP_TRY(ctx, hipEventRecord(s.ev[6], st));
+  HIP_TRY(ctx, mark(6, false));
   HIP_TRY(ctx, hipEventRecord(s.smvp_done, st));
 
   HIP_TRY(ctx, hipStreamWaitEvent(rs, s.smvp_done, 0));
-  HIP_TRY(ctx, hipEventRecord(s.red0, rs));
+  if (tl >= 2) HIP_TRY(ctx, hipEventRecord(s.red0, rs));
   uint32_t* d_rows = s.d_partials;
   uint32_t* d_cols = d_rows + (size_t)NWIN * 256 * XYZZ_WORDS;
   uint32_t* d_parts = d_cols + (size_t)NWIN * 256 * XYZZ_WORDS;
@@ -241,16 +248,18 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     hipLaunchKernelGGL(k_bpr_rowcol<3>, dim3(bpr_rowcol_blocks<3>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols);
   hipLaunchKernelGGL(k_bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts);
   hipLaunchKernelGGL(k_bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out);
-  HIP_TRY(ctx, hipEventRecord(s.red1, rs));
+  if (tl >= 2) HIP_TRY(ctx, hipEventRecord(s.red1, rs));
   if (to_host) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * 96, hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums + WSUM_BYTES, d_err, 4, hipMemcpyDeviceToHost, rs));
+  HIP_TRY(ctx, hipMemsetAsync(d_err, 0, 4, rs));  // ready for the slot's next occupant
   HIP_TRY(ctx, hipEventRecord(s.done, rs));
   HIP_TRY(ctx, hipGetLastError());
 
   s.w_begin = w_begin;
   s.w_count = w_count;
   s.n = n;
-  s.timed = true;
+  s.timed = tl >= 1;
+  s.timing_level = tl;
   s.pending = true;
   s.to_host = to_host;
   ctx->last_n = n;
@@ -266,9 +275,14 @@ int wait_slot(msm_hip_ctx* ctx, Slot& s) {
   s.pending = false;
   if (s.timed) {
     s.timed = false;
-    for (int i = 0; i < 6; i++) HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[i], s.ev[i], s.ev[i + 1]));
-    HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[6], s.red0, s.red1));
-    HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[7], s.ev[0], s.red1));
+    for (int i = 0; i < 8; i++) ctx->stage_ms[i] = 0.0f;
+    if (s.timing_level >= 2) {
+      for (int i = 0; i < 6; i++) HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[i], s.ev[i], s.ev[i + 1]));
+      HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[6], s.red0, s.red1));
+      HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[7], s.ev[0], s.red1));
+    } else {
+      HIP_TRY(ctx, hipEventElapsedTime(&ctx->stage_ms[4], s.ev[4], s.ev[5]));
+    }
   }
   uint32_t bits;
   memcpy(&bits, s.h_wsums + WSUM_BYTES, 4);
@@ -368,6 +382,7 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
     if (hipHostMalloc((void**)&s.h_wsums, WSUM_BYTES + 4, hipHostMallocDefault) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
     memset(s.h_wsums, 0, WSUM_BYTES + 4);
     if ((rc = dev_alloc(ctx, s.d_wsums, WSUM_BYTES + 4))) return fail(rc);
+    if (hipMemset(s.d_wsums, 0, WSUM_BYTES + 4) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
     if ((rc = dev_alloc(ctx, s.d_buckets, (size_t)NWIN * HALF * REC_WORDS))) return fail(rc);
     if ((rc = dev_alloc(ctx, s.d_partials, (size_t)NWIN * (256 + 256 + 3) * XYZZ_WORDS))) return fail(rc);
     if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
@@ -583,6 +598,12 @@ static int read_back(msm_hip_ctx* ctx, void* out, const void* src, size_t bytes,
   for (hipStream_t r : ctx->reduce_stream) HIP_TRY(ctx, hipStreamSynchronize(r));
   HIP_TRY(ctx, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSM_HIP_OK;
+}
+
+int msm_hip_set_stage_timing(msm_hip_ctx* ctx, int level) {
+  if (!ctx || level < 0 || level > 2) return MSM_HIP_ERR_INVALID_ARG;
+  ctx->timing_level = level;
   return MSM_HIP_OK;
 }
 
