@@ -1,0 +1,20 @@
+"""Randomised differential test against the oracle (sizes on tile / chunk / alignment edges, skewed and edge-case scalar
+distributions, duplicate and negated points, host / device / window-sharded / batch entry points): tools/fuzz_gpu.py."""
+import os
+import runpy
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fuzz_against_oracle(built, capsys):
+    argv = sys.argv
+    sys.argv = ["fuzz_gpu.py", "40", "20261003"]
+    try:
+        runpy.run_path(os.path.join(ROOT, "tools", "fuzz_gpu.py"), run_name="__main__")
+    finally:
+        sys.argv = argv
+    assert "fuzz ok: 40 cases" in capsys.readouterr().out

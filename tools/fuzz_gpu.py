@@ -1,0 +1,65 @@
+"""Randomised differential test of the HIP engine against the CPU oracle: random sizes (tile / chunk / alignment edges),
+random scalar distributions (uniform, few distinct values, small values, zeros, equal), random window ranges.
+Usage: python tools/fuzz_gpu.py [cases] [seed]   (test infrastructure: uses the oracle)"""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import msm_webgpu_amd as m
+from msm_webgpu_amd.sharding import window_range
+from oracle import cpu, bn254_ref as ref
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rnd = random.Random(seed)
+ctx = m.MsmContext(0)
+R = ref.R
+special_n = [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8193, 16385, 32769, 65535, 65537]
+t0 = time.time()
+for case in range(cases):
+    n = rnd.choice(special_n) if rnd.random() < 0.4 else rnd.randrange(1, 70000)
+    pseed, sseed = rnd.randrange(1 << 30), rnd.randrange(1 << 30)
+    points = cpu.sample_points(pseed, n)
+    base = ref.bytes_to_scalars(cpu.sample_scalars(sseed, n))
+    kind = rnd.choice(["uniform", "few", "small", "zeros", "equal", "dup_points", "edge"])
+    if kind == "few":
+        vals = [base[rnd.randrange(n)] for _ in range(rnd.randrange(1, 6))]
+        sc = [rnd.choice(vals) for _ in range(n)]
+    elif kind == "small":
+        bits = rnd.choice([1, 2, 8, 15, 16, 17, 31, 33])
+        sc = [rnd.randrange(1 << bits) for _ in range(n)]
+    elif kind == "zeros":
+        sc = [0 if rnd.random() < 0.7 else base[i] for i in range(n)]
+    elif kind == "equal":
+        sc = [base[0]] * n
+    elif kind == "edge":
+        pool = [0, 1, R - 1, R - 2, 0x8000, 0x7FFF, 0xFFFF, int("8000" * 15, 16), (1 << 250) - 1, int("7fff" * 15, 16), (1 << 253) + 12345]
+        sc = [rnd.choice(pool) for _ in range(n)]
+    else:
+        sc = base
+    if kind == "dup_points":
+        pts = ref.bytes_to_points(points)
+        k = max(1, n // 3)
+        pts = [pts[i % k] if rnd.random() < 0.8 else ref.neg(pts[i % k]) for i in range(n)]
+        points = ref.points_to_bytes(pts)
+        sc = [base[i % max(1, n // 5)] for i in range(n)]
+    sb = ref.scalars_to_bytes(sc)
+    want = cpu.to_affine64(cpu.cpu_msm(points, sb))
+    ctx.set_bases(points)
+    mode = rnd.choice(["host", "device", "windows", "batch"])
+    if mode == "host":
+        got = ctx.msm(sb)
+    elif mode == "device":
+        t = torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda()
+        got = ctx.msm(t)
+    elif mode == "batch":
+        t = torch.frombuffer(bytearray(sb + sb), dtype=torch.uint8).cuda()
+        got = ctx.msm_batch(t, n)[1]
+    else:
+        t = torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda()
+        world = rnd.choice([2, 3, 4, 5, 8, 16])
+        parts = [ctx.msm_windows(t, *window_range(r, world)) for r in range(world)]
+        got = m.MsmContext.combine_windows(torch.cat(parts, dim=0))
+    if got.to_affine_bytes() != want:
+        print("MISMATCH case", case, "n", n, "kind", kind, "mode", mode, "seeds", pseed, sseed)
+        sys.exit(1)
+print("fuzz ok: %d cases in %.1f s (seed %d)" % (cases, time.time() - t0, seed))
