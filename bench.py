@@ -24,6 +24,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the engine runs 3 HIP streams and the sharded path adds torch's copy stream and RCCL's: keep them on separate hardware
+# queues (ROCm's default is 4 per process; must be set before the HIP runtime initialises)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

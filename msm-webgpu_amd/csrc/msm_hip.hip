@@ -7,7 +7,7 @@
 //
 // Execution model.  Every MSM runs in one of MSM_HIP_NUM_SLOTS result slots (own bucket and window-sum buffers):
 //   stream "main"   : recode + sort + SMVP accumulate + stitch                  -> event smvp_done[slot]
-//   stream "reduce" : (waits smvp_done) bucket reduce -> window sums -> D2H     -> event done[slot]   (two of them)
+//   stream "reduce" : (waits smvp_done) bucket reduce -> window sums -> D2H     -> event done[slot]
 // The bucket reduce is bound by the depth of dependent group additions and occupies few waves; putting it on its own
 // stream lets the sort + SMVP of the NEXT MSM (other slot, own bucket buffer) start while it runs.  The host window
 // combine of a slot (src/cuzk/msm.rs:411-416) runs in the caller's thread inside msm_hip_finish_bn254.
@@ -30,7 +30,11 @@ namespace {
 constexpr int N_MAIN_EVENTS = 7;  // boundaries of the 6 timed stages on the main stream
 constexpr uint32_t MAX_TILES = 1024;
 constexpr size_t WSUM_BYTES = (size_t)NWIN * 96;
-constexpr int NSLOT = MSM_HIP_NUM_SLOTS;  // result slots; slot k reduces on reduce stream k & 1
+constexpr int NSLOT = MSM_HIP_NUM_SLOTS;  // result slots
+constexpr int NREDUCE = 2;  // reduce streams (slot k uses stream k % NREDUCE): two bucket reduces may be in flight when the
+                            // main-stream work of one MSM is shorter than its bucket reduce (few windows per GPU).  The context
+                            // then owns 3 streams; callers that add their own (copies, RCCL) should raise GPU_MAX_HW_QUEUES
+                            // above ROCm's default of 4 so that streams do not share hardware queues (bench.py does).
 
 struct Slot {
   uint8_t* h_wsums = nullptr;      // pinned: NWIN x 96 B window sums + 4 B error word
@@ -52,7 +56,7 @@ struct Slot {
 struct msm_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;         // main
-  hipStream_t reduce_stream[2] = {nullptr, nullptr};  // bucket reduce + result copies (slot k uses stream k & 1)
+  hipStream_t reduce_stream[NREDUCE] = {};  // bucket reduce + result copies
   int last_hip_error = 0;
 
   uint32_t* d_bases = nullptr;  // n_bases x 16 words
@@ -189,7 +193,7 @@ int err_from_bits(uint32_t bits) {
 // copied to the slot's pinned buffer.  Returns without waiting.
 int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count, Slot& s, uint32_t* wsums_out,
             bool to_host) {
-  hipStream_t st = ctx->stream, rs = ctx->reduce_stream[(&s - ctx->slot) & 1];
+  hipStream_t st = ctx->stream, rs = ctx->reduce_stream[(&s - ctx->slot) % NREDUCE];
   // tiles of scalars for the two global sort passes: >= 2048 scalars each, at most MAX_TILES of them
   uint32_t tile_len = 2048;
   if ((n + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n + MAX_TILES - 1) / MAX_TILES) + 255) / 256 * 256);
@@ -367,7 +371,7 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
     return code;
   };
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(MSM_HIP_ERR_NO_DEVICE);
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < NREDUCE; k++)
     if (hipStreamCreateWithFlags(&ctx->reduce_stream[k], hipStreamNonBlocking) != hipSuccess) return fail(MSM_HIP_ERR_NO_DEVICE);
   if ((rc = dev_alloc(ctx, ctx->d_counts, (size_t)NWIN * MAX_TILES * NCOARSE))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_bin_total, (size_t)NWIN * NCOARSE))) return fail(rc);
@@ -457,8 +461,8 @@ int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_de
     s.timed = false;
     memset(s.h_wsums, 0, WSUM_BYTES + 4);
     if (window_sums_dev) {
-      HIP_TRY(ctx, hipMemsetAsync(window_sums_dev, 0, (size_t)w_count * 96, ctx->reduce_stream[slot & 1]));
-      HIP_TRY(ctx, hipEventRecord(s.done, ctx->reduce_stream[slot & 1]));
+      HIP_TRY(ctx, hipMemsetAsync(window_sums_dev, 0, (size_t)w_count * 96, ctx->reduce_stream[slot % NREDUCE]));
+      HIP_TRY(ctx, hipEventRecord(s.done, ctx->reduce_stream[slot % NREDUCE]));
     }
     return MSM_HIP_OK;
   }
