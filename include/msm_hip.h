@@ -92,6 +92,10 @@ int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot);
 /* result = sum_w 2^(16 w) * S_w over num_windows records (host memory): src/cuzk/msm.rs:411-416 */
 int msm_hip_combine_windows_bn254(const uint8_t* window_sums_host, int num_windows, uint8_t out_xyz[96]);
 
+/* host-only helper (≙ Curve::to_affine as used by tests/cuzk.rs:88-94): 96 B Jacobian -> 64 B canonical affine x || y.
+ * Returns 1 when the point is the identity (out zeroed), 0 otherwise, negative on error. */
+int msm_hip_g1_to_affine_bn254(const uint8_t xyz[96], uint8_t out_xy[64]);
+
 /* ---- one-shot: create context, set bases, run, destroy (≙ compute_msm as the reference calls it) ---- */
 int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
 

@@ -1,0 +1,122 @@
+// C++ host-side mirror of the reference's Rust surface for the MSM path, over the C ABI of msm_hip.h.
+//
+// The reference is a Rust crate (/root/reference/src/lib.rs); this image has no Rust toolchain, so the host side above
+// the ABI is C++ (header-only, links libmsm_hip.so).  Names, argument meaning and error behaviour follow the reference:
+//
+//   sample_scalars / sample_points            src/lib.rs:20-42    (seeded here; thread_rng there)
+//   scalars_to_bytes / points_to_bytes        src/lib.rs:50-65
+//   cpu_msm                                   src/lib.rs:45-47    NOT provided: the product has no CPU path (the oracle is
+//                                                                 test infrastructure)
+//   run_webgpu_msm / compute_msm              src/lib.rs:76-82, src/cuzk/msm.rs:75-417
+//   G1 == G1 (projective equality)            src/lib.rs:166
+//
+// Where the reference panics (no device gpu.rs:22,51; infinity in the input lib.rs:58; non-canonical bytes utils.rs:20;
+// off-curve read-back msm.rs:399) these functions throw msm_webgpu::Error carrying the C-ABI code.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "msm_hip.h"
+
+namespace msm_webgpu {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const char* where) : std::runtime_error(std::string(where) + ": " + msm_hip_strerror(c)), code(c) {}
+};
+inline void check(int code, const char* where) {
+  if (code != MSM_HIP_OK) throw Error(code, where);
+}
+
+// field elements and points travel as canonical little-endian bytes, exactly the reference's to_repr() (utils.rs:10-14)
+using Fr = std::array<uint8_t, 32>;   // scalar in [0, r)
+using Fq = std::array<uint8_t, 32>;   // coordinate in [0, p)
+struct G1Affine {
+  Fq x{}, y{};
+  bool infinity = false;              // the reference's points_to_bytes panics on it (lib.rs:58)
+};
+
+// Jacobian result (≙ C::Curve), z = 0 <=> identity
+struct G1 {
+  std::array<uint8_t, 96> xyz{};
+  bool is_identity() const {
+    for (int i = 64; i < 96; i++)
+      if (xyz[i]) return false;
+    return true;
+  }
+  G1Affine to_affine() const {  // ≙ Curve::to_affine
+    G1Affine a;
+    std::array<uint8_t, 64> xy{};
+    const int r = msm_hip_g1_to_affine_bn254(xyz.data(), xy.data());
+    if (r < 0) throw Error(r, "msm_hip_g1_to_affine_bn254");
+    a.infinity = r == 1;
+    std::memcpy(a.x.data(), xy.data(), 32);
+    std::memcpy(a.y.data(), xy.data() + 32, 32);
+    return a;
+  }
+  bool operator==(const G1& o) const {  // projective equality, as G1's PartialEq
+    const G1Affine a = to_affine(), b = o.to_affine();
+    return a.infinity == b.infinity && a.x == b.x && a.y == b.y;
+  }
+  bool operator!=(const G1& o) const { return !(*this == o); }
+};
+
+/// Convert scalars to bytes (src/lib.rs:50-52)
+inline std::vector<uint8_t> scalars_to_bytes(const std::vector<Fr>& v) {
+  std::vector<uint8_t> out(v.size() * 32);
+  for (size_t i = 0; i < v.size(); i++) std::memcpy(out.data() + 32 * i, v[i].data(), 32);
+  return out;
+}
+
+/// Convert points to bytes as [x0, y0, x1, y1, ...] (src/lib.rs:55-65); the point at infinity has no coordinates
+inline std::vector<uint8_t> points_to_bytes(const std::vector<G1Affine>& g) {
+  std::vector<uint8_t> out(g.size() * 64);
+  for (size_t i = 0; i < g.size(); i++) {
+    if (g[i].infinity) throw std::invalid_argument("points_to_bytes: point at infinity has no coordinates (src/lib.rs:58)");
+    std::memcpy(out.data() + 64 * i, g[i].x.data(), 32);
+    std::memcpy(out.data() + 64 * i + 32, g[i].y.data(), 32);
+  }
+  return out;
+}
+
+/// Persistent engine on one GPU (replaces the per-call device creation of src/cuzk/msm.rs:88-94)
+class MsmContext {
+ public:
+  explicit MsmContext(int device = 0) { check(msm_hip_ctx_create(&ctx_, device), "msm_hip_ctx_create"); }
+  ~MsmContext() { msm_hip_ctx_destroy(ctx_); }
+  MsmContext(const MsmContext&) = delete;
+  MsmContext& operator=(const MsmContext&) = delete;
+
+  void set_bases(const std::vector<G1Affine>& g, bool check_on_curve = false) {
+    const std::vector<uint8_t> b = points_to_bytes(g);
+    check(msm_hip_set_bases_bn254(ctx_, b.data(), g.size(), check_on_curve ? MSM_HIP_CHECK_ON_CURVE : 0u), "msm_hip_set_bases_bn254");
+  }
+  G1 msm(const std::vector<Fr>& v) {
+    const std::vector<uint8_t> b = scalars_to_bytes(v);
+    G1 r;
+    check(msm_hip_run_bn254(ctx_, b.data(), v.size(), r.xyz.data()), "msm_hip_run_bn254");
+    return r;
+  }
+  msm_hip_ctx* raw() { return ctx_; }
+
+ private:
+  msm_hip_ctx* ctx_ = nullptr;
+};
+
+/// ≙ compute_msm (src/cuzk/msm.rs:75): one-shot MSM including device set-up and base upload
+inline G1 compute_msm(const std::vector<G1Affine>& points, const std::vector<Fr>& scalars) {
+  if (points.size() != scalars.size()) throw std::invalid_argument("compute_msm: points and scalars differ in length");
+  const std::vector<uint8_t> pb = points_to_bytes(points), sb = scalars_to_bytes(scalars);
+  G1 r;
+  check(msm_hip_msm_bn254_g1(pb.data(), sb.data(), scalars.size(), r.xyz.data()), "msm_hip_msm_bn254_g1");
+  return r;
+}
+
+/// ≙ run_webgpu_msm (src/lib.rs:76-82); the name is the reference's, the device is an MI355X
+inline G1 run_webgpu_msm(const std::vector<G1Affine>& g, const std::vector<Fr>& v) { return compute_msm(g, v); }
+
+}  // namespace msm_webgpu

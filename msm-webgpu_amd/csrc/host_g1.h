@@ -111,6 +111,16 @@ inline void hfq_to_bytes(uint8_t b[32], const hfq& a) {
   memcpy(b, t.l, 32);
 }
 
+inline hfq hfq_inv(const hfq& a) {  // a^(p-2), square-and-multiply from the top bit
+  uint64_t e[4] = {FQ_P64[0] - 2, FQ_P64[1], FQ_P64[2], FQ_P64[3]};
+  hfq acc = {{FQ_ONE64[0], FQ_ONE64[1], FQ_ONE64[2], FQ_ONE64[3]}};
+  for (int i = 255; i >= 0; i--) {
+    acc = hfq_sqr(acc);
+    if ((e[i >> 6] >> (i & 63)) & 1) acc = hfq_mul(acc, a);
+  }
+  return acc;
+}
+
 struct hg1 {  // Jacobian, z == 0 <=> identity
   hfq x, y, z;
 };
@@ -175,6 +185,21 @@ inline void hg1_to_bytes96(uint8_t b[96], const hg1& p) {
   hfq_to_bytes(b, p.x);
   hfq_to_bytes(b + 32, p.y);
   hfq_to_bytes(b + 64, p.z);
+}
+
+// Jacobian bytes -> canonical affine x || y (≙ Curve::to_affine); returns 1 for the identity (out zeroed), -1 on a
+// non-canonical coordinate, 0 otherwise
+inline int to_affine64(const uint8_t xyz[96], uint8_t out[64]) {
+  hg1 p;
+  if (!hg1_from_bytes96(p, xyz)) return -1;
+  if (hg1_is_identity(p)) {
+    memset(out, 0, 64);
+    return 1;
+  }
+  const hfq zi = hfq_inv(p.z), zi2 = hfq_sqr(zi);
+  hfq_to_bytes(out, hfq_mul(p.x, zi2));
+  hfq_to_bytes(out + 32, hfq_mul(p.y, hfq_mul(zi2, zi)));
+  return 0;
 }
 
 // result = sum_w 2^(window_bits * w) * S_w, from the top window down  (src/cuzk/msm.rs:411-416)

@@ -556,6 +556,12 @@ int msm_hip_combine_windows_bn254(const uint8_t* window_sums_host, int num_windo
   return MSM_HIP_OK;
 }
 
+int msm_hip_g1_to_affine_bn254(const uint8_t xyz[96], uint8_t out_xy[64]) {
+  if (!xyz || !out_xy) return MSM_HIP_ERR_INVALID_ARG;
+  const int r = bn254::host::to_affine64(xyz, out_xy);
+  return r < 0 ? MSM_HIP_ERR_NONCANONICAL : r;
+}
+
 int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
   msm_hip_ctx* ctx = nullptr;
   int rc = msm_hip_ctx_create(&ctx, 0);

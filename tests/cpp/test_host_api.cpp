@@ -1,0 +1,65 @@
+// C++ host API smoke/parity driver (reads like the reference's src/lib.rs:152-167 test: fast == result).
+// usage: test_host_api <points.bin> <scalars.bin> <expected_affine64.bin>   -> exit 0 on a bit-exact match
+//        test_host_api --no-device                                           -> exit 0 if the API fails loudly without a GPU
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+
+#include "msm_hip.hpp"
+
+using namespace msm_webgpu;
+
+static std::vector<uint8_t> slurp(const char* path) {
+  std::ifstream f(path, std::ios::binary);
+  return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+int main(int argc, char** argv) {
+  if (argc == 2 && std::string(argv[1]) == "--no-device") {
+    try {
+      MsmContext ctx(0);
+    } catch (const Error& e) {
+      std::printf("expected failure: %s (code %d)\n", e.what(), e.code);
+      return e.code == MSM_HIP_ERR_NO_DEVICE ? 0 : 2;
+    }
+    std::printf("a device is present\n");
+    return 3;
+  }
+  if (argc != 4) return 64;
+  const std::vector<uint8_t> pb = slurp(argv[1]), sb = slurp(argv[2]), want = slurp(argv[3]);
+  const size_t n = sb.size() / 32;
+  std::vector<G1Affine> g(n);
+  std::vector<Fr> v(n);
+  for (size_t i = 0; i < n; i++) {
+    std::memcpy(g[i].x.data(), pb.data() + 64 * i, 32);
+    std::memcpy(g[i].y.data(), pb.data() + 64 * i + 32, 32);
+    std::memcpy(v[i].data(), sb.data() + 32 * i, 32);
+  }
+  // one-shot, as the reference calls it ...
+  const G1 fast = run_webgpu_msm(g, v);
+  // ... and through a persistent context
+  MsmContext ctx(0);
+  ctx.set_bases(g, true);
+  const G1 again = ctx.msm(v);
+  if (fast != again) return 1;
+  const G1Affine a = fast.to_affine();
+  std::vector<uint8_t> got(64, 0);
+  if (!a.infinity) {
+    std::memcpy(got.data(), a.x.data(), 32);
+    std::memcpy(got.data() + 32, a.y.data(), 32);
+  }
+  if (got != want) {
+    std::printf("MISMATCH\n");
+    return 1;
+  }
+  // error behaviour: the reference panics on infinity (lib.rs:58); here it throws
+  try {
+    std::vector<G1Affine> bad(1);
+    bad[0].infinity = true;
+    (void)points_to_bytes(bad);
+    return 4;
+  } catch (const std::invalid_argument&) {
+  }
+  std::printf("host api ok: n=%zu\n", n);
+  return 0;
+}

@@ -69,3 +69,18 @@ def test_wire_format_helpers(built):
     g = m.G1(ref.points_to_bytes([pts[0]]) + (1).to_bytes(32, "little"))
     assert g.to_affine() == pts[0] and not g.is_identity()
     assert m.G1(bytes(96)).to_affine() is None and m.G1(bytes(96)).to_affine_bytes() == bytes(64)
+
+
+def test_host_to_affine_helper_matches_oracle(built):
+    import msm_webgpu_amd as m
+
+    L = m.lib()
+    L.msm_hip_g1_to_affine_bn254.argtypes = [C.c_char_p, C.c_char_p]
+    pts = cpu.g1_scalar_mul(cpu.sample_points(5, 8), cpu.sample_scalars(6, 8))  # 8 Jacobian points with z != 1
+    for k in range(8):
+        out = C.create_string_buffer(64)
+        assert L.msm_hip_g1_to_affine_bn254(pts[96 * k:96 * k + 96], out) == 0
+        assert out.raw == cpu.to_affine64(pts[96 * k:96 * k + 96])
+    out = C.create_string_buffer(64)
+    assert L.msm_hip_g1_to_affine_bn254(bytes(96), out) == 1 and out.raw == bytes(64)
+    assert L.msm_hip_g1_to_affine_bn254(b"\xff" * 96, out) == -4
