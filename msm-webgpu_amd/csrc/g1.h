@@ -142,13 +142,6 @@ FQ_HD g1_xyzz g1_add(const g1_xyzz& a, const g1_xyzz& b) {
   return r;
 }
 
-FQ_HD g1_xyzz g1_neg(const g1_xyzz& a) {
-  g1_xyzz r = a;
-  if (!a.inf) r.y = fq_sub<6>(fq_zero(), a.y);          // Y < 5p       -> < 6p ... re-tidied below
-  if (!a.inf) r.y = fq_tidy(r.y);                       // back under the Y < 5p invariant (exact, < 2p)
-  return r;
-}
-
 // k * a for a small scalar, left-to-right double-and-add (≙ double_and_add, ec.template.wgsl:124-139)
 FQ_HD g1_xyzz g1_mul_u32(const g1_xyzz& a, uint32_t k) {
   g1_xyzz acc = g1_identity();

@@ -79,18 +79,6 @@ __device__ __forceinline__ fq fq_three() {
   return r;
 }
 
-// Jacobian record (24 words, Montgomery canonical) <-> XYZZ registers
-__device__ __forceinline__ g1_xyzz ld_jacobian(const uint32_t* p) {
-  const fq X = ld_fq(p), Y = ld_fq(p + 8), Z = ld_fq(p + 16);
-  return g1_from_jacobian(X, Y, Z);
-}
-__device__ __forceinline__ void st_jacobian(uint32_t* p, const g1_xyzz& a) {
-  fq X, Y, Z;
-  g1_to_jacobian(a, X, Y, Z);
-  st_fq(p, X);
-  st_fq(p + 8, Y);
-  st_fq(p + 16, Z);
-}
 // Jacobian record, canonical non-Montgomery integers (the wire format of results)
 __device__ __forceinline__ void st_jacobian_plain(uint32_t* p, const g1_xyzz& a) {
   fq X, Y, Z;
