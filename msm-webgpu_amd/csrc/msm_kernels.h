@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
 // The reference gives one thread one bucket, so a wave runs as long as its fullest bucket.  Here every lane owns a
 // fixed-length chunk of `chunk_len` consecutive entries of the slot-sorted list -- equal work per lane whatever the bucket
 // sizes -- and flushes its accumulator whenever the slot changes.  The host picks chunk_len (a multiple of 4 in
-// [SMVP_CHUNK_MIN, SMVP_CHUNK_MAX]) so that about SMVP_TARGET_LANES lanes exist (one and a half rounds of 4 waves per SIMD).  Runs that cross a chunk boundary leave a "tail" piece
+// [SMVP_CHUNK_MIN, SMVP_CHUNK_MAX]) so that about SMVP_TARGET_LANES lanes exist (about two rounds of 3 waves per SIMD at 132 VGPRs, no scratch).  Runs that cross a chunk boundary leave a "tail" piece
 // (in the chunk where the run starts) and "head" pieces (in the chunks it continues into); k_smvp_stitch adds them.
 // Buckets and pieces are stored as raw XYZZ records (no multiplication on the flush path).
 constexpr int SMVP_CHUNK_MIN = 8;
@@ -489,7 +489,7 @@ __device__ __forceinline__ g1_xyzz ld_rec(const uint32_t* p) {
   return a;
 }
 
-__global__ void __launch_bounds__(256, 4) k_smvp_chunks(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ col_ptr,
+__global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ col_ptr,
                                                      const uint32_t* __restrict__ val_idxs, size_t stride, uint32_t chunks,
                                                      uint32_t chunk_len, const uint32_t* __restrict__ chunk_slot,
                                                      uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
