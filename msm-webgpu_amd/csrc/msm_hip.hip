@@ -72,6 +72,7 @@ struct msm_hip_ctx {
   uint32_t* d_counts = nullptr;      // [W][tiles][128]
   uint32_t* d_bin_total = nullptr;   // [W][128]
   uint32_t* d_coarse_ptr = nullptr;  // [W][129]
+  uint32_t* d_scan_done = nullptr;   // [W] block counters of k_scan_tiles (self re-arming)
   uint32_t* d_col_ptr = nullptr;     // [W][32769]
   uint32_t* d_tmp_val = nullptr;     // [W][stride] coarse-bin order
   uint8_t* d_tmp_fine = nullptr;     // [W][stride]
@@ -217,13 +218,13 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   HIP_TRY(ctx, mark(0, false));
   hipLaunchKernelGGL(k_count, dim3(tiles), dim3(256), 0, st, d_scalars, n, tile_len, tiles, w_begin, w_count, ctx->d_counts, digits, d_err);
   HIP_TRY(ctx, mark(1, false));
-  hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total);
-  hipLaunchKernelGGL(k_bin_starts, dim3(w_count), dim3(128), 0, st, ctx->d_bin_total, ctx->d_coarse_ptr);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total, ctx->d_coarse_ptr,
+                     ctx->d_scan_done);
   HIP_TRY(ctx, mark(2, false));
   hipLaunchKernelGGL(k_scatter_coarse, dim3(tiles), dim3(256), 0, st, d_scalars, n, stride, tile_len, tiles, w_begin, w_count,
                      ctx->d_counts, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine);
   HIP_TRY(ctx, mark(3, false));
-  hipLaunchKernelGGL(k_sort_fine, dim3(NCOARSE, w_count), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
+  hipLaunchKernelGGL(k_sort_fine, dim3(NCOARSE, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
                      ctx->d_col_ptr, ctx->d_val, chunks, chunk_len, ctx->d_chunk_slot);
   HIP_TRY(ctx, mark(4, true));
   hipLaunchKernelGGL(k_smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, ctx->d_col_ptr, ctx->d_val, stride,
@@ -376,6 +377,8 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
   if ((rc = dev_alloc(ctx, ctx->d_counts, (size_t)NWIN * MAX_TILES * NCOARSE))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_bin_total, (size_t)NWIN * NCOARSE))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_coarse_ptr, (size_t)NWIN * (NCOARSE + 1)))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_scan_done, NWIN))) return fail(rc);
+  if (hipMemset(ctx->d_scan_done, 0, NWIN * 4) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
   if ((rc = dev_alloc(ctx, ctx->d_col_ptr, (size_t)NWIN * (HALF + 1)))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_err, 1))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_big_queue, (size_t)STITCH_BIG_CAP + 1))) return fail(rc);
@@ -405,7 +408,7 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipStream_t r : ctx->reduce_stream)
     if (r) (void)hipStreamSynchronize(r);
-  void* bufs[] = {ctx->d_bases,    ctx->d_scalars, ctx->d_digits, ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_col_ptr, ctx->d_tmp_val,
+  void* bufs[] = {ctx->d_bases,    ctx->d_scalars, ctx->d_digits, ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_scan_done, ctx->d_col_ptr, ctx->d_tmp_val,
                   ctx->d_tmp_fine, ctx->d_val,     ctx->d_heads,  ctx->d_tails,  ctx->d_chunk_slot,  ctx->d_err,     ctx->d_stage,
                   ctx->d_big_queue, ctx->d_done_blocks};
   for (void* b : bufs)

@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) k_convert_points(const uint32_t* __restri
 // two-level LDS counting sort over the 15-bit bucket slot, and the recode is fused into both of its global passes
 // (scalars are re-read instead of materialising 16 digit planes: 32 B per scalar either way):
 //   k_count          per tile of scalars: LDS histogram of the 128 coarse bins (slot >> 8) of every window
-//   k_scan_tiles, k_bin_starts   per (window, coarse bin): prefix over tiles; per window: start of every coarse bin
+//   k_scan_tiles     per (window, coarse bin): prefix over tiles; last block per window: start of every coarse bin
 //   k_scatter_coarse per tile: LDS-ranked scatter of (index | sign << 31, slot & 255) into coarse-bin order
 //   k_sort_fine      per (window, coarse bin): LDS counting sort over its 256 slots -> val_idxs + col_ptr
 // Order inside a slot is the arrival order of LDS atomics; the group sum does not depend on it.
@@ -213,9 +213,12 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
 }
 
 // One wave per (window, coarse bin): in place, counts[lw][tile][bin] becomes the number of entries of that bin in earlier
-// tiles; bin_total[lw][bin] receives the bin's size.  k_bin_starts then turns the totals into coarse_ptr[lw][0..128]
-// (start of every coarse bin; [128] = entries in the window).
-__global__ void __launch_bounds__(256) k_scan_tiles(uint32_t* __restrict__ counts, uint32_t tiles, uint32_t* __restrict__ bin_total) {
+// tiles; bin_total[lw][bin] receives the bin's size.  The last block of a window to finish (counted in scan_done[lw]) turns
+// the 128 totals into coarse_ptr[lw][0..128] (start of every coarse bin; [128] = entries in the window) and re-arms the counter.
+__global__ void __launch_bounds__(256) k_scan_tiles(uint32_t* __restrict__ counts, uint32_t tiles, uint32_t* __restrict__ bin_total,
+                                                    uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ scan_done) {
+  __shared__ uint32_t is_last;
+  __shared__ uint32_t wave_tot[2];
   const int lw = blockIdx.y, lane = threadIdx.x & 63;
   const int bin = blockIdx.x * 4 + (threadIdx.x >> 6);
   uint32_t* c = counts + (size_t)lw * tiles * NCOARSE + bin;
@@ -233,23 +236,35 @@ __global__ void __launch_bounds__(256) k_scan_tiles(uint32_t* __restrict__ count
     run += __shfl(x, 63);
   }
   if (lane == 0) bin_total[lw * NCOARSE + bin] = run;
-}
-
-__global__ void __launch_bounds__(128) k_bin_starts(const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr) {
-  __shared__ uint32_t wave_tot[2];
-  const int lw = blockIdx.x, t = threadIdx.x, lane = t & 63;
-  const uint32_t v = bin_total[lw * NCOARSE + t];
-  uint32_t x = v;
+  // last block of this window: exclusive scan of the 128 bin totals.  Hand-off: every storing wave drains its stores and
+  // releases at agent scope before the block's arrival is counted; the explicit waitcnt keeps the write-back ahead of the
+  // counter update (cdna_hip_programming.md, Guideline 16).
+  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(&scan_done[lw], 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  const int t = threadIdx.x;
+  uint32_t v = 0, x = 0;
+  if (t < NCOARSE) {
+    v = __hip_atomic_load(&bin_total[lw * NCOARSE + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x = v;
+  }
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const uint32_t y = __shfl_up(x, off);
     if (lane >= off) x += y;
   }
-  if (lane == 63) wave_tot[t >> 6] = x;
+  if (t < NCOARSE && lane == 63) wave_tot[t >> 6] = x;
   __syncthreads();
-  const uint32_t incl = x + (t >= 64 ? wave_tot[0] : 0u);
-  coarse_ptr[(size_t)lw * (NCOARSE + 1) + t] = incl - v;
-  if (t == NCOARSE - 1) coarse_ptr[(size_t)lw * (NCOARSE + 1) + NCOARSE] = incl;
+  if (t < NCOARSE) {
+    const uint32_t incl = x + (t >= 64 ? wave_tot[0] : 0u);
+    coarse_ptr[(size_t)lw * (NCOARSE + 1) + t] = incl - v;
+    if (t == NCOARSE - 1) coarse_ptr[(size_t)lw * (NCOARSE + 1) + NCOARSE] = incl;
+  }
+  if (t == 0) scan_done[lw] = 0;
 }
 
 // Exclusive prefix sum of one value per thread over a 256-thread block (4 waves); `wave_tot` is 4 words of LDS.
@@ -354,65 +369,143 @@ constexpr int FINE_CHUNK = 4096;  // entries staged per block iteration (16 per 
 __device__ __forceinline__ uint32_t lds_count_rank(uint32_t* counter, uint32_t key, bool valid) {
   const unsigned long long vm = __ballot(valid);
   if (vm == 0) return 0;
-  const int first = __ffsll((long long)vm) - 1;
-  const uint32_t k0 = (uint32_t)__shfl((int)key, first);
+  const int first = __ffsll((long long)vm) - 1;  // wave-uniform: v_readlane, no LDS round trip
+  const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
   const bool same = valid && key == k0;
   const unsigned long long sm = __ballot(same);
   const int lane = threadIdx.x & 63;
   uint32_t base = 0;
   if (lane == first) base = atomicAdd(&counter[k0], (uint32_t)__popcll(sm));
-  base = (uint32_t)__shfl((int)base, first);
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
   uint32_t rank = base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
   if (valid && !same) rank = atomicAdd(&counter[key], 1u);
   return rank;
 }
+// the same without the rank: no atomic has to return, so consecutive calls do not wait for each other
+__device__ __forceinline__ void lds_count_only(uint32_t* counter, uint32_t key, bool valid) {
+  const unsigned long long vm = __ballot(valid);
+  if (vm == 0) return;
+  const int first = __ffsll((long long)vm) - 1;
+  const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
+  const bool same = valid && key == k0;
+  const unsigned long long sm = __ballot(same);
+  if ((int)(threadIdx.x & 63) == first) atomicAdd(&counter[k0], (uint32_t)__popcll(sm));
+  if (valid && !same) atomicAdd(&counter[key], 1u);
+}
+
+// A coarse bin with more than FINE_BIG entries (heavily skewed scalars: e.g. all entries of a window in one slot) is shared
+// by FINE_SPLIT workgroups WITHOUT any cross-block communication: each of them histograms the whole bin (1 byte per entry)
+// and, in the same sweep, the part in front of its own contiguous sub-range -- that gives it the start of every slot and
+// its own offset inside every slot -- and then scatters only its sub-range.  Normal bins are handled by workgroup 0 alone
+// (the other FINE_SPLIT - 1 exit at once).
+constexpr int FINE_SPLIT = 8;
+constexpr uint32_t FINE_BIG = 8 * FINE_CHUNK;
 
 __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ tmp_val, const uint8_t* __restrict__ tmp_fine, size_t stride,
                                                    const uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ col_ptr,
                                                    uint32_t* __restrict__ val_idxs, uint32_t chunks, uint32_t chunk_len,
                                                    uint32_t* __restrict__ chunk_slot) {
   __shared__ uint32_t hist[FINE];
+  __shared__ uint32_t before[FINE];  // entries of every slot in front of this workgroup's sub-range
   __shared__ uint32_t lstart[FINE];
   __shared__ uint32_t gpos[FINE];
   __shared__ uint32_t wave_tot[4];
   __shared__ uint32_t st_val[FINE_CHUNK];
   __shared__ uint32_t st_dst[FINE_CHUNK];
-  const int bin = blockIdx.x, lw = blockIdx.y, tid = threadIdx.x;
+  __shared__ uint32_t skew_flag, long_count;
+  const int bin = blockIdx.x, part = blockIdx.z, lw = blockIdx.y, tid = threadIdx.x;
   const uint32_t begin = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin], end = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin + 1];
+  const bool big = end - begin > FINE_BIG;
+  if (!big && part != 0) return;
+  // this workgroup's sub-range [my_begin, my_end): the whole bin, or one of FINE_SPLIT pieces (multiples of FINE_CHUNK)
+  uint32_t my_begin = begin, my_end = end;
+  if (big) {
+    uint32_t per = (end - begin + FINE_SPLIT - 1) / FINE_SPLIT;
+    per = (per + FINE_CHUNK - 1) / FINE_CHUNK * FINE_CHUNK;
+    my_begin = begin + (uint32_t)part * per < end ? begin + (uint32_t)part * per : end;
+    my_end = my_begin + per < end ? my_begin + per : end;
+  }
   const uint32_t* tv = tmp_val + (size_t)lw * stride;
   const uint8_t* tf = tmp_fine + (size_t)lw * stride;
   uint32_t* out = val_idxs + (size_t)lw * stride;
-  // pass 1: slot histogram of the whole coarse bin -> col_ptr and the global cursor of every slot
+  // pass 1: slot histogram of the whole coarse bin (and of the part in front of the sub-range)
   hist[tid] = 0;
+  before[tid] = 0;
+  if (tid == 0) {
+    skew_flag = 0;
+    long_count = 0;
+  }
   __syncthreads();
-  for (uint32_t i = begin + tid; i < end; i += 256) atomicAdd(&hist[tf[i]], 1u);
+  if (!big) {
+    for (uint32_t i = begin + tid; i < end; i += 256) atomicAdd(&hist[tf[i]], 1u);
+  } else {
+    // FINE_CHUNK entries per sweep step, 16 independent byte loads per thread in flight; a step lies wholly in front of
+    // the sub-range or not (my_begin - begin is a multiple of FINE_CHUNK), so every entry is counted once
+    uint32_t f[16], g[16];  // double buffered: the loads of step k + 1 are in flight while step k is counted
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t i = begin + j * 256 + tid;
+      f[j] = i < end ? tf[i] : 0xffffffffu;
+    }
+    for (uint32_t base = begin; base < end; base += FINE_CHUNK) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint32_t i = base + FINE_CHUNK + j * 256 + tid;
+        g[j] = i < end ? tf[i] : 0xffffffffu;
+      }
+      uint32_t* counter = base < my_begin ? before : hist;
+#pragma unroll
+      for (int j = 0; j < 16; j++) lds_count_only(counter, f[j] & 0xffu, f[j] != 0xffffffffu);
+#pragma unroll
+      for (int j = 0; j < 16; j++) f[j] = g[j];
+    }
+    __syncthreads();
+    hist[tid] += before[tid];
+  }
   __syncthreads();
   // a slot holding more than a quarter of the bin means skewed scalars: pass 2 then ranks with wave-aggregated atomics
-  __shared__ uint32_t skew_flag;
-  if (tid == 0) skew_flag = 0;
-  __syncthreads();
   if (hist[tid] > (end - begin) / 4 && end - begin > (uint32_t)FINE_CHUNK) skew_flag = 1;
   {
     const uint32_t excl = block_excl_scan_256(hist[tid], wave_tot);
-    gpos[tid] = begin + excl;
-    col_ptr[(size_t)lw * (HALF + 1) + bin * FINE + tid] = begin + excl;
-    if (bin == NCOARSE - 1 && tid == FINE - 1) col_ptr[(size_t)lw * (HALF + 1) + HALF] = end;
-    // SMVP chunks whose first entry lies in this slot's run [first, last)
+    gpos[tid] = begin + excl + before[tid];
+    if (part == 0) {
+      col_ptr[(size_t)lw * (HALF + 1) + bin * FINE + tid] = begin + excl;
+      if (bin == NCOARSE - 1 && tid == FINE - 1) col_ptr[(size_t)lw * (HALF + 1) + HALF] = end;
+    }
+    // SMVP chunks whose first entry lies in this slot's run [first, last): short runs are tabulated by their own thread
+    // (of workgroup 0), long ones (skewed scalars) by all threads of all workgroups of the bin together
     const uint32_t first = begin + excl, last = first + hist[tid];
-    for (uint32_t c = (first + chunk_len - 1) / chunk_len; c < chunks && (uint64_t)c * chunk_len < last; c++)
-      chunk_slot[(size_t)lw * chunks + c] = (uint32_t)(bin * FINE + tid);
+    uint32_t c0 = (first + chunk_len - 1) / chunk_len;
+    uint32_t c1 = (uint32_t)(((uint64_t)last + chunk_len - 1) / chunk_len);
+    if (c1 > chunks) c1 = chunks;
+    if (c0 > c1) c0 = c1;
+    const bool long_run = c1 - c0 > 16;
+    if (part == 0 && !long_run)
+      for (uint32_t c = c0; c < c1; c++) chunk_slot[(size_t)lw * chunks + c] = (uint32_t)(bin * FINE + tid);
+    if (long_run) {
+      const uint32_t k = atomicAdd(&long_count, 1u);
+      lstart[k] = c0;
+      st_dst[k] = c1;
+      st_val[k] = (uint32_t)(bin * FINE + tid);
+    }
   }
   __syncthreads();
-  // pass 2: LDS-staged scatter, FINE_CHUNK entries at a time
+  {
+    const uint32_t nl = long_count, nparts = big ? FINE_SPLIT : 1;
+    for (uint32_t k = 0; k < nl; k++)
+      for (uint32_t c = lstart[k] + part * 256 + tid; c < st_dst[k]; c += nparts * 256) chunk_slot[(size_t)lw * chunks + c] = st_val[k];
+  }
+  __syncthreads();
+  // pass 2: LDS-staged scatter of the sub-range, FINE_CHUNK entries at a time
   const bool skewed = skew_flag != 0;  // block-uniform (read after the barriers of the scan above)
-  for (uint32_t base = begin; base < end; base += FINE_CHUNK) {
+  for (uint32_t base = my_begin; base < my_end; base += FINE_CHUNK) {
     hist[tid] = 0;
     __syncthreads();
     uint32_t v[16], fr[16];  // value; slot | rank << 8
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const uint32_t i = base + j * 256 + tid;
-      const bool valid = i < end;
+      const bool valid = i < my_end;
       const uint32_t f = valid ? tf[i] : 0u;
       const uint32_t rank = skewed ? lds_count_rank(hist, f, valid) : (valid ? atomicAdd(&hist[f], 1u) : 0u);
       if (valid) {
@@ -426,7 +519,7 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
     const uint32_t excl = block_excl_scan_256(hist[tid], wave_tot);
     lstart[tid] = excl;
     __syncthreads();
-    const uint32_t total = (end - base) < (uint32_t)FINE_CHUNK ? (end - base) : (uint32_t)FINE_CHUNK;
+    const uint32_t total = (my_end - base) < (uint32_t)FINE_CHUNK ? (my_end - base) : (uint32_t)FINE_CHUNK;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       if (fr[j] != 0xffffffffu) {
@@ -605,6 +698,7 @@ __global__ void __launch_bounds__(256) k_smvp_stitch_big(const uint32_t* __restr
   // last block out resets the queue for the next run
   if (t == 0) {
     __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (atomicAdd(done_blocks, 1u) == gridDim.x - 1) {
       big_queue[0] = 0;
       *done_blocks = 0;

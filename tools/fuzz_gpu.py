@@ -59,6 +59,8 @@ for case in range(cases):
         world = rnd.choice([2, 3, 4, 5, 8, 16])
         parts = [ctx.msm_windows(t, *window_range(r, world)) for r in range(world)]
         got = m.MsmContext.combine_windows(torch.cat(parts, dim=0))
+    if (case + 1) % 25 == 0:
+        print("  %d cases ok, %.0f s" % (case + 1, time.time() - t0), flush=True)
     if got.to_affine_bytes() != want:
         print("MISMATCH case", case, "n", n, "kind", kind, "mode", mode, "seeds", pseed, sseed)
         sys.exit(1)
