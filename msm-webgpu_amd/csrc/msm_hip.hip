@@ -6,10 +6,10 @@
 // (cf. src/cuzk/msm.rs:88-94, src/cuzk/shader_manager.rs:74-100).
 //
 // Execution model.  Every MSM runs in one of MSM_HIP_NUM_SLOTS result slots (own bucket and window-sum buffers):
-//   stream "main"   : recode + sort + SMVP accumulate + stitch                  -> event smvp_done[slot]
-//   stream "reduce" : (waits smvp_done) bucket reduce -> window sums -> D2H     -> event done[slot]
-// The bucket reduce is bound by the depth of dependent group additions and occupies few waves; putting it on its own
-// stream lets the sort + SMVP of the NEXT MSM (other slot, own bucket buffer) start while it runs.  The host window
+//   stream "main"   : recode + sort + SMVP accumulate                               -> event smvp_done[slot]
+//   stream "reduce" : (waits smvp_done) stitch + bucket reduce -> window sums -> D2H -> event done[slot]
+// The stitch and the bucket reduce are bound by the depth of dependent group additions and occupy few waves; putting them
+// on their own stream lets the sort + SMVP of the NEXT MSM (other slot: own bucket, piece and col_ptr buffers) run meanwhile.  The host window
 // combine of a slot (src/cuzk/msm.rs:411-416) runs in the caller's thread inside msm_hip_finish_bn254.
 #include <hip/hip_runtime.h>
 
@@ -41,6 +41,11 @@ struct Slot {
   uint8_t* d_wsums = nullptr;      // device: NWIN x 96 B window sums + 4 B error word
   uint32_t* d_buckets = nullptr;   // [W][32768] XYZZ records
   uint32_t* d_partials = nullptr;  // bucket-reduce scratch: [W][256] row sums, [W][256] column sums, [W][3] parts (XYZZ)
+  uint32_t* d_col_ptr = nullptr;   // [W][32769] start of every bucket slot's run in the sorted entry list
+  uint32_t* d_heads = nullptr;     // [W][chunks] XYZZ records: SMVP pieces of runs that cross chunk boundaries
+  uint32_t* d_tails = nullptr;     // [W][chunks] XYZZ records
+  uint32_t* d_big_queue = nullptr;    // [1 + STITCH_BIG_CAP] buckets with many pieces (skewed scalars), [0] = count
+  uint32_t* d_done_blocks = nullptr;  // block counter of k_smvp_stitch_big
   hipEvent_t ev[N_MAIN_EVENTS] = {};
   hipEvent_t red0 = nullptr, red1 = nullptr;  // bucket reduce begin / end on the reduce stream
   hipEvent_t smvp_done = nullptr;             // main -> reduce hand-off
@@ -72,16 +77,10 @@ struct msm_hip_ctx {
   uint32_t* d_counts = nullptr;      // [W][tiles][128]
   uint32_t* d_bin_total = nullptr;   // [W][128]
   uint32_t* d_coarse_ptr = nullptr;  // [W][129]
-  uint32_t* d_scan_done = nullptr;   // [W] block counters of k_scan_tiles (self re-arming)
-  uint32_t* d_col_ptr = nullptr;     // [W][32769]
   uint32_t* d_tmp_val = nullptr;     // [W][stride] coarse-bin order
   uint8_t* d_tmp_fine = nullptr;     // [W][stride]
   uint32_t* d_val = nullptr;         // [W][stride] slot order
-  uint32_t* d_heads = nullptr;       // [W][chunks] XYZZ records
-  uint32_t* d_tails = nullptr;       // [W][chunks] XYZZ records
   uint32_t* d_chunk_slot = nullptr;  // [W][chunks] bucket slot of every SMVP chunk's first entry
-  uint32_t* d_big_queue = nullptr;   // [1 + STITCH_BIG_CAP] buckets with many pieces (skewed scalars), [0] = count
-  uint32_t* d_done_blocks = nullptr;  // block counter of k_smvp_stitch_big
   uint32_t* d_err = nullptr;
   uint8_t* d_stage = nullptr;  // staging for host byte inputs of set_bases / test hooks
   size_t cap_stage = 0;
@@ -171,8 +170,10 @@ int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count) {
   if ((rc = dev_alloc(ctx, ctx->d_tmp_val, stride * NWIN))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_tmp_fine, stride * NWIN))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_val, stride * NWIN))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_heads, recs * REC_WORDS))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_tails, recs * REC_WORDS))) return rc;
+  for (Slot& sl : ctx->slot) {
+    if ((rc = dev_alloc(ctx, sl.d_heads, recs * REC_WORDS))) return rc;
+    if ((rc = dev_alloc(ctx, sl.d_tails, recs * REC_WORDS))) return rc;
+  }
   if ((rc = dev_alloc(ctx, ctx->d_chunk_slot, recs))) return rc;
   if (ctx->debug && (rc = dev_alloc(ctx, ctx->d_digits, cap * NWIN))) return rc;
   ctx->cap_n = cap;
@@ -218,27 +219,29 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   HIP_TRY(ctx, mark(0, false));
   hipLaunchKernelGGL(k_count, dim3(tiles), dim3(256), 0, st, d_scalars, n, tile_len, tiles, w_begin, w_count, ctx->d_counts, digits, d_err);
   HIP_TRY(ctx, mark(1, false));
-  hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total, ctx->d_coarse_ptr,
-                     ctx->d_scan_done);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total);
   HIP_TRY(ctx, mark(2, false));
   hipLaunchKernelGGL(k_scatter_coarse, dim3(tiles), dim3(256), 0, st, d_scalars, n, stride, tile_len, tiles, w_begin, w_count,
-                     ctx->d_counts, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine);
+                     ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine);
   HIP_TRY(ctx, mark(3, false));
   hipLaunchKernelGGL(k_sort_fine, dim3(NCOARSE, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
-                     ctx->d_col_ptr, ctx->d_val, chunks, chunk_len, ctx->d_chunk_slot);
+                     s.d_col_ptr, ctx->d_val, chunks, chunk_len, ctx->d_chunk_slot);
   HIP_TRY(ctx, mark(4, true));
-  hipLaunchKernelGGL(k_smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, ctx->d_col_ptr, ctx->d_val, stride,
-                     chunks, chunk_len, ctx->d_chunk_slot, s.d_buckets, ctx->d_heads, ctx->d_tails);
+  hipLaunchKernelGGL(k_smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, s.d_col_ptr, ctx->d_val, stride,
+                     chunks, chunk_len, ctx->d_chunk_slot, s.d_buckets, s.d_heads, s.d_tails);
   HIP_TRY(ctx, mark(5, true));
-  hipLaunchKernelGGL(k_smvp_stitch, dim3(HALF / 256, w_count), dim3(256), 0, st, ctx->d_col_ptr, chunks, chunk_len, ctx->d_heads,
-                     ctx->d_tails, s.d_buckets, ctx->d_big_queue);
-  hipLaunchKernelGGL(k_smvp_stitch_big, dim3(256), dim3(256), 0, st, ctx->d_col_ptr, chunks, chunk_len, ctx->d_heads, ctx->d_tails,
-                     s.d_buckets, ctx->d_big_queue, ctx->d_done_blocks);
-  HIP_TRY(ctx, mark(6, false));
   HIP_TRY(ctx, hipEventRecord(s.smvp_done, st));
 
+  // stitch + bucket reduce on the slot's reduce stream: few waves, long dependent chains
   HIP_TRY(ctx, hipStreamWaitEvent(rs, s.smvp_done, 0));
-  if (tl >= 2) HIP_TRY(ctx, hipEventRecord(s.red0, rs));
+  hipLaunchKernelGGL(k_smvp_stitch, dim3(HALF / 256, w_count), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails,
+                     s.d_buckets, s.d_big_queue);
+  hipLaunchKernelGGL(k_smvp_stitch_big, dim3(256), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails, s.d_buckets,
+                     s.d_big_queue, s.d_done_blocks);
+  if (tl >= 2) {
+    HIP_TRY(ctx, hipEventRecord(s.ev[6], rs));
+    HIP_TRY(ctx, hipEventRecord(s.red0, rs));
+  }
   uint32_t* d_rows = s.d_partials;
   uint32_t* d_cols = d_rows + (size_t)NWIN * 256 * XYZZ_WORDS;
   uint32_t* d_parts = d_cols + (size_t)NWIN * 256 * XYZZ_WORDS;
@@ -377,13 +380,7 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
   if ((rc = dev_alloc(ctx, ctx->d_counts, (size_t)NWIN * MAX_TILES * NCOARSE))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_bin_total, (size_t)NWIN * NCOARSE))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_coarse_ptr, (size_t)NWIN * (NCOARSE + 1)))) return fail(rc);
-  if ((rc = dev_alloc(ctx, ctx->d_scan_done, NWIN))) return fail(rc);
-  if (hipMemset(ctx->d_scan_done, 0, NWIN * 4) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
-  if ((rc = dev_alloc(ctx, ctx->d_col_ptr, (size_t)NWIN * (HALF + 1)))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_err, 1))) return fail(rc);
-  if ((rc = dev_alloc(ctx, ctx->d_big_queue, (size_t)STITCH_BIG_CAP + 1))) return fail(rc);
-  if ((rc = dev_alloc(ctx, ctx->d_done_blocks, 1))) return fail(rc);
-  if (hipMemset(ctx->d_big_queue, 0, 4) != hipSuccess || hipMemset(ctx->d_done_blocks, 0, 4) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
   for (int k = 0; k < NSLOT; k++) {
     Slot& s = ctx->slot[k];
     if (hipHostMalloc((void**)&s.h_wsums, WSUM_BYTES + 4, hipHostMallocDefault) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
@@ -392,6 +389,10 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
     if (hipMemset(s.d_wsums, 0, WSUM_BYTES + 4) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
     if ((rc = dev_alloc(ctx, s.d_buckets, (size_t)NWIN * HALF * REC_WORDS))) return fail(rc);
     if ((rc = dev_alloc(ctx, s.d_partials, (size_t)NWIN * (256 + 256 + 3) * XYZZ_WORDS))) return fail(rc);
+    if ((rc = dev_alloc(ctx, s.d_col_ptr, (size_t)NWIN * (HALF + 1)))) return fail(rc);
+    if ((rc = dev_alloc(ctx, s.d_big_queue, (size_t)STITCH_BIG_CAP + 1))) return fail(rc);
+    if ((rc = dev_alloc(ctx, s.d_done_blocks, 1))) return fail(rc);
+    if (hipMemset(s.d_big_queue, 0, 4) != hipSuccess || hipMemset(s.d_done_blocks, 0, 4) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
     if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
     if (hipEventCreateWithFlags(&s.smvp_done, hipEventDisableTiming) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
     if (hipEventCreate(&s.red0) != hipSuccess || hipEventCreate(&s.red1) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
@@ -408,9 +409,8 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipStream_t r : ctx->reduce_stream)
     if (r) (void)hipStreamSynchronize(r);
-  void* bufs[] = {ctx->d_bases,    ctx->d_scalars, ctx->d_digits, ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_scan_done, ctx->d_col_ptr, ctx->d_tmp_val,
-                  ctx->d_tmp_fine, ctx->d_val,     ctx->d_heads,  ctx->d_tails,  ctx->d_chunk_slot,  ctx->d_err,     ctx->d_stage,
-                  ctx->d_big_queue, ctx->d_done_blocks};
+  void* bufs[] = {ctx->d_bases,   ctx->d_scalars,  ctx->d_digits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
+                  ctx->d_tmp_val, ctx->d_tmp_fine, ctx->d_val,    ctx->d_chunk_slot, ctx->d_err,       ctx->d_stage};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int k = 0; k < NSLOT; k++) {
@@ -418,7 +418,9 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
     if (s.h_wsums) (void)hipHostFree(s.h_wsums);
     if (s.d_wsums) (void)hipFree(s.d_wsums);
     if (s.d_buckets) (void)hipFree(s.d_buckets);
-    if (s.d_partials) (void)hipFree(s.d_partials);
+    void* sbufs[] = {s.d_partials, s.d_col_ptr, s.d_heads, s.d_tails, s.d_big_queue, s.d_done_blocks};
+    for (void* b : sbufs)
+      if (b) (void)hipFree(b);
     hipEvent_t evs[] = {s.done, s.smvp_done, s.red0, s.red1};
     for (hipEvent_t e : evs)
       if (e) (void)hipEventDestroy(e);
@@ -632,7 +634,7 @@ int msm_hip_read_digits(msm_hip_ctx* ctx, uint16_t* out, size_t cap_elems) {
 }
 int msm_hip_read_col_ptr(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
-  return read_back(ctx, out, ctx->d_col_ptr, (size_t)ctx->last_w_count * (HALF + 1) * 4, cap_elems * 4);
+  return read_back(ctx, out, ctx->slot[ctx->last_slot].d_col_ptr, (size_t)ctx->last_w_count * (HALF + 1) * 4, cap_elems * 4);
 }
 int msm_hip_read_val_idxs(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;

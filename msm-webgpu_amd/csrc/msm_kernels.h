@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) k_convert_points(const uint32_t* __restri
 // two-level LDS counting sort over the 15-bit bucket slot, and the recode is fused into both of its global passes
 // (scalars are re-read instead of materialising 16 digit planes: 32 B per scalar either way):
 //   k_count          per tile of scalars: LDS histogram of the 128 coarse bins (slot >> 8) of every window
-//   k_scan_tiles     per (window, coarse bin): prefix over tiles; last block per window: start of every coarse bin
+//   k_scan_tiles     per (window, coarse bin): prefix over tiles, bin totals
 //   k_scatter_coarse per tile: LDS-ranked scatter of (index | sign << 31, slot & 255) into coarse-bin order
 //   k_sort_fine      per (window, coarse bin): LDS counting sort over its 256 slots -> val_idxs + col_ptr
 // Order inside a slot is the arrival order of LDS atomics; the group sum does not depend on it.
@@ -213,12 +213,10 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
 }
 
 // One wave per (window, coarse bin): in place, counts[lw][tile][bin] becomes the number of entries of that bin in earlier
-// tiles; bin_total[lw][bin] receives the bin's size.  The last block of a window to finish (counted in scan_done[lw]) turns
-// the 128 totals into coarse_ptr[lw][0..128] (start of every coarse bin; [128] = entries in the window) and re-arms the counter.
-__global__ void __launch_bounds__(256) k_scan_tiles(uint32_t* __restrict__ counts, uint32_t tiles, uint32_t* __restrict__ bin_total,
-                                                    uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ scan_done) {
-  __shared__ uint32_t is_last;
-  __shared__ uint32_t wave_tot[2];
+// tiles; bin_total[lw][bin] receives the bin's size.  (The 128 totals of a window are turned into bin starts by every
+// workgroup of k_scatter_coarse for itself: a last-block hand-off here needs agent-scope releases, i.e. L2 write-backs,
+// which cost 70 us.)
+__global__ void __launch_bounds__(256) k_scan_tiles(uint32_t* __restrict__ counts, uint32_t tiles, uint32_t* __restrict__ bin_total) {
   const int lw = blockIdx.y, lane = threadIdx.x & 63;
   const int bin = blockIdx.x * 4 + (threadIdx.x >> 6);
   uint32_t* c = counts + (size_t)lw * tiles * NCOARSE + bin;
@@ -236,35 +234,6 @@ __global__ void __launch_bounds__(256) k_scan_tiles(uint32_t* __restrict__ count
     run += __shfl(x, 63);
   }
   if (lane == 0) bin_total[lw * NCOARSE + bin] = run;
-  // last block of this window: exclusive scan of the 128 bin totals.  Hand-off: every storing wave drains its stores and
-  // releases at agent scope before the block's arrival is counted; the explicit waitcnt keeps the write-back ahead of the
-  // counter update (cdna_hip_programming.md, Guideline 16).
-  __threadfence();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) is_last = atomicAdd(&scan_done[lw], 1u) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
-  const int t = threadIdx.x;
-  uint32_t v = 0, x = 0;
-  if (t < NCOARSE) {
-    v = __hip_atomic_load(&bin_total[lw * NCOARSE + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    x = v;
-  }
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t y = __shfl_up(x, off);
-    if (lane >= off) x += y;
-  }
-  if (t < NCOARSE && lane == 63) wave_tot[t >> 6] = x;
-  __syncthreads();
-  if (t < NCOARSE) {
-    const uint32_t incl = x + (t >= 64 ? wave_tot[0] : 0u);
-    coarse_ptr[(size_t)lw * (NCOARSE + 1) + t] = incl - v;
-    if (t == NCOARSE - 1) coarse_ptr[(size_t)lw * (NCOARSE + 1) + NCOARSE] = incl;
-  }
-  if (t == 0) scan_done[lw] = 0;
 }
 
 // Exclusive prefix sum of one value per thread over a 256-thread block (4 waves); `wave_tot` is 4 words of LDS.
@@ -291,7 +260,8 @@ constexpr int SCAT_SUB = 2048;  // scalars staged per block iteration (8 per thr
 
 __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
                                                         uint32_t tiles, int w_begin, int w_count, const uint32_t* __restrict__ counts,
-                                                        const uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ tmp_val,
+                                                        const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr,
+                                                        uint32_t* __restrict__ tmp_val,
                                                         uint8_t* __restrict__ tmp_fine) {
   __shared__ uint32_t gpos[NWIN * NCOARSE];  // global write cursor of every (window, coarse bin) run of this tile
   __shared__ uint32_t hist[NCOARSE];
@@ -301,9 +271,27 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
   __shared__ uint32_t st_dst[SCAT_SUB];
   __shared__ uint8_t st_fine[SCAT_SUB];
   const int tid = threadIdx.x;
-  for (int i = tid; i < w_count * NCOARSE; i += 256) {
-    const int lw = i / NCOARSE, bin = i % NCOARSE;
-    gpos[i] = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin] + counts[((size_t)lw * tiles + blockIdx.x) * NCOARSE + bin];
+  // start of every (window, coarse bin): exclusive scan of the window's 128 bin totals -- a pair of waves per window, two
+  // windows per step; workgroup 0 also publishes them as coarse_ptr[lw][0..128] for k_sort_fine
+  for (int i0 = 0; i0 < w_count * NCOARSE; i0 += 256) {
+    const int i = i0 + tid, lw = i / NCOARSE, bin = i % NCOARSE, lane = tid & 63;
+    const bool live = i < w_count * NCOARSE;  // odd window counts: the last step has one idle pair of waves
+    const uint32_t v = live ? bin_total[i] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[tid >> 6] = x;
+    __syncthreads();
+    const uint32_t incl = x + ((tid >> 6) & 1 ? wave_tot[(tid >> 6) - 1] : 0u);
+    if (live) gpos[i] = incl - v + counts[((size_t)lw * tiles + blockIdx.x) * NCOARSE + bin];
+    if (live && blockIdx.x == 0) {
+      coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin] = incl - v;
+      if (bin == NCOARSE - 1) coarse_ptr[(size_t)lw * (NCOARSE + 1) + NCOARSE] = incl;
+    }
+    __syncthreads();
   }
   const size_t tile_base = (size_t)blockIdx.x * tile_len;
   const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
