@@ -425,7 +425,17 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
   }
   __syncthreads();
   if (!big) {
-    for (uint32_t i = begin + tid; i < end; i += 256) atomicAdd(&hist[tf[i]], 1u);
+    for (uint32_t base = begin; base < end; base += FINE_CHUNK) {  // 16 independent byte loads in flight per thread
+      uint32_t f[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint32_t i = base + j * 256 + tid;
+        f[j] = i < end ? tf[i] : 0xffffffffu;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+        if (f[j] != 0xffffffffu) atomicAdd(&hist[f[j]], 1u);
+    }
   } else {
     // FINE_CHUNK entries per sweep step, 16 independent byte loads per thread in flight; a step lies wholly in front of
     // the sub-range or not (my_begin - begin is a multiple of FINE_CHUNK), so every entry is counted once
