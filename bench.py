@@ -43,8 +43,8 @@ def smvp_algorithmic_bytes(n, w_local):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--logn", type=int, default=20, help="log2 of the MSM size (20 = the config the metric is quoted on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-logn", type=int, default=None, help="bounded CPU sample size (default: min(logn, 20))")

@@ -6,6 +6,8 @@ carry chain runs across windows), then ONE collective -- an all-gather of world_
 brings all 16 window sums to every rank, and the host window combine (src/cuzk/msm.rs:411-416) finishes.  Elliptic-curve
 addition is not an RCCL reduction operator, hence gather + local combine rather than all-reduce.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -79,14 +81,20 @@ class ShardedMsmPipeline:
         self.copied = [torch.cuda.Event() for _ in range(self.SLOTS)]
         self.issued = 0
         self.completed = 0
+        # MSM_SHARD_FORCE_COLLECTIVE=1: issue the RCCL all-gather even with a single rank (rehearsal of the multi-GPU
+        # stream / queue layout on a one-GPU box; needs an initialised process group)
+        self.collective = world_size > 1 or (os.environ.get("MSM_SHARD_FORCE_COLLECTIVE") == "1" and dist.is_initialized())
 
     def issue(self, scalars_dev):
         assert self.issued - self.completed < self.depth, "pipeline full: call complete() first"
         slot = self.issued % self.SLOTS
         w_local = self.w_end - self.w_begin
         self.ctx.launch_windows(scalars_dev, self.w_begin, self.w_end, slot, self.padded[slot][:w_local])
+        # gather + copies go to the CURRENT torch stream (normally the default stream): with GPU_MAX_HW_QUEUES=8 this
+        # layout -- 3 engine streams, the default stream, RCCL's own -- keeps three MSMs in flight; a dedicated side stream
+        # (or a 4th engine stream) was measured to collapse the pipeline to one MSM at a time
         self.ctx.slot_wait_stream(slot)
-        if self.world > 1:
+        if self.collective:
             dist.all_gather_into_tensor(self.gathered[slot].view(-1), self.padded[slot].view(-1), group=self.group)
         else:
             self.gathered[slot].copy_(self.padded[slot].unsqueeze(0))
