@@ -160,6 +160,25 @@ def main():
             isolated = ctx.stage_ms()
         latency_ms = sorted(lat)[len(lat) // 2]
 
+    # timing scopes B and C of SURVEY.md section 8(d), informational (never `value`): B = scalars arrive from host memory
+    # (32 MiB H2D per MSM at 2^20), bases resident; C = one-shot incl. context creation and base upload (≙ compute_msm)
+    scope_ms = None
+    if world == 1 and emulate <= 1 and args.logn <= 22:
+        sb_host = scalar_sets[0].cpu().numpy().tobytes()
+        pb_host = points.cpu().numpy().tobytes()
+        tb = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            ctx.msm(sb_host)
+            tb.append((time.perf_counter() - t1) * 1e3)
+        import ctypes
+
+        one = ctypes.create_string_buffer(96)
+        t1 = time.perf_counter()
+        rc1 = m.lib().msm_hip_msm_bn254_g1(pb_host, sb_host, n, one)  # creates a context, uploads, runs, destroys
+        assert rc1 == 0, rc1
+        scope_ms = {"B_host_scalars_resident_bases": sorted(tb)[1], "C_one_shot_with_base_upload": (time.perf_counter() - t1) * 1e3}
+
     # sharded runs: check the gathered + combined result against this rank's own whole 16-window MSM (outside the timed region)
     sharded_ok = None
     if sharded and emulate <= 1:
@@ -204,6 +223,7 @@ def main():
         "sharded_result_equals_single_gpu": sharded_ok,
         "latency_ms_single_msm": latency_ms,
         "stage_ms_single_msm": isolated,
+        "scope_ms": scope_ms,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

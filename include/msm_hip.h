@@ -74,6 +74,9 @@ int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]);
  *      out: batch x 96 B.  Internally a software pipeline over the result slots (BASELINE.json config 5: many MSMs over
  *      one shared base). ---- */
 int msm_hip_run_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, size_t batch, uint8_t* out_xyz);
+/* same with the scalar vectors in host memory (batch x n x 32 B): each vector is copied to the device just ahead of its own
+ * MSM, inside the same pipeline */
+int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz);
 
 /* ---- window-sharded execution (multi-GPU; Pippenger windows are independent).
  *      Computes the window sums S_w for w in [w_begin, w_end) and writes (w_end - w_begin) x 96 B Jacobian

@@ -50,6 +50,7 @@ def lib():
         L.msm_hip_set_bases_device_bn254.argtypes = [vp, vp, sz, C.c_uint32]
         L.msm_hip_run_bn254.argtypes = [vp, u8p, sz, u8p]
         L.msm_hip_run_device_bn254.argtypes = [vp, vp, sz, u8p]
+        L.msm_hip_run_batch_bn254.argtypes = [vp, u8p, sz, sz, u8p]
         L.msm_hip_run_batch_device_bn254.argtypes = [vp, vp, sz, sz, u8p]
         L.msm_hip_launch_device_bn254.argtypes = [vp, vp, sz, i]
         L.msm_hip_finish_bn254.argtypes = [vp, i, u8p]
@@ -208,7 +209,16 @@ class MsmContext:
         return G1(out.raw)
 
     def msm_batch(self, scalars_dev, n):
-        """`batch` MSMs over the resident bases: scalars_dev is a CUDA uint8 tensor of batch x n x 32 bytes -> [G1, ...]."""
+        """`batch` MSMs over the resident bases: scalars_dev is a CUDA uint8 tensor of batch x n x 32 bytes (or host bytes
+        of the same layout) -> [G1, ...]."""
+        if isinstance(scalars_dev, (bytes, bytearray)):
+            b = bytes(scalars_dev)
+            if n <= 0 or len(b) % (32 * n):
+                raise ValueError("scalars must hold a whole number of n-element vectors")
+            batch = len(b) // (32 * n)
+            out = C.create_string_buffer(96 * batch)
+            _check(lib().msm_hip_run_batch_bn254(self._h, b, n, batch, out), "msm_hip_run_batch_bn254")
+            return [G1(out.raw[96 * k:96 * k + 96]) for k in range(batch)]
         t, rows = _as_device_u8(scalars_dev, 32, "scalars")
         if n <= 0 or rows % n:
             raise ValueError("scalars must hold a whole number of n-element vectors")

@@ -70,7 +70,9 @@ struct msm_hip_ctx {
   size_t cap_n = 0;   // capacity of the per-run work buffers (entries per window)
   size_t stride = 0;  // per-window stride of the entry arrays: cap_n rounded up to a multiple of 4
   size_t cap_recs = 0;  // capacity (records) of the head / tail piece arrays
-  uint32_t* d_scalars = nullptr;
+  uint32_t* d_scalars = nullptr;      // staging for host scalars of msm_hip_run_bn254
+  uint8_t* d_batch_stage = nullptr;   // staging ring (NSLOT vectors) of msm_hip_run_batch_bn254, allocated on first use
+  size_t cap_batch_stage = 0;
   uint16_t* d_digits = nullptr;  // digit-code planes, only written when debug read-back is enabled
   bool debug = false;
   int timing_level = 2;  // 0: no stage events, 1: only around the SMVP kernel, 2: every stage boundary
@@ -409,7 +411,7 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipStream_t r : ctx->reduce_stream)
     if (r) (void)hipStreamSynchronize(r);
-  void* bufs[] = {ctx->d_bases,   ctx->d_scalars,  ctx->d_digits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
+  void* bufs[] = {ctx->d_bases,   ctx->d_scalars,  ctx->d_batch_stage, ctx->d_digits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
                   ctx->d_tmp_val, ctx->d_tmp_fine, ctx->d_val,    ctx->d_chunk_slot, ctx->d_err,       ctx->d_stage};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -543,6 +545,39 @@ int msm_hip_run_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, si
       if ((rc = msm_hip_finish_bn254(ctx, (int)(j % NSLOT), out_xyz + 96 * j))) return rc;
     }
     if (i < batch && (rc = msm_hip_launch_device_bn254(ctx, sc + i * n * 32, n, (int)(i % NSLOT)))) return rc;
+  }
+  return MSM_HIP_OK;
+}
+
+int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz) {
+  if (!out_xyz && batch) return MSM_HIP_ERR_INVALID_ARG;
+  int rc = check_run_args(ctx, scalars_host, n);
+  if (rc) return rc;
+  if (n == 0) {
+    if (batch) memset(out_xyz, 0, 96 * batch);
+    return MSM_HIP_OK;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t vec = n * 32;
+  if (vec * NSLOT > ctx->cap_batch_stage) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cap_batch_stage = 0;
+    if ((rc = dev_alloc(ctx, ctx->d_batch_stage, vec * NSLOT))) return rc;
+    ctx->cap_batch_stage = vec * NSLOT;
+  }
+  // same software pipeline as the device-resident batch; vector i is staged in ring entry i % NSLOT on the main stream
+  // just ahead of its own sort (the entry's previous reader, MSM i - NSLOT, was finished DEPTH + 1 iterations ago)
+  constexpr size_t DEPTH = NSLOT - 1;
+  for (size_t i = 0; i < batch + DEPTH; i++) {
+    if (i >= DEPTH) {
+      const size_t j = i - DEPTH;
+      if ((rc = msm_hip_finish_bn254(ctx, (int)(j % NSLOT), out_xyz + 96 * j))) return rc;
+    }
+    if (i < batch) {
+      uint8_t* stage = ctx->d_batch_stage + (i % NSLOT) * vec;
+      HIP_TRY(ctx, hipMemcpyAsync(stage, scalars_host + i * vec, vec, hipMemcpyHostToDevice, ctx->stream));
+      if ((rc = msm_hip_launch_device_bn254(ctx, stage, n, (int)(i % NSLOT)))) return rc;
+    }
   }
   return MSM_HIP_OK;
 }

@@ -56,6 +56,44 @@ def sharded_msm(ctx, scalars_dev, rank, world_size, group=None):
     return MsmContext.combine_windows(all_sums)
 
 
+def batch_range(rank, world_size, batch):
+    """Contiguous, balanced share of `batch` independent MSMs for `rank` (BASELINE config 5: many MSMs, one shared base)."""
+    return window_range(rank, world_size, batch)
+
+
+def gather_batch_results(local_results, rank, world_size, batch, group=None):
+    """local_results: uint8 [B_local, 96] Jacobian records of this rank's share (device tensor under nccl, CPU tensor
+    under gloo).  Returns uint8 [batch, 96] in MSM order on every rank -- the only collective of the batch-sharded path."""
+    per = max_windows_per_rank(world_size, batch)
+    padded = torch.zeros((per, 96), dtype=torch.uint8, device=local_results.device)
+    padded[: local_results.shape[0]] = local_results
+    if world_size == 1:
+        gathered = padded.unsqueeze(0)
+    else:
+        gathered = torch.empty((world_size, per, 96), dtype=torch.uint8, device=local_results.device)
+        dist.all_gather_into_tensor(gathered.view(-1), padded.view(-1), group=group)
+    rows = []
+    for r in range(world_size):
+        b, e = batch_range(r, world_size, batch)
+        rows.append(gathered[r, : e - b])
+    return torch.cat(rows, dim=0)
+
+
+def sharded_batch_msm(ctx, scalars_dev, n, rank, world_size, group=None):
+    """`batch` independent MSMs over the resident bases, whole MSMs sharded over the ranks (no exchange on the data path;
+    one all-gather of batch x 96 B at the end).  scalars_dev: CUDA uint8 [batch * n, 32], identical on every rank (or at
+    least this rank's share valid).  Returns the list of all G1 results on every rank."""
+    from .api import G1
+
+    batch = scalars_dev.shape[0] // n
+    b, e = batch_range(rank, world_size, batch)
+    mine = ctx.msm_batch(scalars_dev[b * n:e * n], n) if e > b else []
+    dev = scalars_dev.device
+    local = torch.tensor(list(b"".join(g.xyz for g in mine)), dtype=torch.uint8, device=dev).view(len(mine), 96)
+    allr = gather_batch_results(local, rank, world_size, batch, group).cpu().numpy().tobytes()
+    return [G1(allr[96 * k:96 * k + 96]) for k in range(batch)]
+
+
 class ShardedMsmPipeline:
     """Back-to-back window-sharded MSMs with everything asynchronous: rank-local device work (result slots and
     main/reduce HIP streams inside the engine), the RCCL all-gather on the torch stream (ordered after the slot by a device-side

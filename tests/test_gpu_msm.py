@@ -208,3 +208,10 @@ def test_batch_over_shared_base(ctx):
     for k in range(batch):
         sb = sc[k * n:(k + 1) * n].cpu().numpy().tobytes()
         assert got[k].to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb, sb)), k
+    # the same vectors handed over as host bytes (msm_hip_run_batch_bn254: staged per MSM inside the pipeline)
+    host = ctx.msm_batch(sc.cpu().numpy().tobytes(), n)
+    assert [g.to_affine_bytes() for g in host] == [g.to_affine_bytes() for g in got]
+    # whole-MSM sharding (config 5 on several GPUs), degenerate single-rank case: same results in MSM order
+    from msm_webgpu_amd.sharding import sharded_batch_msm
+
+    assert [g.to_affine_bytes() for g in sharded_batch_msm(ctx, sc, n, 0, 1)] == [g.to_affine_bytes() for g in got]

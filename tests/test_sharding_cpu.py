@@ -72,3 +72,46 @@ def test_sharded_gather_and_combine_gloo(built, world):
         assert p.exitcode == 0
     want = cpu.to_affine64(cpu.cpu_msm(cpu.sample_points(91, n), cpu.sample_scalars(92, n)))
     assert all(g[1] == want for g in got)
+
+
+def _batch_worker(rank, world, port, n, batch, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from msm_webgpu_amd.sharding import batch_range, gather_batch_results
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    points = cpu.sample_points(71, n)
+    b, e = batch_range(rank, world, batch)
+    mine = b"".join(cpu.cpu_msm(points, cpu.sample_scalars(500 + k, n)) for k in range(b, e))  # this rank's whole MSMs (oracle)
+    local = torch.from_numpy(np.frombuffer(mine, dtype=np.uint8).copy()).view(e - b, 96)
+    allr = gather_batch_results(local, rank, world, batch)
+    q.put((rank, allr.numpy().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batch_sharding_gloo(built):
+    # BASELINE config 5 shape: whole MSMs sharded over ranks, results gathered in MSM order on every rank
+    from msm_webgpu_amd.sharding import batch_range
+
+    assert [batch_range(r, 8, 64) for r in (0, 7)] == [(0, 8), (56, 64)]
+    world, n, batch = 2, 200, 5
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, n, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    points = cpu.sample_points(71, n)
+    want = [cpu.to_affine64(cpu.cpu_msm(points, cpu.sample_scalars(500 + k, n))) for k in range(batch)]
+    for _, blob in got:
+        assert [cpu.to_affine64(blob[96 * k:96 * k + 96]) for k in range(batch)] == want
