@@ -38,6 +38,7 @@ extern "C" {
 #define MSM_HIP_ERR_NOT_ON_CURVE (-5)  /* only with MSM_HIP_CHECK_ON_CURVE                                      */
 #define MSM_HIP_ERR_NO_BASES (-6)      /* run called before set_bases                                            */
 #define MSM_HIP_ERR_HIP (-7)           /* a HIP runtime call failed; msm_hip_last_hip_error() has the code        */
+#define MSM_HIP_ERR_SLOT_BUSY (-8)     /* launch into a result slot whose previous MSM was not finished / synced   */
 
 #define MSM_HIP_NUM_WINDOWS 16         /* num_subtasks = ceil(256 / 16)                       src/cuzk/msm.rs:82 */
 #define MSM_HIP_WINDOW_BITS 16         /* chunk_size                                           src/cuzk/msm.rs:79 */

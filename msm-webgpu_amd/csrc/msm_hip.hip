@@ -299,6 +299,12 @@ int wait_slot(msm_hip_ctx* ctx, Slot& s) {
   return err_from_bits(bits);
 }
 
+// after a failed batch: collect every slot that is still pending so that the context stays usable
+void drain_slots(msm_hip_ctx* ctx) {
+  for (Slot& s : ctx->slot)
+    if (s.pending) (void)wait_slot(ctx, s);
+}
+
 constexpr size_t MAX_POINTS = (size_t)1 << 28;  // point indices carry the digit sign in bit 31; 2^28 keeps every per-window offset in u32
 
 int check_run_args(msm_hip_ctx* ctx, const void* scalars, size_t n) {
@@ -342,7 +348,7 @@ __global__ void __launch_bounds__(256) k_export_buckets(const uint32_t* __restri
 
 extern "C" {
 
-int msm_hip_abi_version(void) { return 2; }
+int msm_hip_abi_version(void) { return 3; }
 
 const char* msm_hip_strerror(int code) {
   switch (code) {
@@ -354,6 +360,7 @@ const char* msm_hip_strerror(int code) {
     case MSM_HIP_ERR_NOT_ON_CURVE: return "base point not on the curve";
     case MSM_HIP_ERR_NO_BASES: return "bases not set";
     case MSM_HIP_ERR_HIP: return "HIP runtime error";
+    case MSM_HIP_ERR_SLOT_BUSY: return "result slot still holds an unfinished MSM";
     default: return "unknown error";
   }
 }
@@ -458,6 +465,7 @@ int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_de
   if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > NWIN || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   Slot& s = ctx->slot[slot];
+  if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;  // its result was never collected (msm_hip_finish_bn254 / msm_hip_slot_sync)
   const int w_count = w_end - w_begin;
   s.n = n;
   s.w_begin = w_begin;
@@ -542,11 +550,12 @@ int msm_hip_run_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, si
   for (size_t i = 0; i < batch + DEPTH; i++) {
     if (i >= DEPTH) {
       const size_t j = i - DEPTH;
-      if ((rc = msm_hip_finish_bn254(ctx, (int)(j % NSLOT), out_xyz + 96 * j))) return rc;
+      if ((rc = msm_hip_finish_bn254(ctx, (int)(j % NSLOT), out_xyz + 96 * j))) break;
     }
-    if (i < batch && (rc = msm_hip_launch_device_bn254(ctx, sc + i * n * 32, n, (int)(i % NSLOT)))) return rc;
+    if (i < batch && (rc = msm_hip_launch_device_bn254(ctx, sc + i * n * 32, n, (int)(i % NSLOT)))) break;
   }
-  return MSM_HIP_OK;
+  if (rc) drain_slots(ctx);
+  return rc;
 }
 
 int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz) {
@@ -571,15 +580,19 @@ int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_
   for (size_t i = 0; i < batch + DEPTH; i++) {
     if (i >= DEPTH) {
       const size_t j = i - DEPTH;
-      if ((rc = msm_hip_finish_bn254(ctx, (int)(j % NSLOT), out_xyz + 96 * j))) return rc;
+      if ((rc = msm_hip_finish_bn254(ctx, (int)(j % NSLOT), out_xyz + 96 * j))) break;
     }
     if (i < batch) {
       uint8_t* stage = ctx->d_batch_stage + (i % NSLOT) * vec;
-      HIP_TRY(ctx, hipMemcpyAsync(stage, scalars_host + i * vec, vec, hipMemcpyHostToDevice, ctx->stream));
-      if ((rc = msm_hip_launch_device_bn254(ctx, stage, n, (int)(i % NSLOT)))) return rc;
+      if (hipMemcpyAsync(stage, scalars_host + i * vec, vec, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        rc = MSM_HIP_ERR_HIP;
+        break;
+      }
+      if ((rc = msm_hip_launch_device_bn254(ctx, stage, n, (int)(i % NSLOT)))) break;
     }
   }
-  return MSM_HIP_OK;
+  if (rc) drain_slots(ctx);
+  return rc;
 }
 
 int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end,

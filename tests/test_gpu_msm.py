@@ -60,6 +60,12 @@ def test_async_slots_pipeline(ctx):
     ctx.launch(s1, 1)
     r1 = ctx.finish(1)
     assert r0 == ctx.msm(s0) and r1 == ctx.msm(s1) and r0 != r1
+    # a slot must be collected before it is reused
+    ctx.launch(s0, 2)
+    with pytest.raises(m.MsmHipError) as e:
+        ctx.launch(s1, 2)
+    assert e.value.code == -8
+    assert ctx.finish(2) == r0
 
 
 def test_window_sharded_equals_whole(ctx):
@@ -215,3 +221,10 @@ def test_batch_over_shared_base(ctx):
     from msm_webgpu_amd.sharding import sharded_batch_msm
 
     assert [g.to_affine_bytes() for g in sharded_batch_msm(ctx, sc, n, 0, 1)] == [g.to_affine_bytes() for g in got]
+    # a non-canonical scalar in the middle of a batch fails the batch and leaves the context usable (all slots collected)
+    bad = bytearray(sc.cpu().numpy().tobytes())
+    bad[3 * n * 32:3 * n * 32 + 32] = b"\xff" * 32
+    with pytest.raises(m.MsmHipError) as e:
+        ctx.msm_batch(bytes(bad), n)
+    assert e.value.code == -4
+    assert ctx.msm_batch(sc, n)[0].to_affine_bytes() == got[0].to_affine_bytes()
