@@ -59,7 +59,7 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     import msm_webgpu_amd as m  # fails loudly if libmsm_hip.so is missing
-    from msm_webgpu_amd.sharding import ShardedMsmPipeline, window_range
+    from msm_webgpu_amd.sharding import ShardedMsmPipeline, msms_per_launch, window_range
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
@@ -89,18 +89,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    smvp_ms, stage_acc = [], {}
+    smvp_ms, smvp_windows = [], []
     sharded = world > 1 or force_sharded or emulate > 1
-    pipe = ShardedMsmPipeline(ctx, rank, world, depth=int(os.environ.get("BENCH_PIPE_DEPTH", "3"))) if sharded else None
-    if emulate > 1:
-        pipe.w_begin, pipe.w_end = window_range(0, emulate)
+    # window-sharded runs put the shares of several independent MSMs through one launch (as many as fit 16 local windows:
+    # 8 MSMs x 2 windows at 8 GPUs) -- one kernel sequence and one RCCL all-gather per group; BENCH_MSMS_PER_LAUNCH overrides
+    group = 1
+    pipe = None
+    if sharded:
+        group = int(os.environ.get("BENCH_MSMS_PER_LAUNCH", "0")) or msms_per_launch(emulate if emulate > 1 else world)
+        pipe = ShardedMsmPipeline(ctx, rank, world, depth=int(os.environ.get("BENCH_PIPE_DEPTH", "3")), msms_per_issue=group,
+                                  emulate_world=emulate)
         w_local = pipe.w_end - pipe.w_begin
+        # vector k of a group is scalar set k & 1
+        group_scalars = torch.cat([scalar_sets[k & 1] for k in range(group)], dim=0).contiguous() if group > 1 else None
 
-    def note_stages():
-        st = ctx.stage_ms()
-        smvp_ms.append(st["smvp"])
-        for k, v in st.items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    def note_stages(w_eff):
+        smvp_ms.append(ctx.stage_ms()["smvp"])
+        smvp_windows.append(w_eff)
 
     def run_steps(count, record):
         """`count` MSMs; returns the last result.  N = 1 pipelines the host combine of MSM i with the device work of i+1."""
@@ -111,26 +116,30 @@ def main():
                 ctx.launch(scalar_sets[i & 1], i & 1)
                 result = ctx.finish((i - 1) & 1)
                 if record:
-                    note_stages()
+                    note_stages(w_local)
             result = ctx.finish((count - 1) & 1)
             if record:
-                note_stages()
+                note_stages(w_local)
         else:
             # windows sharded over the ranks; device work, RCCL all-gather, D2H and host combine all pipelined
-            inflight = 0
-            for i in range(count):
-                pipe.issue(scalar_sets[i & 1])
-                inflight += 1
-                if inflight == pipe.depth:
+            sizes = [group] * (count // group) + ([count % group] if count % group else [])
+            inflight = []
+            for k, gs in enumerate(sizes):
+                if group > 1:
+                    pipe.issue(group_scalars[: gs * n], n)
+                else:
+                    pipe.issue(scalar_sets[k & 1])
+                inflight.append(gs)
+                if len(inflight) == pipe.depth:
                     result = pipe.complete()
-                    inflight -= 1
                     if record:
-                        note_stages()
+                        note_stages(inflight[0] * w_local)
+                    inflight.pop(0)
             while inflight:
                 result = pipe.complete()
-                inflight -= 1
                 if record:
-                    note_stages()
+                    note_stages(inflight[0] * w_local)
+                inflight.pop(0)
         return result
 
     # timed region: HIP events only around the SMVP accumulate kernel (the roofline figure); every extra stage event
@@ -182,19 +191,26 @@ def main():
     # sharded runs: check the gathered + combined result against this rank's own whole 16-window MSM (outside the timed region)
     sharded_ok = None
     if sharded and emulate <= 1:
-        whole = ctx.msm(scalar_sets[(args.steps - 1) & 1])
-        sharded_ok = bool(whole == last)
+        if group > 1:  # `last` is the result list of the final group; its vector k used scalar set k & 1
+            whole = ctx.msm(scalar_sets[(len(last) - 1) & 1])
+            sharded_ok = bool(whole == last[-1])
+        else:
+            whole = ctx.msm(scalar_sets[(args.steps - 1) & 1])
+            sharded_ok = bool(whole == last)
 
     ms_per_step = elapsed * 1e3 / args.steps
-    smvp_avg_ms = sum(smvp_ms) / len(smvp_ms)
-    alg_bytes = smvp_algorithmic_bytes(n, w_local)
+    # roofline of the SMVP accumulate kernel: algorithmic bytes of all timed launches / their summed durations
+    launches = len(smvp_ms)
+    smvp_avg_ms = sum(smvp_ms) / launches
+    alg_bytes = sum(smvp_algorithmic_bytes(n, w) for w in smvp_windows) / launches
     achieved = alg_bytes / (smvp_avg_ms * 1e-3) / 1e9
+    w_launch = max(smvp_windows)
 
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "smvp_pmc_traffic.json")) as f:
             pmc = json.load(f)
-        if pmc.get("logn") == args.logn and pmc.get("w_local") == w_local:
+        if pmc.get("logn") == args.logn and pmc.get("w_local") == w_launch and min(smvp_windows) == w_launch:
             traffic = pmc.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
@@ -213,7 +229,8 @@ def main():
         "dtype": "u32",
         "data": "synthetic",
         "config": {"workload": "2^%d BN254 G1 MSM, 16-bit signed-bucket windows, inputs resident in HBM" % args.logn,
-                   "windows_per_gpu": w_local, "parallelism": "windows/%d + RCCL all-gather" % world if sharded else "single GPU",
+                   "windows_per_gpu": w_local, "msms_per_launch": group,
+                   "parallelism": "windows/%d + RCCL all-gather" % world if sharded else "single GPU",
                    "host_combine": "pipelined one MSM behind"},
         "roofline": {"bound": "hbm", "kernel": "k_smvp_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,

@@ -91,6 +91,12 @@ int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, 
  *   msm_hip_slot_sync         blocks the host until the slot is complete and returns its error status. */
 int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot,
                                         void* window_sums_dev);
+/* several MSMs per launch: `nvec` scalar vectors (contiguous, nvec x n x 32 B) over the resident bases, windows
+ * [w_begin, w_end) of each, nvec * (w_end - w_begin) <= 16; window_sums_dev receives nvec x (w_end - w_begin) x 96 B
+ * (vector-major).  One kernel sequence sorts, accumulates and reduces all of them: a rank of a window-sharded run whose
+ * own share (2 windows of one MSM at 8 GPUs) cannot fill the GPU processes 8 MSMs' shares at once. */
+int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin,
+                                              int w_end, int slot, void* window_sums_dev);
 int msm_hip_slot_wait_stream(msm_hip_ctx* ctx, int slot, void* hip_stream);
 int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot);
 /* result = sum_w 2^(16 w) * S_w over num_windows records (host memory): src/cuzk/msm.rs:411-416 */

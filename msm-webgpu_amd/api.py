@@ -51,6 +51,7 @@ def lib():
         L.msm_hip_run_bn254.argtypes = [vp, u8p, sz, u8p]
         L.msm_hip_run_device_bn254.argtypes = [vp, vp, sz, u8p]
         L.msm_hip_run_batch_bn254.argtypes = [vp, u8p, sz, sz, u8p]
+        L.msm_hip_launch_windows_batch_device_bn254.argtypes = [vp, vp, sz, i, i, i, i, vp]
         L.msm_hip_run_batch_device_bn254.argtypes = [vp, vp, sz, sz, u8p]
         L.msm_hip_launch_device_bn254.argtypes = [vp, vp, sz, i]
         L.msm_hip_finish_bn254.argtypes = [vp, i, u8p]
@@ -257,6 +258,16 @@ class MsmContext:
         self._keepalive = (t, out_dev)
         _check(lib().msm_hip_launch_windows_device_bn254(self._h, t.data_ptr(), n, w_begin, w_end, slot, out_dev.data_ptr()),
                "msm_hip_launch_windows_device_bn254")
+
+    def launch_windows_batch(self, scalars_dev, n, w_begin, w_end, slot, out_dev):
+        """Several MSMs per launch: scalars_dev holds nvec contiguous vectors of n scalars (CUDA uint8 [nvec * n, 32]);
+        `out_dev` (CUDA uint8 [nvec * (w_end - w_begin), 96], vector-major) receives the window sums.  nvec * windows <= 16."""
+        t, rows = _as_device_u8(scalars_dev, 32, "scalars")
+        if n <= 0 or rows % n:
+            raise ValueError("scalars must hold a whole number of n-element vectors")
+        self._keepalive = (t, out_dev)
+        _check(lib().msm_hip_launch_windows_batch_device_bn254(self._h, t.data_ptr(), n, rows // n, w_begin, w_end, slot, out_dev.data_ptr()),
+               "msm_hip_launch_windows_batch_device_bn254")
 
     def slot_wait_stream(self, slot, stream=None):
         """Make a torch CUDA stream (default: the current one) wait, on the device, for the slot's results."""

@@ -52,7 +52,7 @@ struct Slot {
   hipEvent_t done = nullptr;                  // everything of this slot finished (recorded on the reduce stream)
   bool timed = false, pending = false, to_host = false;
   int timing_level = 0;
-  int w_begin = 0, w_count = 0;
+  int w_begin = 0, w_count = 0, nvec = 1;  // windows [w_begin, w_begin + w_count) of nvec scalar vectors
   size_t n = 0;
 };
 
@@ -195,8 +195,11 @@ int err_from_bits(uint32_t bits) {
 // Enqueue one MSM (windows [w_begin, w_begin + w_count)) into slot `s`.  Window sums (canonical Jacobian bytes) go to
 // `wsums_out` (device memory; the slot's own buffer when null); the error word and, if `to_host`, the window sums are
 // copied to the slot's pinned buffer.  Returns without waiting.
-int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count, Slot& s, uint32_t* wsums_out,
-            bool to_host) {
+int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count_vec, int nvec, Slot& s,
+            uint32_t* wsums_out, bool to_host) {
+  // `nvec` scalar vectors (contiguous, n x 32 B each) share this launch: local window lw = v * w_count_vec + (w - w_begin);
+  // everything after the two scalar-reading kernels only sees w_count = nvec * w_count_vec local windows
+  const int w_count = nvec * w_count_vec;
   hipStream_t st = ctx->stream, rs = ctx->reduce_stream[(&s - ctx->slot) % NREDUCE];
   // tiles of scalars for the two global sort passes: >= 2048 scalars each, at most MAX_TILES of them
   uint32_t tile_len = 2048;
@@ -219,11 +222,12 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   };
   HIP_TRY(ctx, hipStreamWaitEvent(st, s.done, 0));
   HIP_TRY(ctx, mark(0, false));
-  hipLaunchKernelGGL(k_count, dim3(tiles), dim3(256), 0, st, d_scalars, n, tile_len, tiles, w_begin, w_count, ctx->d_counts, digits, d_err);
+  hipLaunchKernelGGL(k_count, dim3(tiles), dim3(256), 0, st, d_scalars, n, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts,
+                     digits, d_err);
   HIP_TRY(ctx, mark(1, false));
   hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total);
   HIP_TRY(ctx, mark(2, false));
-  hipLaunchKernelGGL(k_scatter_coarse, dim3(tiles), dim3(256), 0, st, d_scalars, n, stride, tile_len, tiles, w_begin, w_count,
+  hipLaunchKernelGGL(k_scatter_coarse, dim3(tiles), dim3(256), 0, st, d_scalars, n, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8,
                      ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine);
   HIP_TRY(ctx, mark(3, false));
   hipLaunchKernelGGL(k_sort_fine, dim3(NCOARSE, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
@@ -266,7 +270,8 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   HIP_TRY(ctx, hipGetLastError());
 
   s.w_begin = w_begin;
-  s.w_count = w_count;
+  s.w_count = w_count_vec;
+  s.nvec = nvec;
   s.n = n;
   s.timed = tl >= 1;
   s.timing_level = tl;
@@ -458,32 +463,40 @@ int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, 
   return set_bases_from_device(ctx, reinterpret_cast<const uint32_t*>(ctx->d_stage), n, flags);
 }
 
-int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot,
-                                        void* window_sums_dev) {
+int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end,
+                                              int slot, void* window_sums_dev) {
   int rc = check_run_args(ctx, scalars_dev, n);
   if (rc) return rc;
   if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > NWIN || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
+  const int w_count = w_end - w_begin;
+  if (nvec < 1 || nvec * w_count > NWIN) return MSM_HIP_ERR_INVALID_ARG;
+  if (nvec > 1 && !window_sums_dev) return MSM_HIP_ERR_INVALID_ARG;  // several vectors: sums go to caller memory
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   Slot& s = ctx->slot[slot];
   if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;  // its result was never collected (msm_hip_finish_bn254 / msm_hip_slot_sync)
-  const int w_count = w_end - w_begin;
   s.n = n;
   s.w_begin = w_begin;
   s.w_count = w_count;
+  s.nvec = nvec;
   s.to_host = window_sums_dev == nullptr;
   if (n == 0) {  // identity window sums, nothing to compute
     s.pending = true;
     s.timed = false;
     memset(s.h_wsums, 0, WSUM_BYTES + 4);
     if (window_sums_dev) {
-      HIP_TRY(ctx, hipMemsetAsync(window_sums_dev, 0, (size_t)w_count * 96, ctx->reduce_stream[slot % NREDUCE]));
+      HIP_TRY(ctx, hipMemsetAsync(window_sums_dev, 0, (size_t)nvec * w_count * 96, ctx->reduce_stream[slot % NREDUCE]));
       HIP_TRY(ctx, hipEventRecord(s.done, ctx->reduce_stream[slot % NREDUCE]));
     }
     return MSM_HIP_OK;
   }
-  if ((rc = ensure_work(ctx, n, w_count))) return rc;
-  return enqueue(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, s, static_cast<uint32_t*>(window_sums_dev),
+  if ((rc = ensure_work(ctx, n, nvec * w_count))) return rc;
+  return enqueue(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, nvec, s, static_cast<uint32_t*>(window_sums_dev),
                  window_sums_dev == nullptr);
+}
+
+int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot,
+                                        void* window_sums_dev) {
+  return msm_hip_launch_windows_batch_device_bn254(ctx, scalars_dev, n, 1, w_begin, w_end, slot, window_sums_dev);
 }
 
 int msm_hip_launch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot) {
@@ -508,7 +521,7 @@ int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot) {
 int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]) {
   if (!ctx || !out_xyz || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   Slot& s = ctx->slot[slot];
-  if (!s.pending || !s.to_host || s.w_count != NWIN) return MSM_HIP_ERR_INVALID_ARG;
+  if (!s.pending || !s.to_host || s.w_count != NWIN || s.nvec != 1) return MSM_HIP_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = wait_slot(ctx, s);
   if (rc) return rc;

@@ -181,9 +181,13 @@ __device__ __forceinline__ uint32_t code_of_window(const uint32_t t[8], int w) {
   return 0x8000u | (((uint32_t)HALF - b) & 0x7fffu);          // d = -(2^15 - b), magnitude 1 .. 2^15 (2^15 -> slot 0)
 }
 
+// `nvec` scalar vectors (vec_stride words apart) may share one launch: vector v, window w is handled as local window
+// lw = v * w_count + (w - w_begin), nvec * w_count <= NWIN -- several MSMs over the same bases sorted, accumulated and reduced
+// by one kernel sequence (used by the window-sharded multi-GPU pipeline, where one MSM's share is too small to fill a GPU).
 __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles,
-                                               int w_begin, int w_count, uint32_t* __restrict__ counts,
-                                               uint16_t* __restrict__ digits_dbg, uint32_t* __restrict__ err) {
+                                               int w_begin, int w_count, int nvec, size_t vec_stride,
+                                               uint32_t* __restrict__ counts, uint16_t* __restrict__ digits_dbg,
+                                               uint32_t* __restrict__ err) {
   __shared__ uint32_t cnt[NWIN * NCOARSE];
   const int tid = threadIdx.x;
   for (int i = tid; i < NWIN * NCOARSE; i += 256) cnt[i] = 0;
@@ -191,24 +195,29 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
   const size_t base = (size_t)blockIdx.x * tile_len;
   const size_t end = base + tile_len < n ? base + tile_len : n;
   uint32_t bad = 0;
-  for (size_t i = base + tid; i < end; i += 256) {
-    uint32_t s[8], tb[8];
-    ld8(scalars + i * 8, s);
-    bad |= bias_scalar(s, tb);
+  for (int v = 0; v < nvec; v++) {
+    const uint32_t* sv = scalars + (size_t)v * vec_stride;
+    for (size_t i = base + tid; i < end; i += 256) {
+      uint32_t s[8], tb[8];
+      ld8(sv + i * 8, s);
+      bad |= bias_scalar(s, tb);
 #pragma unroll
-    for (int w = 0; w < NWIN; w++) {
-      const int lw = w - w_begin;
-      if (lw >= 0 && lw < w_count) {
-        const uint32_t code = code_of_window(tb, w);
-        if (code != 0) atomicAdd(&cnt[lw * NCOARSE + ((code & 0x7fffu) >> 8)], 1u);
-        if (digits_dbg) digits_dbg[(size_t)lw * n + i] = (uint16_t)code;
+      for (int w = 0; w < NWIN; w++) {
+        const int lw = w - w_begin;
+        if (lw >= 0 && lw < w_count) {
+          const int le = v * w_count + lw;
+          const uint32_t code = code_of_window(tb, w);
+          if (code != 0) atomicAdd(&cnt[le * NCOARSE + ((code & 0x7fffu) >> 8)], 1u);
+          if (digits_dbg) digits_dbg[(size_t)le * n + i] = (uint16_t)code;
+        }
       }
     }
   }
   if (bad) atomicOr(err, ERRBIT_SCALAR_CARRY);
   __syncthreads();
   // counts[lw][tile][bin]
-  for (int i = tid; i < w_count * NCOARSE; i += 256)
+  const int w_eff = nvec * w_count;
+  for (int i = tid; i < w_eff * NCOARSE; i += 256)
     counts[((size_t)(i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[i];
 }
 
@@ -259,7 +268,8 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* wa
 constexpr int SCAT_SUB = 2048;  // scalars staged per block iteration (8 per thread)
 
 __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
-                                                        uint32_t tiles, int w_begin, int w_count, const uint32_t* __restrict__ counts,
+                                                        uint32_t tiles, int w_begin, int w_count, int nvec, size_t vec_stride,
+                                                        const uint32_t* __restrict__ counts,
                                                         const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr,
                                                         uint32_t* __restrict__ tmp_val,
                                                         uint8_t* __restrict__ tmp_fine) {
@@ -273,9 +283,10 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
   const int tid = threadIdx.x;
   // start of every (window, coarse bin): exclusive scan of the window's 128 bin totals -- a pair of waves per window, two
   // windows per step; workgroup 0 also publishes them as coarse_ptr[lw][0..128] for k_sort_fine
-  for (int i0 = 0; i0 < w_count * NCOARSE; i0 += 256) {
+  const int w_eff = nvec * w_count;  // local windows of all vectors of this launch
+  for (int i0 = 0; i0 < w_eff * NCOARSE; i0 += 256) {
     const int i = i0 + tid, lw = i / NCOARSE, bin = i % NCOARSE, lane = tid & 63;
-    const bool live = i < w_count * NCOARSE;  // odd window counts: the last step has one idle pair of waves
+    const bool live = i < w_eff * NCOARSE;  // odd window counts: the last step has one idle pair of waves
     const uint32_t v = live ? bin_total[i] : 0u;
     uint32_t x = v;
 #pragma unroll
@@ -295,20 +306,22 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
   }
   const size_t tile_base = (size_t)blockIdx.x * tile_len;
   const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
+  for (int v = 0; v < nvec; v++)
   for (size_t sub = tile_base; sub < tile_end; sub += SCAT_SUB) {
     // this thread's 8 biased scalars stay in registers; every window's digit code is read from them
+    const uint32_t* sv = scalars + (size_t)v * vec_stride;
     uint32_t sc[8][8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const size_t i = sub + (size_t)j * 256 + tid;
       uint32_t raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // an all-zero scalar recodes to all-zero digits: no entries
-      if (i < tile_end) ld8(scalars + i * 8, raw);
+      if (i < tile_end) ld8(sv + i * 8, raw);
       (void)bias_scalar(raw, sc[j]);
     }
 #pragma unroll
     for (int w = 0; w < NWIN; w++) {
-      const int lw = w - w_begin;
-      if (lw < 0 || lw >= w_count) continue;  // block-uniform
+      if (w < w_begin || w >= w_begin + w_count) continue;  // block-uniform
+      const int lw = v * w_count + (w - w_begin);
       if (tid < NCOARSE) hist[tid] = 0;
       __syncthreads();
       uint32_t rank[8];

@@ -94,6 +94,23 @@ def sharded_batch_msm(ctx, scalars_dev, n, rank, world_size, group=None):
     return [G1(allr[96 * k:96 * k + 96]) for k in range(batch)]
 
 
+def msms_per_launch(world_size, num_windows=NUM_WINDOWS):
+    """How many MSMs a rank processes per launch in the window-sharded pipeline: as many as fit 16 local windows.  A rank's
+    share of ONE MSM (2 windows at 8 GPUs) is too small to fill a GPU -- kernel latencies, not work, set its time -- so the
+    shares of several independent MSMs go through one kernel sequence (msm_hip_launch_windows_batch_device_bn254)."""
+    return max(1, num_windows // max_windows_per_rank(world_size, num_windows))
+
+
+def group_window_rows(gathered, v, world_size, num_windows=NUM_WINDOWS, window_ranges=None):
+    """gathered: uint8 [world, rows, 96] where rank r wrote its records vector-major ([nvec][w_r][96], w_r = its window count)
+    at the front of its row block.  Returns the num_windows x 96 records of vector `v` in window order."""
+    rows = []
+    for r in range(world_size):
+        b, e = window_ranges[r] if window_ranges else window_range(r, world_size, num_windows)
+        rows.append(gathered[r, v * (e - b):(v + 1) * (e - b)])
+    return torch.cat(rows, dim=0)
+
+
 class ShardedMsmPipeline:
     """Back-to-back window-sharded MSMs with everything asynchronous: rank-local device work (result slots and
     main/reduce HIP streams inside the engine), the RCCL all-gather on the torch stream (ordered after the slot by a device-side
@@ -101,37 +118,57 @@ class ShardedMsmPipeline:
 
         pipe = ShardedMsmPipeline(ctx, rank, world_size, group)
         pipe.issue(scalars_0); pipe.issue(scalars_1); r0 = pipe.complete(); pipe.issue(scalars_2); r1 = pipe.complete(); ...
-    At most `depth` (<= 3) MSMs may be in flight; each uses one of the engine's four result slots.
+    At most `depth` (<= 3) launches may be in flight; each uses one of the engine's four result slots.
+
+    `group` > 1: every issue() takes `group` (or fewer) scalar vectors at once (CUDA uint8 [g * n, 32], contiguous) and
+    complete() returns the list of their results; one launch and ONE all-gather serve all of them.
     """
 
     SLOTS = 4
 
-    def __init__(self, ctx, rank, world_size, group=None, num_windows=NUM_WINDOWS, depth=3):
+    def __init__(self, ctx, rank, world_size, group=None, num_windows=NUM_WINDOWS, depth=3, msms_per_issue=1, emulate_world=0):
         assert 1 <= depth < self.SLOTS
         self.depth = depth
         self.ctx, self.rank, self.world, self.group, self.num_windows = ctx, rank, world_size, group, num_windows
         self.w_begin, self.w_end = window_range(rank, world_size, num_windows)
         self.per = max_windows_per_rank(world_size, num_windows)
+        # tuning aid: a single rank does the share rank 0 would have in a run of `emulate_world` ranks; its results are the
+        # PARTIAL sums over those windows only (never a reported result)
+        self.emulate = emulate_world if emulate_world > 1 and world_size == 1 else 0
+        if self.emulate:
+            self.w_begin, self.w_end = window_range(0, self.emulate, num_windows)
+            self.per = max_windows_per_rank(self.emulate, num_windows)
+        self.g = msms_per_issue
+        assert self.g * self.per <= num_windows, "msms_per_issue x windows per rank must not exceed 16"
         dev = torch.device("cuda", ctx.device)
-        self.padded = [torch.zeros((self.per, 96), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
-        self.gathered = [torch.empty((world_size, self.per, 96), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
-        self.host = [torch.empty((world_size, self.per, 96), dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
+        rows = self.g * self.per
+        self.padded = [torch.zeros((rows, 96), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
+        self.gathered = [torch.empty((world_size, rows, 96), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
+        self.host = [torch.empty((world_size, rows, 96), dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
         self.copied = [torch.cuda.Event() for _ in range(self.SLOTS)]
+        self.nvec = [1] * self.SLOTS
         self.issued = 0
         self.completed = 0
         # MSM_SHARD_FORCE_COLLECTIVE=1: issue the RCCL all-gather even with a single rank (rehearsal of the multi-GPU
         # stream / queue layout on a one-GPU box; needs an initialised process group)
         self.collective = world_size > 1 or (os.environ.get("MSM_SHARD_FORCE_COLLECTIVE") == "1" and dist.is_initialized())
 
-    def issue(self, scalars_dev):
+    def issue(self, scalars_dev, n=None):
+        """scalars_dev: one vector (CUDA uint8 [n, 32]) or, with `n` given, up to msms_per_issue contiguous vectors."""
         assert self.issued - self.completed < self.depth, "pipeline full: call complete() first"
         slot = self.issued % self.SLOTS
         w_local = self.w_end - self.w_begin
-        self.ctx.launch_windows(scalars_dev, self.w_begin, self.w_end, slot, self.padded[slot][:w_local])
-        # gather + copies go to the CURRENT torch stream (normally the default stream): with GPU_MAX_HW_QUEUES=8 this
-        # layout -- 3 engine streams, the default stream, RCCL's own -- keeps three MSMs in flight; a dedicated side stream
-        # (or a 4th engine stream) was measured to collapse the pipeline to one MSM at a time (DESIGN.md section 7)
-        self.ctx.slot_wait_stream(slot)
+        rows = scalars_dev.shape[0] if scalars_dev.dim() == 2 else scalars_dev.numel() // 32
+        n = rows if n is None else n
+        nvec = rows // n
+        assert 1 <= nvec <= self.g and nvec * n == rows
+        self.nvec[slot] = nvec
+        if w_local > 0:
+            self.ctx.launch_windows_batch(scalars_dev, n, self.w_begin, self.w_end, slot, self.padded[slot][: nvec * w_local])
+            # gather + copies go to the CURRENT torch stream (normally the default stream): with GPU_MAX_HW_QUEUES=8 this
+            # layout -- 3 engine streams, the default stream, RCCL's own -- keeps three launches in flight; a dedicated side
+            # stream (or a 4th engine stream) was measured to collapse the pipeline to one at a time (DESIGN.md section 7)
+            self.ctx.slot_wait_stream(slot)
         if self.collective:
             dist.all_gather_into_tensor(self.gathered[slot].view(-1), self.padded[slot].view(-1), group=self.group)
         else:
@@ -141,13 +178,16 @@ class ShardedMsmPipeline:
         self.issued += 1
 
     def complete(self):
+        """Result of the oldest launch in flight: a G1, or the list of its G1 results when msms_per_issue > 1."""
         assert self.completed < self.issued
         slot = self.completed % self.SLOTS
         self.copied[slot].synchronize()
-        self.ctx.slot_sync(slot)
-        rows = []
-        for r in range(self.world):
-            b, e = window_range(r, self.world, self.num_windows)
-            rows.append(self.host[slot][r, : min(e - b, self.per)])
+        if self.w_end > self.w_begin:
+            self.ctx.slot_sync(slot)
+        nvec = self.nvec[slot]
+        out = []
+        ranges = [(self.w_begin, self.w_end)] if self.emulate else None
+        for v in range(nvec):
+            out.append(MsmContext.combine_windows(group_window_rows(self.host[slot], v, self.world, self.num_windows, ranges)))
         self.completed += 1
-        return MsmContext.combine_windows(torch.cat(rows, dim=0))
+        return out if self.g > 1 else out[0]

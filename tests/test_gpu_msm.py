@@ -228,3 +228,41 @@ def test_batch_over_shared_base(ctx):
         ctx.msm_batch(bytes(bad), n)
     assert e.value.code == -4
     assert ctx.msm_batch(sc, n)[0].to_affine_bytes() == got[0].to_affine_bytes()
+
+
+def test_several_msms_per_launch(ctx):
+    # msm_hip_launch_windows_batch_device_bn254: the window shares of several MSMs through one kernel sequence
+    from msm_webgpu_amd.sharding import ShardedMsmPipeline, msms_per_launch
+
+    assert [msms_per_launch(w) for w in (1, 2, 3, 4, 8, 16)] == [1, 2, 2, 4, 8, 16]
+    n = 5000
+    pts = ctx.sample_points(n, 170)
+    ctx.set_bases(pts)
+    vecs = [ctx.sample_scalars(n, 171 + k) for k in range(8)]
+    vecs[3] = torch.zeros_like(vecs[3])  # an all-zero vector inside the group: identity
+    want = [ctx.msm(v) for v in vecs]
+    assert want[3].is_identity()
+    batch = torch.cat(vecs, dim=0).contiguous()
+    # raw entry point: 8 vectors x windows [6, 8) -> 16 local windows
+    out = torch.empty((16, 96), dtype=torch.uint8, device=batch.device)
+    ctx.launch_windows_batch(batch, n, 6, 8, 0, out)
+    ctx.slot_sync(0)
+    for k in (0, 3, 7):  # same group elements (the Jacobian representation depends on the chunking, the point does not)
+        ref = ctx.msm_windows(vecs[k], 6, 8)
+        for j in range(2):
+            assert m.MsmContext.combine_windows(out[2 * k + j:2 * k + j + 1]) == m.MsmContext.combine_windows(ref[j:j + 1]), (k, j)
+    with pytest.raises(m.MsmHipError):
+        ctx.launch_windows_batch(batch, n, 0, 3, 1, out)  # 8 x 3 windows do not fit
+    # pipeline with groups: single rank doing all 16 windows can only take one MSM per launch ...
+    pipe = ShardedMsmPipeline(ctx, 0, 1, msms_per_issue=1)
+    pipe.issue(vecs[0])
+    assert pipe.complete() == want[0]
+    # ... the share of an 8-rank run takes 8: results are the partial sums over windows [0, 2) of every vector
+    pipe8 = ShardedMsmPipeline(ctx, 0, 1, msms_per_issue=8, emulate_world=8)
+    pipe8.issue(batch, n)
+    pipe8.issue(batch[: 3 * n], n)  # a short final group
+    got, got3 = pipe8.complete(), pipe8.complete()
+    assert len(got) == 8 and len(got3) == 3
+    for k in range(8):
+        part = m.MsmContext.combine_windows(ctx.msm_windows(vecs[k], 0, 2))
+        assert got[k] == part and (k >= 3 or got3[k] == part), k

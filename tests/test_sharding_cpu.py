@@ -115,3 +115,49 @@ def test_batch_sharding_gloo(built):
     want = [cpu.to_affine64(cpu.cpu_msm(points, cpu.sample_scalars(500 + k, n))) for k in range(batch)]
     for _, blob in got:
         assert [cpu.to_affine64(blob[96 * k:96 * k + 96]) for k in range(batch)] == want
+
+
+def _group_worker(rank, world, port, nvec, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from msm_webgpu_amd.sharding import group_window_rows, max_windows_per_rank, window_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = max_windows_per_rank(world)
+    b, e = window_range(rank, world)
+    # what a rank's launch writes: [nvec][w_local] records, vector-major; record (v, w) is tagged with bytes v, w
+    padded = torch.zeros((nvec * per, 96), dtype=torch.uint8)
+    for v in range(nvec):
+        for w in range(b, e):
+            padded[v * (e - b) + (w - b)] = torch.tensor([v, w] + [0] * 94, dtype=torch.uint8)
+    gathered = torch.empty((world, nvec * per, 96), dtype=torch.uint8)
+    dist.all_gather_into_tensor(gathered.view(-1), padded.view(-1))
+    ok = all(group_window_rows(gathered, v, world)[:, :2].tolist() == [[v, w] for w in range(16)] for v in range(nvec))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grouped_launch_layout_gloo():
+    # several MSMs per launch: the all-gathered block of every rank is vector-major; uneven window counts (3 ranks: 6, 5, 5)
+    from msm_webgpu_amd.sharding import msms_per_launch
+
+    world = 3
+    nvec = msms_per_launch(world)
+    assert nvec == 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, nvec, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in got)
