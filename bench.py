@@ -6,8 +6,10 @@
 
 A step = one whole MSM (decompose, sort, SMVP accumulate, bucket reduce on the GPU; window combine on the host) over
 synthetic inputs that are already resident in HBM when the timed region starts.  N = 1: one GPU does all 16 windows.
-N > 1: the 16 Pippenger windows are sharded over the ranks (one process per GPU), one RCCL all-gather of the window
-sums per MSM, host combine -- total work is fixed, so "scaling" is "strong".  Rank 0 prints ONE JSON line.
+N > 1: the 16 Pippenger windows of every MSM are sharded over the ranks (one process per GPU); a rank puts its shares of
+16 / windows_per_rank consecutive MSMs through one launch (config.msms_per_launch; one MSM's share cannot fill a GPU),
+ONE RCCL all-gather brings their window sums to every rank, host combine -- total work is fixed, so "scaling" is
+"strong".  Rank 0 prints ONE JSON line.
 
 roofline: the SMVP accumulate kernel.  achieved = ALGORITHMIC bytes per launch (N * W_local * 68 B read +
 W_local * 2^15 * 96 B written) / its average duration measured with HIP events on the engine's own stream over the
