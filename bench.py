@@ -64,6 +64,10 @@ def main():
     from msm_webgpu_amd.sharding import ShardedMsmPipeline, msms_per_launch, window_range
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # rehearsal aid for a one-GPU box: BENCH_ALL_ON_GPU0=1 puts every rank on GPU 0 (with BENCH_DIST_BACKEND=gloo, since
+    # RCCL refuses two ranks on one device) -- checks the multi-rank logic end to end; its timings mean nothing
+    if os.environ.get("BENCH_ALL_ON_GPU0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # BENCH_FORCE_SHARDED=1 drives the multi-GPU code path (RCCL process group + sharded pipeline) even with one rank,
     # so that it can be exercised on a single-GPU box under torch.distributed.run --nproc-per-node 1
@@ -71,7 +75,11 @@ def main():
     use_dist = world > 1 or (force_sharded and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n = 1 << args.logn
     ctx = m.MsmContext(local_rank)
