@@ -220,7 +220,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "smvp_pmc_traffic.json")) as f:
             pmc = json.load(f)
-        if pmc.get("logn") == args.logn and pmc.get("w_local") == w_launch and min(smvp_windows) == w_launch:
+        if pmc.get("logn") == args.logn and pmc.get("w_local") == w_launch:  # PMC bytes of one full 16-window launch
             traffic = pmc.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
