@@ -101,6 +101,23 @@ class MsmContext {
     check(msm_hip_run_bn254(ctx_, b.data(), v.size(), r.xyz.data()), "msm_hip_run_bn254");
     return r;
   }
+  /// Many MSMs over the resident bases (BASELINE config 5), pipelined inside the library: one result per scalar vector
+  std::vector<G1> msm_batch(const std::vector<std::vector<Fr>>& vs) {
+    if (vs.empty()) return {};
+    const size_t n = vs[0].size();
+    std::vector<uint8_t> all;
+    all.reserve(vs.size() * n * 32);
+    for (const auto& v : vs) {
+      if (v.size() != n) throw std::invalid_argument("msm_batch: scalar vectors differ in length");
+      const std::vector<uint8_t> b = scalars_to_bytes(v);
+      all.insert(all.end(), b.begin(), b.end());
+    }
+    std::vector<uint8_t> out(96 * vs.size());
+    check(msm_hip_run_batch_bn254(ctx_, all.data(), n, vs.size(), out.data()), "msm_hip_run_batch_bn254");
+    std::vector<G1> r(vs.size());
+    for (size_t k = 0; k < vs.size(); k++) std::memcpy(r[k].xyz.data(), out.data() + 96 * k, 96);
+    return r;
+  }
   msm_hip_ctx* raw() { return ctx_; }
 
  private:

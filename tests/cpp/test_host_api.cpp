@@ -42,6 +42,9 @@ int main(int argc, char** argv) {
   ctx.set_bases(g, true);
   const G1 again = ctx.msm(v);
   if (fast != again) return 1;
+  // many MSMs over the resident bases: [v, 0, v] -> [result, identity, result]
+  const std::vector<G1> many = ctx.msm_batch({v, std::vector<Fr>(n), v});
+  if (many.size() != 3 || many[0] != fast || many[2] != fast || !many[1].to_affine().infinity) return 5;
   const G1Affine a = fast.to_affine();
   std::vector<uint8_t> got(64, 0);
   if (!a.infinity) {

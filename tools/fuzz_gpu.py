@@ -45,7 +45,7 @@ for case in range(cases):
     sb = ref.scalars_to_bytes(sc)
     want = cpu.to_affine64(cpu.cpu_msm(points, sb))
     ctx.set_bases(points)
-    mode = rnd.choice(["host", "device", "windows", "batch"])
+    mode = rnd.choice(["host", "device", "windows", "batch", "group", "hostbatch"])
     if mode == "host":
         got = ctx.msm(sb)
     elif mode == "device":
@@ -54,6 +54,25 @@ for case in range(cases):
     elif mode == "batch":
         t = torch.frombuffer(bytearray(sb + sb), dtype=torch.uint8).cuda()
         got = ctx.msm_batch(t, n)[1]
+    elif mode == "hostbatch":
+        got = ctx.msm_batch(sb + sb + sb, n)[2]
+    elif mode == "group":
+        # several MSMs per launch (the multi-GPU pipeline's grouped launches): vector `pos` of the group is this case's,
+        # the others are all-zero / copies; every rank's share is run and the window sums are combined on the host
+        world = rnd.choice([2, 4, 8, 16])
+        g = 16 // (16 // world)
+        pos = rnd.randrange(g)
+        vecs = [bytes(len(sb)) if rnd.random() < 0.5 else sb for _ in range(g)]
+        vecs[pos] = sb
+        t = torch.frombuffer(bytearray(b"".join(vecs)), dtype=torch.uint8).cuda()
+        parts = []
+        for r in range(world):
+            b, e = window_range(r, world)
+            out = torch.empty((g * (e - b), 96), dtype=torch.uint8, device="cuda")
+            ctx.launch_windows_batch(t, n, b, e, r % 4, out)
+            ctx.slot_sync(r % 4)
+            parts.append(out[pos * (e - b):(pos + 1) * (e - b)])
+        got = m.MsmContext.combine_windows(torch.cat(parts, dim=0))
     else:
         t = torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda()
         world = rnd.choice([2, 3, 4, 5, 8, 16])
