@@ -113,6 +113,10 @@ def main():
         # vector k of a group is scalar set k & 1
         group_scalars = torch.cat([scalar_sets[k & 1] for k in range(group)], dim=0).contiguous() if group > 1 else None
 
+    # single GPU, small MSMs: whole MSMs grouped per launch (vector k of a group is scalar set k & 1)
+    group1 = 1 if sharded else max(1, min(4, (1 << 20) // n))
+    group1_scalars = torch.cat([scalar_sets[k & 1] for k in range(group1)], dim=0).contiguous() if group1 > 1 else None
+
     def note_stages(w_eff):
         smvp_ms.append(ctx.stage_ms()["smvp"])
         smvp_windows.append(w_eff)
@@ -120,7 +124,7 @@ def main():
     def run_steps(count, record):
         """`count` MSMs; returns the last result.  N = 1 pipelines the host combine of MSM i with the device work of i+1."""
         result = None
-        if not sharded:
+        if not sharded and group1 == 1:
             ctx.launch(scalar_sets[0], 0)
             for i in range(1, count):
                 ctx.launch(scalar_sets[i & 1], i & 1)
@@ -130,6 +134,18 @@ def main():
             result = ctx.finish((count - 1) & 1)
             if record:
                 note_stages(w_local)
+        elif not sharded:
+            # small MSMs (n < 2^19): up to 4 whole MSMs per launch, as msm_hip_run_batch_* does; same two-slot pipeline
+            sizes = [group1] * (count // group1) + ([count % group1] if count % group1 else [])
+            for k, gs in enumerate(sizes):
+                ctx.launch_batch(group1_scalars[: gs * n], n, k & 1)
+                if k:
+                    result = ctx.finish_batch((k - 1) & 1, sizes[k - 1])[-1]
+                    if record:
+                        note_stages(sizes[k - 1] * w_local)
+            result = ctx.finish_batch((len(sizes) - 1) & 1, sizes[-1])[-1]
+            if record:
+                note_stages(sizes[-1] * w_local)
         else:
             # windows sharded over the ranks; device work, RCCL all-gather, D2H and host combine all pipelined
             sizes = [group] * (count // group) + ([count % group] if count % group else [])
@@ -239,7 +255,7 @@ def main():
         "dtype": "u32",
         "data": "synthetic",
         "config": {"workload": "2^%d BN254 G1 MSM, 16-bit signed-bucket windows, inputs resident in HBM" % args.logn,
-                   "windows_per_gpu": w_local, "msms_per_launch": group,
+                   "windows_per_gpu": w_local, "msms_per_launch": group if sharded else group1,
                    "parallelism": "windows/%d + RCCL all-gather" % world if sharded else "single GPU",
                    "host_combine": "pipelined one MSM behind"},
         "roofline": {"bound": "hbm", "kernel": "k_smvp_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -259,7 +275,8 @@ def main():
         logs = args.cpu_sample_logn if args.cpu_sample_logn is not None else min(args.logn, 20)
         ns = 1 << logs
         pb = points[:ns].cpu().numpy().tobytes()
-        last_set = scalar_sets[(args.steps - 1) & 1]
+        last_idx = (args.steps - 1) & 1 if group1 == 1 else (((args.steps % group1) or group1) - 1) & 1
+        last_set = scalar_sets[last_idx]
         sb = last_set[:ns].cpu().numpy().tobytes()
         t1 = time.perf_counter()
         want = oracle_cpu.cpu_msm(pb, sb, 1)

@@ -42,6 +42,7 @@ extern "C" {
 
 #define MSM_HIP_NUM_WINDOWS 16         /* num_subtasks = ceil(256 / 16)                       src/cuzk/msm.rs:82 */
 #define MSM_HIP_WINDOW_BITS 16         /* chunk_size                                           src/cuzk/msm.rs:79 */
+#define MSM_HIP_MAX_LOCAL_WINDOWS 64   /* (scalar vectors) x (windows of each) one launch may carry                */
 #define MSM_HIP_NUM_SLOTS 4            /* asynchronous result slots per context                                 */
 #define MSM_HIP_BUCKETS_PER_WINDOW 32768 /* 2^(c-1) signed buckets                             src/cuzk/msm.rs:191 */
 
@@ -94,9 +95,13 @@ int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_de
 /* several MSMs per launch: `nvec` scalar vectors (contiguous, nvec x n x 32 B) over the resident bases, windows
  * [w_begin, w_end) of each, nvec * (w_end - w_begin) <= 16; window_sums_dev receives nvec x (w_end - w_begin) x 96 B
  * (vector-major).  One kernel sequence sorts, accumulates and reduces all of them: a rank of a window-sharded run whose
- * own share (2 windows of one MSM at 8 GPUs) cannot fill the GPU processes 8 MSMs' shares at once. */
+ * own share (2 windows of one MSM at 8 GPUs) cannot fill the GPU processes 8 MSMs' shares at once.
+ * Up to MSM_HIP_MAX_LOCAL_WINDOWS = 64 local windows per launch, i.e. also up to 4 WHOLE small MSMs (w_begin = 0, w_end = 16,
+ * window_sums_dev = NULL): msm_hip_finish_batch_bn254 then waits for the slot and writes nvec x 96 B results.  The batch
+ * entry points above group small MSMs this way on their own. */
 int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin,
                                               int w_end, int slot, void* window_sums_dev);
+int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz);
 int msm_hip_slot_wait_stream(msm_hip_ctx* ctx, int slot, void* hip_stream);
 int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot);
 /* result = sum_w 2^(16 w) * S_w over num_windows records (host memory): src/cuzk/msm.rs:411-416 */

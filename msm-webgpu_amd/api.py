@@ -52,6 +52,7 @@ def lib():
         L.msm_hip_run_device_bn254.argtypes = [vp, vp, sz, u8p]
         L.msm_hip_run_batch_bn254.argtypes = [vp, u8p, sz, sz, u8p]
         L.msm_hip_launch_windows_batch_device_bn254.argtypes = [vp, vp, sz, i, i, i, i, vp]
+        L.msm_hip_finish_batch_bn254.argtypes = [vp, i, u8p]
         L.msm_hip_run_batch_device_bn254.argtypes = [vp, vp, sz, sz, u8p]
         L.msm_hip_launch_device_bn254.argtypes = [vp, vp, sz, i]
         L.msm_hip_finish_bn254.argtypes = [vp, i, u8p]
@@ -266,8 +267,20 @@ class MsmContext:
         if n <= 0 or rows % n:
             raise ValueError("scalars must hold a whole number of n-element vectors")
         self._keepalive = (t, out_dev)
-        _check(lib().msm_hip_launch_windows_batch_device_bn254(self._h, t.data_ptr(), n, rows // n, w_begin, w_end, slot, out_dev.data_ptr()),
+        _check(lib().msm_hip_launch_windows_batch_device_bn254(self._h, t.data_ptr(), n, rows // n, w_begin, w_end, slot,
+                                                               out_dev.data_ptr() if out_dev is not None else None),
                "msm_hip_launch_windows_batch_device_bn254")
+
+    def launch_batch(self, scalars_dev, n, slot=0):
+        """Enqueue up to 4 WHOLE MSMs (contiguous scalar vectors, CUDA uint8 [nvec * n, 32]) as one launch; finish_batch collects."""
+        self.launch_windows_batch(scalars_dev, n, 0, NUM_WINDOWS, slot, None)
+        return scalars_dev.numel() // (32 * n)
+
+    def finish_batch(self, slot, nvec):
+        """Wait for a launch_batch slot, run the host window combines, return the list of G1 results."""
+        out = C.create_string_buffer(96 * nvec)
+        _check(lib().msm_hip_finish_batch_bn254(self._h, slot, out), "msm_hip_finish_batch_bn254")
+        return [G1(out.raw[96 * k:96 * k + 96]) for k in range(nvec)]
 
     def slot_wait_stream(self, slot, stream=None):
         """Make a torch CUDA stream (default: the current one) wait, on the device, for the slot's results."""

@@ -29,7 +29,7 @@ namespace {
 
 constexpr int N_MAIN_EVENTS = 7;  // boundaries of the 6 timed stages on the main stream
 constexpr uint32_t MAX_TILES = 1024;
-constexpr size_t WSUM_BYTES = (size_t)NWIN * 96;
+constexpr size_t WSUM_BYTES = (size_t)MAXLW * 96;
 constexpr int NSLOT = MSM_HIP_NUM_SLOTS;  // result slots
 constexpr int NREDUCE = 2;  // reduce streams (slot k uses stream k % NREDUCE): two bucket reduces may be in flight when the
                             // main-stream work of one MSM is shorter than its bucket reduce (few windows per GPU).  The context
@@ -37,9 +37,10 @@ constexpr int NREDUCE = 2;  // reduce streams (slot k uses stream k % NREDUCE): 
                             // above ROCm's default of 4 so that streams do not share hardware queues (bench.py does).
 
 struct Slot {
-  uint8_t* h_wsums = nullptr;      // pinned: NWIN x 96 B window sums + 4 B error word
-  uint8_t* d_wsums = nullptr;      // device: NWIN x 96 B window sums + 4 B error word
-  uint32_t* d_buckets = nullptr;   // [W][32768] XYZZ records
+  uint8_t* h_wsums = nullptr;      // pinned: MAXLW x 96 B window sums + 4 B error word
+  uint8_t* d_wsums = nullptr;      // device: MAXLW x 96 B window sums + 4 B error word
+  uint32_t* d_buckets = nullptr;   // [cap_lw][32768] XYZZ records
+  int cap_lw = 0;                  // local windows d_buckets holds (NWIN, or MAXLW once a larger launch was seen)
   uint32_t* d_partials = nullptr;  // bucket-reduce scratch: [W][256] row sums, [W][256] column sums, [W][3] parts (XYZZ)
   uint32_t* d_col_ptr = nullptr;   // [W][32769] start of every bucket slot's run in the sorted entry list
   uint32_t* d_heads = nullptr;     // [W][chunks] XYZZ records: SMVP pieces of runs that cross chunk boundaries
@@ -67,8 +68,9 @@ struct msm_hip_ctx {
   uint32_t* d_bases = nullptr;  // n_bases x 16 words
   size_t n_bases = 0, cap_bases = 0;
 
-  size_t cap_n = 0;   // capacity of the per-run work buffers (entries per window)
-  size_t stride = 0;  // per-window stride of the entry arrays: cap_n rounded up to a multiple of 4
+  size_t cap_n = 0;        // largest n seen: capacity of the host-scalar staging buffer
+  size_t cap_entries = 0;  // capacity of the entry arrays (tmp_val, tmp_fine, val): local windows x per-window stride
+  size_t last_stride = 0;  // per-window stride of the last launch (n rounded up to a multiple of 4)
   size_t cap_recs = 0;  // capacity (records) of the head / tail piece arrays
   uint32_t* d_scalars = nullptr;      // staging for host scalars of msm_hip_run_bn254
   uint8_t* d_batch_stage = nullptr;   // staging ring (NSLOT vectors) of msm_hip_run_batch_bn254, allocated on first use
@@ -154,33 +156,56 @@ inline size_t piece_records_for(size_t n) {
   return worst;
 }
 
+inline size_t stride_for(size_t n) { return (n + 3) & ~(size_t)3; }
+
+// make the pools fit a launch of `w_count` local windows (vectors x windows) over n points
 int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count) {
   const size_t need_recs = (size_t)w_count * chunks_for(n, chunk_len_for(n, w_count));
-  if (n <= ctx->cap_n && need_recs <= ctx->cap_recs && (!ctx->debug || ctx->d_digits)) return MSM_HIP_OK;
+  const size_t need_entries = stride_for(n) * (size_t)w_count;
+  bool lw_ok = true;
+  for (const Slot& sl : ctx->slot) lw_ok = lw_ok && w_count <= sl.cap_lw;
+  if (n <= ctx->cap_n && need_entries <= ctx->cap_entries && need_recs <= ctx->cap_recs && lw_ok && (!ctx->debug || ctx->d_digits))
+    return MSM_HIP_OK;
   // growing the pools: nothing may still be running on them
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (hipStream_t r : ctx->reduce_stream) HIP_TRY(ctx, hipStreamSynchronize(r));
   const size_t cap = n > ctx->cap_n ? n : ctx->cap_n;
-  ctx->cap_n = 0;
-  const size_t stride = (cap + 3) & ~(size_t)3;
+  size_t entries = stride_for(cap) * NWIN;  // any single MSM over up to cap points
+  if (entries < need_entries) entries = need_entries;
+  if (entries < ctx->cap_entries) entries = ctx->cap_entries;
   size_t recs = piece_records_for(cap);
   if (recs < need_recs) recs = need_recs;
   if (recs < ctx->cap_recs) recs = ctx->cap_recs;
-  ctx->cap_recs = 0;
   int rc;
-  if ((rc = dev_alloc(ctx, ctx->d_scalars, cap * 8))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_tmp_val, stride * NWIN))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_tmp_fine, stride * NWIN))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_val, stride * NWIN))) return rc;
-  for (Slot& sl : ctx->slot) {
-    if ((rc = dev_alloc(ctx, sl.d_heads, recs * REC_WORDS))) return rc;
-    if ((rc = dev_alloc(ctx, sl.d_tails, recs * REC_WORDS))) return rc;
+  if (cap > ctx->cap_n) {
+    ctx->cap_n = 0;
+    if ((rc = dev_alloc(ctx, ctx->d_scalars, cap * 8))) return rc;
+    ctx->cap_n = cap;
   }
-  if ((rc = dev_alloc(ctx, ctx->d_chunk_slot, recs))) return rc;
-  if (ctx->debug && (rc = dev_alloc(ctx, ctx->d_digits, cap * NWIN))) return rc;
-  ctx->cap_n = cap;
-  ctx->stride = stride;
-  ctx->cap_recs = recs;
+  if (entries > ctx->cap_entries || (ctx->debug && !ctx->d_digits)) {
+    ctx->cap_entries = 0;
+    if ((rc = dev_alloc(ctx, ctx->d_tmp_val, entries))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->d_tmp_fine, entries))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->d_val, entries))) return rc;
+    if (ctx->debug && (rc = dev_alloc(ctx, ctx->d_digits, entries))) return rc;
+    ctx->cap_entries = entries;
+  }
+  if (recs > ctx->cap_recs) {
+    ctx->cap_recs = 0;
+    for (Slot& sl : ctx->slot) {
+      if ((rc = dev_alloc(ctx, sl.d_heads, recs * REC_WORDS))) return rc;
+      if ((rc = dev_alloc(ctx, sl.d_tails, recs * REC_WORDS))) return rc;
+    }
+    if ((rc = dev_alloc(ctx, ctx->d_chunk_slot, recs))) return rc;
+    ctx->cap_recs = recs;
+  }
+  if (!lw_ok) {  // a launch with more than NWIN local windows: bucket arrays for MAXLW from now on
+    for (Slot& sl : ctx->slot) {
+      sl.cap_lw = 0;
+      if ((rc = dev_alloc(ctx, sl.d_buckets, (size_t)MAXLW * HALF * REC_WORDS))) return rc;
+      sl.cap_lw = MAXLW;
+    }
+  }
   return MSM_HIP_OK;
 }
 
@@ -207,7 +232,8 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   const uint32_t tiles = (uint32_t)((n + tile_len - 1) / tile_len);
   const uint32_t chunk_len = chunk_len_for(n, w_count);
   const uint32_t chunks = chunks_for(n, chunk_len);
-  const size_t stride = ctx->stride;
+  const size_t stride = stride_for(n);
+  ctx->last_stride = stride;
   uint16_t* digits = ctx->debug ? ctx->d_digits : nullptr;
   uint32_t* d_err = reinterpret_cast<uint32_t*>(s.d_wsums + WSUM_BYTES);
   if (!wsums_out) wsums_out = reinterpret_cast<uint32_t*>(s.d_wsums);
@@ -249,8 +275,8 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     HIP_TRY(ctx, hipEventRecord(s.red0, rs));
   }
   uint32_t* d_rows = s.d_partials;
-  uint32_t* d_cols = d_rows + (size_t)NWIN * 256 * XYZZ_WORDS;
-  uint32_t* d_parts = d_cols + (size_t)NWIN * 256 * XYZZ_WORDS;
+  uint32_t* d_cols = d_rows + (size_t)MAXLW * 256 * XYZZ_WORDS;
+  uint32_t* d_parts = d_cols + (size_t)MAXLW * 256 * XYZZ_WORDS;
   static const int force_logr = [] { const char* e = getenv("MSM_HIP_BPR_LOGR"); return e ? atoi(e) : 0; }();  // tuning aid
   // serial run per thread before the LDS tree: 16 buckets when many windows are reduced at once (fewest wave-additions),
   // 4 for a few windows (shallowest); measured optimum for 16 and for 2 windows respectively
@@ -351,6 +377,41 @@ __global__ void __launch_bounds__(256) k_export_buckets(const uint32_t* __restri
 
 }  // namespace
 
+namespace {
+// MSMs per launch of the batch runners: small MSMs cannot fill the GPU one at a time (kernel latencies dominate below
+// ~2^19 points), so up to MAXLW / NWIN = 4 of them -- at most about 2^20 points together -- share one kernel sequence
+size_t batch_group(size_t n, size_t batch) {
+  size_t g = n ? ((size_t)1 << 20) / n : 1;
+  if (g > (size_t)(MAXLW / NWIN)) g = MAXLW / NWIN;
+  if (g > batch) g = batch;
+  return g ? g : 1;
+}
+
+// software pipeline over the result slots: the host combine of group j overlaps the device work of groups j+1 .. j+2.
+// `stage` (may be null) copies group j's scalars to the device and returns their device address.
+template <typename Stage>
+int run_batch_groups(msm_hip_ctx* ctx, size_t n, size_t batch, uint8_t* out_xyz, Stage stage) {
+  const size_t g = batch_group(n, batch);
+  const size_t groups = (batch + g - 1) / g;
+  constexpr size_t DEPTH = NSLOT - 1;
+  int rc = MSM_HIP_OK;
+  for (size_t j = 0; j < groups + DEPTH; j++) {
+    if (j >= DEPTH) {
+      const size_t k = j - DEPTH;
+      if ((rc = msm_hip_finish_batch_bn254(ctx, (int)(k % NSLOT), out_xyz + 96 * k * g))) break;
+    }
+    if (j < groups) {
+      const size_t first = j * g, count = first + g <= batch ? g : batch - first;
+      const void* dev = nullptr;
+      if ((rc = stage(j, first, count, &dev))) break;
+      if ((rc = msm_hip_launch_windows_batch_device_bn254(ctx, dev, n, (int)count, 0, NWIN, (int)(j % NSLOT), nullptr))) break;
+    }
+  }
+  if (rc) drain_slots(ctx);
+  return rc;
+}
+}  // namespace
+
 extern "C" {
 
 int msm_hip_abi_version(void) { return 3; }
@@ -391,9 +452,9 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(MSM_HIP_ERR_NO_DEVICE);
   for (int k = 0; k < NREDUCE; k++)
     if (hipStreamCreateWithFlags(&ctx->reduce_stream[k], hipStreamNonBlocking) != hipSuccess) return fail(MSM_HIP_ERR_NO_DEVICE);
-  if ((rc = dev_alloc(ctx, ctx->d_counts, (size_t)NWIN * MAX_TILES * NCOARSE))) return fail(rc);
-  if ((rc = dev_alloc(ctx, ctx->d_bin_total, (size_t)NWIN * NCOARSE))) return fail(rc);
-  if ((rc = dev_alloc(ctx, ctx->d_coarse_ptr, (size_t)NWIN * (NCOARSE + 1)))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_counts, (size_t)MAXLW * MAX_TILES * NCOARSE))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_bin_total, (size_t)MAXLW * NCOARSE))) return fail(rc);
+  if ((rc = dev_alloc(ctx, ctx->d_coarse_ptr, (size_t)MAXLW * (NCOARSE + 1)))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_err, 1))) return fail(rc);
   for (int k = 0; k < NSLOT; k++) {
     Slot& s = ctx->slot[k];
@@ -402,8 +463,9 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
     if ((rc = dev_alloc(ctx, s.d_wsums, WSUM_BYTES + 4))) return fail(rc);
     if (hipMemset(s.d_wsums, 0, WSUM_BYTES + 4) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
     if ((rc = dev_alloc(ctx, s.d_buckets, (size_t)NWIN * HALF * REC_WORDS))) return fail(rc);
-    if ((rc = dev_alloc(ctx, s.d_partials, (size_t)NWIN * (256 + 256 + 3) * XYZZ_WORDS))) return fail(rc);
-    if ((rc = dev_alloc(ctx, s.d_col_ptr, (size_t)NWIN * (HALF + 1)))) return fail(rc);
+    s.cap_lw = NWIN;
+    if ((rc = dev_alloc(ctx, s.d_partials, (size_t)MAXLW * (256 + 256 + 3) * XYZZ_WORDS))) return fail(rc);
+    if ((rc = dev_alloc(ctx, s.d_col_ptr, (size_t)MAXLW * (HALF + 1)))) return fail(rc);
     if ((rc = dev_alloc(ctx, s.d_big_queue, (size_t)STITCH_BIG_CAP + 1))) return fail(rc);
     if ((rc = dev_alloc(ctx, s.d_done_blocks, 1))) return fail(rc);
     if (hipMemset(s.d_big_queue, 0, 4) != hipSuccess || hipMemset(s.d_done_blocks, 0, 4) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
@@ -469,8 +531,7 @@ int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scal
   if (rc) return rc;
   if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > NWIN || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
   const int w_count = w_end - w_begin;
-  if (nvec < 1 || nvec * w_count > NWIN) return MSM_HIP_ERR_INVALID_ARG;
-  if (nvec > 1 && !window_sums_dev) return MSM_HIP_ERR_INVALID_ARG;  // several vectors: sums go to caller memory
+  if (nvec < 1 || nvec * w_count > MAXLW) return MSM_HIP_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   Slot& s = ctx->slot[slot];
   if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;  // its result was never collected (msm_hip_finish_bn254 / msm_hip_slot_sync)
@@ -518,17 +579,23 @@ int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot) {
   return wait_slot(ctx, s);
 }
 
-int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]) {
+int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   if (!ctx || !out_xyz || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   Slot& s = ctx->slot[slot];
-  if (!s.pending || !s.to_host || s.w_count != NWIN || s.nvec != 1) return MSM_HIP_ERR_INVALID_ARG;
+  if (!s.pending || !s.to_host || s.w_count != NWIN) return MSM_HIP_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = wait_slot(ctx, s);
   if (rc) return rc;
   auto t0 = std::chrono::steady_clock::now();
-  if (!bn254::host::combine_windows(s.h_wsums, NWIN, WBITS, out_xyz)) return MSM_HIP_ERR_HIP;
+  for (int v = 0; v < s.nvec; v++)
+    if (!bn254::host::combine_windows(s.h_wsums + (size_t)v * NWIN * 96, NWIN, WBITS, out_xyz + 96 * (size_t)v)) return MSM_HIP_ERR_HIP;
   ctx->stage_ms[8] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return MSM_HIP_OK;
+}
+
+int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]) {
+  if (!ctx || slot < 0 || slot >= NSLOT || ctx->slot[slot].nvec != 1) return MSM_HIP_ERR_INVALID_ARG;
+  return msm_hip_finish_batch_bn254(ctx, slot, out_xyz);
 }
 
 int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]) {
@@ -557,18 +624,11 @@ int msm_hip_run_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, si
   if (!out_xyz && batch) return MSM_HIP_ERR_INVALID_ARG;
   int rc = check_run_args(ctx, scalars_dev, n);
   if (rc) return rc;
-  // software pipeline over the result slots: the host combine of MSM i overlaps the device work of MSM i+1 .. i+2
   const uint8_t* sc = static_cast<const uint8_t*>(scalars_dev);
-  constexpr size_t DEPTH = NSLOT - 1;
-  for (size_t i = 0; i < batch + DEPTH; i++) {
-    if (i >= DEPTH) {
-      const size_t j = i - DEPTH;
-      if ((rc = msm_hip_finish_bn254(ctx, (int)(j % NSLOT), out_xyz + 96 * j))) break;
-    }
-    if (i < batch && (rc = msm_hip_launch_device_bn254(ctx, sc + i * n * 32, n, (int)(i % NSLOT)))) break;
-  }
-  if (rc) drain_slots(ctx);
-  return rc;
+  return run_batch_groups(ctx, n, batch, out_xyz, [&](size_t, size_t first, size_t, const void** dev) {
+    *dev = sc + first * n * 32;
+    return (int)MSM_HIP_OK;
+  });
 }
 
 int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz) {
@@ -580,32 +640,22 @@ int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_
     return MSM_HIP_OK;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const size_t vec = n * 32;
-  if (vec * NSLOT > ctx->cap_batch_stage) {
+  const size_t vec = n * 32, entry = vec * batch_group(n, batch);
+  if (entry * NSLOT > ctx->cap_batch_stage) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cap_batch_stage = 0;
-    if ((rc = dev_alloc(ctx, ctx->d_batch_stage, vec * NSLOT))) return rc;
-    ctx->cap_batch_stage = vec * NSLOT;
+    if ((rc = dev_alloc(ctx, ctx->d_batch_stage, entry * NSLOT))) return rc;
+    ctx->cap_batch_stage = entry * NSLOT;
   }
-  // same software pipeline as the device-resident batch; vector i is staged in ring entry i % NSLOT on the main stream
-  // just ahead of its own sort (the entry's previous reader, MSM i - NSLOT, was finished DEPTH + 1 iterations ago)
-  constexpr size_t DEPTH = NSLOT - 1;
-  for (size_t i = 0; i < batch + DEPTH; i++) {
-    if (i >= DEPTH) {
-      const size_t j = i - DEPTH;
-      if ((rc = msm_hip_finish_bn254(ctx, (int)(j % NSLOT), out_xyz + 96 * j))) break;
-    }
-    if (i < batch) {
-      uint8_t* stage = ctx->d_batch_stage + (i % NSLOT) * vec;
-      if (hipMemcpyAsync(stage, scalars_host + i * vec, vec, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-        rc = MSM_HIP_ERR_HIP;
-        break;
-      }
-      if ((rc = msm_hip_launch_device_bn254(ctx, stage, n, (int)(i % NSLOT)))) break;
-    }
-  }
-  if (rc) drain_slots(ctx);
-  return rc;
+  // group j is staged in ring entry j % NSLOT on the main stream just ahead of its own sort (the entry's previous
+  // reader, group j - NSLOT, was finished DEPTH + 1 iterations ago)
+  return run_batch_groups(ctx, n, batch, out_xyz, [&](size_t j, size_t first, size_t count, const void** dev) {
+    uint8_t* stage = ctx->d_batch_stage + (j % NSLOT) * entry;
+    if (hipMemcpyAsync(stage, scalars_host + first * vec, count * vec, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return (int)MSM_HIP_ERR_HIP;
+    *dev = stage;
+    return (int)MSM_HIP_OK;
+  });
 }
 
 int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end,
@@ -704,7 +754,7 @@ int msm_hip_read_val_idxs(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
   if (!out || n * ctx->last_w_count > cap_elems) return MSM_HIP_ERR_INVALID_ARG;
   if (n == 0) return MSM_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipMemcpy2DAsync(out, n * 4, ctx->d_val, ctx->stride * 4, n * 4, (size_t)ctx->last_w_count, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpy2DAsync(out, n * 4, ctx->d_val, ctx->last_stride * 4, n * 4, (size_t)ctx->last_w_count, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MSM_HIP_OK;
 }

@@ -28,6 +28,7 @@ using namespace bn254;
 
 constexpr int WBITS = 16;
 constexpr int NWIN = 16;
+constexpr int MAXLW = 64;  // local windows one launch may carry: (scalar vectors of the launch) x (windows of each)
 constexpr int HALF = 1 << (WBITS - 1);  // 32768 bucket slots per window
 
 __device__ __constant__ uint32_t c_pp1d4[8] = {FQ_PP1D4_32[0], FQ_PP1D4_32[1], FQ_PP1D4_32[2], FQ_PP1D4_32[3],
@@ -182,15 +183,15 @@ __device__ __forceinline__ uint32_t code_of_window(const uint32_t t[8], int w) {
 }
 
 // `nvec` scalar vectors (vec_stride words apart) may share one launch: vector v, window w is handled as local window
-// lw = v * w_count + (w - w_begin), nvec * w_count <= NWIN -- several MSMs over the same bases sorted, accumulated and reduced
+// lw = v * w_count + (w - w_begin), nvec * w_count <= MAXLW -- several MSMs over the same bases sorted, accumulated and reduced
 // by one kernel sequence (used by the window-sharded multi-GPU pipeline, where one MSM's share is too small to fill a GPU).
 __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles,
                                                int w_begin, int w_count, int nvec, size_t vec_stride,
                                                uint32_t* __restrict__ counts, uint16_t* __restrict__ digits_dbg,
                                                uint32_t* __restrict__ err) {
-  __shared__ uint32_t cnt[NWIN * NCOARSE];
+  __shared__ uint32_t cnt[MAXLW * NCOARSE];
   const int tid = threadIdx.x;
-  for (int i = tid; i < NWIN * NCOARSE; i += 256) cnt[i] = 0;
+  for (int i = tid; i < nvec * w_count * NCOARSE; i += 256) cnt[i] = 0;
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * tile_len;
   const size_t end = base + tile_len < n ? base + tile_len : n;
@@ -273,7 +274,7 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
                                                         const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr,
                                                         uint32_t* __restrict__ tmp_val,
                                                         uint8_t* __restrict__ tmp_fine) {
-  __shared__ uint32_t gpos[NWIN * NCOARSE];  // global write cursor of every (window, coarse bin) run of this tile
+  __shared__ uint32_t gpos[MAXLW * NCOARSE];  // global write cursor of every (window, coarse bin) run of this tile
   __shared__ uint32_t hist[NCOARSE];
   __shared__ uint32_t lstart[NCOARSE];
   __shared__ uint32_t wave_tot[4];

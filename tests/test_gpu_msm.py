@@ -252,7 +252,7 @@ def test_several_msms_per_launch(ctx):
         for j in range(2):
             assert m.MsmContext.combine_windows(out[2 * k + j:2 * k + j + 1]) == m.MsmContext.combine_windows(ref[j:j + 1]), (k, j)
     with pytest.raises(m.MsmHipError):
-        ctx.launch_windows_batch(batch, n, 0, 3, 1, out)  # 8 x 3 windows do not fit
+        ctx.launch_windows_batch(batch, n, 0, 9, 1, out)  # 8 x 9 local windows exceed the 64 a launch may carry
     # pipeline with groups: single rank doing all 16 windows can only take one MSM per launch ...
     pipe = ShardedMsmPipeline(ctx, 0, 1, msms_per_issue=1)
     pipe.issue(vecs[0])
@@ -266,3 +266,23 @@ def test_several_msms_per_launch(ctx):
     for k in range(8):
         part = m.MsmContext.combine_windows(ctx.msm_windows(vecs[k], 0, 2))
         assert got[k] == part and (k >= 3 or got3[k] == part), k
+
+
+def test_whole_small_msms_share_a_launch(ctx):
+    # up to 4 whole MSMs (64 local windows) per launch: what the batch entry points do for small n
+    n = 3000
+    pts = ctx.sample_points(n, 180)
+    ctx.set_bases(pts)
+    vecs = [ctx.sample_scalars(n, 181 + k) for k in range(4)]
+    want = [ctx.msm(v) for v in vecs]
+    batch = torch.cat(vecs, dim=0).contiguous()
+    assert ctx.launch_batch(batch, n, 1) == 4
+    assert ctx.finish_batch(1, 4) == want
+    assert ctx.launch_batch(batch[: 3 * n], n, 2) == 3
+    assert ctx.finish_batch(2, 3) == want[:3]
+    with pytest.raises(m.MsmHipError):
+        ctx.launch_batch(torch.cat(vecs + vecs[:1], dim=0).contiguous(), n, 3)  # 5 x 16 local windows do not fit
+    # the library's own batch runner groups them (9 MSMs -> groups of 4, 4, 1) and still returns them in order
+    nine = torch.cat([vecs[k % 4] for k in range(9)], dim=0).contiguous()
+    assert ctx.msm_batch(nine, n) == [want[k % 4] for k in range(9)]
+    assert ctx.msm(vecs[0]) == want[0]  # single launches still fine afterwards
