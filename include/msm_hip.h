@@ -93,7 +93,7 @@ int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, 
 int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot,
                                         void* window_sums_dev);
 /* several MSMs per launch: `nvec` scalar vectors (contiguous, nvec x n x 32 B) over the resident bases, windows
- * [w_begin, w_end) of each, nvec * (w_end - w_begin) <= 16; window_sums_dev receives nvec x (w_end - w_begin) x 96 B
+ * [w_begin, w_end) of each, nvec * (w_end - w_begin) <= MSM_HIP_MAX_LOCAL_WINDOWS; window_sums_dev receives nvec x (w_end - w_begin) x 96 B
  * (vector-major).  One kernel sequence sorts, accumulates and reduces all of them: a rank of a window-sharded run whose
  * own share (2 windows of one MSM at 8 GPUs) cannot fill the GPU processes 8 MSMs' shares at once.
  * Up to MSM_HIP_MAX_LOCAL_WINDOWS = 64 local windows per launch, i.e. also up to 4 WHOLE small MSMs (w_begin = 0, w_end = 16,

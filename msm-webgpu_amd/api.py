@@ -262,7 +262,7 @@ class MsmContext:
 
     def launch_windows_batch(self, scalars_dev, n, w_begin, w_end, slot, out_dev):
         """Several MSMs per launch: scalars_dev holds nvec contiguous vectors of n scalars (CUDA uint8 [nvec * n, 32]);
-        `out_dev` (CUDA uint8 [nvec * (w_end - w_begin), 96], vector-major) receives the window sums.  nvec * windows <= 16."""
+        `out_dev` (CUDA uint8 [nvec * (w_end - w_begin), 96], vector-major) receives the window sums.  nvec * windows <= 64; out_dev None keeps the sums in the slot (whole MSMs: finish_batch)."""
         t, rows = _as_device_u8(scalars_dev, 32, "scalars")
         if n <= 0 or rows % n:
             raise ValueError("scalars must hold a whole number of n-element vectors")

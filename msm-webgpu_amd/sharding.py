@@ -139,7 +139,7 @@ class ShardedMsmPipeline:
             self.w_begin, self.w_end = window_range(0, self.emulate, num_windows)
             self.per = max_windows_per_rank(self.emulate, num_windows)
         self.g = msms_per_issue
-        assert self.g * self.per <= num_windows, "msms_per_issue x windows per rank must not exceed 16"
+        assert self.g * self.per <= 64, "msms_per_issue x windows per rank must not exceed 64 local windows"
         dev = torch.device("cuda", ctx.device)
         rows = self.g * self.per
         self.padded = [torch.zeros((rows, 96), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
