@@ -1,16 +1,17 @@
 // libmsm_hip.so -- host side of the MI355X BN254 MSM engine behind the C ABI of include/msm_hip.h.
 //
 // Replaces, for the hot path only, the reference's orchestrator compute_msm (src/cuzk/msm.rs:75-417) and its wgpu
-// wrappers (src/cuzk/gpu.rs): one persistent context = two HIP streams, pooled device buffers, bases resident in HBM
+// wrappers (src/cuzk/gpu.rs): one persistent context = three HIP streams, pooled device buffers, bases resident in HBM
 // in device Montgomery form; no per-call device creation, shader generation or pipeline compilation
 // (cf. src/cuzk/msm.rs:88-94, src/cuzk/shader_manager.rs:74-100).
 //
-// Execution model.  Every MSM runs in one of MSM_HIP_NUM_SLOTS result slots (own bucket and window-sum buffers):
+// Execution model.  Every launch (one MSM, or several scalar vectors sharing one kernel sequence: up to MAXLW local
+// windows) runs in one of MSM_HIP_NUM_SLOTS result slots (own bucket, piece, col_ptr and window-sum buffers):
 //   stream "main"   : recode + sort + SMVP accumulate                               -> event smvp_done[slot]
 //   stream "reduce" : (waits smvp_done) stitch + bucket reduce -> window sums -> D2H -> event done[slot]
 // The stitch and the bucket reduce are bound by the depth of dependent group additions and occupy few waves; putting them
-// on their own stream lets the sort + SMVP of the NEXT MSM (other slot: own bucket, piece and col_ptr buffers) run meanwhile.  The host window
-// combine of a slot (src/cuzk/msm.rs:411-416) runs in the caller's thread inside msm_hip_finish_bn254.
+// on their own stream lets the sort + SMVP of the NEXT launch (other slot) run meanwhile.  The host window combine of a
+// slot (src/cuzk/msm.rs:411-416) runs in the caller's thread inside msm_hip_finish_bn254 / msm_hip_finish_batch_bn254.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
