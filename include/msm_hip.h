@@ -143,6 +143,9 @@ void* msm_hip_stream(msm_hip_ctx* ctx);
  * ---- */
 /* digit-code planes are only materialised for read-back when enabled here (the sort recomputes digits on the fly) */
 int msm_hip_set_debug(msm_hip_ctx* ctx, int keep_digit_planes);
+/* from `n` points on, the fine sort gets the sub-range histograms of huge coarse bins from a separate pass (default 32769:
+ * whenever such a bin can exist); tests raise it to drive the fallback in which every sharer of a bin histograms it itself */
+int msm_hip_set_fine_hist_min_n(msm_hip_ctx* ctx, size_t n);
 int msm_hip_read_digits(msm_hip_ctx* ctx, uint16_t* out, size_t cap_elems);
 int msm_hip_read_col_ptr(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems);
 int msm_hip_read_val_idxs(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems);

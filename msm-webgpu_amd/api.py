@@ -68,6 +68,7 @@ def lib():
         L.msm_hip_stream.argtypes = [vp]
         L.msm_hip_stream.restype = vp
         L.msm_hip_set_debug.argtypes = [vp, i]
+        L.msm_hip_set_fine_hist_min_n.argtypes = [vp, sz]
         L.msm_hip_set_stage_timing.argtypes = [vp, i]
         L.msm_hip_read_digits.argtypes = [vp, vp, sz]
         L.msm_hip_read_col_ptr.argtypes = [vp, vp, sz]
@@ -326,6 +327,9 @@ class MsmContext:
         return {names[j]: float(buf[j]) for j in range(k)}
 
     # -- stage read-back (parity tests)
+    def set_fine_hist_min_n(self, n):
+        _check(lib().msm_hip_set_fine_hist_min_n(self._h, n), "msm_hip_set_fine_hist_min_n")
+
     def set_debug(self, keep_digit_planes=True):
         _check(lib().msm_hip_set_debug(self._h, 1 if keep_digit_planes else 0), "msm_hip_set_debug")
 

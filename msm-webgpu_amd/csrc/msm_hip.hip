@@ -86,6 +86,8 @@ struct msm_hip_ctx {
   uint8_t* d_tmp_fine = nullptr;     // [W][stride]
   uint32_t* d_val = nullptr;         // [W][stride] slot order
   uint32_t* d_chunk_slot = nullptr;  // [W][chunks] bucket slot of every SMVP chunk's first entry
+  uint32_t* d_part_hist = nullptr;  // [MAXLW][128][FINE_SPLIT][256] sub-range histograms of huge coarse bins (k_fine_hist), on first use
+  size_t fine_hist_min_n = FINE_BIG + 1;  // any n that can produce a coarse bin beyond FINE_BIG: run k_fine_hist (3 us when none does)
   uint32_t* d_err = nullptr;
   uint8_t* d_stage = nullptr;  // staging for host byte inputs of set_bases / test hooks
   size_t cap_stage = 0;
@@ -165,7 +167,9 @@ int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count) {
   const size_t need_entries = stride_for(n) * (size_t)w_count;
   bool lw_ok = true;
   for (const Slot& sl : ctx->slot) lw_ok = lw_ok && w_count <= sl.cap_lw;
-  if (n <= ctx->cap_n && need_entries <= ctx->cap_entries && need_recs <= ctx->cap_recs && lw_ok && (!ctx->debug || ctx->d_digits))
+  const bool hist_ok = n < ctx->fine_hist_min_n || ctx->d_part_hist;
+  if (n <= ctx->cap_n && need_entries <= ctx->cap_entries && need_recs <= ctx->cap_recs && lw_ok && hist_ok &&
+      (!ctx->debug || ctx->d_digits))
     return MSM_HIP_OK;
   // growing the pools: nothing may still be running on them
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -200,6 +204,9 @@ int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count) {
     if ((rc = dev_alloc(ctx, ctx->d_chunk_slot, recs))) return rc;
     ctx->cap_recs = recs;
   }
+  if (n >= ctx->fine_hist_min_n && !ctx->d_part_hist &&
+      (rc = dev_alloc(ctx, ctx->d_part_hist, (size_t)MAXLW * NCOARSE * FINE_SPLIT * FINE)))
+    return rc;
   if (!lw_ok) {  // a launch with more than NWIN local windows: bucket arrays for MAXLW from now on
     for (Slot& sl : ctx->slot) {
       sl.cap_lw = 0;
@@ -257,8 +264,14 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   hipLaunchKernelGGL(k_scatter_coarse, dim3(tiles), dim3(256), 0, st, d_scalars, n, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8,
                      ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine);
   HIP_TRY(ctx, mark(3, false));
+  const uint32_t* part_hist = nullptr;
+  if (n >= ctx->fine_hist_min_n) {  // large n: the sub-range histograms of huge coarse bins are made once, not by every sharer
+    hipLaunchKernelGGL(k_fine_hist, dim3(NCOARSE, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
+                       ctx->d_part_hist);
+    part_hist = ctx->d_part_hist;
+  }
   hipLaunchKernelGGL(k_sort_fine, dim3(NCOARSE, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
-                     s.d_col_ptr, ctx->d_val, chunks, chunk_len, ctx->d_chunk_slot);
+                     s.d_col_ptr, ctx->d_val, chunks, chunk_len, ctx->d_chunk_slot, part_hist);
   HIP_TRY(ctx, mark(4, true));
   hipLaunchKernelGGL(k_smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, s.d_col_ptr, ctx->d_val, stride,
                      chunks, chunk_len, ctx->d_chunk_slot, s.d_buckets, s.d_heads, s.d_tails);
@@ -445,6 +458,10 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
   msm_hip_ctx* ctx = new (std::nothrow) msm_hip_ctx();
   if (!ctx) return MSM_HIP_ERR_OUT_OF_MEMORY;
   ctx->device = device_id;
+  if (const char* e = getenv("MSM_HIP_FINE_HIST_MIN_LOGN")) {  // tuning aid
+    const int l = atoi(e);
+    if (l >= 0 && l < 40) ctx->fine_hist_min_n = (size_t)1 << l;
+  }
   int rc = MSM_HIP_OK;
   auto fail = [&](int code) {
     msm_hip_ctx_destroy(ctx);
@@ -486,7 +503,7 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipStream_t r : ctx->reduce_stream)
     if (r) (void)hipStreamSynchronize(r);
-  void* bufs[] = {ctx->d_bases,   ctx->d_scalars,  ctx->d_batch_stage, ctx->d_digits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
+  void* bufs[] = {ctx->d_bases,   ctx->d_scalars,  ctx->d_batch_stage, ctx->d_part_hist, ctx->d_digits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
                   ctx->d_tmp_val, ctx->d_tmp_fine, ctx->d_val,    ctx->d_chunk_slot, ctx->d_err,       ctx->d_stage};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -731,6 +748,12 @@ static int read_back(msm_hip_ctx* ctx, void* out, const void* src, size_t bytes,
 int msm_hip_set_stage_timing(msm_hip_ctx* ctx, int level) {
   if (!ctx || level < 0 || level > 2) return MSM_HIP_ERR_INVALID_ARG;
   ctx->timing_level = level;
+  return MSM_HIP_OK;
+}
+
+int msm_hip_set_fine_hist_min_n(msm_hip_ctx* ctx, size_t n) {
+  if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  ctx->fine_hist_min_n = n;
   return MSM_HIP_OK;
 }
 

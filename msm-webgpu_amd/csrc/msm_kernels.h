@@ -403,10 +403,40 @@ __device__ __forceinline__ void lds_count_only(uint32_t* counter, uint32_t key, 
 constexpr int FINE_SPLIT = 8;
 constexpr uint32_t FINE_BIG = 8 * FINE_CHUNK;
 
+// Histograms of the FINE_SPLIT sub-ranges of every coarse bin that exceeds FINE_BIG (part_hist[lw][bin][part][256]); launched
+// ahead of k_sort_fine when n is large enough for uniform scalars to produce such bins (the host decides), so that the
+// FINE_SPLIT workgroups of a bin do not each histogram the whole bin.  Smaller bins: nothing to do.
+__global__ void __launch_bounds__(256) k_fine_hist(const uint8_t* __restrict__ tmp_fine, size_t stride,
+                                                   const uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ part_hist) {
+  __shared__ uint32_t hist[FINE];
+  const int bin = blockIdx.x, part = blockIdx.z, lw = blockIdx.y, tid = threadIdx.x;
+  const uint32_t begin = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin], end = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin + 1];
+  if (end - begin <= FINE_BIG) return;
+  uint32_t per = (end - begin + FINE_SPLIT - 1) / FINE_SPLIT;
+  per = (per + FINE_CHUNK - 1) / FINE_CHUNK * FINE_CHUNK;
+  const uint32_t my_begin = begin + (uint32_t)part * per < end ? begin + (uint32_t)part * per : end;
+  const uint32_t my_end = my_begin + per < end ? my_begin + per : end;
+  const uint8_t* tf = tmp_fine + (size_t)lw * stride;
+  hist[tid] = 0;
+  __syncthreads();
+  for (uint32_t base = my_begin; base < my_end; base += FINE_CHUNK) {
+    uint32_t f[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t i = base + j * 256 + tid;
+      f[j] = i < my_end ? tf[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) lds_count_only(hist, f[j] & 0xffu, f[j] != 0xffffffffu);
+  }
+  __syncthreads();
+  part_hist[(((size_t)lw * NCOARSE + bin) * FINE_SPLIT + part) * FINE + tid] = hist[tid];
+}
+
 __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ tmp_val, const uint8_t* __restrict__ tmp_fine, size_t stride,
                                                    const uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ col_ptr,
                                                    uint32_t* __restrict__ val_idxs, uint32_t chunks, uint32_t chunk_len,
-                                                   uint32_t* __restrict__ chunk_slot) {
+                                                   uint32_t* __restrict__ chunk_slot, const uint32_t* __restrict__ part_hist) {
   __shared__ uint32_t hist[FINE];
   __shared__ uint32_t before[FINE];  // entries of every slot in front of this workgroup's sub-range
   __shared__ uint32_t lstart[FINE];
@@ -450,6 +480,18 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
       for (int j = 0; j < 16; j++)
         if (f[j] != 0xffffffffu) atomicAdd(&hist[f[j]], 1u);
     }
+  } else if (part_hist) {
+    // the sub-range histograms were made by k_fine_hist: sum them (and the ones in front of this workgroup's sub-range)
+    const uint32_t* ph = part_hist + ((size_t)lw * NCOARSE + bin) * FINE_SPLIT * FINE + tid;
+    uint32_t all = 0, front = 0;
+#pragma unroll
+    for (int q = 0; q < FINE_SPLIT; q++) {
+      const uint32_t c = ph[q * FINE];
+      all += c;
+      if (q < part) front += c;
+    }
+    hist[tid] = all;
+    before[tid] = front;
   } else {
     // FINE_CHUNK entries per sweep step, 16 independent byte loads per thread in flight; a step lies wholly in front of
     // the sub-range or not (my_begin - begin is a multiple of FINE_CHUNK), so every entry is counted once

@@ -177,6 +177,17 @@ def test_skewed_scalars_many_equal(ctx):
     ones = (1).to_bytes(32, "little") * n
     total = ctx.msm(ones).to_affine()          # sum of all points (also a single-bucket case)
     assert got == ref.mul(s, total)
+    # huge coarse bins get their sub-range histograms from k_fine_hist (above); the fallback -- every sharer of a bin
+    # histograms it itself -- must agree
+    half = bytearray(sb)
+    half[: 32 * (n // 2)] = ctx.sample_scalars(n // 2, 131).cpu().numpy().tobytes()  # half uniform, half equal
+    mixed = ctx.msm(bytes(half))
+    ctx.set_fine_hist_min_n(1 << 40)
+    try:
+        assert ctx.msm(sb).to_affine() == got
+        assert ctx.msm(bytes(half)) == mixed
+    finally:
+        ctx.set_fine_hist_min_n(32769)
     pb = pts[:4096].cpu().numpy().tobytes()
     ctx.set_bases(pb)
     assert ctx.msm(ones[: 32 * 4096]).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb, ones[: 32 * 4096]))
