@@ -117,6 +117,12 @@ def main():
     group1 = 1 if sharded else max(1, min(4, (1 << 20) // n))
     group1_scalars = torch.cat([scalar_sets[k & 1] for k in range(group1)], dim=0).contiguous() if group1 > 1 else None
 
+    def group_sizes(count, g):
+        """`count` MSMs in ceil(count / g) launches of nearly equal size (a small remainder launch would run at the
+        one-MSM-per-launch rate)."""
+        k = -(-count // g)
+        return [count // k + (1 if i < count % k else 0) for i in range(k)]
+
     def note_stages(w_eff):
         smvp_ms.append(ctx.stage_ms()["smvp"])
         smvp_windows.append(w_eff)
@@ -136,7 +142,7 @@ def main():
                 note_stages(w_local)
         elif not sharded:
             # small MSMs (n < 2^19): up to 4 whole MSMs per launch, as msm_hip_run_batch_* does; same two-slot pipeline
-            sizes = [group1] * (count // group1) + ([count % group1] if count % group1 else [])
+            sizes = group_sizes(count, group1)
             for k, gs in enumerate(sizes):
                 ctx.launch_batch(group1_scalars[: gs * n], n, k & 1)
                 if k:
@@ -148,7 +154,7 @@ def main():
                 note_stages(sizes[-1] * w_local)
         else:
             # windows sharded over the ranks; device work, RCCL all-gather, D2H and host combine all pipelined
-            sizes = [group] * (count // group) + ([count % group] if count % group else [])
+            sizes = group_sizes(count, group)
             inflight = []
             for k, gs in enumerate(sizes):
                 if group > 1:
@@ -275,7 +281,7 @@ def main():
         logs = args.cpu_sample_logn if args.cpu_sample_logn is not None else min(args.logn, 20)
         ns = 1 << logs
         pb = points[:ns].cpu().numpy().tobytes()
-        last_idx = (args.steps - 1) & 1 if group1 == 1 else (((args.steps % group1) or group1) - 1) & 1
+        last_idx = (args.steps - 1) & 1 if group1 == 1 else (group_sizes(args.steps, group1)[-1] - 1) & 1
         last_set = scalar_sets[last_idx]
         sb = last_set[:ns].cpu().numpy().tobytes()
         t1 = time.perf_counter()
