@@ -16,7 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def H(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("fq29") / "fq29_harness.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFQ_CHECK", "-fPIC", "-shared", "-I", os.path.join(ROOT, "msm-webgpu_amd", "csrc"),
+    # MSM_TEST_SANITIZE=1: the same headers under UBSan (signed overflow, shifts, alignment ...), aborting on the first report
+    san = ["-fsanitize=undefined", "-fno-sanitize-recover=all"] if os.environ.get("MSM_TEST_SANITIZE") == "1" else []
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFQ_CHECK", "-fPIC", "-shared"] + san + ["-I", os.path.join(ROOT, "msm-webgpu_amd", "csrc"),
                            os.path.join(ROOT, "tests", "host_harness", "fq29_harness.cpp"), "-o", so])
     return C.CDLL(so)
 
