@@ -240,7 +240,8 @@ def main():
 
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "smvp_pmc_traffic.json")) as f:
+        pmc_name = "smvp_pmc_traffic.json" if args.logn == 20 else "smvp_pmc_traffic_logn%d.json" % args.logn
+        with open(os.path.join(ROOT, "profiles", pmc_name)) as f:
             pmc = json.load(f)
         if pmc.get("logn") == args.logn and pmc.get("w_local") == w_launch:  # PMC bytes of one full 16-window launch
             traffic = pmc.get("hbm_bytes_per_launch")
