@@ -48,6 +48,10 @@ extern "C" {
 
 /* flags for msm_hip_set_bases_* */
 #define MSM_HIP_CHECK_ON_CURVE 1u      /* verify y^2 = x^3 + 3 for every base (one extra square + cube per point) */
+#define MSM_HIP_BASES_MONT256 2u       /* coordinates are x * 2^256 mod p, little-endian (the in-memory form of a 4 x 64-bit
+                                          Montgomery field library with R = 2^256 -- what halo2curves is believed to hold;
+                                          its layout could not be verified here, so the canonical format is the contract and
+                                          this one an opt-in that saves the caller two from-Montgomery conversions per point) */
 
 typedef struct msm_hip_ctx msm_hip_ctx;
 

@@ -258,6 +258,13 @@ FQ_HD fq fq_to_mont(const fq& x_plain) {
   for (int i = 0; i < 9; i++) r2.v[i] = FQ_R2_29[i];
   return fq_canonical(fq_mul(x_plain, r2));
 }
+// x * 2^256 mod p (the in-memory form of a 4 x 64-bit Montgomery library with R = 2^256, canonical) -> device Montgomery form
+FQ_HD fq fq_from_mont256(const fq& x_r256) {
+  fq c;
+#pragma unroll
+  for (int i = 0; i < 9; i++) c.v[i] = FQ_2P266_29[i];
+  return fq_canonical(fq_mul(x_r256, c));  // x 2^256 * 2^266 / 2^261 = x 2^261
+}
 FQ_HD fq fq_from_mont(const fq& x) {  // x normal, value <= 84p
   fq one = fq_zero();
   one.v[0] = 1;

@@ -135,7 +135,10 @@ __global__ void __launch_bounds__(256) k_convert_points(const uint32_t* __restri
   ld8(in + i * 16, wx);
   ld8(in + i * 16 + 8, wy);
   if (geq_modulus<0>(wx) || geq_modulus<0>(wy)) atomicOr(err, ERRBIT_NONCANONICAL);
-  const fq x = fq_to_mont(fq_unpack(wx)), y = fq_to_mont(fq_unpack(wy));
+  // flags bit 1 (MSM_HIP_BASES_MONT256): the words are x * 2^256 mod p, not x
+  const bool m256 = (flags & 2u) != 0;
+  const fq x = m256 ? fq_from_mont256(fq_unpack(wx)) : fq_to_mont(fq_unpack(wx));
+  const fq y = m256 ? fq_from_mont256(fq_unpack(wy)) : fq_to_mont(fq_unpack(wy));
   if (flags & 1u) {
     const fq lhs = fq_canonical(fq_sqr(y));
     const fq rhs = fq_canonical(fq_tidy(fq_add(fq_mul(fq_sqr(x), x), fq_three())));

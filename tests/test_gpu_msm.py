@@ -297,3 +297,20 @@ def test_whole_small_msms_share_a_launch(ctx):
     nine = torch.cat([vecs[k % 4] for k in range(9)], dim=0).contiguous()
     assert ctx.msm_batch(nine, n) == [want[k % 4] for k in range(9)]
     assert ctx.msm(vecs[0]) == want[0]  # single launches still fine afterwards
+
+
+def test_bases_in_r256_montgomery_form(ctx):
+    # MSM_HIP_BASES_MONT256: x * 2^256 mod p words (a 4 x 64-bit Montgomery library's in-memory form) give the same MSM
+    n = 777
+    points, scalars = cpu.sample_points(190, n), cpu.sample_scalars(191, n)
+    pts = ref.bytes_to_points(points)
+    P = m.api.P
+    mont = b"".join(((x << 256) % P).to_bytes(32, "little") + ((y << 256) % P).to_bytes(32, "little") for x, y in pts)
+    want = cpu.to_affine64(cpu.cpu_msm(points, scalars))
+    ctx.set_bases(mont, check_on_curve=True, mont256=True)
+    assert ctx.msm(scalars).to_affine_bytes() == want
+    ctx.set_bases(points, check_on_curve=True)
+    assert ctx.msm(scalars).to_affine_bytes() == want
+    with pytest.raises(m.MsmHipError) as e:  # canonical bytes read as Montgomery words describe points that are not on the curve
+        ctx.set_bases(points, check_on_curve=True, mont256=True)
+    assert e.value.code == -5
