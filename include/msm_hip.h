@@ -66,6 +66,15 @@ int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, 
 /* same, bytes already in device memory (plain device pointer, e.g. a torch tensor's data_ptr) */
 int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t n, uint32_t flags);
 
+/* ---- scalar format of all following runs of this context: canonical little-endian integers (default, = scalars_to_bytes,
+ *      src/lib.rs:50-52), or s * 2^256 mod r, little-endian -- the in-memory limbs of a 4 x 64-bit Montgomery library with
+ *      R = 2^256 (what halo2curves is believed to hold; unverified here, hence opt-in).  The second form spares the caller
+ *      one from-Montgomery conversion per scalar (`to_repr`, ~40 ms of one CPU core per 2^20 scalars -- 25 x the GPU time of
+ *      the whole MSM); the device converts them in a pre-pass (one extra read and write of the scalars). ---- */
+#define MSM_HIP_SCALARS_CANONICAL 0u
+#define MSM_HIP_SCALARS_MONT256 1u
+int msm_hip_set_scalar_format(msm_hip_ctx* ctx, uint32_t format);
+
 /* ---- run: sum_i scalars[i] * bases[i] over the first n bases (n <= number of bases set).
  *      ≙ compute_msm stages 1-5, src/cuzk/msm.rs:96-416 (decompose, transpose, SMVP, bucket reduce, Horner) ---- */
 int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);

@@ -69,6 +69,7 @@ def lib():
         L.msm_hip_stream.restype = vp
         L.msm_hip_set_debug.argtypes = [vp, i]
         L.msm_hip_set_fine_hist_min_n.argtypes = [vp, sz]
+        L.msm_hip_set_scalar_format.argtypes = [vp, C.c_uint32]
         L.msm_hip_set_stage_timing.argtypes = [vp, i]
         L.msm_hip_read_digits.argtypes = [vp, vp, sz]
         L.msm_hip_read_col_ptr.argtypes = [vp, vp, sz]
@@ -328,6 +329,10 @@ class MsmContext:
         return {names[j]: float(buf[j]) for j in range(k)}
 
     # -- stage read-back (parity tests)
+    def set_scalar_format(self, mont256):
+        """False: canonical little-endian scalars (default); True: s * 2^256 mod r words (R = 2^256 Montgomery limbs)."""
+        _check(lib().msm_hip_set_scalar_format(self._h, 1 if mont256 else 0), "msm_hip_set_scalar_format")
+
     def set_fine_hist_min_n(self, n):
         _check(lib().msm_hip_set_fine_hist_min_n(self._h, n), "msm_hip_set_fine_hist_min_n")
 

@@ -86,6 +86,9 @@ struct msm_hip_ctx {
   uint8_t* d_tmp_fine = nullptr;     // [W][stride]
   uint32_t* d_val = nullptr;         // [W][stride] slot order
   uint32_t* d_chunk_slot = nullptr;  // [W][chunks] bucket slot of every SMVP chunk's first entry
+  uint32_t* d_scalar_conv = nullptr;  // canonical copies of scalars handed over in R = 2^256 Montgomery form (one launch's worth)
+  size_t cap_scalar_conv = 0;         // in scalars
+  uint32_t scalar_format = 0;         // MSM_HIP_SCALARS_CANONICAL / MSM_HIP_SCALARS_MONT256
   uint32_t* d_part_hist = nullptr;  // [MAXLW][128][FINE_SPLIT][256] sub-range histograms of huge coarse bins (k_fine_hist), on first use
   size_t fine_hist_min_n = FINE_BIG + 1;  // any n that can produce a coarse bin beyond FINE_BIG: run k_fine_hist (3 us when none does)
   uint32_t* d_err = nullptr;
@@ -256,6 +259,11 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   };
   HIP_TRY(ctx, hipStreamWaitEvent(st, s.done, 0));
   HIP_TRY(ctx, mark(0, false));
+  if (ctx->scalar_format == MSM_HIP_SCALARS_MONT256) {  // Montgomery-form scalars: canonical copies first (part of stage 0)
+    const size_t count = (size_t)nvec * n;
+    hipLaunchKernelGGL(k_scalars_from_mont256, dim3(blocks_for(count, 256)), dim3(256), 0, st, d_scalars, ctx->d_scalar_conv, count, d_err);
+    d_scalars = ctx->d_scalar_conv;
+  }
   hipLaunchKernelGGL(k_count, dim3(tiles), dim3(256), 0, st, d_scalars, n, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts,
                      digits, d_err);
   HIP_TRY(ctx, mark(1, false));
@@ -503,7 +511,7 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipStream_t r : ctx->reduce_stream)
     if (r) (void)hipStreamSynchronize(r);
-  void* bufs[] = {ctx->d_bases,   ctx->d_scalars,  ctx->d_batch_stage, ctx->d_part_hist, ctx->d_digits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
+  void* bufs[] = {ctx->d_bases,   ctx->d_scalars,  ctx->d_batch_stage, ctx->d_scalar_conv, ctx->d_part_hist, ctx->d_digits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
                   ctx->d_tmp_val, ctx->d_tmp_fine, ctx->d_val,    ctx->d_chunk_slot, ctx->d_err,       ctx->d_stage};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -569,6 +577,12 @@ int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scal
     return MSM_HIP_OK;
   }
   if ((rc = ensure_work(ctx, n, nvec * w_count))) return rc;
+  if (ctx->scalar_format == MSM_HIP_SCALARS_MONT256 && (size_t)nvec * n > ctx->cap_scalar_conv) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cap_scalar_conv = 0;
+    if ((rc = dev_alloc(ctx, ctx->d_scalar_conv, (size_t)nvec * n * 8))) return rc;
+    ctx->cap_scalar_conv = (size_t)nvec * n;
+  }
   return enqueue(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, nvec, s, static_cast<uint32_t*>(window_sums_dev),
                  window_sums_dev == nullptr);
 }
@@ -748,6 +762,12 @@ static int read_back(msm_hip_ctx* ctx, void* out, const void* src, size_t bytes,
 int msm_hip_set_stage_timing(msm_hip_ctx* ctx, int level) {
   if (!ctx || level < 0 || level > 2) return MSM_HIP_ERR_INVALID_ARG;
   ctx->timing_level = level;
+  return MSM_HIP_OK;
+}
+
+int msm_hip_set_scalar_format(msm_hip_ctx* ctx, uint32_t format) {
+  if (!ctx || (format != MSM_HIP_SCALARS_CANONICAL && format != MSM_HIP_SCALARS_MONT256)) return MSM_HIP_ERR_INVALID_ARG;
+  ctx->scalar_format = format;
   return MSM_HIP_OK;
 }
 

@@ -185,6 +185,54 @@ __device__ __forceinline__ uint32_t code_of_window(const uint32_t t[8], int w) {
   return 0x8000u | (((uint32_t)HALF - b) & 0x7fffu);          // d = -(2^15 - b), magnitude 1 .. 2^15 (2^15 -> slot 0)
 }
 
+// Scalars handed over as s * 2^256 mod r (the in-memory limbs of a 4 x 64-bit Montgomery library with R = 2^256) are turned
+// into the canonical wire format by one pre-pass: a 9-limb Montgomery reduction of (s_mont << 5), i.e. s_mont * 2^5 / 2^261.
+__device__ __forceinline__ void fr_from_mont256(const uint32_t w[8], uint32_t out[8]) {
+  const fq x = fq_unpack(w);
+  uint64_t c[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) c[k] = k < 9 ? (uint64_t)x.v[k] << 5 : 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const uint32_t m = ((uint32_t)c[i] * FR_N0_29) & FQ_MASK;
+#pragma unroll
+    for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)m * FR_R29[j];
+    c[i + 1] += c[i] >> 29;
+  }
+  fq t;
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+    t.v[k - 9] = (uint32_t)c[k] & FQ_MASK;
+    c[k + 1] += c[k] >> 29;
+  }
+  t.v[8] = (uint32_t)c[17];
+  // t <= r: one conditional subtraction makes it canonical
+  fq d;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const uint32_t u = t.v[i] - FR_R29[i] - borrow;
+    borrow = u >> 31;
+    d.v[i] = (i < 8) ? (u & FQ_MASK) : u;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) t.v[i] = borrow ? t.v[i] : d.v[i];
+  fq_pack(out, t);
+}
+
+__global__ void __launch_bounds__(256) k_scalars_from_mont256(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t count,
+                                                              uint32_t* __restrict__ err) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  uint32_t w[8], o[8];
+  ld8(in + i * 8, w);
+  if (geq_modulus<1>(w)) atomicOr(err, ERRBIT_NONCANONICAL);
+  fr_from_mont256(w, o);
+  uint4* q = reinterpret_cast<uint4*>(out + i * 8);
+  q[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  q[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
 // `nvec` scalar vectors (vec_stride words apart) may share one launch: vector v, window w is handled as local window
 // lw = v * w_count + (w - w_begin), nvec * w_count <= MAXLW -- several MSMs over the same bases sorted, accumulated and reduced
 // by one kernel sequence (used by the window-sharded multi-GPU pipeline, where one MSM's share is too small to fill a GPU).

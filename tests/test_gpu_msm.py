@@ -314,3 +314,28 @@ def test_bases_in_r256_montgomery_form(ctx):
     with pytest.raises(m.MsmHipError) as e:  # canonical bytes read as Montgomery words describe points that are not on the curve
         ctx.set_bases(points, check_on_curve=True, mont256=True)
     assert e.value.code == -5
+
+
+def test_scalars_in_r256_montgomery_form(ctx):
+    # MSM_HIP_SCALARS_MONT256: s * 2^256 mod r words are converted on the device; every entry point sees the same scalars
+    n = 1500
+    points = cpu.sample_points(192, n)
+    sc = ref.bytes_to_scalars(cpu.sample_scalars(193, n))
+    sc[:6] = [0, 1, R - 1, R - 2, (R - 1) // 2, 1 << 253]
+    canon = ref.scalars_to_bytes(sc)
+    mont = b"".join(((s << 256) % R).to_bytes(32, "little") for s in sc)
+    want = cpu.to_affine64(cpu.cpu_msm(points, canon))
+    ctx.set_bases(points)
+    ctx.set_scalar_format(True)
+    try:
+        assert ctx.msm(mont).to_affine_bytes() == want                                   # host bytes
+        t = torch.frombuffer(bytearray(mont + mont), dtype=torch.uint8).cuda()
+        assert [g.to_affine_bytes() for g in ctx.msm_batch(t, n)] == [want, want]          # grouped device batch
+        bad = bytearray(mont)
+        bad[32 * 7:32 * 8] = R.to_bytes(32, "little")                                      # not below r
+        with pytest.raises(m.MsmHipError) as e:
+            ctx.msm(bytes(bad))
+        assert e.value.code == -4
+    finally:
+        ctx.set_scalar_format(False)
+    assert ctx.msm(canon).to_affine_bytes() == want
