@@ -45,8 +45,19 @@ for case in range(cases):
     sb = ref.scalars_to_bytes(sc)
     want = cpu.to_affine64(cpu.cpu_msm(points, sb))
     ctx.set_bases(points)
-    mode = rnd.choice(["host", "device", "windows", "batch", "group", "hostbatch"])
-    if mode == "host":
+    mode = rnd.choice(["host", "device", "windows", "batch", "group", "hostbatch", "mont"])
+    if mode == "mont":
+        # both inputs as R = 2^256 Montgomery words (MSM_HIP_BASES_MONT256, MSM_HIP_SCALARS_MONT256)
+        PM, RM = ref.P, ref.R
+        pm = b"".join(((x << 256) % PM).to_bytes(32, "little") + ((y << 256) % PM).to_bytes(32, "little") for x, y in ref.bytes_to_points(points))
+        sm = b"".join(((v << 256) % RM).to_bytes(32, "little") for v in ref.bytes_to_scalars(sb))
+        ctx.set_bases(pm, mont256=True)
+        ctx.set_scalar_format(True)
+        try:
+            got = ctx.msm(sm)
+        finally:
+            ctx.set_scalar_format(False)
+    elif mode == "host":
         got = ctx.msm(sb)
     elif mode == "device":
         t = torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda()
