@@ -95,6 +95,19 @@ class MsmContext {
     const std::vector<uint8_t> b = points_to_bytes(g);
     check(msm_hip_set_bases_bn254(ctx_, b.data(), g.size(), check_on_curve ? MSM_HIP_CHECK_ON_CURVE : 0u), "msm_hip_set_bases_bn254");
   }
+  /// Raw forms for callers whose field elements already sit in memory as bytes: `flags` as in msm_hip_set_bases_bn254
+  /// (e.g. MSM_HIP_BASES_MONT256 for 4 x 64-bit Montgomery limbs); scalars_mont256(true) switches the scalar format likewise.
+  void set_bases_bytes(const uint8_t* xy, size_t n, uint32_t flags = 0) {
+    check(msm_hip_set_bases_bn254(ctx_, xy, n, flags), "msm_hip_set_bases_bn254");
+  }
+  void scalars_mont256(bool on) {
+    check(msm_hip_set_scalar_format(ctx_, on ? MSM_HIP_SCALARS_MONT256 : MSM_HIP_SCALARS_CANONICAL), "msm_hip_set_scalar_format");
+  }
+  G1 msm_bytes(const uint8_t* scalars, size_t n) {
+    G1 r;
+    check(msm_hip_run_bn254(ctx_, scalars, n, r.xyz.data()), "msm_hip_run_bn254");
+    return r;
+  }
   G1 msm(const std::vector<Fr>& v) {
     const std::vector<uint8_t> b = scalars_to_bytes(v);
     G1 r;
