@@ -51,6 +51,13 @@ struct fq {
   uint32_t v[9];
 };
 
+}  // namespace bn254
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FQ29_NO_ASM)
+#define FQ29_ASM 1
+#include "fq29_asm.h"  // fq_mul_asm / fq_sqr_asm: the multipliers as single inline-assembly blocks (tools/gen_fq29_asm.py)
+#endif
+namespace bn254 {
+
 FQ_HD fq fq_zero() {
   fq r;
 #pragma unroll
@@ -187,6 +194,23 @@ FQ_HD fq fq_sqr(const fq& a) {
   }
   r.v[8] = (uint32_t)c[17];
   return r;
+}
+
+// The same products for the hottest loop (the SMVP's mixed addition): on the device one inline-assembly block each, in which
+// every column's multiply-add chain starts from the previous carry (17 fewer VALU instructions than the compiler's form).
+FQ_HD fq fq_mul_fast(const fq& a, const fq& b) {
+#if defined(FQ29_ASM)
+  return fq_mul_asm(a, b);
+#else
+  return fq_mul(a, b);
+#endif
+}
+FQ_HD fq fq_sqr_fast(const fq& a) {
+#if defined(FQ29_ASM)
+  return fq_sqr_asm(a);
+#else
+  return fq_sqr(a);
+#endif
 }
 
 // x exact and < 2p  ->  true iff x == 0 (mod p)

@@ -89,11 +89,11 @@ FQ_HD void g1_madd(g1_xyzz& a, const fq& px, const fq& py) {
     a = g1_from_affine(px, py);
     return;
   }
-  const fq U2 = fq_mul(px, a.zz);                       // < 2p
-  const fq S2 = fq_mul(py, a.zzz);                      // < 2p
+  const fq U2 = fq_mul_fast(px, a.zz);                       // < 2p
+  const fq S2 = fq_mul_fast(py, a.zzz);                      // < 2p
   const fq P = fq_sub<10>(U2, a.x);                     // X < 9p       -> P < 12p
   const fq R = fq_sub<6>(S2, a.y);                      // Y < 5p       -> R < 8p
-  const fq PP = fq_sqr(P);                              // 144 p^2
+  const fq PP = fq_sqr_fast(P);                              // 144 p^2
   if (fq_is_zero_exact(PP)) {                           // same x: P = Q or P = -Q
     if (fq_is_zero_exact(fq_tidy(R)))
       a = g1_double_affine(px, py);
@@ -101,16 +101,16 @@ FQ_HD void g1_madd(g1_xyzz& a, const fq& px, const fq& py) {
       a = g1_identity();
     return;
   }
-  const fq PPP = fq_mul(P, PP);                         // 24 p^2
-  const fq Q = fq_mul(a.x, PP);                         // 18 p^2
-  const fq RR = fq_sqr(R);                              // 64 p^2
+  const fq PPP = fq_mul_fast(P, PP);                         // 24 p^2
+  const fq Q = fq_mul_fast(a.x, PP);                         // 18 p^2
+  const fq RR = fq_sqr_fast(R);                              // 64 p^2
   const fq X3 = fq_sub<7>(RR, fq_add(PPP, fq_dbl(Q)));  // PPP + 2Q < 6p -> X3 < 9p
   const fq T = fq_sub<10>(Q, X3);                       // X3 < 9p      -> T < 12p
   const fq nY = fq_sub<6>(fq_zero(), a.y);              // Y < 5p       -> -Y < 6p
   a.y = fq_mul2(R, T, nY, PPP);                         // 96 + 12 p^2, one reduction -> Y3 < 2p
   a.x = X3;
-  a.zz = fq_mul(a.zz, PP);
-  a.zzz = fq_mul(a.zzz, PPP);
+  a.zz = fq_mul_fast(a.zz, PP);
+  a.zzz = fq_mul_fast(a.zzz, PPP);
 }
 
 // a + b   (EFD add-2008-s: 12M + 2S)
