@@ -205,6 +205,13 @@ FQ_HD fq fq_mul_fast(const fq& a, const fq& b) {
   return fq_mul(a, b);
 #endif
 }
+FQ_HD fq fq_mul2_fast(const fq& a, const fq& b, const fq& c_, const fq& d) {
+#if defined(FQ29_ASM)
+  return fq_mul2_asm(a, b, c_, d);
+#else
+  return fq_mul2(a, b, c_, d);
+#endif
+}
 FQ_HD fq fq_sqr_fast(const fq& a) {
 #if defined(FQ29_ASM)
   return fq_sqr_asm(a);

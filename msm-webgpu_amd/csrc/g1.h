@@ -107,7 +107,7 @@ FQ_HD void g1_madd(g1_xyzz& a, const fq& px, const fq& py) {
   const fq X3 = fq_sub<7>(RR, fq_add(PPP, fq_dbl(Q)));  // PPP + 2Q < 6p -> X3 < 9p
   const fq T = fq_sub<10>(Q, X3);                       // X3 < 9p      -> T < 12p
   const fq nY = fq_sub<6>(fq_zero(), a.y);              // Y < 5p       -> -Y < 6p
-  a.y = fq_mul2(R, T, nY, PPP);                         // 96 + 12 p^2, one reduction -> Y3 < 2p
+  a.y = fq_mul2_fast(R, T, nY, PPP);                    // 96 + 12 p^2, one reduction -> Y3 < 2p
   a.x = X3;
   a.zz = fq_mul_fast(a.zz, PP);
   a.zzz = fq_mul_fast(a.zzz, PPP);
