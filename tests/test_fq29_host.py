@@ -99,3 +99,12 @@ def test_running_sum_feedback(H):
     for i, q in enumerate(bk):
         want = ref.add(want, ref.mul(len(bk) - i, q))
     assert cpu.to_affine64(out.raw) == ref.affine_to_bytes64(want)
+
+
+def test_generated_headers_are_in_sync():
+    # bn254_constants.h and fq29_asm.h are generated; the committed files must be what the generators emit
+    import sys
+
+    for script, header in (("gen_constants.py", "bn254_constants.h"), ("gen_fq29_asm.py", "fq29_asm.h")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)], capture_output=True, text=True, check=True).stdout
+        assert out == open(os.path.join(ROOT, "msm-webgpu_amd", "csrc", header)).read(), header
