@@ -131,16 +131,17 @@ FQ_HD fq fq_mul(const fq& a, const fq& b) {
   return r;
 }
 
-// (a*b + c*d)/R mod p with ONE Montgomery reduction (243 multiply-adds instead of 324).  All four operands must be
-// normal or exact (limbs < 2^29 + 8: 18 products + 9 reduction terms of < 2^58.001 fit a 64-bit column) and
-// value(a)*value(b) + value(c)*value(d) <= 169 p^2.  Result exact, < 2p.
+// (a*b + c*d)/R mod p with ONE Montgomery reduction (243 multiply-adds instead of 324).  b, c, d must be normal or exact
+// (limbs < 2^29 + 8), a may be lazy (limbs < 2^30 + 16): a column then holds at most 9 products < 2^59.01, 9 products
+// < 2^58.01 and 9 reduction terms < 2^58, together < 2^63.2.  value(a)*value(b) + value(c)*value(d) <= 169 p^2.
+// Result exact, < 2p.
 FQ_HD fq fq_mul2(const fq& a, const fq& b, const fq& c_, const fq& d) {
   uint64_t c[18];
 #pragma unroll
   for (int k = 0; k < 18; k++) c[k] = 0;
 #pragma unroll
   for (int i = 0; i < 9; i++) {
-    FQ_ASSERT(a.v[i] <= (1u << 29) + 64 && b.v[i] <= (1u << 29) + 64 && c_.v[i] <= (1u << 29) + 64 && d.v[i] <= (1u << 29) + 64,
+    FQ_ASSERT(a.v[i] <= (1u << 30) + 64 && b.v[i] <= (1u << 29) + 64 && c_.v[i] <= (1u << 29) + 64 && d.v[i] <= (1u << 29) + 64,
               "fq_mul2: operand limb too large");
 #pragma unroll
     for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a.v[j] * b.v[i];

@@ -92,7 +92,8 @@ FQ_HD void g1_madd(g1_xyzz& a, const fq& px, const fq& py) {
   const fq U2 = fq_mul_fast(px, a.zz);                       // < 2p
   const fq S2 = fq_mul_fast(py, a.zzz);                      // < 2p
   const fq P = fq_sub<10>(U2, a.x);                     // X < 9p       -> P < 12p
-  const fq R = fq_sub<6>(S2, a.y);                      // Y < 5p       -> R < 8p
+  const fq nY = fq_sub<6>(fq_zero(), a.y);              // Y < 5p       -> -Y < 6p, normal
+  const fq R = fq_add(S2, nY);                          // S2 - Y + 6p < 8p, lazy limbs (no second subtraction / carry pass)
   const fq PP = fq_sqr_fast(P);                              // 144 p^2
   if (fq_is_zero_exact(PP)) {                           // same x: P = Q or P = -Q
     if (fq_is_zero_exact(fq_tidy(R)))
@@ -106,8 +107,7 @@ FQ_HD void g1_madd(g1_xyzz& a, const fq& px, const fq& py) {
   const fq RR = fq_sqr_fast(R);                              // 64 p^2
   const fq X3 = fq_sub<7>(RR, fq_add(PPP, fq_dbl(Q)));  // PPP + 2Q < 6p -> X3 < 9p
   const fq T = fq_sub<10>(Q, X3);                       // X3 < 9p      -> T < 12p
-  const fq nY = fq_sub<6>(fq_zero(), a.y);              // Y < 5p       -> -Y < 6p
-  a.y = fq_mul2_fast(R, T, nY, PPP);                    // 96 + 12 p^2, one reduction -> Y3 < 2p
+  a.y = fq_mul2_fast(R, T, nY, PPP);                    // 96 + 12 p^2, one reduction -> Y3 < 2p (R lazy, the others normal)
   a.x = X3;
   a.zz = fq_mul_fast(a.zz, PP);
   a.zzz = fq_mul_fast(a.zzz, PPP);
@@ -122,7 +122,8 @@ FQ_HD g1_xyzz g1_add(const g1_xyzz& a, const g1_xyzz& b) {
   const fq S1 = fq_mul(a.y, b.zzz);                     // 10 p^2
   const fq S2 = fq_mul(b.y, a.zzz);
   const fq P = fq_sub<3>(U2, U1);                       // < 2p         -> P < 5p
-  const fq R = fq_sub<3>(S2, S1);                       //              -> R < 5p
+  const fq nS1 = fq_sub<3>(fq_zero(), S1);              // S1 < 2p      -> -S1 < 3p, normal
+  const fq R = fq_add(S2, nS1);                         // S2 - S1 + 3p < 5p, lazy limbs
   const fq PP = fq_sqr(P);
   if (fq_is_zero_exact(PP)) {
     if (fq_is_zero_exact(fq_tidy(R))) return g1_double(a);
@@ -134,8 +135,7 @@ FQ_HD g1_xyzz g1_add(const g1_xyzz& a, const g1_xyzz& b) {
   const fq RR = fq_sqr(R);
   r.x = fq_sub<7>(RR, fq_add(PPP, fq_dbl(Q)));          // < 6p         -> X3 < 9p
   const fq T = fq_sub<10>(Q, r.x);                      // X3 < 9p      -> T < 12p
-  const fq nS1 = fq_sub<3>(fq_zero(), S1);              // S1 < 2p      -> -S1 < 3p
-  r.y = fq_mul2(R, T, nS1, PPP);                        // 60 + 6 p^2, one reduction -> Y3 < 2p
+  r.y = fq_mul2(R, T, nS1, PPP);                        // 60 + 6 p^2, one reduction -> Y3 < 2p (R lazy, the others normal)
   r.zz = fq_mul(fq_mul(a.zz, b.zz), PP);
   r.zzz = fq_mul(fq_mul(a.zzz, b.zzz), PPP);
   r.inf = false;
