@@ -95,7 +95,9 @@ FQ_HD void g1_madd(g1_xyzz& a, const fq& px, const fq& py) {
   const fq nY = fq_sub<6>(fq_zero(), a.y);              // Y < 5p       -> -Y < 6p, normal
   const fq R = fq_add(S2, nY);                          // S2 - Y + 6p < 8p, lazy limbs (no second subtraction / carry pass)
   const fq PP = fq_sqr_fast(P);                              // 144 p^2
-  if (fq_is_zero_exact(PP)) {                           // same x: P = Q or P = -Q
+  // same x (P = Q or P = -Q) <=> PP = 0 mod p, i.e. the exact limbs are all 0 or equal p's: the lowest limb filters first,
+  // so the full comparison is almost never executed
+  if ((PP.v[0] == 0u || PP.v[0] == FQ_P29[0]) && fq_is_zero_exact(PP)) {
     if (fq_is_zero_exact(fq_tidy(R)))
       a = g1_double_affine(px, py);
     else
@@ -125,7 +127,7 @@ FQ_HD g1_xyzz g1_add(const g1_xyzz& a, const g1_xyzz& b) {
   const fq nS1 = fq_sub<3>(fq_zero(), S1);              // S1 < 2p      -> -S1 < 3p, normal
   const fq R = fq_add(S2, nS1);                         // S2 - S1 + 3p < 5p, lazy limbs
   const fq PP = fq_sqr(P);
-  if (fq_is_zero_exact(PP)) {
+  if ((PP.v[0] == 0u || PP.v[0] == FQ_P29[0]) && fq_is_zero_exact(PP)) {  // lowest limb filters first (see g1_madd)
     if (fq_is_zero_exact(fq_tidy(R))) return g1_double(a);
     return g1_identity();
   }
