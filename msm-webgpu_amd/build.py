@@ -24,6 +24,8 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
            os.path.join(CSRC, "msm_hip.hip"), "-o", SO + ".tmp"]
+    if os.environ.get("MSM_HIP_NO_ASM") == "1":  # the C++ multipliers everywhere (the inline-assembly ones are only in g1_madd)
+        cmd.insert(1, "-DFQ29_NO_ASM")
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
