@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libmsm_hip.so")
-SOURCES = ["msm_hip.hip", "msm_kernels.h", "g1.h", "fq29.h", "host_g1.h", "bn254_constants.h"]
+SOURCES = ["msm_hip.hip", "msm_kernels.h", "g1.h", "fq29.h", "fq29_asm.h", "host_g1.h", "bn254_constants.h"]
 HEADER = os.path.join(HERE, "..", "include", "msm_hip.h")
 
 
