@@ -30,9 +30,6 @@ sys.path.insert(0, ROOT)
 # queues (ROCm's default is 4 per process; must be set before the HIP runtime initialises)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0
 NUM_WINDOWS = 16
 BUCKETS = 1 << 15
@@ -40,6 +37,38 @@ BUCKETS = 1 << 15
 
 def smvp_algorithmic_bytes(n, w_local):
     return n * w_local * (64 + 4) + w_local * BUCKETS * 96
+
+
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: this parent (which never touches the GPU and never execs) starts one
+    child per GPU with the torch.distributed environment set, lets rank 0 print the JSON line on the shared stdout, and
+    exits with the worst child status.  A failing rank takes the others down (killed by PID) instead of leaving them in a
+    collective."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    pending = set(range(n_ranks))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                for q in pending:
+                    procs[q].kill()
+        time.sleep(0.05)
+    return worst
 
 
 def main():
@@ -52,13 +81,33 @@ def main():
     ap.add_argument("--cpu-sample-logn", type=int, default=None, help="bounded CPU sample size (default: min(logn, 20))")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:  # no launcher around us: be the launcher
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    global torch, dist
+    import torch
+    import torch.distributed as dist
+
+    # BENCH_DRY_RUN=1: rendezvous rehearsal without a GPU (the CPU test of the launcher): every rank joins a gloo group,
+    # contributes its id to one all-gather, rank 0 prints what it saw.  Measures nothing.
+    if os.environ.get("BENCH_DRY_RUN"):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ids = [torch.zeros(1, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([rank], dtype=torch.int32))
+        if os.environ["BENCH_DRY_RUN"] == "fail_last" and rank == world - 1:
+            raise SystemExit(3)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "dist_backend": "gloo", "dist_ranks": sorted(int(t.item()) for t in ids)}))
+        dist.destroy_process_group()
+        return
 
     import msm_webgpu_amd as m  # fails loudly if libmsm_hip.so is missing
     from msm_webgpu_amd.sharding import ShardedMsmPipeline, msms_per_launch, window_range
@@ -80,6 +129,15 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    # ranks that really take part in the collectives: every rank contributes its id to one all-gather
+    dist_ranks, dist_backend = None, None
+    if use_dist:
+        dist_backend = dist.get_backend()
+        ids = torch.full((world,), -1, dtype=torch.int32, device="cuda")
+        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int32, device="cuda"))
+        dist_ranks = int((ids.cpu() == torch.arange(world, dtype=torch.int32)).sum().item())
+        assert dist_ranks == dist.get_world_size() == world
 
     n = 1 << args.logn
     ctx = m.MsmContext(local_rank)
@@ -269,6 +327,9 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                      "kernel_ms": smvp_avg_ms},
         "smvp_ms_pipelined": smvp_avg_ms,
+        "rccl_ranks": dist_ranks if dist_backend == "nccl" else None,
+        "dist_backend": dist_backend,
+        "dist_ranks": dist_ranks,
         "emulated_world": emulate if emulate > 1 else None,
         "sharded_result_equals_single_gpu": sharded_ok,
         "latency_ms_single_msm": latency_ms,

@@ -57,8 +57,19 @@ typedef struct msm_hip_ctx msm_hip_ctx;
 
 /* ---- context: replaces get_adapter/get_device + per-call buffer/pipeline creation (src/cuzk/gpu.rs:11-54,
  *      src/cuzk/msm.rs:88-94).  Persistent: one stream, pooled device buffers, resident bases. ---- */
+/* Every entry point runs on the context's device and restores the caller's current HIP device before it returns.
+ * Result slots (bucket and piece arrays, events) are set up by the first launch that uses them, so a context that runs one
+ * MSM at a time -- the reference's call shape, src/cuzk/msm.rs:75-94 -- holds one slot's memory, not MSM_HIP_NUM_SLOTS. */
 int msm_hip_ctx_create(msm_hip_ctx** out, int device_id);
 void msm_hip_ctx_destroy(msm_hip_ctx* ctx);
+
+/* ---- ordering contract for DEVICE inputs.  The engine works on its own non-blocking HIP streams, which are not ordered
+ *      with the caller's streams (nor with the null stream).  Device scalars / bases handed to any *_device_* entry point
+ *      must therefore be complete before the call -- or the caller names the stream that produces them:
+ *      msm_hip_wait_stream makes the engine's main stream wait (on the device, no host block) for everything enqueued so
+ *      far on `producer_stream` (a hipStream_t; NULL = the legacy default stream); call it just before the launch.
+ *      Input buffers must stay alive and unmodified until the launch's slot is collected (finish / slot_sync). ---- */
+int msm_hip_wait_stream(msm_hip_ctx* ctx, void* producer_stream);
 
 /* ---- bases: upload + convert to the device's Montgomery form once (≙ the point half of the decompose shader,
  *      src/cuzk/wgsl/cuzk/decompose_scalars.template.wgsl:41-70, launched at src/cuzk/msm.rs:441-524) ---- */
@@ -84,6 +95,11 @@ int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n
  * Lets a caller overlap the host Horner of MSM i with the device work of MSM i+1. */
 int msm_hip_launch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot);
 int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]);
+/* `launch` with the scalars in HOST memory (msm_hip_run_bn254 = this + finish on slot 0): they are copied into the slot's own
+ * device staging buffer on a separate copy stream, so the copy of MSM i+1 overlaps the device work of MSM i when the caller
+ * alternates slots.  Pageable memory: returns once the bytes have left the caller's buffer.  Pinned memory (hipHostMalloc /
+ * hipHostRegister): returns at once and the buffer must stay untouched until the slot is collected. */
+int msm_hip_launch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int slot);
 
 /* ---- batch: `batch` independent scalar vectors (batch x n x 32 B, contiguous, device memory) over the resident bases;
  *      out: batch x 96 B.  Internally a software pipeline over the result slots (BASELINE.json config 5: many MSMs over

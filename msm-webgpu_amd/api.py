@@ -55,6 +55,8 @@ def lib():
         L.msm_hip_finish_batch_bn254.argtypes = [vp, i, u8p]
         L.msm_hip_run_batch_device_bn254.argtypes = [vp, vp, sz, sz, u8p]
         L.msm_hip_launch_device_bn254.argtypes = [vp, vp, sz, i]
+        L.msm_hip_launch_bn254.argtypes = [vp, u8p, sz, i]
+        L.msm_hip_wait_stream.argtypes = [vp, vp]
         L.msm_hip_finish_bn254.argtypes = [vp, i, u8p]
         L.msm_hip_run_windows_device_bn254.argtypes = [vp, vp, sz, i, i, vp]
         L.msm_hip_launch_windows_device_bn254.argtypes = [vp, vp, sz, i, i, i, vp]
@@ -167,7 +169,15 @@ class MsmContext:
         _check(lib().msm_hip_ctx_create(C.byref(self._h), int(device)), "msm_hip_ctx_create")
         self.device = int(device)
         self.n_bases = 0
-        self._keepalive = None
+        self._keepalive = {}  # slot -> tensors the slot's launch still reads / writes; released when the slot is collected
+
+    def _order_after_torch(self, *tensors):
+        """The engine's streams are not ordered with torch's: make its main stream wait (on the device) for everything
+        enqueued so far on the torch stream that produced the inputs (include/msm_hip.h, ordering contract)."""
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                _check(lib().msm_hip_wait_stream(self._h, torch.cuda.current_stream(t.device).cuda_stream), "msm_hip_wait_stream")
+                return
 
     def close(self):
         if self._h:
@@ -187,7 +197,7 @@ class MsmContext:
         flags = (1 if check_on_curve else 0) | (2 if mont256 else 0)
         if isinstance(points, torch.Tensor) and points.is_cuda:
             t, n = _as_device_u8(points, 64, "points")
-            torch.cuda.current_stream(t.device).synchronize()
+            self._order_after_torch(t)
             _check(lib().msm_hip_set_bases_device_bn254(self._h, t.data_ptr(), n, flags), "msm_hip_set_bases_device_bn254")
         else:
             b = bytes(points)
@@ -204,7 +214,7 @@ class MsmContext:
         out = C.create_string_buffer(96)
         if isinstance(scalars, torch.Tensor) and scalars.is_cuda:
             t, n = _as_device_u8(scalars, 32, "scalars")
-            torch.cuda.current_stream(t.device).synchronize()
+            self._order_after_torch(t)
             _check(lib().msm_hip_run_device_bn254(self._h, t.data_ptr(), n, out), "msm_hip_run_device_bn254")
         else:
             b = bytes(scalars)
@@ -229,20 +239,32 @@ class MsmContext:
             raise ValueError("scalars must hold a whole number of n-element vectors")
         batch = rows // n
         out = C.create_string_buffer(96 * batch)
-        torch.cuda.current_stream(t.device).synchronize()
+        self._order_after_torch(t)
         _check(lib().msm_hip_run_batch_device_bn254(self._h, t.data_ptr(), n, batch, out), "msm_hip_run_batch_device_bn254")
         return [G1(out.raw[96 * k:96 * k + 96]) for k in range(batch)]
 
     def launch(self, scalars_dev, slot=0):
         """Enqueue the device work of one MSM into a result slot (0..3) and return at once."""
         t, n = _as_device_u8(scalars_dev, 32, "scalars")
-        self._keepalive = t
+        self._order_after_torch(t)
         _check(lib().msm_hip_launch_device_bn254(self._h, t.data_ptr(), n, slot), "msm_hip_launch_device_bn254")
+        self._keepalive[slot] = t
+
+    def launch_host(self, scalars_host, slot=0):
+        """`launch` with the scalars in host memory (bytes, n x 32 B): copied on the engine's copy stream into the slot's own
+        staging buffer, so the copy of the next MSM overlaps the device work of the current one when slots alternate."""
+        b = bytes(scalars_host)
+        if len(b) % 32:
+            raise ValueError("scalars must be n x 32 bytes")
+        _check(lib().msm_hip_launch_bn254(self._h, b, len(b) // 32, slot), "msm_hip_launch_bn254")
 
     def finish(self, slot=0):
         """Wait for the slot's device work, run the host window combine, return G1."""
         out = C.create_string_buffer(96)
-        _check(lib().msm_hip_finish_bn254(self._h, slot, out), "msm_hip_finish_bn254")
+        try:
+            _check(lib().msm_hip_finish_bn254(self._h, slot, out), "msm_hip_finish_bn254")
+        finally:
+            self._keepalive.pop(slot, None)
         return G1(out.raw)
 
     # -- window shard (multi-GPU)
@@ -251,7 +273,7 @@ class MsmContext:
         t, n = _as_device_u8(scalars_dev, 32, "scalars")
         if out_dev is None:
             out_dev = torch.empty((w_end - w_begin, 96), dtype=torch.uint8, device=t.device)
-        torch.cuda.current_stream(t.device).synchronize()
+        self._order_after_torch(t)
         _check(lib().msm_hip_run_windows_device_bn254(self._h, t.data_ptr(), n, w_begin, w_end, out_dev.data_ptr()),
                "msm_hip_run_windows_device_bn254")
         return out_dev
@@ -259,9 +281,10 @@ class MsmContext:
     def launch_windows(self, scalars_dev, w_begin, w_end, slot, out_dev):
         """Asynchronous msm_windows into a result slot (0..3); `out_dev` (CUDA uint8 [w_end - w_begin, 96]) receives the sums."""
         t, n = _as_device_u8(scalars_dev, 32, "scalars")
-        self._keepalive = (t, out_dev)
+        self._order_after_torch(t)
         _check(lib().msm_hip_launch_windows_device_bn254(self._h, t.data_ptr(), n, w_begin, w_end, slot, out_dev.data_ptr()),
                "msm_hip_launch_windows_device_bn254")
+        self._keepalive[slot] = (t, out_dev)
 
     def launch_windows_batch(self, scalars_dev, n, w_begin, w_end, slot, out_dev):
         """Several MSMs per launch: scalars_dev holds nvec contiguous vectors of n scalars (CUDA uint8 [nvec * n, 32]);
@@ -269,10 +292,11 @@ class MsmContext:
         t, rows = _as_device_u8(scalars_dev, 32, "scalars")
         if n <= 0 or rows % n:
             raise ValueError("scalars must hold a whole number of n-element vectors")
-        self._keepalive = (t, out_dev)
+        self._order_after_torch(t)
         _check(lib().msm_hip_launch_windows_batch_device_bn254(self._h, t.data_ptr(), n, rows // n, w_begin, w_end, slot,
                                                                out_dev.data_ptr() if out_dev is not None else None),
                "msm_hip_launch_windows_batch_device_bn254")
+        self._keepalive[slot] = (t, out_dev)
 
     def launch_batch(self, scalars_dev, n, slot=0):
         """Enqueue up to 4 WHOLE MSMs (contiguous scalar vectors, CUDA uint8 [nvec * n, 32]) as one launch; finish_batch collects."""
@@ -282,7 +306,10 @@ class MsmContext:
     def finish_batch(self, slot, nvec):
         """Wait for a launch_batch slot, run the host window combines, return the list of G1 results."""
         out = C.create_string_buffer(96 * nvec)
-        _check(lib().msm_hip_finish_batch_bn254(self._h, slot, out), "msm_hip_finish_batch_bn254")
+        try:
+            _check(lib().msm_hip_finish_batch_bn254(self._h, slot, out), "msm_hip_finish_batch_bn254")
+        finally:
+            self._keepalive.pop(slot, None)
         return [G1(out.raw[96 * k:96 * k + 96]) for k in range(nvec)]
 
     def slot_wait_stream(self, slot, stream=None):
@@ -293,7 +320,10 @@ class MsmContext:
 
     def slot_sync(self, slot):
         """Block until the slot is complete; raises on a device-side input error."""
-        _check(lib().msm_hip_slot_sync(self._h, slot), "msm_hip_slot_sync")
+        try:
+            _check(lib().msm_hip_slot_sync(self._h, slot), "msm_hip_slot_sync")
+        finally:
+            self._keepalive.pop(slot, None)
 
     @staticmethod
     def combine_windows(window_sums):

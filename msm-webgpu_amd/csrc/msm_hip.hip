@@ -52,6 +52,11 @@ struct Slot {
   hipEvent_t red0 = nullptr, red1 = nullptr;  // bucket reduce begin / end on the reduce stream
   hipEvent_t smvp_done = nullptr;             // main -> reduce hand-off
   hipEvent_t done = nullptr;                  // everything of this slot finished (recorded on the reduce stream)
+  hipEvent_t staged = nullptr;                // host scalars of this slot have landed in d_host_scalars (copy stream)
+  uint32_t* d_host_scalars = nullptr;         // staging of msm_hip_launch_bn254's host scalars (this slot's own: no launch of
+  size_t cap_host_scalars = 0;                // another slot can still be reading it), in scalars; allocated on first use
+  size_t cap_recs = 0;                        // capacity (records) of d_heads / d_tails
+  bool ready = false;                         // small buffers + events exist (slots are set up on first use)
   bool timed = false, pending = false, to_host = false;
   int timing_level = 0;
   int w_begin = 0, w_count = 0, nvec = 1;  // windows [w_begin, w_begin + w_count) of nvec scalar vectors
@@ -69,11 +74,11 @@ struct msm_hip_ctx {
   uint32_t* d_bases = nullptr;  // n_bases x 16 words
   size_t n_bases = 0, cap_bases = 0;
 
-  size_t cap_n = 0;        // largest n seen: capacity of the host-scalar staging buffer
+  hipStream_t copy_stream = nullptr;    // H2D of host scalars (created on first use by msm_hip_launch_bn254)
+  hipEvent_t input_ready = nullptr;     // a caller's producer stream -> main stream (msm_hip_wait_stream)
   size_t cap_entries = 0;  // capacity of the entry arrays (tmp_val, tmp_fine, val): local windows x per-window stride
   size_t last_stride = 0;  // per-window stride of the last launch (n rounded up to a multiple of 4)
-  size_t cap_recs = 0;  // capacity (records) of the head / tail piece arrays
-  uint32_t* d_scalars = nullptr;      // staging for host scalars of msm_hip_run_bn254
+  size_t cap_chunk_slot = 0;  // capacity (records) of d_chunk_slot
   uint8_t* d_batch_stage = nullptr;   // staging ring (NSLOT vectors) of msm_hip_run_batch_bn254, allocated on first use
   size_t cap_batch_stage = 0;
   uint16_t* d_digits = nullptr;  // digit-code planes, only written when debug read-back is enabled
@@ -164,58 +169,103 @@ inline size_t piece_records_for(size_t n) {
 
 inline size_t stride_for(size_t n) { return (n + 3) & ~(size_t)3; }
 
-// make the pools fit a launch of `w_count` local windows (vectors x windows) over n points
-int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count) {
+// RAII: every ABI entry point runs on its context's device and leaves the caller's current device as it found it
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = prev == device || hipSetDevice(device) == hipSuccess;
+    if (prev == device) prev = -1;  // nothing to restore
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ON_DEVICE(ctx)                     \
+  DeviceGuard device_guard_((ctx)->device); \
+  if (!device_guard_.ok) return MSM_HIP_ERR_NO_DEVICE
+
+// first use of a result slot: its events and small buffers (the big ones -- buckets, pieces -- follow in ensure_work).
+// Slots are set up lazily so that a context that only ever runs one MSM at a time (the reference's call shape,
+// src/cuzk/msm.rs:75-94: create, run once, destroy) allocates one slot's worth of memory, not four.
+int setup_slot(msm_hip_ctx* ctx, Slot& s) {
+  if (s.ready) return MSM_HIP_OK;
+  int rc;
+  if (!s.h_wsums) {
+    HIP_TRY(ctx, hipHostMalloc((void**)&s.h_wsums, WSUM_BYTES + 4, hipHostMallocDefault));
+    memset(s.h_wsums, 0, WSUM_BYTES + 4);
+  }
+  if ((rc = dev_alloc(ctx, s.d_wsums, WSUM_BYTES + 4))) return rc;
+  if ((rc = dev_alloc(ctx, s.d_partials, (size_t)MAXLW * (256 + 256 + 3) * XYZZ_WORDS))) return rc;
+  if ((rc = dev_alloc(ctx, s.d_col_ptr, (size_t)MAXLW * (HALF + 1)))) return rc;
+  if ((rc = dev_alloc(ctx, s.d_big_queue, (size_t)STITCH_BIG_CAP + 1))) return rc;
+  if ((rc = dev_alloc(ctx, s.d_done_blocks, 1))) return rc;
+  // zeroed on the stream that first reads them (the slot's reduce stream; the error word is first written on the main
+  // stream, which waits for `done` below) -- not on the null stream, which the non-blocking streams do not order with
+  hipStream_t rs = ctx->reduce_stream[(&s - ctx->slot) % NREDUCE];
+  HIP_TRY(ctx, hipMemsetAsync(s.d_wsums, 0, WSUM_BYTES + 4, rs));
+  HIP_TRY(ctx, hipMemsetAsync(s.d_big_queue, 0, 4, rs));
+  HIP_TRY(ctx, hipMemsetAsync(s.d_done_blocks, 0, 4, rs));
+  if (!s.done) HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  if (!s.smvp_done) HIP_TRY(ctx, hipEventCreateWithFlags(&s.smvp_done, hipEventDisableTiming));
+  if (!s.staged) HIP_TRY(ctx, hipEventCreateWithFlags(&s.staged, hipEventDisableTiming));
+  if (!s.red0) HIP_TRY(ctx, hipEventCreate(&s.red0));
+  if (!s.red1) HIP_TRY(ctx, hipEventCreate(&s.red1));
+  for (int i = 0; i < N_MAIN_EVENTS; i++)
+    if (!s.ev[i]) HIP_TRY(ctx, hipEventCreate(&s.ev[i]));
+  HIP_TRY(ctx, hipEventRecord(s.done, rs));  // the first launch into the slot waits for the memsets through this event
+  s.ready = true;
+  return MSM_HIP_OK;
+}
+
+// make the pools fit a launch of `w_count` local windows (vectors x windows) over n points into slot `s` (not pending)
+int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, Slot& s) {
+  int rc;
+  if ((rc = setup_slot(ctx, s))) return rc;
   const size_t need_recs = (size_t)w_count * chunks_for(n, chunk_len_for(n, w_count));
   const size_t need_entries = stride_for(n) * (size_t)w_count;
-  bool lw_ok = true;
-  for (const Slot& sl : ctx->slot) lw_ok = lw_ok && w_count <= sl.cap_lw;
-  const bool hist_ok = n < ctx->fine_hist_min_n || ctx->d_part_hist;
-  if (n <= ctx->cap_n && need_entries <= ctx->cap_entries && need_recs <= ctx->cap_recs && lw_ok && hist_ok &&
-      (!ctx->debug || ctx->d_digits))
-    return MSM_HIP_OK;
-  // growing the pools: nothing may still be running on them
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  for (hipStream_t r : ctx->reduce_stream) HIP_TRY(ctx, hipStreamSynchronize(r));
-  const size_t cap = n > ctx->cap_n ? n : ctx->cap_n;
-  size_t entries = stride_for(cap) * NWIN;  // any single MSM over up to cap points
-  if (entries < need_entries) entries = need_entries;
-  if (entries < ctx->cap_entries) entries = ctx->cap_entries;
-  size_t recs = piece_records_for(cap);
-  if (recs < need_recs) recs = need_recs;
-  if (recs < ctx->cap_recs) recs = ctx->cap_recs;
-  int rc;
-  if (cap > ctx->cap_n) {
-    ctx->cap_n = 0;
-    if ((rc = dev_alloc(ctx, ctx->d_scalars, cap * 8))) return rc;
-    ctx->cap_n = cap;
-  }
-  if (entries > ctx->cap_entries || (ctx->debug && !ctx->d_digits)) {
-    ctx->cap_entries = 0;
-    if ((rc = dev_alloc(ctx, ctx->d_tmp_val, entries))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->d_tmp_fine, entries))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->d_val, entries))) return rc;
-    if (ctx->debug && (rc = dev_alloc(ctx, ctx->d_digits, entries))) return rc;
-    ctx->cap_entries = entries;
-  }
-  if (recs > ctx->cap_recs) {
-    ctx->cap_recs = 0;
-    for (Slot& sl : ctx->slot) {
-      if ((rc = dev_alloc(ctx, sl.d_heads, recs * REC_WORDS))) return rc;
-      if ((rc = dev_alloc(ctx, sl.d_tails, recs * REC_WORDS))) return rc;
+  if (need_entries > ctx->cap_entries || need_recs > ctx->cap_chunk_slot || (ctx->debug && !ctx->d_digits)) {
+    // growing the context-wide sort arrays (main stream only): nothing may still be running on them
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    size_t entries = stride_for(n) * NWIN;  // any single MSM over up to n points
+    if (entries < need_entries) entries = need_entries;
+    if (entries > ctx->cap_entries || (ctx->debug && !ctx->d_digits)) {
+      if (entries < ctx->cap_entries) entries = ctx->cap_entries;
+      ctx->cap_entries = 0;
+      if ((rc = dev_alloc(ctx, ctx->d_tmp_val, entries))) return rc;
+      if ((rc = dev_alloc(ctx, ctx->d_tmp_fine, entries))) return rc;
+      if ((rc = dev_alloc(ctx, ctx->d_val, entries))) return rc;
+      if (ctx->debug && (rc = dev_alloc(ctx, ctx->d_digits, entries))) return rc;
+      ctx->cap_entries = entries;
     }
-    if ((rc = dev_alloc(ctx, ctx->d_chunk_slot, recs))) return rc;
-    ctx->cap_recs = recs;
-  }
-  if (n >= ctx->fine_hist_min_n && !ctx->d_part_hist &&
-      (rc = dev_alloc(ctx, ctx->d_part_hist, (size_t)MAXLW * NCOARSE * FINE_SPLIT * FINE)))
-    return rc;
-  if (!lw_ok) {  // a launch with more than NWIN local windows: bucket arrays for MAXLW from now on
-    for (Slot& sl : ctx->slot) {
-      sl.cap_lw = 0;
-      if ((rc = dev_alloc(ctx, sl.d_buckets, (size_t)MAXLW * HALF * REC_WORDS))) return rc;
-      sl.cap_lw = MAXLW;
+    size_t recs = piece_records_for(n);
+    if (recs < need_recs) recs = need_recs;
+    if (recs > ctx->cap_chunk_slot) {
+      ctx->cap_chunk_slot = 0;
+      if ((rc = dev_alloc(ctx, ctx->d_chunk_slot, recs))) return rc;
+      ctx->cap_chunk_slot = recs;
     }
+  }
+  if (need_recs > s.cap_recs) {  // this slot's piece arrays (the slot is idle: its previous occupant was collected)
+    size_t recs = piece_records_for(n);
+    if (recs < need_recs) recs = need_recs;
+    s.cap_recs = 0;
+    if ((rc = dev_alloc(ctx, s.d_heads, recs * REC_WORDS))) return rc;
+    if ((rc = dev_alloc(ctx, s.d_tails, recs * REC_WORDS))) return rc;
+    s.cap_recs = recs;
+  }
+  if (w_count > s.cap_lw) {  // NWIN windows for single MSMs; a launch with more local windows: MAXLW from then on
+    const int lw = w_count > NWIN ? MAXLW : NWIN;
+    s.cap_lw = 0;
+    if ((rc = dev_alloc(ctx, s.d_buckets, (size_t)lw * HALF * REC_WORDS))) return rc;
+    s.cap_lw = lw;
+  }
+  if (n >= ctx->fine_hist_min_n && !ctx->d_part_hist) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = dev_alloc(ctx, ctx->d_part_hist, (size_t)MAXLW * NCOARSE * FINE_SPLIT * FINE))) return rc;
   }
   return MSM_HIP_OK;
 }
@@ -367,17 +417,22 @@ int check_run_args(msm_hip_ctx* ctx, const void* scalars, size_t n) {
   return MSM_HIP_OK;
 }
 
-int set_bases_from_device(msm_hip_ctx* ctx, const uint32_t* d_xy, size_t n, uint32_t flags) {
-  // no run may still be reading the old bases
+// room for n bases; no run may still be reading the old ones (the SMVP on the main stream)
+int reserve_bases(msm_hip_ctx* ctx, size_t n) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (n > MAX_POINTS) return MSM_HIP_ERR_INVALID_ARG;
+  ctx->n_bases = 0;
   if (n > ctx->cap_bases) {
-    ctx->n_bases = ctx->cap_bases = 0;
+    ctx->cap_bases = 0;
     int rc = dev_alloc(ctx, ctx->d_bases, n * 16);
     if (rc) return rc;
     ctx->cap_bases = n;
   }
-  ctx->n_bases = 0;
+  return MSM_HIP_OK;
+}
+
+// wire bytes at d_xy (may be ctx->d_bases itself: the conversion is element-wise) -> resident Montgomery bases
+int set_bases_from_device(msm_hip_ctx* ctx, const uint32_t* d_xy, size_t n, uint32_t flags) {
   if (n == 0) return MSM_HIP_OK;
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0, 4, ctx->stream));
   hipLaunchKernelGGL(k_convert_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_xy, ctx->d_bases, n, flags, ctx->d_err);
@@ -436,7 +491,7 @@ int run_batch_groups(msm_hip_ctx* ctx, size_t n, size_t batch, uint8_t* out_xyz,
 
 extern "C" {
 
-int msm_hip_abi_version(void) { return 3; }
+int msm_hip_abi_version(void) { return 4; }
 
 const char* msm_hip_strerror(int code) {
   switch (code) {
@@ -462,7 +517,8 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MSM_HIP_ERR_NO_DEVICE;
   if (device_id < 0 || device_id >= count) return MSM_HIP_ERR_INVALID_ARG;
-  if (hipSetDevice(device_id) != hipSuccess) return MSM_HIP_ERR_NO_DEVICE;
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return MSM_HIP_ERR_NO_DEVICE;
   msm_hip_ctx* ctx = new (std::nothrow) msm_hip_ctx();
   if (!ctx) return MSM_HIP_ERR_OUT_OF_MEMORY;
   ctx->device = device_id;
@@ -478,77 +534,71 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(MSM_HIP_ERR_NO_DEVICE);
   for (int k = 0; k < NREDUCE; k++)
     if (hipStreamCreateWithFlags(&ctx->reduce_stream[k], hipStreamNonBlocking) != hipSuccess) return fail(MSM_HIP_ERR_NO_DEVICE);
+  if (hipEventCreateWithFlags(&ctx->input_ready, hipEventDisableTiming) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
   if ((rc = dev_alloc(ctx, ctx->d_counts, (size_t)MAXLW * MAX_TILES * NCOARSE))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_bin_total, (size_t)MAXLW * NCOARSE))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_coarse_ptr, (size_t)MAXLW * (NCOARSE + 1)))) return fail(rc);
   if ((rc = dev_alloc(ctx, ctx->d_err, 1))) return fail(rc);
-  for (int k = 0; k < NSLOT; k++) {
-    Slot& s = ctx->slot[k];
-    if (hipHostMalloc((void**)&s.h_wsums, WSUM_BYTES + 4, hipHostMallocDefault) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
-    memset(s.h_wsums, 0, WSUM_BYTES + 4);
-    if ((rc = dev_alloc(ctx, s.d_wsums, WSUM_BYTES + 4))) return fail(rc);
-    if (hipMemset(s.d_wsums, 0, WSUM_BYTES + 4) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
-    if ((rc = dev_alloc(ctx, s.d_buckets, (size_t)NWIN * HALF * REC_WORDS))) return fail(rc);
-    s.cap_lw = NWIN;
-    if ((rc = dev_alloc(ctx, s.d_partials, (size_t)MAXLW * (256 + 256 + 3) * XYZZ_WORDS))) return fail(rc);
-    if ((rc = dev_alloc(ctx, s.d_col_ptr, (size_t)MAXLW * (HALF + 1)))) return fail(rc);
-    if ((rc = dev_alloc(ctx, s.d_big_queue, (size_t)STITCH_BIG_CAP + 1))) return fail(rc);
-    if ((rc = dev_alloc(ctx, s.d_done_blocks, 1))) return fail(rc);
-    if (hipMemset(s.d_big_queue, 0, 4) != hipSuccess || hipMemset(s.d_done_blocks, 0, 4) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
-    if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
-    if (hipEventCreateWithFlags(&s.smvp_done, hipEventDisableTiming) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
-    if (hipEventCreate(&s.red0) != hipSuccess || hipEventCreate(&s.red1) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
-    for (int i = 0; i < N_MAIN_EVENTS; i++)
-      if (hipEventCreate(&s.ev[i]) != hipSuccess) return fail(MSM_HIP_ERR_HIP);
-  }
+  // result slots (buckets, piece arrays, events) are set up by the first launch that uses them: setup_slot / ensure_work
   *out = ctx;
   return MSM_HIP_OK;
 }
 
 void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
+  DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   for (hipStream_t r : ctx->reduce_stream)
     if (r) (void)hipStreamSynchronize(r);
-  void* bufs[] = {ctx->d_bases,   ctx->d_scalars,  ctx->d_batch_stage, ctx->d_scalar_conv, ctx->d_part_hist, ctx->d_digits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
+  void* bufs[] = {ctx->d_bases,   ctx->d_batch_stage, ctx->d_scalar_conv, ctx->d_part_hist, ctx->d_digits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
                   ctx->d_tmp_val, ctx->d_tmp_fine, ctx->d_val,    ctx->d_chunk_slot, ctx->d_err,       ctx->d_stage};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int k = 0; k < NSLOT; k++) {
     Slot& s = ctx->slot[k];
     if (s.h_wsums) (void)hipHostFree(s.h_wsums);
-    if (s.d_wsums) (void)hipFree(s.d_wsums);
-    if (s.d_buckets) (void)hipFree(s.d_buckets);
-    void* sbufs[] = {s.d_partials, s.d_col_ptr, s.d_heads, s.d_tails, s.d_big_queue, s.d_done_blocks};
+    void* sbufs[] = {s.d_wsums, s.d_buckets, s.d_partials, s.d_col_ptr, s.d_heads, s.d_tails, s.d_big_queue, s.d_done_blocks, s.d_host_scalars};
     for (void* b : sbufs)
       if (b) (void)hipFree(b);
-    hipEvent_t evs[] = {s.done, s.smvp_done, s.red0, s.red1};
+    hipEvent_t evs[] = {s.done, s.smvp_done, s.staged, s.red0, s.red1};
     for (hipEvent_t e : evs)
       if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < N_MAIN_EVENTS; i++)
       if (s.ev[i]) (void)hipEventDestroy(s.ev[i]);
   }
+  if (ctx->input_ready) (void)hipEventDestroy(ctx->input_ready);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   for (hipStream_t r : ctx->reduce_stream)
     if (r) (void)hipStreamDestroy(r);
   delete ctx;
 }
 
+int msm_hip_wait_stream(msm_hip_ctx* ctx, void* producer_stream) {
+  if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  ON_DEVICE(ctx);
+  HIP_TRY(ctx, hipEventRecord(ctx->input_ready, static_cast<hipStream_t>(producer_stream)));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->input_ready, 0));
+  return MSM_HIP_OK;
+}
+
 int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t n, uint32_t flags) {
   if (!ctx || (!xy_dev && n)) return MSM_HIP_ERR_INVALID_ARG;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
+  int rc = reserve_bases(ctx, n);
+  if (rc) return rc;
   return set_bases_from_device(ctx, static_cast<const uint32_t*>(xy_dev), n, flags);
 }
 
 int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, uint32_t flags) {
   if (!ctx || (!xy_host && n)) return MSM_HIP_ERR_INVALID_ARG;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  int rc = ensure_stage(ctx, n * 64 + 16);
+  ON_DEVICE(ctx);
+  int rc = reserve_bases(ctx, n);
   if (rc) return rc;
-  if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage, xy_host, n * 64, hipMemcpyHostToDevice, ctx->stream));
-  return set_bases_from_device(ctx, reinterpret_cast<const uint32_t*>(ctx->d_stage), n, flags);
+  // the wire bytes land in the bases array itself and are converted in place (same 64 B per point): no staging buffer
+  if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bases, xy_host, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  return set_bases_from_device(ctx, ctx->d_bases, n, flags);
 }
 
 int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end,
@@ -558,9 +608,10 @@ int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scal
   if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > NWIN || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
   const int w_count = w_end - w_begin;
   if (nvec < 1 || nvec * w_count > MAXLW) return MSM_HIP_ERR_INVALID_ARG;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   Slot& s = ctx->slot[slot];
   if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;  // its result was never collected (msm_hip_finish_bn254 / msm_hip_slot_sync)
+  if ((rc = setup_slot(ctx, s))) return rc;
   s.n = n;
   s.w_begin = w_begin;
   s.w_count = w_count;
@@ -576,7 +627,7 @@ int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scal
     }
     return MSM_HIP_OK;
   }
-  if ((rc = ensure_work(ctx, n, nvec * w_count))) return rc;
+  if ((rc = ensure_work(ctx, n, nvec * w_count, s))) return rc;
   if (ctx->scalar_format == MSM_HIP_SCALARS_MONT256 && (size_t)nvec * n > ctx->cap_scalar_conv) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cap_scalar_conv = 0;
@@ -598,7 +649,7 @@ int msm_hip_launch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_
 
 int msm_hip_slot_wait_stream(msm_hip_ctx* ctx, int slot, void* foreign_stream) {
   if (!ctx || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   HIP_TRY(ctx, hipStreamWaitEvent(static_cast<hipStream_t>(foreign_stream), ctx->slot[slot].done, 0));
   return MSM_HIP_OK;
 }
@@ -607,7 +658,7 @@ int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot) {
   if (!ctx || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   Slot& s = ctx->slot[slot];
   if (!s.pending) return MSM_HIP_ERR_INVALID_ARG;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   return wait_slot(ctx, s);
 }
 
@@ -615,7 +666,7 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   if (!ctx || !out_xyz || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   Slot& s = ctx->slot[slot];
   if (!s.pending || !s.to_host || s.w_count != NWIN) return MSM_HIP_ERR_INVALID_ARG;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   int rc = wait_slot(ctx, s);
   if (rc) return rc;
   auto t0 = std::chrono::steady_clock::now();
@@ -637,19 +688,36 @@ int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n
   return msm_hip_finish_bn254(ctx, 0, out_xyz);
 }
 
-int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
+int msm_hip_launch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int slot) {
   int rc = check_run_args(ctx, scalars_host, n);
   if (rc) return rc;
-  if (!out_xyz) return MSM_HIP_ERR_INVALID_ARG;
-  if (n == 0) {
-    memset(out_xyz, 0, 96);
-    return MSM_HIP_OK;
+  if (slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
+  ON_DEVICE(ctx);
+  Slot& s = ctx->slot[slot];
+  if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;
+  if (n == 0) return msm_hip_launch_device_bn254(ctx, scalars_host, 0, slot);
+  if ((rc = setup_slot(ctx, s))) return rc;
+  if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (n > s.cap_host_scalars) {  // the slot's own staging buffer: idle, since the slot is not pending
+    s.cap_host_scalars = 0;
+    if ((rc = dev_alloc(ctx, s.d_host_scalars, n * 8))) return rc;
+    s.cap_host_scalars = n;
   }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if ((rc = ensure_work(ctx, n, NWIN))) return rc;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer may still feed an earlier launch
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scalars, scalars_host, n * 32, hipMemcpyHostToDevice, ctx->stream));
-  return msm_hip_run_device_bn254(ctx, ctx->d_scalars, n, out_xyz);
+  // H2D on the copy stream, so that it overlaps whatever the main and reduce streams still hold of earlier launches
+  // (a caller that alternates two slots gets the copy of MSM i+1 under the device work of MSM i); the main stream waits
+  // for it on the device.  From pageable memory the call returns when the bytes have left the caller's buffer; from
+  // pinned memory (hipHostMalloc / hipHostRegister) at once -- the buffer must then stay untouched until finish / slot_sync.
+  HIP_TRY(ctx, hipMemcpyAsync(s.d_host_scalars, scalars_host, n * 32, hipMemcpyHostToDevice, ctx->copy_stream));
+  HIP_TRY(ctx, hipEventRecord(s.staged, ctx->copy_stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.staged, 0));
+  return msm_hip_launch_device_bn254(ctx, s.d_host_scalars, n, slot);
+}
+
+int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
+  if (!out_xyz) return MSM_HIP_ERR_INVALID_ARG;
+  int rc = msm_hip_launch_bn254(ctx, scalars_host, n, 0);
+  if (rc) return rc;
+  return msm_hip_finish_bn254(ctx, 0, out_xyz);
 }
 
 int msm_hip_run_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, size_t batch, uint8_t* out_xyz) {
@@ -671,7 +739,7 @@ int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_
     if (batch) memset(out_xyz, 0, 96 * batch);
     return MSM_HIP_OK;
   }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   const size_t vec = n * 32, entry = vec * batch_group(n, batch);
   if (entry * NSLOT > ctx->cap_batch_stage) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -712,7 +780,9 @@ int msm_hip_g1_to_affine_bn254(const uint8_t xyz[96], uint8_t out_xy[64]) {
 
 int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
   msm_hip_ctx* ctx = nullptr;
-  int rc = msm_hip_ctx_create(&ctx, 0);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return MSM_HIP_ERR_NO_DEVICE;  // the caller's current device (0 unless it chose another)
+  int rc = msm_hip_ctx_create(&ctx, dev);
   if (rc) return rc;
   rc = msm_hip_set_bases_bn254(ctx, xy_host, n, 0);
   if (!rc) rc = msm_hip_run_bn254(ctx, scalars_host, n, out_xyz);
@@ -723,7 +793,7 @@ int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, si
 int msm_hip_sample_scalars_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void* scalars_dev) {
   if (!ctx || (!scalars_dev && n)) return MSM_HIP_ERR_INVALID_ARG;
   if (n == 0) return MSM_HIP_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   hipLaunchKernelGGL(k_sample_scalars, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, seed, n, static_cast<uint32_t*>(scalars_dev));
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -733,7 +803,7 @@ int msm_hip_sample_scalars_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, voi
 int msm_hip_sample_points_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void* xy_dev) {
   if (!ctx || (!xy_dev && n)) return MSM_HIP_ERR_INVALID_ARG;
   if (n == 0) return MSM_HIP_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   hipLaunchKernelGGL(k_sample_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, seed, n, static_cast<uint32_t*>(xy_dev));
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -752,7 +822,7 @@ static int read_back(msm_hip_ctx* ctx, void* out, const void* src, size_t bytes,
   if (!ctx || !out) return MSM_HIP_ERR_INVALID_ARG;
   if (bytes > cap_bytes) return MSM_HIP_ERR_INVALID_ARG;
   if (bytes == 0) return MSM_HIP_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   for (hipStream_t r : ctx->reduce_stream) HIP_TRY(ctx, hipStreamSynchronize(r));
   HIP_TRY(ctx, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -797,7 +867,7 @@ int msm_hip_read_val_idxs(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
   const size_t n = ctx->last_n;
   if (!out || n * ctx->last_w_count > cap_elems) return MSM_HIP_ERR_INVALID_ARG;
   if (n == 0) return MSM_HIP_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   HIP_TRY(ctx, hipMemcpy2DAsync(out, n * 4, ctx->d_val, ctx->last_stride * 4, n * 4, (size_t)ctx->last_w_count, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MSM_HIP_OK;
@@ -808,7 +878,7 @@ int msm_hip_read_buckets(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
   const size_t count = (size_t)ctx->last_w_count * HALF;
   if (count * 96 > cap_bytes) return MSM_HIP_ERR_INVALID_ARG;
   if (count == 0) return MSM_HIP_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   for (hipStream_t r : ctx->reduce_stream) HIP_TRY(ctx, hipStreamSynchronize(r));
   int rc = ensure_stage(ctx, count * 96);
   if (rc) return rc;
@@ -827,7 +897,7 @@ int msm_hip_read_window_sums(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
 static int run_hook(msm_hip_ctx* ctx, const uint8_t* a, size_t a_bytes, const uint8_t* b, size_t b_bytes, uint8_t* out,
                     size_t out_bytes, uint8_t*& da, uint8_t*& db, uint8_t*& dout) {
   if (!ctx || !a || !out) return MSM_HIP_ERR_INVALID_ARG;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
   int rc = ensure_stage(ctx, up16(a_bytes) + up16(b_bytes) + up16(out_bytes) + 16);

@@ -127,7 +127,7 @@ constexpr uint32_t ERRBIT_SCALAR_CARRY = 4u;
 
 // ------------------------------------------------------------------------------------------------ stage 0: bases
 // canonical wire bytes -> packed Montgomery affine (≙ decompose_scalars.template.wgsl:41-70, the point half)
-__global__ void __launch_bounds__(256) k_convert_points(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n,
+__global__ void __launch_bounds__(256) k_convert_points(const uint32_t* in, uint32_t* out, size_t n,  // in may alias out (element-wise)
                                                         uint32_t flags, uint32_t* __restrict__ err) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -181,13 +181,15 @@ class ShardedMsmPipeline:
         """Result of the oldest launch in flight: a G1, or the list of its G1 results when msms_per_issue > 1."""
         assert self.completed < self.issued
         slot = self.completed % self.SLOTS
-        self.copied[slot].synchronize()
-        if self.w_end > self.w_begin:
-            self.ctx.slot_sync(slot)
-        nvec = self.nvec[slot]
-        out = []
-        ranges = [(self.w_begin, self.w_end)] if self.emulate else None
-        for v in range(nvec):
-            out.append(MsmContext.combine_windows(group_window_rows(self.host[slot], v, self.world, self.num_windows, ranges)))
-        self.completed += 1
+        try:  # a launch that failed (device-side input error) is retired too: the pipeline stays usable
+            self.copied[slot].synchronize()
+            if self.w_end > self.w_begin:
+                self.ctx.slot_sync(slot)
+            nvec = self.nvec[slot]
+            out = []
+            ranges = [(self.w_begin, self.w_end)] if self.emulate else None
+            for v in range(nvec):
+                out.append(MsmContext.combine_windows(group_window_rows(self.host[slot], v, self.world, self.num_windows, ranges)))
+        finally:
+            self.completed += 1
         return out if self.g > 1 else out[0]

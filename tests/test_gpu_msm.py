@@ -339,3 +339,23 @@ def test_scalars_in_r256_montgomery_form(ctx):
     finally:
         ctx.set_scalar_format(False)
     assert ctx.msm(canon).to_affine_bytes() == want
+
+
+def test_inputs_produced_asynchronously_on_the_torch_stream(ctx):
+    # the engine's streams are not ordered with torch's: every launch wrapper makes the engine wait for the producing torch
+    # stream (msm_hip_wait_stream), and a slot keeps its temporaries alive until it is collected
+    n = 1 << 18
+    pts = ctx.sample_points(n, 200)
+    base = [ctx.sample_scalars(n, 201 + k) for k in range(3)]
+    ctx.set_bases(pts)
+    want = [ctx.msm(b) for b in base]
+    filler = torch.empty((64 << 20,), dtype=torch.uint8, device=pts.device)
+    for rep in range(3):
+        for k in range(3):
+            filler.fill_(rep)                                   # keeps the torch stream busy ahead of the producer
+            t = torch.cat([base[k][: n // 2], base[k][n // 2:]], dim=0)  # fresh temporary, produced asynchronously
+            ctx.launch(t, k)
+            del t                                                # the caching allocator may hand the block out again
+            junk = torch.full((n, 32), 0xFF, dtype=torch.uint8, device=pts.device)  # ... to this (non-canonical scalars)
+            del junk
+        assert [ctx.finish(k) for k in range(3)] == want
