@@ -184,6 +184,7 @@ int msm_hip_read_window_sums(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes);
 /* ---- device op hooks for parity tests (≙ the single-op shaders src/cuzk/wgsl/test/test_field.wgsl:13-62 and
  *      test_point.wgsl:18-88 driven by tests/field.rs:68, tests/point.rs:71).  Host buffers, canonical LE.
  *      fq op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg ; a, b, out: n x 32 B
+ *             5 mul, 6 sqr, 7 a*b + b*a, 8 (a+b)*2a, 9 (a+b)^2 through the SMVP's inline-assembly multipliers (fq29_asm.h)
  *      g1 op: 0 add, 1 double(a), 2 a + affine(b: n x 64 B) ; a, b, out: n x 96 B Jacobian
  *      g1_mul_u32: out[i] = k[i] * a[i] (≙ double_and_add) ---- */
 int msm_hip_test_fq_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);

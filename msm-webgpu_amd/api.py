@@ -396,7 +396,8 @@ class MsmContext:
 
     # -- single-op hooks (≙ tests/field.rs, tests/point.rs)
     def fq_op(self, op, a, b=None):
-        code = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "neg": 4}[op]
+        code = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "neg": 4, "mul_asm": 5, "sqr_asm": 6, "mul2_asm": 7, "mul_asm_lazy": 8,
+                "sqr_asm_lazy": 9}[op]
         n = len(a) // 32
         out = C.create_string_buffer(max(32 * n, 1))
         _check(lib().msm_hip_test_fq_op(self._h, code, a, b, out, n), "msm_hip_test_fq_op")

@@ -4,7 +4,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SO = os.path.join(HERE, "libmsm_hip.so")
+# MSM_HIP_SO: load (and build into) another file, e.g. a diagnostic variant next to the product library
+SO = os.environ.get("MSM_HIP_SO") or os.path.join(HERE, "libmsm_hip.so")
 SOURCES = ["msm_hip.hip", "msm_kernels.h", "g1.h", "fq29.h", "fq29_asm.h", "host_g1.h", "bn254_constants.h"]
 HEADER = os.path.join(HERE, "..", "include", "msm_hip.h")
 
@@ -26,6 +27,9 @@ def build(force=False, verbose=False):
            os.path.join(CSRC, "msm_hip.hip"), "-o", SO + ".tmp"]
     if os.environ.get("MSM_HIP_NO_ASM") == "1":  # the C++ multipliers everywhere (the inline-assembly ones are only in g1_madd)
         cmd.insert(1, "-DFQ29_NO_ASM")
+    if os.environ.get("MSM_HIP_ASM_EVERYWHERE") == "1":  # diagnostic: the inline-assembly multipliers in every kernel
+        cmd.insert(1, "-DFQ29_ASM_EVERYWHERE")
+    cmd[1:1] = os.environ.get("MSM_HIP_EXTRA_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -270,6 +270,27 @@ int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, Slot& s) {
   return MSM_HIP_OK;
 }
 
+// MSM_HIP_DEBUG_SYNC=1 (diagnostic): wait after every kernel of a launch and name it on stderr, so that a device fault is
+// pinned to a kernel.  Destroys all overlap; never set for measurements.
+inline bool debug_sync() {
+  static const bool v = [] { const char* e = getenv("MSM_HIP_DEBUG_SYNC"); return e && e[0] == '1'; }();
+  return v;
+}
+#define AFTER_KERNEL(ctx, name, stream)                                   \
+  do {                                                                    \
+    if (debug_sync()) {                                                   \
+      fprintf(stderr, "[msm_hip] %s ...", name);                          \
+      fflush(stderr);                                                     \
+      hipError_t e_ = hipStreamSynchronize(stream);                       \
+      fprintf(stderr, " %s\n", e_ == hipSuccess ? "ok" : hipGetErrorString(e_)); \
+      fflush(stderr);                                                     \
+      if (e_ != hipSuccess) {                                             \
+        (ctx)->last_hip_error = (int)e_;                                  \
+        return MSM_HIP_ERR_HIP;                                           \
+      }                                                                   \
+    }                                                                     \
+  } while (0)
+
 inline unsigned blocks_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 int err_from_bits(uint32_t bits) {
@@ -312,27 +333,34 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   if (ctx->scalar_format == MSM_HIP_SCALARS_MONT256) {  // Montgomery-form scalars: canonical copies first (part of stage 0)
     const size_t count = (size_t)nvec * n;
     hipLaunchKernelGGL(k_scalars_from_mont256, dim3(blocks_for(count, 256)), dim3(256), 0, st, d_scalars, ctx->d_scalar_conv, count, d_err);
+    AFTER_KERNEL(ctx, "k_scalars_from_mont256", st);
     d_scalars = ctx->d_scalar_conv;
   }
   hipLaunchKernelGGL(k_count, dim3(tiles), dim3(256), 0, st, d_scalars, n, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts,
                      digits, d_err);
+  AFTER_KERNEL(ctx, "k_count", st);
   HIP_TRY(ctx, mark(1, false));
   hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total);
+  AFTER_KERNEL(ctx, "k_scan_tiles", st);
   HIP_TRY(ctx, mark(2, false));
   hipLaunchKernelGGL(k_scatter_coarse, dim3(tiles), dim3(256), 0, st, d_scalars, n, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8,
                      ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine);
+  AFTER_KERNEL(ctx, "k_scatter_coarse", st);
   HIP_TRY(ctx, mark(3, false));
   const uint32_t* part_hist = nullptr;
   if (n >= ctx->fine_hist_min_n) {  // large n: the sub-range histograms of huge coarse bins are made once, not by every sharer
     hipLaunchKernelGGL(k_fine_hist, dim3(NCOARSE, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
                        ctx->d_part_hist);
+    AFTER_KERNEL(ctx, "k_fine_hist", st);
     part_hist = ctx->d_part_hist;
   }
   hipLaunchKernelGGL(k_sort_fine, dim3(NCOARSE, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
                      s.d_col_ptr, ctx->d_val, chunks, chunk_len, ctx->d_chunk_slot, part_hist);
+  AFTER_KERNEL(ctx, "k_sort_fine", st);
   HIP_TRY(ctx, mark(4, true));
   hipLaunchKernelGGL(k_smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, s.d_col_ptr, ctx->d_val, stride,
                      chunks, chunk_len, ctx->d_chunk_slot, s.d_buckets, s.d_heads, s.d_tails);
+  AFTER_KERNEL(ctx, "k_smvp_chunks", st);
   HIP_TRY(ctx, mark(5, true));
   HIP_TRY(ctx, hipEventRecord(s.smvp_done, st));
 
@@ -340,8 +368,10 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   HIP_TRY(ctx, hipStreamWaitEvent(rs, s.smvp_done, 0));
   hipLaunchKernelGGL(k_smvp_stitch, dim3(HALF / 256, w_count), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails,
                      s.d_buckets, s.d_big_queue);
+  AFTER_KERNEL(ctx, "k_smvp_stitch", rs);
   hipLaunchKernelGGL(k_smvp_stitch_big, dim3(256), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails, s.d_buckets,
                      s.d_big_queue, s.d_done_blocks);
+  AFTER_KERNEL(ctx, "k_smvp_stitch_big", rs);
   if (tl >= 2) {
     HIP_TRY(ctx, hipEventRecord(s.ev[6], rs));
     HIP_TRY(ctx, hipEventRecord(s.red0, rs));
@@ -358,8 +388,11 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     hipLaunchKernelGGL(k_bpr_rowcol<2>, dim3(bpr_rowcol_blocks<2>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols);
   else
     hipLaunchKernelGGL(k_bpr_rowcol<3>, dim3(bpr_rowcol_blocks<3>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols);
+  AFTER_KERNEL(ctx, "k_bpr_rowcol", rs);
   hipLaunchKernelGGL(k_bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts);
+  AFTER_KERNEL(ctx, "k_bpr_w256", rs);
   hipLaunchKernelGGL(k_bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out);
+  AFTER_KERNEL(ctx, "k_bpr_final", rs);
   if (tl >= 2) HIP_TRY(ctx, hipEventRecord(s.red1, rs));
   if (to_host) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * 96, hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums + WSUM_BYTES, d_err, 4, hipMemcpyDeviceToHost, rs));
@@ -913,7 +946,7 @@ static int run_hook(msm_hip_ctx* ctx, const uint8_t* a, size_t a_bytes, const ui
 
 int msm_hip_test_fq_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
   if (n == 0) return MSM_HIP_OK;
-  if (op < 0 || op > 4) return MSM_HIP_ERR_INVALID_ARG;
+  if (op < 0 || op > 9) return MSM_HIP_ERR_INVALID_ARG;
   uint8_t *da, *db, *dout;
   int rc = run_hook(ctx, a, n * 32, b, b ? n * 32 : 0, out, n * 32, da, db, dout);
   if (rc) return rc;

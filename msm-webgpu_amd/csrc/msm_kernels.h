@@ -1269,7 +1269,13 @@ __global__ void __launch_bounds__(256) k_test_fq(int op, const uint32_t* __restr
     case 1: z = fq_sub<2>(x, y); break;
     case 2: z = fq_mul(x, y); break;
     case 3: z = fq_sqr(x); break;
-    default: z = fq_neg_canonical(x); break;
+    case 4: z = fq_neg_canonical(x); break;
+    // the SMVP's multipliers (inline assembly on the device, fq29_asm.h), called directly; 8 and 9 feed them lazy limbs
+    case 5: z = fq_mul_fast(x, y); break;
+    case 6: z = fq_sqr_fast(x); break;
+    case 7: z = fq_mul2_fast(x, y, y, x); break;                    // x y + y x
+    case 8: z = fq_mul_fast(fq_add(x, y), fq_dbl(x)); break;        // (x + y) * 2x, limbs up to 2^30
+    default: z = fq_sqr_fast(fq_add(x, y)); break;                  // (x + y)^2
   }
   st_fq(out + i * 8, fq_from_mont(z));
 }

@@ -1,0 +1,51 @@
+"""Gate on a hipcc code-generation hazard in large kernels (tools/check_long_branch_hazard.py): an
+expanded long branch whose scavenged SGPR pair still has a scalar load in flight makes the wave jump to a data address --
+an intermittent "Memory access fault by GPU".  The product build must contain none."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import check_long_branch_hazard as chk  # noqa: E402
+
+HAZARD = """
+k_demo:                                 ; @k_demo
+	s_load_dwordx2 s[0:1], s[0:1], 0x8
+	s_cmp_lg_u32 s2, 0
+	s_cbranch_scc1 .LBB0_1
+	s_getpc_b64 s[2:3]
+.Lpost_getpc0:
+	s_add_u32 s2, s2, (.LBB0_2-.Lpost_getpc0)&4294967295
+	s_addc_u32 s3, s3, (.LBB0_2-.Lpost_getpc0)>>32
+	s_setpc_b64 s[2:3]
+.LBB0_1:
+	s_waitcnt lgkmcnt(0)
+	s_endpgm
+.LBB0_2:
+	%s
+	s_getpc_b64 s[0:1]
+.Lpost_getpc1:
+	s_add_u32 s0, s0, (.LBB0_1-.Lpost_getpc1)&4294967295
+	s_addc_u32 s1, s1, (.LBB0_1-.Lpost_getpc1)>>32
+	s_setpc_b64 s[0:1]
+.Lfunc_end0:
+"""
+
+
+def _hazards(text):
+    return [h for name, lines in chk.functions(text) for h in chk.analyse(name, lines)]
+
+
+def test_checker_sees_the_hazard_and_its_absence():
+    bad = _hazards(HAZARD % "s_nop 0")
+    assert len(bad) == 1 and bad[0][0] == "k_demo" and bad[0][2] == [0, 1]
+    assert _hazards(HAZARD % "s_waitcnt lgkmcnt(0)") == []
+    assert _hazards(HAZARD % "s_waitcnt vmcnt(0) lgkmcnt(1)") != []  # scalar loads return out of order: only lgkmcnt(0) settles
+
+
+def test_product_device_code_has_no_long_branch_over_a_pending_scalar_load():
+    path = chk.compile_to_asm([])
+    long_branches, found = chk.check_file(path)
+    assert found == [], found
+    assert long_branches >= 0

@@ -71,3 +71,13 @@ def test_double_and_add_small_scalars(ctx):
     got = affine64_list(ctx.g1_mul_u32(A, np.array(ks, dtype=np.uint32)))
     want = [ref.affine_to_bytes64(ref.mul(k, p)) for k, p in zip(ks, pts)]
     assert got == want
+
+
+@pytest.mark.parametrize("op", ["mul_asm", "sqr_asm", "mul2_asm", "mul_asm_lazy", "sqr_asm_lazy"])
+def test_assembly_multipliers_match_oracle(ctx, op):
+    # fq_mul_asm / fq_sqr_asm / fq_mul2_asm (csrc/fq29_asm.h) called directly, on the edge operand set and on lazy limbs
+    a, b = _operands(20000, 16)
+    mul, add = (lambda x, y: cpu.fq_op("mul", x, y)), (lambda x, y: cpu.fq_op("add", x, y))
+    want = {"mul_asm": lambda: mul(a, b), "sqr_asm": lambda: mul(a, a), "mul2_asm": lambda: add(mul(a, b), mul(b, a)),
+            "mul_asm_lazy": lambda: mul(add(a, b), add(a, a)), "sqr_asm_lazy": lambda: mul(add(a, b), add(a, b))}[op]()
+    assert ctx.fq_op(op, a, b) == want
