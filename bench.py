@@ -31,6 +31,10 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0
+# the SMVP accumulate is VALU-issue bound: one mixed addition = 1467 v_mad_u64_u32 per lane; measured peak issue
+# rate of that instruction = 1024 SIMDs x 64 lanes / 2.3 ns (profiles/r01_ubench_valu_rates.txt)
+MADS_PER_MIXED_ADD = 1467
+VALU_PEAK_LANE_MADS = 1024 * 64 / 2.3e-9
 NUM_WINDOWS = 16
 BUCKETS = 1 << 15
 
@@ -326,6 +330,11 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_smvp_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                      "kernel_ms": smvp_avg_ms},
+        # beside (not instead of) the HBM figure: the kernel's multiply-add rate against the instruction's measured issue peak
+        "roofline_valu": {"bound": "valu_issue", "kernel": "k_smvp_chunks", "unit": "T lane-mad/s (v_mad_u64_u32)",
+                          "achieved": n * w_launch * MADS_PER_MIXED_ADD / (smvp_avg_ms * 1e-3) / 1e12 if w_launch == smvp_windows[0] else None,
+                          "peak": VALU_PEAK_LANE_MADS / 1e12,
+                          "frac": (n * w_launch * MADS_PER_MIXED_ADD / (smvp_avg_ms * 1e-3)) / VALU_PEAK_LANE_MADS if w_launch == smvp_windows[0] else None},
         "smvp_ms_pipelined": smvp_avg_ms,
         "rccl_ranks": dist_ranks if dist_backend == "nccl" else None,
         "dist_backend": dist_backend,
