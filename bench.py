@@ -299,6 +299,7 @@ def main():
     alg_bytes = sum(smvp_algorithmic_bytes(n, w) for w in smvp_windows) / launches
     achieved = alg_bytes / (smvp_avg_ms * 1e-3) / 1e9
     w_launch = max(smvp_windows)
+    lane_mads_per_s = sum(n * w for w in smvp_windows) * MADS_PER_MIXED_ADD / (sum(smvp_ms) * 1e-3)
 
     traffic = None
     try:
@@ -332,9 +333,7 @@ def main():
                      "kernel_ms": smvp_avg_ms},
         # beside (not instead of) the HBM figure: the kernel's multiply-add rate against the instruction's measured issue peak
         "roofline_valu": {"bound": "valu_issue", "kernel": "k_smvp_chunks", "unit": "T lane-mad/s (v_mad_u64_u32)",
-                          "achieved": n * w_launch * MADS_PER_MIXED_ADD / (smvp_avg_ms * 1e-3) / 1e12 if w_launch == smvp_windows[0] else None,
-                          "peak": VALU_PEAK_LANE_MADS / 1e12,
-                          "frac": (n * w_launch * MADS_PER_MIXED_ADD / (smvp_avg_ms * 1e-3)) / VALU_PEAK_LANE_MADS if w_launch == smvp_windows[0] else None},
+                          "achieved": lane_mads_per_s / 1e12, "peak": VALU_PEAK_LANE_MADS / 1e12, "frac": lane_mads_per_s / VALU_PEAK_LANE_MADS},
         "smvp_ms_pipelined": smvp_avg_ms,
         "rccl_ranks": dist_ranks if dist_backend == "nccl" else None,
         "dist_backend": dist_backend,
