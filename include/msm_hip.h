@@ -136,6 +136,29 @@ int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot);
 /* result = sum_w 2^(16 w) * S_w over num_windows records (host memory): src/cuzk/msm.rs:411-416 */
 int msm_hip_combine_windows_bn254(const uint8_t* window_sums_host, int num_windows, uint8_t out_xyz[96]);
 
+/* ---- multi-GPU in ONE host process (BASELINE.json north star: "independent Pippenger windows shard across the 8 GPUs of one
+ *      node with a final RCCL gather/reduce of partial sums over xGMI"; the reference is single-device, src/cuzk/msm.rs:88-94).
+ *      One engine context per listed device.  msm_hip_mgpu_run_bn254: device d computes the window sums of window range d
+ *      (msm_hip_window_range(d, n_devices, 16, ...); bases replicated, every device receives all scalars), the sums are gathered
+ *      -- ncclAllGather over RCCL (librccl is loaded at run time; not a link dependency) or through the slots' pinned result
+ *      buffers -- and the host window combine (src/cuzk/msm.rs:411-416) runs once.  msm_hip_mgpu_run_batch_bn254 deals whole
+ *      MSMs out contiguously (BASELINE config 5: many MSMs over one shared base): no exchange at all.
+ *      Device ids may repeat with MSM_HIP_MGPU_GATHER_HOST (several contexts on one GPU: rehearsal on a one-GPU box). ---- */
+typedef struct msm_hip_mgpu msm_hip_mgpu;
+#define MSM_HIP_MGPU_GATHER_AUTO 0u /* RCCL if more than one distinct device and librccl loads, else the pinned-buffer gather */
+#define MSM_HIP_MGPU_GATHER_HOST 1u /* every device's sums leave through its slot's pinned buffer                        */
+#define MSM_HIP_MGPU_GATHER_RCCL 2u /* ncclAllGather; creation fails if RCCL cannot be initialised on these devices       */
+int msm_hip_mgpu_create(msm_hip_mgpu** out, const int* device_ids, int n_devices, uint32_t gather_flags);
+void msm_hip_mgpu_destroy(msm_hip_mgpu* m);
+int msm_hip_mgpu_device_count(const msm_hip_mgpu* m);
+int msm_hip_mgpu_uses_rccl(const msm_hip_mgpu* m);
+int msm_hip_mgpu_set_bases_bn254(msm_hip_mgpu* m, const uint8_t* xy_host, size_t n, uint32_t flags);
+int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
+int msm_hip_mgpu_run_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz);
+/* contiguous balanced partition of [0, num) over `world` ranks (the first num % world ranks take one more): the window ranges of
+ * msm_hip_mgpu_run_bn254 and the MSM ranges of msm_hip_mgpu_run_batch_bn254; host-only */
+int msm_hip_window_range(int rank, int world, int num, int* begin, int* end);
+
 /* host-only helper (≙ Curve::to_affine as used by tests/cuzk.rs:88-94): 96 B Jacobian -> 64 B canonical affine x || y.
  * Returns 1 when the point is the identity (out zeroed), 0 otherwise, negative on error. */
 int msm_hip_g1_to_affine_bn254(const uint8_t xyz[96], uint8_t out_xy[64]);

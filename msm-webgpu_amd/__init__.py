@@ -10,6 +10,7 @@ from .api import (  # noqa: F401
     G1,
     MsmContext,
     MsmHipError,
+    MultiGpuMsm,
     compute_msm,
     lib,
     points_to_bytes,
@@ -20,5 +21,5 @@ from .api import (  # noqa: F401
 )
 from .build import build  # noqa: F401
 
-__all__ = ["G1", "MsmContext", "MsmHipError", "compute_msm", "run_webgpu_msm", "points_to_bytes", "scalars_to_bytes",
+__all__ = ["G1", "MsmContext", "MultiGpuMsm", "MsmHipError", "compute_msm", "run_webgpu_msm", "points_to_bytes", "scalars_to_bytes",
            "sample_points", "sample_scalars", "build", "lib"]

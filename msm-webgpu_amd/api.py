@@ -82,6 +82,15 @@ def lib():
         L.msm_hip_test_g1_op.argtypes = [vp, i, u8p, u8p, u8p, sz]
         L.msm_hip_test_g1_mul_u32.argtypes = [vp, u8p, vp, u8p, sz]
         L.msm_hip_last_hip_error.argtypes = [vp]
+        L.msm_hip_mgpu_create.argtypes = [C.POINTER(vp), C.POINTER(i), i, C.c_uint32]
+        L.msm_hip_mgpu_destroy.argtypes = [vp]
+        L.msm_hip_mgpu_destroy.restype = None
+        L.msm_hip_mgpu_device_count.argtypes = [vp]
+        L.msm_hip_mgpu_uses_rccl.argtypes = [vp]
+        L.msm_hip_mgpu_set_bases_bn254.argtypes = [vp, u8p, sz, C.c_uint32]
+        L.msm_hip_mgpu_run_bn254.argtypes = [vp, u8p, sz, u8p]
+        L.msm_hip_mgpu_run_batch_bn254.argtypes = [vp, u8p, sz, sz, u8p]
+        L.msm_hip_window_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
         _lib = L
     return _lib
 
@@ -416,6 +425,63 @@ class MsmContext:
         out = C.create_string_buffer(max(96 * n, 1))
         _check(lib().msm_hip_test_g1_mul_u32(self._h, a, k.ctypes.data, out, n), "msm_hip_test_g1_mul_u32")
         return out.raw[:96 * n]
+
+
+class MultiGpuMsm:
+    """Several GPUs driven by ONE process through the C ABI (msm_hip_mgpu_*, include/msm_hip.h): windows of one MSM sharded
+    over the devices + gather (RCCL or pinned buffers) + one host window combine; batches dealt out as whole MSMs.
+    (bench.py's multi-GPU path is the other shape: one process per GPU over torch.distributed, msm-webgpu_amd/sharding.py.)"""
+
+    GATHER = {"auto": 0, "host": 1, "rccl": 2}
+
+    def __init__(self, device_ids, gather="auto"):
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        self._h = C.c_void_p()
+        _check(lib().msm_hip_mgpu_create(C.byref(self._h), ids, len(device_ids), self.GATHER[gather]), "msm_hip_mgpu_create")
+
+    def close(self):
+        if self._h:
+            lib().msm_hip_mgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_count(self):
+        return lib().msm_hip_mgpu_device_count(self._h)
+
+    @property
+    def uses_rccl(self):
+        return lib().msm_hip_mgpu_uses_rccl(self._h) == 1
+
+    def set_bases(self, points, check_on_curve=False):
+        b = bytes(points)
+        _check(lib().msm_hip_mgpu_set_bases_bn254(self._h, b, len(b) // 64, 1 if check_on_curve else 0), "msm_hip_mgpu_set_bases_bn254")
+        return len(b) // 64
+
+    def msm(self, scalars):
+        b = bytes(scalars)
+        out = C.create_string_buffer(96)
+        _check(lib().msm_hip_mgpu_run_bn254(self._h, b, len(b) // 32, out), "msm_hip_mgpu_run_bn254")
+        return G1(out.raw)
+
+    def msm_batch(self, scalars, n):
+        b = bytes(scalars)
+        batch = len(b) // (32 * n)
+        out = C.create_string_buffer(max(96 * batch, 1))
+        _check(lib().msm_hip_mgpu_run_batch_bn254(self._h, b, n, batch, out), "msm_hip_mgpu_run_batch_bn254")
+        return [G1(out.raw[96 * k:96 * k + 96]) for k in range(batch)]
+
+
+def window_range_abi(rank, world, num=NUM_WINDOWS):
+    """msm_hip_window_range: the C ABI's partition (must equal sharding.window_range)."""
+    b, e = C.c_int(), C.c_int()
+    _check(lib().msm_hip_window_range(rank, world, num, C.byref(b), C.byref(e)), "msm_hip_window_range")
+    return b.value, e.value
 
 
 # ------------------------------------------------------------------------------------------------ reference-shaped functions

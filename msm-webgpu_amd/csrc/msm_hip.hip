@@ -721,14 +721,18 @@ int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n
   return msm_hip_finish_bn254(ctx, 0, out_xyz);
 }
 
-int msm_hip_launch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int slot) {
+}  // extern "C"
+
+namespace {
+// host scalars -> the slot's own staging buffer (copy stream) -> windows [w_begin, w_end) of one MSM into `slot`
+int launch_host_windows(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int w_begin, int w_end, int slot, void* window_sums_dev) {
   int rc = check_run_args(ctx, scalars_host, n);
   if (rc) return rc;
   if (slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   Slot& s = ctx->slot[slot];
   if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;
-  if (n == 0) return msm_hip_launch_device_bn254(ctx, scalars_host, 0, slot);
+  if (n == 0) return msm_hip_launch_windows_batch_device_bn254(ctx, scalars_host, 0, 1, w_begin, w_end, slot, window_sums_dev);
   if ((rc = setup_slot(ctx, s))) return rc;
   if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
   if (n > s.cap_host_scalars) {  // the slot's own staging buffer: idle, since the slot is not pending
@@ -743,7 +747,14 @@ int msm_hip_launch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n
   HIP_TRY(ctx, hipMemcpyAsync(s.d_host_scalars, scalars_host, n * 32, hipMemcpyHostToDevice, ctx->copy_stream));
   HIP_TRY(ctx, hipEventRecord(s.staged, ctx->copy_stream));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.staged, 0));
-  return msm_hip_launch_device_bn254(ctx, s.d_host_scalars, n, slot);
+  return msm_hip_launch_windows_batch_device_bn254(ctx, s.d_host_scalars, n, 1, w_begin, w_end, slot, window_sums_dev);
+}
+}  // namespace
+
+extern "C" {
+
+int msm_hip_launch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int slot) {
+  return launch_host_windows(ctx, scalars_host, n, 0, NWIN, slot, nullptr);
 }
 
 int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
@@ -982,3 +993,5 @@ int msm_hip_test_g1_mul_u32(msm_hip_ctx* ctx, const uint8_t* a, const uint32_t* 
 }
 
 }  // extern "C"
+
+#include "msm_mgpu.h"

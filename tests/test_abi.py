@@ -84,3 +84,26 @@ def test_host_to_affine_helper_matches_oracle(built):
     out = C.create_string_buffer(64)
     assert L.msm_hip_g1_to_affine_bn254(bytes(96), out) == 1 and out.raw == bytes(64)
     assert L.msm_hip_g1_to_affine_bn254(b"\xff" * 96, out) == -4
+
+
+def test_abi_window_partition_equals_the_python_harness(built):
+    # msm_hip_window_range (what msm_hip_mgpu_* shards by) == sharding.window_range (what the torch.distributed harness shards by)
+    from msm_webgpu_amd.api import window_range_abi
+    from msm_webgpu_amd.sharding import batch_range, window_range
+
+    for world in range(1, 17):
+        ranges = [window_range_abi(r, world) for r in range(world)]
+        assert ranges == [window_range(r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == 16 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    for batch in (0, 1, 7, 64, 1000):
+        assert [window_range_abi(r, 8, batch) for r in range(8)] == [batch_range(r, 8, batch) for r in range(8)]
+
+
+def test_mgpu_without_gpu_fails_loudly(built):
+    import msm_webgpu_amd as m
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(m.MsmHipError) as e:
+        m.MultiGpuMsm([0])
+    assert e.value.code == -1

@@ -1,0 +1,62 @@
+"""msm_hip_mgpu_*: several engine contexts driven by one process behind the C ABI (windows sharded + gather + ONE host
+combine; batches dealt out as whole MSMs).  The GPU box has one GPU, so device ids repeat (pinned-buffer gather) or the list
+has one entry (RCCL all-gather with a single rank); the 8-device case is the driver's to run."""
+import pytest
+
+import msm_webgpu_amd as m
+from oracle import cpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def data(ctx):
+    n = 50000
+    points, scalars = cpu.sample_points(900, n), cpu.sample_scalars(901, n)
+    return n, points, scalars, cpu.to_affine64(cpu.cpu_msm(points, scalars, 8))
+
+
+@pytest.mark.parametrize("ids,gather", [([0], "host"), ([0, 0], "host"), ([0, 0, 0], "host"), ([0] * 8, "host"), ([0], "rccl"), ([0], "auto")])
+def test_mgpu_window_sharded_msm(data, ids, gather):
+    n, points, scalars, want = data
+    mg = m.MultiGpuMsm(ids, gather)
+    try:
+        assert mg.device_count == len(ids)
+        assert mg.uses_rccl == (gather == "rccl")
+        assert mg.set_bases(points, check_on_curve=True) == n
+        assert mg.msm(scalars).to_affine_bytes() == want
+        assert mg.msm(scalars[: 32 * 1000]).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points[: 64 * 1000], scalars[: 32 * 1000]))
+        assert mg.msm(b"").is_identity()
+        with pytest.raises(m.MsmHipError) as e:  # a non-canonical scalar: every device reports it, the call returns the code
+            mg.msm(scalars[:32] + b"\xff" * 32)
+        assert e.value.code == -4
+        assert mg.msm(scalars).to_affine_bytes() == want  # still usable
+    finally:
+        mg.close()
+
+
+def test_mgpu_batch_of_whole_msms(data):
+    n, points, scalars, _ = data
+    k, batch = 3000, 7
+    vecs = cpu.sample_scalars(902, k * batch)
+    mg = m.MultiGpuMsm([0, 0, 0], "host")
+    try:
+        mg.set_bases(points[: 64 * k])
+        got = mg.msm_batch(vecs, k)
+        assert len(got) == batch
+        for j in range(batch):
+            assert got[j].to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points[: 64 * k], vecs[32 * k * j:32 * k * (j + 1)])), j
+        assert mg.msm_batch(b"", k) == []
+    finally:
+        mg.close()
+
+
+def test_mgpu_bad_arguments():
+    with pytest.raises(m.MsmHipError) as e:
+        m.MultiGpuMsm([])
+    assert e.value.code == -2
+    with pytest.raises(m.MsmHipError) as e:
+        m.MultiGpuMsm([0] * 17)
+    assert e.value.code == -2
+    with pytest.raises(m.MsmHipError):
+        m.MultiGpuMsm([0, 0], "rccl")  # RCCL cannot put two ranks on one device
