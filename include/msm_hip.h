@@ -86,6 +86,20 @@ int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t 
 #define MSM_HIP_SCALARS_MONT256 1u
 int msm_hip_set_scalar_format(msm_hip_ctx* ctx, uint32_t format);
 
+/* ---- window size (the reference hard-codes chunk_size = 16 for n >= 2^16, src/cuzk/msm.rs:79-82).
+ *      WHOLE-MSM entry points (run, launch, finish, batch) pick the signed-digit window from n: 12 bits (22 windows, 2^11 buckets each)
+ *      up to 2^15 points, 14 bits (19 windows, 2^13 buckets) up to 2^17, 16 bits (16 windows, 2^15 buckets) beyond -- small MSMs are
+ *      otherwise dominated by reducing 16 x 2^15 mostly empty buckets.  msm_hip_set_window_bits fixes it (12, 14 or 16; 0 = by n).
+ *      The result is the same group element for every window size.  The window-sharding entry points below (w_begin / w_end) and
+ *      msm_hip_combine_windows_bn254 always use the reference's 16-bit windows. ---- */
+int msm_hip_set_window_bits(msm_hip_ctx* ctx, int bits);
+int msm_hip_window_config(int bits, int* num_windows, int* buckets_per_window); /* host-only: the shape of a window size */
+int msm_hip_last_window_bits(msm_hip_ctx* ctx);                                 /* window size of the last launch       */
+/* how many whole MSMs of n points the batch entry points put through ONE launch (what msm_hip_launch_windows_batch_device_bn254
+ * with w_begin = 0, w_end = 16, window_sums_dev = NULL should be given for best throughput): 1 from 2^20 points up, at most
+ * MSM_HIP_MAX_LOCAL_WINDOWS / (windows of the size picked for n) below */
+int msm_hip_batch_group_size(msm_hip_ctx* ctx, size_t n);
+
 /* ---- run: sum_i scalars[i] * bases[i] over the first n bases (n <= number of bases set).
  *      ≙ compute_msm stages 1-5, src/cuzk/msm.rs:96-416 (decompose, transpose, SMVP, bucket reduce, Horner) ---- */
 int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
@@ -187,6 +201,7 @@ void* msm_hip_stream(msm_hip_ctx* ctx);
  *      buffer left by the last run to host memory.  Layouts:
  *      digits    : u16[num_windows_run][n]    code = sign << 15 | (|d| & 0x7fff); 0 = digit 0 (no entry);
  *                  0x8000 = digit -2^15 (bucket slot 0)        cf. decompose_scalars.template.wgsl:93-112
+ *      (shapes for 16-bit windows; with b-bit windows: 2^(b-1) buckets per window, col_ptr rows of 2^(b-1) + 1 entries)
  *      col_ptr   : u32[num_windows_run][32769] start of bucket slot k in val_idxs   cf. transpose.template.wgsl:58-61
  *      val_idxs  : u32[num_windows_run][n]    point index | sign << 31, grouped by slot (order within a slot is
  *                  unspecified)                                 cf. transpose.template.wgsl:66-73

@@ -73,6 +73,10 @@ def lib():
         L.msm_hip_set_fine_hist_min_n.argtypes = [vp, sz]
         L.msm_hip_set_scalar_format.argtypes = [vp, C.c_uint32]
         L.msm_hip_set_stage_timing.argtypes = [vp, i]
+        L.msm_hip_set_window_bits.argtypes = [vp, i]
+        L.msm_hip_window_config.argtypes = [i, C.POINTER(i), C.POINTER(i)]
+        L.msm_hip_last_window_bits.argtypes = [vp]
+        L.msm_hip_batch_group_size.argtypes = [vp, sz]
         L.msm_hip_read_digits.argtypes = [vp, vp, sz]
         L.msm_hip_read_col_ptr.argtypes = [vp, vp, sz]
         L.msm_hip_read_val_idxs.argtypes = [vp, vp, sz]
@@ -367,6 +371,25 @@ class MsmContext:
                  "device_total", "host_finalise"]
         return {names[j]: float(buf[j]) for j in range(k)}
 
+    # -- window size
+    def set_window_bits(self, bits):
+        """0: whole-MSM launches pick the signed-digit window from n (12 / 14 / 16 bits); 12, 14 or 16 fixes it."""
+        _check(lib().msm_hip_set_window_bits(self._h, int(bits)), "msm_hip_set_window_bits")
+
+    def batch_group_size(self, n):
+        """Whole MSMs of n points per launch (launch_batch) for best throughput."""
+        return lib().msm_hip_batch_group_size(self._h, n)
+
+    def last_window_bits(self):
+        return lib().msm_hip_last_window_bits(self._h)
+
+    @staticmethod
+    def window_config(bits):
+        """(number of windows, buckets per window) of a window size."""
+        nw, nb = C.c_int(), C.c_int()
+        _check(lib().msm_hip_window_config(int(bits), C.byref(nw), C.byref(nb)), "msm_hip_window_config")
+        return nw.value, nb.value
+
     # -- stage read-back (parity tests)
     def set_scalar_format(self, mont256):
         """False: canonical little-endian scalars (default); True: s * 2^256 mod r words (R = 2^256 Montgomery limbs)."""
@@ -383,8 +406,8 @@ class MsmContext:
         _check(lib().msm_hip_read_digits(self._h, a.ctypes.data, a.size), "msm_hip_read_digits")
         return a
 
-    def read_col_ptr(self, w_count=NUM_WINDOWS):
-        a = np.empty((w_count, BUCKETS_PER_WINDOW + 1), dtype=np.uint32)
+    def read_col_ptr(self, w_count=NUM_WINDOWS, buckets=BUCKETS_PER_WINDOW):
+        a = np.empty((w_count, buckets + 1), dtype=np.uint32)
         _check(lib().msm_hip_read_col_ptr(self._h, a.ctypes.data, a.size), "msm_hip_read_col_ptr")
         return a
 
@@ -393,8 +416,8 @@ class MsmContext:
         _check(lib().msm_hip_read_val_idxs(self._h, a.ctypes.data, a.size), "msm_hip_read_val_idxs")
         return a
 
-    def read_buckets(self, w_count=NUM_WINDOWS):
-        a = np.empty((w_count, BUCKETS_PER_WINDOW, 96), dtype=np.uint8)
+    def read_buckets(self, w_count=NUM_WINDOWS, buckets=BUCKETS_PER_WINDOW):
+        a = np.empty((w_count, buckets, 96), dtype=np.uint8)
         _check(lib().msm_hip_read_buckets(self._h, a.ctypes.data, a.size), "msm_hip_read_buckets")
         return a
 

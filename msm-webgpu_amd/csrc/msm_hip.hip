@@ -41,7 +41,8 @@ struct Slot {
   uint8_t* h_wsums = nullptr;      // pinned: MAXLW x 96 B window sums + 4 B error word
   uint8_t* d_wsums = nullptr;      // device: MAXLW x 96 B window sums + 4 B error word
   uint32_t* d_buckets = nullptr;   // [cap_lw][32768] XYZZ records
-  int cap_lw = 0;                  // local windows d_buckets holds (NWIN, or MAXLW once a larger launch was seen)
+  size_t cap_buckets = 0;          // bucket records d_buckets holds (local windows x slots per window of the largest launch seen)
+  int wbits = WBITS;               // window bits of the launch in this slot
   uint32_t* d_partials = nullptr;  // bucket-reduce scratch: [W][256] row sums, [W][256] column sums, [W][3] parts (XYZZ)
   uint32_t* d_col_ptr = nullptr;   // [W][32769] start of every bucket slot's run in the sorted entry list
   uint32_t* d_heads = nullptr;     // [W][chunks] XYZZ records: SMVP pieces of runs that cross chunk boundaries
@@ -94,6 +95,7 @@ struct msm_hip_ctx {
   uint32_t* d_scalar_conv = nullptr;  // canonical copies of scalars handed over in R = 2^256 Montgomery form (one launch's worth)
   size_t cap_scalar_conv = 0;         // in scalars
   uint32_t scalar_format = 0;         // MSM_HIP_SCALARS_CANONICAL / MSM_HIP_SCALARS_MONT256
+  int window_bits = 0;                // 0: chosen from n for whole-MSM launches (pick_window_bits); else 12 / 14 / 16
   uint32_t* d_part_hist = nullptr;  // [MAXLW][128][FINE_SPLIT][256] sub-range histograms of huge coarse bins (k_fine_hist), on first use
   size_t fine_hist_min_n = FINE_BIG + 1;  // any n that can produce a coarse bin beyond FINE_BIG: run k_fine_hist (3 us when none does)
   uint32_t* d_err = nullptr;
@@ -103,7 +105,7 @@ struct msm_hip_ctx {
   Slot slot[NSLOT];
   // description of the last launched run (for the stage read-back hooks)
   size_t last_n = 0;
-  int last_w_count = 0, last_slot = 0;
+  int last_w_count = 0, last_slot = 0, last_wbits = WBITS;
   bool last_has_digits = false;
   float stage_ms[10] = {};
 };
@@ -222,7 +224,7 @@ int setup_slot(msm_hip_ctx* ctx, Slot& s) {
 }
 
 // make the pools fit a launch of `w_count` local windows (vectors x windows) over n points into slot `s` (not pending)
-int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, Slot& s) {
+int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, Slot& s) {
   int rc;
   if ((rc = setup_slot(ctx, s))) return rc;
   const size_t need_recs = (size_t)w_count * chunks_for(n, chunk_len_for(n, w_count));
@@ -257,17 +259,32 @@ int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, Slot& s) {
     if ((rc = dev_alloc(ctx, s.d_tails, recs * REC_WORDS))) return rc;
     s.cap_recs = recs;
   }
-  if (w_count > s.cap_lw) {  // NWIN windows for single MSMs; a launch with more local windows: MAXLW from then on
-    const int lw = w_count > NWIN ? MAXLW : NWIN;
-    s.cap_lw = 0;
-    if ((rc = dev_alloc(ctx, s.d_buckets, (size_t)lw * HALF * REC_WORDS))) return rc;
-    s.cap_lw = lw;
+  const size_t need_buckets = (size_t)w_count << (wbits - 1);
+  if (need_buckets > s.cap_buckets) {  // one MSM's worth (16 x 2^15 at 16 bits) at least; larger launches grow it
+    size_t recs = (size_t)NWIN * HALF;
+    if (recs < need_buckets) recs = need_buckets;
+    s.cap_buckets = 0;
+    if ((rc = dev_alloc(ctx, s.d_buckets, recs * REC_WORDS))) return rc;
+    s.cap_buckets = recs;
   }
   if (n >= ctx->fine_hist_min_n && !ctx->d_part_hist) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if ((rc = dev_alloc(ctx, ctx->d_part_hist, (size_t)MAXLW * NCOARSE * FINE_SPLIT * FINE))) return rc;
   }
   return MSM_HIP_OK;
+}
+
+// Window size of a WHOLE-MSM launch (the reference hard-codes c = 16 for n >= 2^16, src/cuzk/msm.rs:79).
+// Below ~2^17 points the bucket reduce of 16 x 2^15 mostly empty buckets costs more than the accumulation, so smaller windows
+// win although they need more windows (19 at 14 bits, 22 at 12).  Thresholds: measured single-MSM latency on MI355X
+// (profiles/r02_window_bits_latency.txt).  `nvec` whole MSMs must fit MAXLW local windows.  The window-sharding entry points
+// always use 16-bit windows: their w_begin / w_end index the reference's 16 windows.
+inline int pick_window_bits(const msm_hip_ctx* ctx, size_t n, int nvec) {
+  static const int forced = [] { const char* e = getenv("MSM_HIP_WINDOW_BITS"); return e ? atoi(e) : 0; }();  // tuning aid
+  int bits = ctx->window_bits ? ctx->window_bits : (forced == 12 || forced == 14 || forced == 16 ? forced : 0);
+  if (!bits) bits = n <= ((size_t)1 << 15) ? 12 : (n <= ((size_t)1 << 17) ? 14 : 16);
+  while (bits < 16 && nvec * nwin_of(bits) > MAXLW) bits += 2;
+  return bits;
 }
 
 // MSM_HIP_DEBUG_SYNC=1 (diagnostic): wait after every kernel of a launch and name it on stderr, so that a device fault is
@@ -302,8 +319,10 @@ int err_from_bits(uint32_t bits) {
 // Enqueue one MSM (windows [w_begin, w_begin + w_count)) into slot `s`.  Window sums (canonical Jacobian bytes) go to
 // `wsums_out` (device memory; the slot's own buffer when null); the error word and, if `to_host`, the window sums are
 // copied to the slot's pinned buffer.  Returns without waiting.
-int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count_vec, int nvec, Slot& s,
+int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count_vec, int nvec, int wbits, Slot& s,
             uint32_t* wsums_out, bool to_host) {
+  const uint32_t half = 1u << (wbits - 1);   // bucket slots per window
+  const unsigned ncoarse = half / FINE;      // coarse bins that can hold entries
   // `nvec` scalar vectors (contiguous, n x 32 B each) share this launch: local window lw = v * w_count_vec + (w - w_begin);
   // everything after the two scalar-reading kernels only sees w_count = nvec * w_count_vec local windows
   const int w_count = nvec * w_count_vec;
@@ -336,41 +355,47 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     AFTER_KERNEL(ctx, "k_scalars_from_mont256", st);
     d_scalars = ctx->d_scalar_conv;
   }
-  hipLaunchKernelGGL(k_count, dim3(tiles), dim3(256), 0, st, d_scalars, n, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts,
-                     digits, d_err);
+#define LAUNCH_BY_WBITS(KERNEL, ...)                                                     \
+  do {                                                                                   \
+    if (wbits == 16) hipLaunchKernelGGL(KERNEL<16>, dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
+    else if (wbits == 14) hipLaunchKernelGGL(KERNEL<14>, dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<12>, dim3(tiles), dim3(256), 0, st, __VA_ARGS__);     \
+  } while (0)
+  LAUNCH_BY_WBITS(k_count, d_scalars, n, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, digits, d_err);
   AFTER_KERNEL(ctx, "k_count", st);
   HIP_TRY(ctx, mark(1, false));
-  hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total);  // all 128 bins: the scatter scans them
   AFTER_KERNEL(ctx, "k_scan_tiles", st);
   HIP_TRY(ctx, mark(2, false));
-  hipLaunchKernelGGL(k_scatter_coarse, dim3(tiles), dim3(256), 0, st, d_scalars, n, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8,
-                     ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine);
+  LAUNCH_BY_WBITS(k_scatter_coarse, d_scalars, n, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
+                  ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine);
+#undef LAUNCH_BY_WBITS
   AFTER_KERNEL(ctx, "k_scatter_coarse", st);
   HIP_TRY(ctx, mark(3, false));
   const uint32_t* part_hist = nullptr;
   if (n >= ctx->fine_hist_min_n) {  // large n: the sub-range histograms of huge coarse bins are made once, not by every sharer
-    hipLaunchKernelGGL(k_fine_hist, dim3(NCOARSE, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
+    hipLaunchKernelGGL(k_fine_hist, dim3(ncoarse, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
                        ctx->d_part_hist);
     AFTER_KERNEL(ctx, "k_fine_hist", st);
     part_hist = ctx->d_part_hist;
   }
-  hipLaunchKernelGGL(k_sort_fine, dim3(NCOARSE, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
+  hipLaunchKernelGGL(k_sort_fine, dim3(ncoarse, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
                      s.d_col_ptr, ctx->d_val, chunks, chunk_len, ctx->d_chunk_slot, part_hist);
   AFTER_KERNEL(ctx, "k_sort_fine", st);
   HIP_TRY(ctx, mark(4, true));
   hipLaunchKernelGGL(k_smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, s.d_col_ptr, ctx->d_val, stride,
-                     chunks, chunk_len, ctx->d_chunk_slot, s.d_buckets, s.d_heads, s.d_tails);
+                     chunks, chunk_len, ctx->d_chunk_slot, s.d_buckets, s.d_heads, s.d_tails, half);
   AFTER_KERNEL(ctx, "k_smvp_chunks", st);
   HIP_TRY(ctx, mark(5, true));
   HIP_TRY(ctx, hipEventRecord(s.smvp_done, st));
 
   // stitch + bucket reduce on the slot's reduce stream: few waves, long dependent chains
   HIP_TRY(ctx, hipStreamWaitEvent(rs, s.smvp_done, 0));
-  hipLaunchKernelGGL(k_smvp_stitch, dim3(HALF / 256, w_count), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails,
+  hipLaunchKernelGGL(k_smvp_stitch, dim3(half / 256, w_count), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails,
                      s.d_buckets, s.d_big_queue);
   AFTER_KERNEL(ctx, "k_smvp_stitch", rs);
   hipLaunchKernelGGL(k_smvp_stitch_big, dim3(256), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails, s.d_buckets,
-                     s.d_big_queue, s.d_done_blocks);
+                     s.d_big_queue, s.d_done_blocks, half);
   AFTER_KERNEL(ctx, "k_smvp_stitch_big", rs);
   if (tl >= 2) {
     HIP_TRY(ctx, hipEventRecord(s.ev[6], rs));
@@ -382,14 +407,21 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   static const int force_logr = [] { const char* e = getenv("MSM_HIP_BPR_LOGR"); return e ? atoi(e) : 0; }();  // tuning aid
   // serial run per thread before the LDS tree: 16 buckets when many windows are reduced at once (fewest wave-additions),
   // 4 for a few windows (shallowest); measured optimum for 16 and for 2 windows respectively
-  if (force_logr == 4 || (force_logr == 0 && w_count >= 8))
-    hipLaunchKernelGGL(k_bpr_rowcol<4>, dim3(bpr_rowcol_blocks<4>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols);
-  else if (force_logr == 2 || force_logr == 0)
-    hipLaunchKernelGGL(k_bpr_rowcol<2>, dim3(bpr_rowcol_blocks<2>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols);
-  else
-    hipLaunchKernelGGL(k_bpr_rowcol<3>, dim3(bpr_rowcol_blocks<3>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols);
+#define ROWCOL(LOG_R, LOG_ROWS) \
+  hipLaunchKernelGGL((k_bpr_rowcol<LOG_R, LOG_ROWS>), dim3(bpr_rowcol_blocks<LOG_R, LOG_ROWS>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols)
+  if (wbits == 16) {
+    if (force_logr == 4 || (force_logr == 0 && w_count >= 8)) ROWCOL(4, 8);
+    else if (force_logr == 2 || force_logr == 0) ROWCOL(2, 8);
+    else ROWCOL(3, 8);
+  } else if (wbits == 14) {  // 64 rows x 128 columns
+    if (force_logr == 4 || (force_logr == 0 && w_count > 2 * nwin_of(14))) ROWCOL(4, 6);
+    else ROWCOL(2, 6);
+  } else {  // 16 rows x 128 columns
+    ROWCOL(2, 4);
+  }
+#undef ROWCOL
   AFTER_KERNEL(ctx, "k_bpr_rowcol", rs);
-  hipLaunchKernelGGL(k_bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts);
+  hipLaunchKernelGGL(k_bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts, (int)(half / BPR_COLS));
   AFTER_KERNEL(ctx, "k_bpr_w256", rs);
   hipLaunchKernelGGL(k_bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out);
   AFTER_KERNEL(ctx, "k_bpr_final", rs);
@@ -403,6 +435,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   s.w_begin = w_begin;
   s.w_count = w_count_vec;
   s.nvec = nvec;
+  s.wbits = wbits;
   s.n = n;
   s.timed = tl >= 1;
   s.timing_level = tl;
@@ -410,6 +443,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   s.to_host = to_host;
   ctx->last_n = n;
   ctx->last_w_count = w_count;
+  ctx->last_wbits = wbits;
   ctx->last_slot = (int)(&s - ctx->slot);
   ctx->last_has_digits = digits != nullptr;
   return MSM_HIP_OK;
@@ -490,9 +524,10 @@ __global__ void __launch_bounds__(256) k_export_buckets(const uint32_t* __restri
 namespace {
 // MSMs per launch of the batch runners: small MSMs cannot fill the GPU one at a time (kernel latencies dominate below
 // ~2^19 points), so up to MAXLW / NWIN = 4 of them -- at most about 2^20 points together -- share one kernel sequence
-size_t batch_group(size_t n, size_t batch) {
+size_t batch_group(msm_hip_ctx* ctx, size_t n, size_t batch) {
+  const size_t fit = (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 1)));  // 4 at 16 bits, 3 at 14, 2 at 12
   size_t g = n ? ((size_t)1 << 20) / n : 1;
-  if (g > (size_t)(MAXLW / NWIN)) g = MAXLW / NWIN;
+  if (g > fit) g = fit;
   if (g > batch) g = batch;
   return g ? g : 1;
 }
@@ -501,7 +536,7 @@ size_t batch_group(size_t n, size_t batch) {
 // `stage` (may be null) copies group j's scalars to the device and returns their device address.
 template <typename Stage>
 int run_batch_groups(msm_hip_ctx* ctx, size_t n, size_t batch, uint8_t* out_xyz, Stage stage) {
-  const size_t g = batch_group(n, batch);
+  const size_t g = batch_group(ctx, n, batch);
   const size_t groups = (batch + g - 1) / g;
   constexpr size_t DEPTH = NSLOT - 1;
   int rc = MSM_HIP_OK;
@@ -634,11 +669,15 @@ int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, 
   return set_bases_from_device(ctx, ctx->d_bases, n, flags);
 }
 
-int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end,
-                                              int slot, void* window_sums_dev) {
+}  // extern "C"
+
+namespace {
+// windows [w_begin, w_end) -- in units of `wbits`-bit windows -- of `nvec` scalar vectors into `slot`
+int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end, int wbits, int slot,
+                void* window_sums_dev) {
   int rc = check_run_args(ctx, scalars_dev, n);
   if (rc) return rc;
-  if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > NWIN || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
+  if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > nwin_of(wbits) || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
   const int w_count = w_end - w_begin;
   if (nvec < 1 || nvec * w_count > MAXLW) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
@@ -649,6 +688,7 @@ int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scal
   s.w_begin = w_begin;
   s.w_count = w_count;
   s.nvec = nvec;
+  s.wbits = wbits;
   s.to_host = window_sums_dev == nullptr;
   if (n == 0) {  // identity window sums, nothing to compute
     s.pending = true;
@@ -660,15 +700,29 @@ int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scal
     }
     return MSM_HIP_OK;
   }
-  if ((rc = ensure_work(ctx, n, nvec * w_count, s))) return rc;
+  if ((rc = ensure_work(ctx, n, nvec * w_count, wbits, s))) return rc;
   if (ctx->scalar_format == MSM_HIP_SCALARS_MONT256 && (size_t)nvec * n > ctx->cap_scalar_conv) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cap_scalar_conv = 0;
     if ((rc = dev_alloc(ctx, ctx->d_scalar_conv, (size_t)nvec * n * 8))) return rc;
     ctx->cap_scalar_conv = (size_t)nvec * n;
   }
-  return enqueue(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, nvec, s, static_cast<uint32_t*>(window_sums_dev),
+  return enqueue(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, nvec, wbits, s, static_cast<uint32_t*>(window_sums_dev),
                  window_sums_dev == nullptr);
+}
+}  // namespace
+
+extern "C" {
+
+int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end,
+                                              int slot, void* window_sums_dev) {
+  if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  // whole MSMs whose sums stay in the slot (finish / finish_batch combines them): the window size follows n
+  if (w_begin == 0 && w_end == NWIN && window_sums_dev == nullptr && nvec >= 1 && nvec * NWIN <= MAXLW) {
+    const int wbits = pick_window_bits(ctx, n, nvec);
+    return launch_impl(ctx, scalars_dev, n, nvec, 0, nwin_of(wbits), wbits, slot, nullptr);
+  }
+  return launch_impl(ctx, scalars_dev, n, nvec, w_begin, w_end, WBITS, slot, window_sums_dev);
 }
 
 int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot,
@@ -698,13 +752,14 @@ int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot) {
 int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   if (!ctx || !out_xyz || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   Slot& s = ctx->slot[slot];
-  if (!s.pending || !s.to_host || s.w_count != NWIN) return MSM_HIP_ERR_INVALID_ARG;
+  const int nwin = nwin_of(s.wbits);
+  if (!s.pending || !s.to_host || s.w_count != nwin) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   int rc = wait_slot(ctx, s);
   if (rc) return rc;
   auto t0 = std::chrono::steady_clock::now();
   for (int v = 0; v < s.nvec; v++)
-    if (!bn254::host::combine_windows(s.h_wsums + (size_t)v * NWIN * 96, NWIN, WBITS, out_xyz + 96 * (size_t)v)) return MSM_HIP_ERR_HIP;
+    if (!bn254::host::combine_windows(s.h_wsums + (size_t)v * nwin * 96, nwin, s.wbits, out_xyz + 96 * (size_t)v)) return MSM_HIP_ERR_HIP;
   ctx->stage_ms[8] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return MSM_HIP_OK;
 }
@@ -725,14 +780,16 @@ int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n
 
 namespace {
 // host scalars -> the slot's own staging buffer (copy stream) -> windows [w_begin, w_end) of one MSM into `slot`
-int launch_host_windows(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int w_begin, int w_end, int slot, void* window_sums_dev) {
+// (windows in units of the reference's 16-bit windows; `auto_bits`: a whole MSM whose window size follows n)
+int launch_host_windows(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int w_begin, int w_end, int slot, void* window_sums_dev,
+                        bool auto_bits = false) {
   int rc = check_run_args(ctx, scalars_host, n);
   if (rc) return rc;
   if (slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   Slot& s = ctx->slot[slot];
   if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;
-  if (n == 0) return msm_hip_launch_windows_batch_device_bn254(ctx, scalars_host, 0, 1, w_begin, w_end, slot, window_sums_dev);
+  if (n == 0) return launch_impl(ctx, scalars_host, 0, 1, w_begin, w_end, WBITS, slot, window_sums_dev);
   if ((rc = setup_slot(ctx, s))) return rc;
   if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
   if (n > s.cap_host_scalars) {  // the slot's own staging buffer: idle, since the slot is not pending
@@ -747,14 +804,15 @@ int launch_host_windows(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n,
   HIP_TRY(ctx, hipMemcpyAsync(s.d_host_scalars, scalars_host, n * 32, hipMemcpyHostToDevice, ctx->copy_stream));
   HIP_TRY(ctx, hipEventRecord(s.staged, ctx->copy_stream));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.staged, 0));
-  return msm_hip_launch_windows_batch_device_bn254(ctx, s.d_host_scalars, n, 1, w_begin, w_end, slot, window_sums_dev);
+  if (auto_bits) return msm_hip_launch_windows_batch_device_bn254(ctx, s.d_host_scalars, n, 1, 0, NWIN, slot, nullptr);
+  return launch_impl(ctx, s.d_host_scalars, n, 1, w_begin, w_end, WBITS, slot, window_sums_dev);
 }
 }  // namespace
 
 extern "C" {
 
 int msm_hip_launch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int slot) {
-  return launch_host_windows(ctx, scalars_host, n, 0, NWIN, slot, nullptr);
+  return launch_host_windows(ctx, scalars_host, n, 0, NWIN, slot, nullptr, true);
 }
 
 int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
@@ -784,7 +842,7 @@ int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_
     return MSM_HIP_OK;
   }
   ON_DEVICE(ctx);
-  const size_t vec = n * 32, entry = vec * batch_group(n, batch);
+  const size_t vec = n * 32, entry = vec * batch_group(ctx, n, batch);
   if (entry * NSLOT > ctx->cap_batch_stage) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cap_batch_stage = 0;
@@ -885,6 +943,26 @@ int msm_hip_set_scalar_format(msm_hip_ctx* ctx, uint32_t format) {
   return MSM_HIP_OK;
 }
 
+int msm_hip_set_window_bits(msm_hip_ctx* ctx, int bits) {
+  if (!ctx || (bits != 0 && bits != 12 && bits != 14 && bits != 16)) return MSM_HIP_ERR_INVALID_ARG;
+  ctx->window_bits = bits;
+  return MSM_HIP_OK;
+}
+
+int msm_hip_window_config(int bits, int* num_windows, int* buckets_per_window) {
+  if (bits != 12 && bits != 14 && bits != 16) return MSM_HIP_ERR_INVALID_ARG;
+  if (num_windows) *num_windows = nwin_of(bits);
+  if (buckets_per_window) *buckets_per_window = 1 << (bits - 1);
+  return MSM_HIP_OK;
+}
+
+int msm_hip_last_window_bits(msm_hip_ctx* ctx) { return ctx ? ctx->last_wbits : MSM_HIP_ERR_INVALID_ARG; }
+
+int msm_hip_batch_group_size(msm_hip_ctx* ctx, size_t n) {
+  if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  return (int)batch_group(ctx, n, (size_t)MAXLW);
+}
+
 int msm_hip_set_fine_hist_min_n(msm_hip_ctx* ctx, size_t n) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
   ctx->fine_hist_min_n = n;
@@ -903,7 +981,8 @@ int msm_hip_read_digits(msm_hip_ctx* ctx, uint16_t* out, size_t cap_elems) {
 }
 int msm_hip_read_col_ptr(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
-  return read_back(ctx, out, ctx->slot[ctx->last_slot].d_col_ptr, (size_t)ctx->last_w_count * (HALF + 1) * 4, cap_elems * 4);
+  const size_t half = (size_t)1 << (ctx->last_wbits - 1);  // [w][half + 1]
+  return read_back(ctx, out, ctx->slot[ctx->last_slot].d_col_ptr, (size_t)ctx->last_w_count * (half + 1) * 4, cap_elems * 4);
 }
 int msm_hip_read_val_idxs(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
@@ -919,7 +998,7 @@ int msm_hip_read_val_idxs(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
 
 int msm_hip_read_buckets(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
   if (!ctx || !out) return MSM_HIP_ERR_INVALID_ARG;
-  const size_t count = (size_t)ctx->last_w_count * HALF;
+  const size_t count = (size_t)ctx->last_w_count << (ctx->last_wbits - 1);  // [w][2^(bits-1)]
   if (count * 96 > cap_bytes) return MSM_HIP_ERR_INVALID_ARG;
   if (count == 0) return MSM_HIP_OK;
   ON_DEVICE(ctx);

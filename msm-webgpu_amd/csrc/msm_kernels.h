@@ -26,10 +26,25 @@
 namespace msmk {
 using namespace bn254;
 
-constexpr int WBITS = 16;
+constexpr int WBITS = 16;   // the reference's window (chunk_size, src/cuzk/msm.rs:79) and the unit of the window-sharding API
 constexpr int NWIN = 16;
 constexpr int MAXLW = 64;  // local windows one launch may carry: (scalar vectors of the launch) x (windows of each)
-constexpr int HALF = 1 << (WBITS - 1);  // 32768 bucket slots per window
+constexpr int HALF = 1 << (WBITS - 1);  // 32768 bucket slots per window at 16 bits (the largest window supported)
+
+// Window size as a parameter (the reference hard-codes c, src/cuzk/msm.rs:79-82): C-bit signed digits,
+// 2^(C-1) bucket slots per window, NWIN = ceil(255 / C) windows (254-bit scalars + one bit for the recode's carry).
+// Small MSMs are dominated by the bucket reduce of 16 x 2^15 mostly empty buckets; a smaller C trades a few more
+// additions per point for 16 x / 4 x fewer buckets.  The host picks C from n (msm_hip.hip: pick_window_bits).
+template <int C>
+struct WinCfg {
+  static_assert(C >= 10 && C <= 16, "window bits");
+  static constexpr int BITS = C;
+  static constexpr int NWIN = (254 + C) / C;               // 16: 16, 14: 19, 12: 22
+  static constexpr int HALF = 1 << (C - 1);                // bucket slots per window
+  static constexpr int TBITS = NWIN * C;                   // bits of the biased scalar that carry digits
+  static constexpr int WORDS = (TBITS + 31) / 32;          // 8 (C = 16) or 9
+};
+__host__ __device__ constexpr int nwin_of(int bits) { return (254 + bits) / bits; }
 
 __device__ __constant__ uint32_t c_pp1d4[8] = {FQ_PP1D4_32[0], FQ_PP1D4_32[1], FQ_PP1D4_32[2], FQ_PP1D4_32[3],
                                                FQ_PP1D4_32[4], FQ_PP1D4_32[5], FQ_PP1D4_32[6], FQ_PP1D4_32[7]};
@@ -168,21 +183,41 @@ constexpr int FINE = HALF / NCOARSE;  // 256 slots per coarse bin
 // Adding 0x8000 to every 16-bit halfword of the 256-bit scalar (one multiword addition) performs the whole carry chain
 // at once: halfword w of t = s + 0x8000...8000 is the reference's biased digit d_w + 2^15 (decompose_scalars.template.wgsl:
 // 105-112), and the carry out of bit 255 is its "final carry".  Each window's digit is then read independently.
-__device__ __forceinline__ uint32_t bias_scalar(const uint32_t s[8], uint32_t t[8]) {
+// The same for C-bit windows: the bias constant has bit C w + C - 1 set for every window w (word i of it below), the biased
+// scalar t has WinCfg<C>::WORDS words, and the recode overflows iff t has a bit at or above C * NWIN.
+template <int C>
+__host__ __device__ constexpr uint32_t bias_word(int i) {
+  uint32_t v = 0;
+  for (int w = 0; w < WinCfg<C>::NWIN; w++) {
+    const int bit = C * w + C - 1;
+    if (bit / 32 == i) v |= 1u << (bit % 32);
+  }
+  return v;
+}
+template <int C>
+__device__ __forceinline__ uint32_t bias_scalar(const uint32_t s[8], uint32_t t[WinCfg<C>::WORDS]) {
+  constexpr int WORDS = WinCfg<C>::WORDS;
   uint64_t c = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    c += (uint64_t)s[i] + 0x80008000u;
+  for (int i = 0; i < WORDS; i++) {
+    c += (uint64_t)(i < 8 ? s[i] : 0u) + bias_word<C>(i);
     t[i] = (uint32_t)c;
     c >>= 32;
   }
-  return (uint32_t)c;  // 1: the recode does not fit 16 windows ("final carry is 1", test/utils.rs:150-152)
+  // 1: the recode does not fit NWIN windows ("final carry is 1", test/utils.rs:150-152)
+  if constexpr (WinCfg<C>::TBITS == 32 * WORDS) return (uint32_t)c;
+  else return (t[WORDS - 1] >> (WinCfg<C>::TBITS - 32 * (WORDS - 1))) != 0u ? 1u : 0u;
 }
-// biased digit b = d + 2^15 of window w  ->  signed-magnitude code
-__device__ __forceinline__ uint32_t code_of_window(const uint32_t t[8], int w) {
-  const uint32_t b = (t[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
-  if (b >= (uint32_t)HALF) return b - (uint32_t)HALF;        // d = 0 .. 2^15 - 1 (0: no entry)
-  return 0x8000u | (((uint32_t)HALF - b) & 0x7fffu);          // d = -(2^15 - b), magnitude 1 .. 2^15 (2^15 -> slot 0)
+// biased digit b = d + 2^(C-1) of window w  ->  signed-magnitude code: sign << 15 | (|d| mod 2^(C-1))
+template <int C>
+__device__ __forceinline__ uint32_t code_of_window(const uint32_t t[WinCfg<C>::WORDS], int w) {
+  constexpr uint32_t H = (uint32_t)WinCfg<C>::HALF;
+  const int bit = C * w, i = bit >> 5, sh = bit & 31;
+  uint32_t b = t[i] >> sh;
+  if (sh + C > 32) b |= t[i + 1] << (32 - sh);  // (only then is i + 1 < WORDS)
+  b &= (1u << C) - 1u;
+  if (b >= H) return b - H;                       // d = 0 .. 2^(C-1) - 1 (0: no entry)
+  return 0x8000u | ((H - b) & (H - 1u));          // d = -(2^(C-1) - b): magnitude 1 .. 2^(C-1) (2^(C-1) -> slot 0)
 }
 
 // Scalars handed over as s * 2^256 mod r (the in-memory limbs of a 4 x 64-bit Montgomery library with R = 2^256) are turned
@@ -236,6 +271,7 @@ __global__ void __launch_bounds__(256) k_scalars_from_mont256(const uint32_t* __
 // `nvec` scalar vectors (vec_stride words apart) may share one launch: vector v, window w is handled as local window
 // lw = v * w_count + (w - w_begin), nvec * w_count <= MAXLW -- several MSMs over the same bases sorted, accumulated and reduced
 // by one kernel sequence (used by the window-sharded multi-GPU pipeline, where one MSM's share is too small to fill a GPU).
+template <int C>
 __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles,
                                                int w_begin, int w_count, int nvec, size_t vec_stride,
                                                uint32_t* __restrict__ counts, uint16_t* __restrict__ digits_dbg,
@@ -250,15 +286,15 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
   for (int v = 0; v < nvec; v++) {
     const uint32_t* sv = scalars + (size_t)v * vec_stride;
     for (size_t i = base + tid; i < end; i += 256) {
-      uint32_t s[8], tb[8];
+      uint32_t s[8], tb[WinCfg<C>::WORDS];
       ld8(sv + i * 8, s);
-      bad |= bias_scalar(s, tb);
+      bad |= bias_scalar<C>(s, tb);
 #pragma unroll
-      for (int w = 0; w < NWIN; w++) {
+      for (int w = 0; w < WinCfg<C>::NWIN; w++) {
         const int lw = w - w_begin;
         if (lw >= 0 && lw < w_count) {
           const int le = v * w_count + lw;
-          const uint32_t code = code_of_window(tb, w);
+          const uint32_t code = code_of_window<C>(tb, w);
           if (code != 0) atomicAdd(&cnt[le * NCOARSE + ((code & 0x7fffu) >> 8)], 1u);
           if (digits_dbg) digits_dbg[(size_t)le * n + i] = (uint16_t)code;
         }
@@ -319,6 +355,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* wa
 // addresses inside each (tile, bin) run instead of 64 unrelated 4-byte stores per wave instruction.
 constexpr int SCAT_SUB = 2048;  // scalars staged per block iteration (8 per thread)
 
+template <int C>
 __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
                                                         uint32_t tiles, int w_begin, int w_count, int nvec, size_t vec_stride,
                                                         const uint32_t* __restrict__ counts,
@@ -362,16 +399,16 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
   for (size_t sub = tile_base; sub < tile_end; sub += SCAT_SUB) {
     // this thread's 8 biased scalars stay in registers; every window's digit code is read from them
     const uint32_t* sv = scalars + (size_t)v * vec_stride;
-    uint32_t sc[8][8];
+    uint32_t sc[8][WinCfg<C>::WORDS];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const size_t i = sub + (size_t)j * 256 + tid;
       uint32_t raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // an all-zero scalar recodes to all-zero digits: no entries
       if (i < tile_end) ld8(sv + i * 8, raw);
-      (void)bias_scalar(raw, sc[j]);
+      (void)bias_scalar<C>(raw, sc[j]);
     }
 #pragma unroll
-    for (int w = 0; w < NWIN; w++) {
+    for (int w = 0; w < WinCfg<C>::NWIN; w++) {
       if (w < w_begin || w >= w_begin + w_count) continue;  // block-uniform
       const int lw = v * w_count + (w - w_begin);
       if (tid < NCOARSE) hist[tid] = 0;
@@ -379,7 +416,7 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
       uint32_t rank[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const uint32_t code = code_of_window(sc[j], w);
+        const uint32_t code = code_of_window<C>(sc[j], w);
         rank[j] = code ? atomicAdd(&hist[(code & 0x7fffu) >> 8], 1u) : 0u;
       }
       __syncthreads();
@@ -390,7 +427,7 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
       const uint32_t total = lstart[NCOARSE - 1] + hist[NCOARSE - 1];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const uint32_t code = code_of_window(sc[j], w);
+        const uint32_t code = code_of_window<C>(sc[j], w);
         if (code) {
           const uint32_t slot = code & 0x7fffu, bin = slot >> 8;
           const uint32_t e = lstart[bin] + rank[j];
@@ -497,6 +534,7 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
   __shared__ uint32_t st_dst[FINE_CHUNK];
   __shared__ uint32_t skew_flag, long_count;
   const int bin = blockIdx.x, part = blockIdx.z, lw = blockIdx.y, tid = threadIdx.x;
+  const uint32_t half = gridDim.x * FINE;  // bucket slots per window: the grid covers exactly the window's coarse bins
   const uint32_t begin = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin], end = coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin + 1];
   const bool big = end - begin > FINE_BIG;
   if (!big && part != 0) return;
@@ -574,8 +612,8 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
     const uint32_t excl = block_excl_scan_256(hist[tid], wave_tot);
     gpos[tid] = begin + excl + before[tid];
     if (part == 0) {
-      col_ptr[(size_t)lw * (HALF + 1) + bin * FINE + tid] = begin + excl;
-      if (bin == NCOARSE - 1 && tid == FINE - 1) col_ptr[(size_t)lw * (HALF + 1) + HALF] = end;
+      col_ptr[(size_t)lw * (half + 1) + bin * FINE + tid] = begin + excl;
+      if (bin == (int)gridDim.x - 1 && tid == FINE - 1) col_ptr[(size_t)lw * (half + 1) + half] = end;
     }
     // SMVP chunks whose first entry lies in this slot's run [first, last): short runs are tabulated by their own thread
     // (of workgroup 0), long ones (skewed scalars) by all threads of all workgroups of the bin together
@@ -691,11 +729,11 @@ __global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restri
                                                      const uint32_t* __restrict__ val_idxs, size_t stride, uint32_t chunks,
                                                      uint32_t chunk_len, const uint32_t* __restrict__ chunk_slot,
                                                      uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
-                                                     uint32_t* __restrict__ tails) {
+                                                     uint32_t* __restrict__ tails, uint32_t half) {
   const int lw = blockIdx.y;
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t* cp = col_ptr + (size_t)lw * (HALF + 1);
-  const uint32_t nw = cp[HALF];
+  const uint32_t* cp = col_ptr + (size_t)lw * (half + 1);
+  const uint32_t nw = cp[half];
   const uint64_t begin64 = (uint64_t)c * chunk_len;
   if (c >= chunks || begin64 >= nw) return;
   const uint32_t begin = (uint32_t)begin64;
@@ -725,7 +763,7 @@ __global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restri
       ld8(pt + 8, wy);
     }
     if (t == run_end) {  // the run of slot s ended inside this chunk
-      if (run_begin >= begin) st_rec(buckets + ((size_t)lw * HALF + s) * REC_WORDS, acc);
+      if (run_begin >= begin) st_rec(buckets + ((size_t)lw * half + s) * REC_WORDS, acc);
       else st_rec(heads + rec, acc);
       acc = g1_identity();
       run_begin = run_end;
@@ -736,7 +774,7 @@ __global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restri
   }
   // last run of the chunk: complete only if it started here and ends exactly at or before `end`
   if (run_begin >= begin && run_end <= end) {
-    st_rec(buckets + ((size_t)lw * HALF + s) * REC_WORDS, acc);
+    st_rec(buckets + ((size_t)lw * half + s) * REC_WORDS, acc);
   } else if (run_begin < begin) {
     st_rec(heads + rec, acc);  // continuation of a run from an earlier chunk (it may continue further)
   } else {
@@ -760,10 +798,11 @@ __global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict_
                                                      const uint32_t* __restrict__ heads, const uint32_t* __restrict__ tails,
                                                      uint32_t* __restrict__ buckets, uint32_t* __restrict__ big_queue) {
   const int lw = blockIdx.y;
-  const uint32_t s = blockIdx.x * 256 + threadIdx.x;  // < HALF by grid construction
-  const uint32_t* cp = col_ptr + (size_t)lw * (HALF + 1);
+  const uint32_t half = gridDim.x * 256;              // bucket slots per window: one lane per slot
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;  // < half by grid construction
+  const uint32_t* cp = col_ptr + (size_t)lw * (half + 1);
   const uint32_t b = cp[s], e = cp[s + 1];
-  uint32_t* out = buckets + ((size_t)lw * HALF + s) * REC_WORDS;
+  uint32_t* out = buckets + ((size_t)lw * half + s) * REC_WORDS;
   if (b == e) {
     st_rec(out, g1_identity());
     return;
@@ -787,7 +826,7 @@ __global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict_
 __global__ void __launch_bounds__(256) k_smvp_stitch_big(const uint32_t* __restrict__ col_ptr, uint32_t chunks, uint32_t chunk_len,
                                                          const uint32_t* __restrict__ heads, const uint32_t* __restrict__ tails,
                                                          uint32_t* __restrict__ buckets, uint32_t* __restrict__ big_queue,
-                                                         uint32_t* __restrict__ done_blocks) {
+                                                         uint32_t* __restrict__ done_blocks, uint32_t half) {
   __shared__ uint32_t x[256 * XYZZ_WORDS];
   const int t = threadIdx.x;
   uint32_t count = big_queue[0];
@@ -795,7 +834,7 @@ __global__ void __launch_bounds__(256) k_smvp_stitch_big(const uint32_t* __restr
   for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
     const uint32_t code = big_queue[1 + item];
     const uint32_t lw = code >> 16, s = code & 0xffffu;
-    const uint32_t* cp = col_ptr + (size_t)lw * (HALF + 1);
+    const uint32_t* cp = col_ptr + (size_t)lw * (half + 1);
     const uint32_t c0 = cp[s] / chunk_len, c1 = (cp[s + 1] - 1) / chunk_len;
     g1_xyzz acc = g1_identity();
     for (uint32_t c = c0 + t; c <= c1; c += 256) {
@@ -808,7 +847,7 @@ __global__ void __launch_bounds__(256) k_smvp_stitch_big(const uint32_t* __restr
       if (t < sft) lds_add_pair(x, t, t + sft);
       __syncthreads();
     }
-    if (t == 0) st_rec(buckets + ((size_t)lw * HALF + s) * REC_WORDS, ld_xyzz(x));
+    if (t == 0) st_rec(buckets + ((size_t)lw * half + s) * REC_WORDS, ld_xyzz(x));
     __syncthreads();
   }
   // last block out resets the queue for the next run
@@ -843,22 +882,27 @@ constexpr int BPR_ROWS = 256, BPR_COLS = 128;
 // LOG_R = log2 of the buckets each thread adds serially before the LDS tree.  The host picks 4 (16 buckets) when many
 // windows are reduced at once -- fewer, better-filled wave-additions: the stage is then bound by the ~7 us a SIMD needs
 // per wave-addition -- and 2 for few windows, where only the depth counts.
-template <int LOG_R>
+// LOG_ROWS = log2 of the rows of the window's bucket grid: 2^(C-1) buckets = 2^LOG_ROWS rows x 128 columns (8 / 6 / 4 for
+// C = 16 / 14 / 12).  The row sums of window w land in rows[w][0 .. ROWS) (stride BPR_ROWS), the column sums in cols[w][0 .. 128).
+template <int LOG_R, int LOG_ROWS>
 __global__ void __launch_bounds__(256) k_bpr_rowcol(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ rows,
                                                     uint32_t* __restrict__ cols) {
-  constexpr int R = 1 << LOG_R;
-  constexpr int ROW_LANES = BPR_COLS / R, COL_LANES = BPR_ROWS / R;  // threads per row / per column
+  constexpr int R = 1 << LOG_R, ROWS = 1 << LOG_ROWS, NB = ROWS * BPR_COLS;
+  static_assert(ROWS <= BPR_ROWS && R <= ROWS && R <= BPR_COLS, "bucket grid");
+  constexpr int ROW_LANES = BPR_COLS / R, COL_LANES = ROWS / R;  // threads per row / per column
   constexpr int ROWS_PER_BLOCK = 256 / ROW_LANES, COLS_PER_BLOCK = 256 / COL_LANES;
-  constexpr int ROW_BLOCKS = BPR_ROWS / ROWS_PER_BLOCK;
+  constexpr int ROW_BLOCKS = (ROWS + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
   __shared__ uint32_t x[256 * XYZZ_WORDS];
   const int w = blockIdx.y, t = threadIdx.x;
-  const uint32_t* bw = buckets + (size_t)w * HALF * REC_WORDS;
+  const uint32_t* bw = buckets + (size_t)w * NB * REC_WORDS;
   const bool row_block = (int)blockIdx.x < ROW_BLOCKS;
-  // element e = q - 1 = 128 * hi + lo  ->  slot (e + 1) & 32767
+  // element e = q - 1 = 128 * hi + lo  ->  slot (e + 1) & (NB - 1)
   int e0, estep, group, lanes_per_group, out_index;
+  bool live = true;  // a block may hold more row / column groups than the grid has left (small grids)
   if (row_block) {  // R consecutive lo per thread
     group = t / ROW_LANES;
     const int row = blockIdx.x * ROWS_PER_BLOCK + group, seg = t % ROW_LANES;
+    live = row < ROWS;
     e0 = row * BPR_COLS + seg * R;
     estep = 1;
     lanes_per_group = ROW_LANES;
@@ -866,14 +910,18 @@ __global__ void __launch_bounds__(256) k_bpr_rowcol(const uint32_t* __restrict__
   } else {  // R consecutive hi per thread
     group = t / COL_LANES;
     const int col = ((int)blockIdx.x - ROW_BLOCKS) * COLS_PER_BLOCK + group, part = t % COL_LANES;
+    live = col < BPR_COLS;
     e0 = part * R * BPR_COLS + col;
     estep = BPR_COLS;
     lanes_per_group = COL_LANES;
     out_index = col;
   }
-  g1_xyzz acc = ld_rec(bw + (size_t)((e0 + 1) & (HALF - 1)) * REC_WORDS);
+  g1_xyzz acc = g1_identity();
+  if (live) {
+    acc = ld_rec(bw + (size_t)((e0 + 1) & (NB - 1)) * REC_WORDS);
 #pragma unroll 1
-  for (int i = 1; i < R; i++) acc = g1_add(acc, ld_rec(bw + (size_t)((e0 + i * estep + 1) & (HALF - 1)) * REC_WORDS));
+    for (int i = 1; i < R; i++) acc = g1_add(acc, ld_rec(bw + (size_t)((e0 + i * estep + 1) & (NB - 1)) * REC_WORDS));
+  }
   st_xyzz(x + t * XYZZ_WORDS, acc);
   __syncthreads();
   const int k = t & (lanes_per_group - 1);
@@ -881,14 +929,16 @@ __global__ void __launch_bounds__(256) k_bpr_rowcol(const uint32_t* __restrict__
     if (k < sft) lds_add_pair(x, t, t + sft);
     __syncthreads();
   }
-  if (k == 0) {
+  if (k == 0 && live) {
     uint32_t* out = (row_block ? rows + (size_t)w * BPR_ROWS * XYZZ_WORDS : cols + (size_t)w * 256 * XYZZ_WORDS) + (size_t)out_index * XYZZ_WORDS;
     for (int i = 0; i < XYZZ_WORDS; i++) out[i] = x[t * XYZZ_WORDS + i];
   }
 }
-template <int LOG_R>
+template <int LOG_R, int LOG_ROWS>
 constexpr int bpr_rowcol_blocks() {
-  return BPR_ROWS / (256 / (BPR_COLS >> LOG_R)) + BPR_COLS / (256 / (BPR_ROWS >> LOG_R));
+  constexpr int R = 1 << LOG_R, ROWS = 1 << LOG_ROWS;
+  constexpr int rpb = 256 / (BPR_COLS / R), cpb = 256 / (ROWS / R);
+  return (ROWS + rpb - 1) / rpb + (BPR_COLS + cpb - 1) / cpb;
 }
 
 // ---- cooperative group operations: 8 lanes share ONE addition / doubling -------------------------------------------
@@ -1049,7 +1099,7 @@ __device__ __noinline__ void coop_double(uint32_t* sc_all, const uint32_t* pa, u
 // W16(V) by a 4 x 4 split: W16 = 4 * W4(r) + W4(c); W4(u) = u1 + 2 u2 + 3 u3 = (u1 + u3) + 2 (u2 + u3).
 // Levels with at most 32 independent operations use the cooperative octet operations above.
 __global__ void __launch_bounds__(256) k_bpr_w256(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ cols,
-                                                  uint32_t* __restrict__ out) {
+                                                  uint32_t* __restrict__ out, int nrows) {
   __shared__ uint32_t x[256 * XYZZ_WORDS];
   __shared__ uint32_t sc[32 * COOP_WORDS];
   const int w = blockIdx.y, which_in = blockIdx.x, t = threadIdx.x;
@@ -1062,7 +1112,7 @@ __global__ void __launch_bounds__(256) k_bpr_w256(const uint32_t* __restrict__ r
   auto T = [&](int j) { return x + (8 * j + 5) * XYZZ_WORDS; };                   // j < 8 (total of the row sums)
   auto Q = [&](int j) { return x + (8 * j + 6) * XYZZ_WORDS; };                   // j < 8 (W4 temporaries)
   g1_xyzz xi;
-  if (which_in == 0) xi = ld_xyzz(rows + ((size_t)w * BPR_ROWS + t) * XYZZ_WORDS);
+  if (which_in == 0) xi = t < nrows ? ld_xyzz(rows + ((size_t)w * BPR_ROWS + t) * XYZZ_WORDS) : g1_identity();  // rows padded to 256
   else xi = t < BPR_COLS ? ld_xyzz(cols + ((size_t)w * 256 + t) * XYZZ_WORDS) : g1_identity();
   st_xyzz(X(t), xi);
   __syncthreads();

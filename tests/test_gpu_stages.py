@@ -11,16 +11,19 @@ from tests.util import affine64_list
 
 pytestmark = pytest.mark.gpu
 
-H = 1 << 15
 N = 70000  # > 2^16 so every window sees multi-entry buckets
 
 
-@pytest.fixture(scope="module")
-def run(ctx):
+@pytest.fixture(scope="module", params=[16, 14, 12], ids=lambda b: "c%d" % b)
+def run(ctx, request):
+    # every window size the engine supports (the reference's is 16, src/cuzk/msm.rs:79); the CPU stage models take the window
+    # size as a parameter (src/cuzk/test/utils.rs:121 `word_size`)
+    bits = request.param
+    W, H = ctx.window_config(bits)
     points, scalars = cpu.sample_points(60, N), cpu.sample_scalars(61, N)
-    # adversarial rows: digit -2^15 (slot 0), zero scalar, duplicates
+    # adversarial rows: digit -2^(c-1) (slot 0), zero scalar, duplicates
     sc = bytearray(scalars)
-    sc[0:32] = (0x8000).to_bytes(32, "little")
+    sc[0:32] = (H).to_bytes(32, "little")
     sc[32:64] = bytes(32)
     sc[64:96] = sc[96:128]
     pt = bytearray(points)
@@ -28,34 +31,40 @@ def run(ctx):
     points, scalars = bytes(pt), bytes(sc)
     ctx.set_bases(points)
     ctx.set_debug(True)
-    result = ctx.msm(scalars)
-    ctx.set_debug(False)
-    return {"points": points, "scalars": scalars, "result": result, "digits": ctx.read_digits(N), "col_ptr": ctx.read_col_ptr(),
-            "val": ctx.read_val_idxs(N), "buckets": ctx.read_buckets(), "wsums": ctx.read_window_sums(),
-            "model_digits": cpu.decompose_scalars_signed(scalars)}
+    ctx.set_window_bits(bits)
+    try:
+        result = ctx.msm(scalars)
+        assert ctx.last_window_bits() == bits
+    finally:
+        ctx.set_debug(False)
+        ctx.set_window_bits(0)
+    return {"bits": bits, "W": W, "H": H, "points": points, "scalars": scalars, "result": result, "digits": ctx.read_digits(N, W),
+            "col_ptr": ctx.read_col_ptr(W, H), "val": ctx.read_val_idxs(N, W), "buckets": ctx.read_buckets(W, H),
+            "wsums": ctx.read_window_sums(W), "model_digits": cpu.decompose_scalars_signed(scalars, W, bits)}
 
 
 def test_decompose_matches_cpu_model(run):
-    biased = run["model_digits"].astype(np.int64)  # d + 2^15
+    H, W, bits = run["H"], run["W"], run["bits"]
+    biased = run["model_digits"].astype(np.int64)  # d + 2^(c-1)
     d = biased - H
     code = run["digits"].astype(np.int64)
     mag = code & 0x7FFF
     sign = code >> 15
     got = np.where(sign == 1, -np.where(mag == 0, H, mag), mag)
     assert np.array_equal(got, d)
-    # every scalar is reassembled exactly from its digits: s = sum_w d_w 2^(16 w)
+    # every scalar is reassembled exactly from its digits: s = sum_w d_w 2^(c w)
     s0 = int.from_bytes(run["scalars"][96:128], "little")
-    assert sum(int(got[w, 3]) << (16 * w) for w in range(16)) == s0
+    assert sum(int(got[w, 3]) << (bits * w) for w in range(W)) == s0
 
 
 def test_transpose_matches_cpu_model_rows(run):
-    col_ptr, val = run["col_ptr"], run["val"]
-    for w in (0, 7, 15):
-        ref_cp, ref_val = cpu.transpose(run["model_digits"][w], 1 << 16)
+    col_ptr, val, H, W = run["col_ptr"], run["val"], run["H"], run["W"]
+    for w in (0, 7, W - 1):
+        ref_cp, ref_val = cpu.transpose(run["model_digits"][w], 2 * H)
         assert col_ptr[w, 0] == 0 and np.all(np.diff(col_ptr[w].astype(np.int64)) >= 0)
         nz = int(np.count_nonzero(run["model_digits"][w] != H))
         assert col_ptr[w, H] == nz
-        for k in list(range(0, 40)) + [12345, H - 1]:
+        for k in list(range(0, 40)) + [12345 % H, H - 1]:
             got = val[w, col_ptr[w, k]:col_ptr[w, k + 1]]
             pos = set() if k == 0 else set(ref_val[ref_cp[H + k]:ref_cp[H + k + 1]].tolist())
             neg_row = 0 if k == 0 else H - k
@@ -65,15 +74,16 @@ def test_transpose_matches_cpu_model_rows(run):
 
 
 def test_smvp_buckets_match_cpu_model(run):
-    for w in (0, 9, 15):
-        cp, vi = cpu.transpose(run["model_digits"][w], 1 << 16)
-        want = cpu.smvp_signed(cp, vi, run["points"], 1 << 16)
+    H, W = run["H"], run["W"]
+    for w in (0, 9, W - 1):
+        cp, vi = cpu.transpose(run["model_digits"][w], 2 * H)
+        want = cpu.smvp_signed(cp, vi, run["points"], 2 * H)
         got = run["buckets"][w].tobytes()
         assert affine64_list(got) == affine64_list(want)
 
 
 def test_bucket_reduction_matches_cpu_models(run):
-    for w in (0, 5, 15):
+    for w in (0, 5, run["W"] - 1):
         buckets = run["buckets"][w].tobytes()
         want = cpu.to_affine64(cpu.bucket_reduction("running_sum", buckets))
         assert cpu.to_affine64(run["wsums"][w].tobytes()) == want
@@ -83,5 +93,5 @@ def test_bucket_reduction_matches_cpu_models(run):
 
 
 def test_horner_of_window_sums_is_the_result(run):
-    assert cpu.to_affine64(cpu.horner(run["wsums"].tobytes())) == run["result"].to_affine_bytes()
+    assert cpu.to_affine64(cpu.horner(run["wsums"].tobytes(), run["bits"])) == run["result"].to_affine_bytes()
     assert run["result"].to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(run["points"], run["scalars"]))
