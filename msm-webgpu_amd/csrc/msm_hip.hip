@@ -275,14 +275,16 @@ int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, Slot& s) {
 }
 
 // Window size of a WHOLE-MSM launch (the reference hard-codes c = 16 for n >= 2^16, src/cuzk/msm.rs:79).
-// Below ~2^17 points the bucket reduce of 16 x 2^15 mostly empty buckets costs more than the accumulation, so smaller windows
-// win although they need more windows (19 at 14 bits, 22 at 12).  Thresholds: measured single-MSM latency on MI355X
-// (profiles/r02_window_bits_latency.txt).  `nvec` whole MSMs must fit MAXLW local windows.  The window-sharding entry points
-// always use 16-bit windows: their w_begin / w_end index the reference's 16 windows.
+// Measured on MI355X (profiles/r02_window_bits_latency.txt): what a small MSM costs is the DEPTH of the bucket reduce (~50
+// dependent group additions at ~7 us each), which does not shrink with the bucket count -- so smaller windows, which need more
+// windows (19 at 14 bits, 22 at 12), only win while the accumulation itself is negligible: 12 bits up to 2^12 points
+// (0.70 vs 0.80 ms latency, 0.34 vs 0.40 ms pipelined), 16 bits from 2^13 up; 14 bits never wins and is kept as an explicit
+// choice (msm_hip_set_window_bits).  `nvec` whole MSMs must fit MAXLW local windows.  The window-sharding entry points always use
+// 16-bit windows: their w_begin / w_end index the reference's 16 windows.
 inline int pick_window_bits(const msm_hip_ctx* ctx, size_t n, int nvec) {
   static const int forced = [] { const char* e = getenv("MSM_HIP_WINDOW_BITS"); return e ? atoi(e) : 0; }();  // tuning aid
   int bits = ctx->window_bits ? ctx->window_bits : (forced == 12 || forced == 14 || forced == 16 ? forced : 0);
-  if (!bits) bits = n <= ((size_t)1 << 15) ? 12 : (n <= ((size_t)1 << 17) ? 14 : 16);
+  if (!bits) bits = n <= ((size_t)1 << 12) ? 12 : 16;
   while (bits < 16 && nvec * nwin_of(bits) > MAXLW) bits += 2;
   return bits;
 }

@@ -289,6 +289,10 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
       uint32_t s[8], tb[WinCfg<C>::WORDS];
       ld8(sv + i * 8, s);
       bad |= bias_scalar<C>(s, tb);
+      if constexpr (C != 16) {  // the same input contract for every window size: scalars that overflow the reference's
+        uint32_t t16[8];        // 16-bit recode ("final carry is 1", test/utils.rs:150-152) are rejected
+        bad |= bias_scalar<16>(s, t16);
+      }
 #pragma unroll
       for (int w = 0; w < WinCfg<C>::NWIN; w++) {
         const int lw = w - w_begin;

@@ -88,10 +88,10 @@ def test_automatic_choice_follows_n(ctx):
     sc = ctx.sample_scalars(1 << 18, 341)
     ctx.set_bases(pts)
     seen = {}
-    for logn in (10, 15, 16, 17, 18):
+    for logn in (10, 12, 13, 16, 18):
         ctx.msm(sc[: 1 << logn].contiguous())
         seen[logn] = ctx.last_window_bits()
-    assert seen[10] == 12 and seen[18] == 16 and seen[10] <= seen[15] <= seen[16] <= seen[17] <= seen[18]
+    assert seen == {10: 12, 12: 12, 13: 16, 16: 16, 18: 16}  # measured optimum: profiles/r02_window_bits_latency.txt
     # the window-sharding entry points keep the reference's 16-bit windows whatever n is
     ctx.msm_windows(sc[:1000].contiguous(), 3, 5)
     assert ctx.last_window_bits() == 16
