@@ -53,6 +53,12 @@ extern "C" {
                                           its layout could not be verified here, so the canonical format is the contract and
                                           this one an opt-in that saves the caller two from-Montgomery conversions per point) */
 
+#define MSM_HIP_BASES_PRECOMPUTE 4u    /* fixed-base tables (reference README.md "Future work"): also store 2^(16 w) P_i
+                                          for w = 1 .. 15 (16 x the base memory: 1 GiB at 2^20 points; at most 2^24 points).  Whole-MSM
+                                          entry points (run, launch / finish, batch) then put all 16 windows of an MSM into ONE bucket
+                                          set: one stitch + bucket reduce instead of 16, no window combine, up to 64 MSMs per launch.
+                                          Same result.  The window-sharding entry points ignore the tables (table 0 is the plain set). */
+
 typedef struct msm_hip_ctx msm_hip_ctx;
 
 /* ---- context: replaces get_adapter/get_device + per-call buffer/pipeline creation (src/cuzk/gpu.rs:11-54,

@@ -204,10 +204,11 @@ class MsmContext:
             pass
 
     # -- bases
-    def set_bases(self, points, check_on_curve=False, mont256=False):
+    def set_bases(self, points, check_on_curve=False, mont256=False, precompute=False):
         """points: bytes (host, n x 64 B wire format) or a CUDA uint8 tensor holding the same bytes.
-        mont256: the coordinates are x * 2^256 mod p (4 x 64-bit Montgomery limbs, R = 2^256) instead of canonical integers."""
-        flags = (1 if check_on_curve else 0) | (2 if mont256 else 0)
+        mont256: the coordinates are x * 2^256 mod p (4 x 64-bit Montgomery limbs, R = 2^256) instead of canonical integers.
+        precompute: fixed-base tables 2^(16 w) P_i (16 x the memory): whole MSMs then use one bucket set for all windows."""
+        flags = (1 if check_on_curve else 0) | (2 if mont256 else 0) | (4 if precompute else 0)
         if isinstance(points, torch.Tensor) and points.is_cuda:
             t, n = _as_device_u8(points, 64, "points")
             self._order_after_torch(t)

@@ -59,6 +59,7 @@ struct Slot {
   size_t cap_recs = 0;                        // capacity (records) of d_heads / d_tails
   bool ready = false;                         // small buffers + events exist (slots are set up on first use)
   bool timed = false, pending = false, to_host = false;
+  bool merged = false;                        // fixed-base launch: one bucket set (one window sum) per scalar vector
   int timing_level = 0;
   int w_begin = 0, w_count = 0, nvec = 1;  // windows [w_begin, w_begin + w_count) of nvec scalar vectors
   size_t n = 0;
@@ -73,7 +74,8 @@ struct msm_hip_ctx {
   int last_hip_error = 0;
 
   uint32_t* d_bases = nullptr;  // n_bases x 16 words
-  size_t n_bases = 0, cap_bases = 0;
+  size_t n_bases = 0, cap_bases = 0;  // points per table; capacity in point records (16 x n_bases with fixed-base tables)
+  bool precomputed = false;           // d_bases holds the 16 tables 2^(16 w) P_i (MSM_HIP_BASES_PRECOMPUTE)
 
   hipStream_t copy_stream = nullptr;    // H2D of host scalars (created on first use by msm_hip_launch_bn254)
   hipEvent_t input_ready = nullptr;     // a caller's producer stream -> main stream (msm_hip_wait_stream)
@@ -289,6 +291,23 @@ inline int pick_window_bits(const msm_hip_ctx* ctx, size_t n, int nvec) {
   return bits;
 }
 
+// The stitch and the row/column sums are wide VALU-bound kernels on the reduce stream; while they run, the NEXT launch's sort
+// (LDS- and latency-bound, main stream) needs LDS and wave slots on the same CUs.  Unused dynamic LDS caps how many of their
+// workgroups a CU takes (160 KiB per CU), so that a sort workgroup always finds room beside them.  MSM_HIP_REDUCE_LDS_PAD=
+// "<stitch bytes>,<rowcol bytes>" overrides the defaults for tuning.
+inline unsigned reduce_lds_pad(int which) {
+  static const struct Pads {
+    unsigned v[2] = {0, 0};
+    Pads() {
+      if (const char* e = getenv("MSM_HIP_REDUCE_LDS_PAD")) {
+        unsigned a = 0, b = 0;
+        if (sscanf(e, "%u,%u", &a, &b) == 2) v[0] = a, v[1] = b;
+      }
+    }
+  } pads;
+  return pads.v[which];
+}
+
 // MSM_HIP_DEBUG_SYNC=1 (diagnostic): wait after every kernel of a launch and name it on stderr, so that a device fault is
 // pinned to a kernel.  Destroys all overlap; never set for measurements.
 inline bool debug_sync() {
@@ -321,23 +340,27 @@ int err_from_bits(uint32_t bits) {
 // Enqueue one MSM (windows [w_begin, w_begin + w_count)) into slot `s`.  Window sums (canonical Jacobian bytes) go to
 // `wsums_out` (device memory; the slot's own buffer when null); the error word and, if `to_host`, the window sums are
 // copied to the slot's pinned buffer.  Returns without waiting.
-int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count_vec, int nvec, int wbits, Slot& s,
+int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count_vec, int nvec, int wbits, bool merge, Slot& s,
             uint32_t* wsums_out, bool to_host) {
   const uint32_t half = 1u << (wbits - 1);   // bucket slots per window
   const unsigned ncoarse = half / FINE;      // coarse bins that can hold entries
+  // fixed-base tables (`merge`): the w_count_vec windows of a vector feed one bucket set -- one local window of up to
+  // n * w_count_vec entries per vector -- whose entries index the tables (window w of point i = record w * n_bases + i)
+  const size_t merge_nb = merge ? ctx->n_bases : 0;
+  const size_t n_entries = merge ? n * (size_t)w_count_vec : n;
   // `nvec` scalar vectors (contiguous, n x 32 B each) share this launch: local window lw = v * w_count_vec + (w - w_begin);
   // everything after the two scalar-reading kernels only sees w_count = nvec * w_count_vec local windows
-  const int w_count = nvec * w_count_vec;
+  const int w_count = merge ? nvec : nvec * w_count_vec;
   hipStream_t st = ctx->stream, rs = ctx->reduce_stream[(&s - ctx->slot) % NREDUCE];
   // tiles of scalars for the two global sort passes: >= 2048 scalars each, at most MAX_TILES of them
   uint32_t tile_len = 2048;
   if ((n + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n + MAX_TILES - 1) / MAX_TILES) + 255) / 256 * 256);
   const uint32_t tiles = (uint32_t)((n + tile_len - 1) / tile_len);
-  const uint32_t chunk_len = chunk_len_for(n, w_count);
-  const uint32_t chunks = chunks_for(n, chunk_len);
-  const size_t stride = stride_for(n);
+  const uint32_t chunk_len = chunk_len_for(n_entries, w_count);
+  const uint32_t chunks = chunks_for(n_entries, chunk_len);
+  const size_t stride = stride_for(n_entries);
   ctx->last_stride = stride;
-  uint16_t* digits = ctx->debug ? ctx->d_digits : nullptr;
+  uint16_t* digits = ctx->debug && !merge ? ctx->d_digits : nullptr;
   uint32_t* d_err = reinterpret_cast<uint32_t*>(s.d_wsums + WSUM_BYTES);
   if (!wsums_out) wsums_out = reinterpret_cast<uint32_t*>(s.d_wsums);
 
@@ -363,19 +386,19 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     else if (wbits == 14) hipLaunchKernelGGL(KERNEL<14>, dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
     else hipLaunchKernelGGL(KERNEL<12>, dim3(tiles), dim3(256), 0, st, __VA_ARGS__);     \
   } while (0)
-  LAUNCH_BY_WBITS(k_count, d_scalars, n, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, digits, d_err);
+  LAUNCH_BY_WBITS(k_count, d_scalars, n, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, digits, d_err, merge_nb);
   AFTER_KERNEL(ctx, "k_count", st);
   HIP_TRY(ctx, mark(1, false));
   hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total);  // all 128 bins: the scatter scans them
   AFTER_KERNEL(ctx, "k_scan_tiles", st);
   HIP_TRY(ctx, mark(2, false));
   LAUNCH_BY_WBITS(k_scatter_coarse, d_scalars, n, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
-                  ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine);
+                  ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb);
 #undef LAUNCH_BY_WBITS
   AFTER_KERNEL(ctx, "k_scatter_coarse", st);
   HIP_TRY(ctx, mark(3, false));
   const uint32_t* part_hist = nullptr;
-  if (n >= ctx->fine_hist_min_n) {  // large n: the sub-range histograms of huge coarse bins are made once, not by every sharer
+  if (n_entries >= ctx->fine_hist_min_n) {  // large n: the sub-range histograms of huge coarse bins are made once, not by every sharer
     hipLaunchKernelGGL(k_fine_hist, dim3(ncoarse, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
                        ctx->d_part_hist);
     AFTER_KERNEL(ctx, "k_fine_hist", st);
@@ -393,7 +416,9 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
 
   // stitch + bucket reduce on the slot's reduce stream: few waves, long dependent chains
   HIP_TRY(ctx, hipStreamWaitEvent(rs, s.smvp_done, 0));
-  hipLaunchKernelGGL(k_smvp_stitch, dim3(half / 256, w_count), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails,
+  // occupancy caps of the two wide reduce-stream kernels (dynamic LDS they never touch): see reduce_lds_pad()
+  const unsigned pad_stitch = reduce_lds_pad(0), pad_rowcol = reduce_lds_pad(1);
+  hipLaunchKernelGGL(k_smvp_stitch, dim3(half / 256, w_count), dim3(256), pad_stitch, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails,
                      s.d_buckets, s.d_big_queue);
   AFTER_KERNEL(ctx, "k_smvp_stitch", rs);
   hipLaunchKernelGGL(k_smvp_stitch_big, dim3(256), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails, s.d_buckets,
@@ -410,7 +435,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   // serial run per thread before the LDS tree: 16 buckets when many windows are reduced at once (fewest wave-additions),
   // 4 for a few windows (shallowest); measured optimum for 16 and for 2 windows respectively
 #define ROWCOL(LOG_R, LOG_ROWS) \
-  hipLaunchKernelGGL((k_bpr_rowcol<LOG_R, LOG_ROWS>), dim3(bpr_rowcol_blocks<LOG_R, LOG_ROWS>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols)
+  hipLaunchKernelGGL((k_bpr_rowcol<LOG_R, LOG_ROWS>), dim3(bpr_rowcol_blocks<LOG_R, LOG_ROWS>(), w_count), dim3(256), pad_rowcol, rs, s.d_buckets, d_rows, d_cols)
   if (wbits == 16) {
     if (force_logr == 4 || (force_logr == 0 && w_count >= 8)) ROWCOL(4, 8);
     else if (force_logr == 2 || force_logr == 0) ROWCOL(2, 8);
@@ -438,6 +463,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   s.w_count = w_count_vec;
   s.nvec = nvec;
   s.wbits = wbits;
+  s.merged = merge;
   s.n = n;
   s.timed = tl >= 1;
   s.timing_level = tl;
@@ -487,15 +513,20 @@ int check_run_args(msm_hip_ctx* ctx, const void* scalars, size_t n) {
 }
 
 // room for n bases; no run may still be reading the old ones (the SMVP on the main stream)
-int reserve_bases(msm_hip_ctx* ctx, size_t n) {
+constexpr size_t MAX_PRECOMPUTE_POINTS = (size_t)1 << 24;  // 16 tables: 16 GiB, and table indices stay below 2^28
+
+int reserve_bases(msm_hip_ctx* ctx, size_t n, uint32_t flags) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (n > MAX_POINTS) return MSM_HIP_ERR_INVALID_ARG;
+  const bool tables = (flags & MSM_HIP_BASES_PRECOMPUTE) != 0;
+  if (n > MAX_POINTS || (tables && n > MAX_PRECOMPUTE_POINTS)) return MSM_HIP_ERR_INVALID_ARG;
   ctx->n_bases = 0;
-  if (n > ctx->cap_bases) {
+  ctx->precomputed = false;
+  const size_t records = tables ? n * NWIN : n;
+  if (records > ctx->cap_bases) {
     ctx->cap_bases = 0;
-    int rc = dev_alloc(ctx, ctx->d_bases, n * 16);
+    int rc = dev_alloc(ctx, ctx->d_bases, records * 16);
     if (rc) return rc;
-    ctx->cap_bases = n;
+    ctx->cap_bases = records;
   }
   return MSM_HIP_OK;
 }
@@ -511,6 +542,12 @@ int set_bases_from_device(msm_hip_ctx* ctx, const uint32_t* d_xy, size_t n, uint
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   int rc = err_from_bits(bits);
   if (rc) return rc;
+  if (flags & MSM_HIP_BASES_PRECOMPUTE) {  // tables 1 .. 15 behind the plain set: T_w[i] = 2^(16 w) P_i
+    hipLaunchKernelGGL(k_precompute_tables, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_bases, n, n, NWIN);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->precomputed = true;
+  }
   ctx->n_bases = n;
   return MSM_HIP_OK;
 }
@@ -527,7 +564,8 @@ namespace {
 // MSMs per launch of the batch runners: small MSMs cannot fill the GPU one at a time (kernel latencies dominate below
 // ~2^19 points), so up to MAXLW / NWIN = 4 of them -- at most about 2^20 points together -- share one kernel sequence
 size_t batch_group(msm_hip_ctx* ctx, size_t n, size_t batch) {
-  const size_t fit = (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 1)));  // 4 at 16 bits, 3 at 14, 2 at 12
+  // 4 at 16 bits, 3 at 14, 2 at 12; with fixed-base tables every MSM is one local window
+  const size_t fit = ctx->precomputed ? (size_t)MAXLW : (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 1)));
   size_t g = n ? ((size_t)1 << 20) / n : 1;
   if (g > fit) g = fit;
   if (g > batch) g = batch;
@@ -656,7 +694,7 @@ int msm_hip_wait_stream(msm_hip_ctx* ctx, void* producer_stream) {
 int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t n, uint32_t flags) {
   if (!ctx || (!xy_dev && n)) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
-  int rc = reserve_bases(ctx, n);
+  int rc = reserve_bases(ctx, n, flags);
   if (rc) return rc;
   return set_bases_from_device(ctx, static_cast<const uint32_t*>(xy_dev), n, flags);
 }
@@ -664,7 +702,7 @@ int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t 
 int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, uint32_t flags) {
   if (!ctx || (!xy_host && n)) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
-  int rc = reserve_bases(ctx, n);
+  int rc = reserve_bases(ctx, n, flags);
   if (rc) return rc;
   // the wire bytes land in the bases array itself and are converted in place (same 64 B per point): no staging buffer
   if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bases, xy_host, n * 64, hipMemcpyHostToDevice, ctx->stream));
@@ -676,12 +714,13 @@ int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, 
 namespace {
 // windows [w_begin, w_end) -- in units of `wbits`-bit windows -- of `nvec` scalar vectors into `slot`
 int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end, int wbits, int slot,
-                void* window_sums_dev) {
+                void* window_sums_dev, bool merge = false) {
   int rc = check_run_args(ctx, scalars_dev, n);
   if (rc) return rc;
   if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > nwin_of(wbits) || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
   const int w_count = w_end - w_begin;
-  if (nvec < 1 || nvec * w_count > MAXLW) return MSM_HIP_ERR_INVALID_ARG;
+  const int w_local = merge ? nvec : nvec * w_count;  // bucket sets of the launch
+  if (nvec < 1 || w_local > MAXLW) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   Slot& s = ctx->slot[slot];
   if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;  // its result was never collected (msm_hip_finish_bn254 / msm_hip_slot_sync)
@@ -691,26 +730,27 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
   s.w_count = w_count;
   s.nvec = nvec;
   s.wbits = wbits;
+  s.merged = merge;
   s.to_host = window_sums_dev == nullptr;
   if (n == 0) {  // identity window sums, nothing to compute
     s.pending = true;
     s.timed = false;
     memset(s.h_wsums, 0, WSUM_BYTES + 4);
     if (window_sums_dev) {
-      HIP_TRY(ctx, hipMemsetAsync(window_sums_dev, 0, (size_t)nvec * w_count * 96, ctx->reduce_stream[slot % NREDUCE]));
+      HIP_TRY(ctx, hipMemsetAsync(window_sums_dev, 0, (size_t)w_local * 96, ctx->reduce_stream[slot % NREDUCE]));
       HIP_TRY(ctx, hipEventRecord(s.done, ctx->reduce_stream[slot % NREDUCE]));
     }
     return MSM_HIP_OK;
   }
-  if ((rc = ensure_work(ctx, n, nvec * w_count, wbits, s))) return rc;
+  if ((rc = ensure_work(ctx, merge ? n * (size_t)w_count : n, w_local, wbits, s))) return rc;
   if (ctx->scalar_format == MSM_HIP_SCALARS_MONT256 && (size_t)nvec * n > ctx->cap_scalar_conv) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cap_scalar_conv = 0;
     if ((rc = dev_alloc(ctx, ctx->d_scalar_conv, (size_t)nvec * n * 8))) return rc;
     ctx->cap_scalar_conv = (size_t)nvec * n;
   }
-  return enqueue(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, nvec, wbits, s, static_cast<uint32_t*>(window_sums_dev),
-                 window_sums_dev == nullptr);
+  return enqueue(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, nvec, wbits, merge, s,
+                 static_cast<uint32_t*>(window_sums_dev), window_sums_dev == nullptr);
 }
 }  // namespace
 
@@ -720,6 +760,8 @@ int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scal
                                               int slot, void* window_sums_dev) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
   // whole MSMs whose sums stay in the slot (finish / finish_batch combines them): the window size follows n
+  if (w_begin == 0 && w_end == NWIN && window_sums_dev == nullptr && nvec >= 1 && ctx->precomputed && n > 0)
+    return launch_impl(ctx, scalars_dev, n, nvec, 0, NWIN, WBITS, slot, nullptr, true);  // fixed-base tables: one bucket set per vector
   if (w_begin == 0 && w_end == NWIN && window_sums_dev == nullptr && nvec >= 1 && nvec * NWIN <= MAXLW) {
     const int wbits = pick_window_bits(ctx, n, nvec);
     return launch_impl(ctx, scalars_dev, n, nvec, 0, nwin_of(wbits), wbits, slot, nullptr);
@@ -754,8 +796,9 @@ int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot) {
 int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   if (!ctx || !out_xyz || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   Slot& s = ctx->slot[slot];
-  const int nwin = nwin_of(s.wbits);
-  if (!s.pending || !s.to_host || s.w_count != nwin) return MSM_HIP_ERR_INVALID_ARG;
+  // fixed-base launches leave ONE sum per vector (every table already carries its power of two): nothing to combine but the copy
+  const int nwin = s.merged ? 1 : nwin_of(s.wbits);
+  if (!s.pending || !s.to_host || s.w_count != nwin_of(s.wbits)) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   int rc = wait_slot(ctx, s);
   if (rc) return rc;

@@ -164,6 +164,39 @@ __global__ void __launch_bounds__(256) k_convert_points(const uint32_t* in, uint
 }
 
 
+// Fixed-base tables (reference README.md "Future work": the Elastic-MSM precomputation trade-off): with
+// T_w[i] = 2^(16 w) P_i stored for every window, sum_i s_i P_i = sum_i sum_w d_{i,w} T_w[i] needs ONE bucket set for all
+// windows -- one stitch / bucket reduce instead of 16 and no window combine -- for 16 x the base memory.
+// bases[(w * nb + i)][16]: table w behind table w - 1; table 0 is the plain converted base set (so every entry point that does
+// not use the tables keeps working on the same buffer).  One thread per point: 16 doublings per table in XYZZ, then back to
+// affine (one inversion by Fermat, a^(p-2)).
+__device__ __constant__ uint32_t c_pm2[8] = {FQ_P32[0] - 2u, FQ_P32[1], FQ_P32[2], FQ_P32[3], FQ_P32[4], FQ_P32[5], FQ_P32[6], FQ_P32[7]};
+__device__ __forceinline__ fq fq_inv(const fq& a) {  // a exact, nonzero; result exact, < 2p
+  fq acc = fq_one();
+  for (int bit = 253; bit >= 0; bit--) {
+    acc = fq_sqr(acc);
+    if ((c_pm2[bit >> 5] >> (bit & 31)) & 1u) acc = fq_mul(acc, a);
+  }
+  return acc;
+}
+__global__ void __launch_bounds__(256) k_precompute_tables(uint32_t* __restrict__ bases, size_t n, size_t nb, int num_tables) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const fq px = ld_fq(bases + i * 16), py = ld_fq(bases + i * 16 + 8);
+  g1_xyzz acc = g1_from_affine(px, py);
+  for (int w = 1; w < num_tables; w++) {
+#pragma unroll 1
+    for (int k = 0; k < WBITS; k++) acc = g1_double(acc);
+    // affine again: x = X / ZZ, y = Y / ZZZ with one inversion of ZZ * ZZZ (a point of prime order never doubles to infinity)
+    const fq t = fq_inv(fq_mul(acc.zz, acc.zzz));
+    const fq x = fq_canonical(fq_mul(acc.x, fq_mul(t, acc.zzz)));
+    const fq y = fq_canonical(fq_mul(acc.y, fq_mul(t, acc.zz)));
+    st_fq(bases + ((size_t)w * nb + i) * 16, x);
+    st_fq(bases + ((size_t)w * nb + i) * 16 + 8, y);
+    acc = g1_from_affine(x, y);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ stage 1+2: recode + sort
 // Signed 16-bit digit recode (≙ decompose_scalars.template.wgsl:83-112, CPU model test/utils.rs:121-161):
 //   d = raw + carry; if d >= 2^15 { d -= 2^16; carry = 1 }  -- computed per window without the serial carry chain.  Signed-magnitude code = sign << 15 | (|d| & 0x7fff):
@@ -275,10 +308,12 @@ template <int C>
 __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles,
                                                int w_begin, int w_count, int nvec, size_t vec_stride,
                                                uint32_t* __restrict__ counts, uint16_t* __restrict__ digits_dbg,
-                                               uint32_t* __restrict__ err) {
+                                               uint32_t* __restrict__ err, size_t merge_nb) {
+  // merge_nb != 0 (fixed-base tables, see k_precompute_tables): every window of vector v feeds ONE bucket set, local window v
   __shared__ uint32_t cnt[MAXLW * NCOARSE];
   const int tid = threadIdx.x;
-  for (int i = tid; i < nvec * w_count * NCOARSE; i += 256) cnt[i] = 0;
+  const int w_eff = merge_nb ? nvec : nvec * w_count;
+  for (int i = tid; i < w_eff * NCOARSE; i += 256) cnt[i] = 0;
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * tile_len;
   const size_t end = base + tile_len < n ? base + tile_len : n;
@@ -297,10 +332,10 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
       for (int w = 0; w < WinCfg<C>::NWIN; w++) {
         const int lw = w - w_begin;
         if (lw >= 0 && lw < w_count) {
-          const int le = v * w_count + lw;
+          const int le = merge_nb ? v : v * w_count + lw;
           const uint32_t code = code_of_window<C>(tb, w);
           if (code != 0) atomicAdd(&cnt[le * NCOARSE + ((code & 0x7fffu) >> 8)], 1u);
-          if (digits_dbg) digits_dbg[(size_t)le * n + i] = (uint16_t)code;
+          if (digits_dbg) digits_dbg[((size_t)v * w_count + lw) * n + i] = (uint16_t)code;
         }
       }
     }
@@ -308,7 +343,6 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
   if (bad) atomicOr(err, ERRBIT_SCALAR_CARRY);
   __syncthreads();
   // counts[lw][tile][bin]
-  const int w_eff = nvec * w_count;
   for (int i = tid; i < w_eff * NCOARSE; i += 256)
     counts[((size_t)(i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[i];
 }
@@ -365,7 +399,7 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
                                                         const uint32_t* __restrict__ counts,
                                                         const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr,
                                                         uint32_t* __restrict__ tmp_val,
-                                                        uint8_t* __restrict__ tmp_fine) {
+                                                        uint8_t* __restrict__ tmp_fine, size_t merge_nb) {
   __shared__ uint32_t gpos[MAXLW * NCOARSE];  // global write cursor of every (window, coarse bin) run of this tile
   __shared__ uint32_t hist[NCOARSE];
   __shared__ uint32_t lstart[NCOARSE];
@@ -376,7 +410,7 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
   const int tid = threadIdx.x;
   // start of every (window, coarse bin): exclusive scan of the window's 128 bin totals -- a pair of waves per window, two
   // windows per step; workgroup 0 also publishes them as coarse_ptr[lw][0..128] for k_sort_fine
-  const int w_eff = nvec * w_count;  // local windows of all vectors of this launch
+  const int w_eff = merge_nb ? nvec : nvec * w_count;  // local windows of all vectors of this launch
   for (int i0 = 0; i0 < w_eff * NCOARSE; i0 += 256) {
     const int i = i0 + tid, lw = i / NCOARSE, bin = i % NCOARSE, lane = tid & 63;
     const bool live = i < w_eff * NCOARSE;  // odd window counts: the last step has one idle pair of waves
@@ -414,7 +448,9 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
 #pragma unroll
     for (int w = 0; w < WinCfg<C>::NWIN; w++) {
       if (w < w_begin || w >= w_begin + w_count) continue;  // block-uniform
-      const int lw = v * w_count + (w - w_begin);
+      // fixed-base tables: window w of point i is table entry w * merge_nb + i, and all windows share local window v
+      const int lw = merge_nb ? v : v * w_count + (w - w_begin);
+      const uint32_t idx_base = merge_nb ? (uint32_t)(w * merge_nb) : 0u;
       if (tid < NCOARSE) hist[tid] = 0;
       __syncthreads();
       uint32_t rank[8];
@@ -435,7 +471,7 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
         if (code) {
           const uint32_t slot = code & 0x7fffu, bin = slot >> 8;
           const uint32_t e = lstart[bin] + rank[j];
-          st_val[e] = (uint32_t)(sub + (size_t)j * 256 + tid) | ((code >> 15) << 31);
+          st_val[e] = (idx_base + (uint32_t)(sub + (size_t)j * 256 + tid)) | ((code >> 15) << 31);
           st_fine[e] = (uint8_t)(slot & 0xffu);
           st_dst[e] = gpos[lw * NCOARSE + bin] + rank[j];
         }
