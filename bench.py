@@ -264,23 +264,38 @@ def main():
         latency_ms = sorted(lat)[len(lat) // 2]
 
     # timing scopes B and C of SURVEY.md section 8(d), informational (never `value`): B = scalars arrive from host memory
-    # (32 MiB H2D per MSM at 2^20), bases resident; C = one-shot incl. context creation and base upload (≙ compute_msm)
+    # (32 MiB H2D per MSM at 2^20), bases resident -- as the latency of one call and as the throughput of two slots alternating
+    # (msm_hip_launch_bn254: the copy of MSM i+1 runs on the copy stream under the device work of MSM i); C = one-shot incl.
+    # context creation, base upload and destruction (≙ the reference's compute_msm call shape)
     scope_ms = None
     if world == 1 and emulate <= 1 and args.logn <= 22:
-        sb_host = scalar_sets[0].cpu().numpy().tobytes()
+        sb_host = [s.cpu().numpy().tobytes() for s in scalar_sets]
         pb_host = points.cpu().numpy().tobytes()
         tb = []
-        for _ in range(3):
+        for i in range(5):
             t1 = time.perf_counter()
-            ctx.msm(sb_host)
+            ctx.msm(sb_host[i & 1])
             tb.append((time.perf_counter() - t1) * 1e3)
+        k = 12
+        ctx.launch_host(sb_host[0], 0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(1, k):
+            ctx.launch_host(sb_host[i & 1], i & 1)
+            ctx.finish((i - 1) & 1)
+        ctx.finish((k - 1) & 1)
+        b_pipe = (time.perf_counter() - t1) * 1e3 / k
         import ctypes
 
         one = ctypes.create_string_buffer(96)
-        t1 = time.perf_counter()
-        rc1 = m.lib().msm_hip_msm_bn254_g1(pb_host, sb_host, n, one)  # creates a context, uploads, runs, destroys
-        assert rc1 == 0, rc1
-        scope_ms = {"B_host_scalars_resident_bases": sorted(tb)[1], "C_one_shot_with_base_upload": (time.perf_counter() - t1) * 1e3}
+        tc = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            rc1 = m.lib().msm_hip_msm_bn254_g1(pb_host, sb_host[0], n, one)  # creates a context, uploads, runs, destroys
+            tc.append((time.perf_counter() - t1) * 1e3)
+            assert rc1 == 0, rc1
+        scope_ms = {"B_host_scalars_resident_bases_latency": sorted(tb)[2], "B_host_scalars_two_slots_pipelined": b_pipe,
+                    "C_one_shot_with_base_upload": sorted(tc)[1]}
 
     # sharded runs: check the gathered + combined result against this rank's own whole 16-window MSM (outside the timed region)
     sharded_ok = None
