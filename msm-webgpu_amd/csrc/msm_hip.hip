@@ -291,23 +291,6 @@ inline int pick_window_bits(const msm_hip_ctx* ctx, size_t n, int nvec) {
   return bits;
 }
 
-// The stitch and the row/column sums are wide VALU-bound kernels on the reduce stream; while they run, the NEXT launch's sort
-// (LDS- and latency-bound, main stream) needs LDS and wave slots on the same CUs.  Unused dynamic LDS caps how many of their
-// workgroups a CU takes (160 KiB per CU), so that a sort workgroup always finds room beside them.  MSM_HIP_REDUCE_LDS_PAD=
-// "<stitch bytes>,<rowcol bytes>" overrides the defaults for tuning.
-inline unsigned reduce_lds_pad(int which) {
-  static const struct Pads {
-    unsigned v[2] = {0, 0};
-    Pads() {
-      if (const char* e = getenv("MSM_HIP_REDUCE_LDS_PAD")) {
-        unsigned a = 0, b = 0;
-        if (sscanf(e, "%u,%u", &a, &b) == 2) v[0] = a, v[1] = b;
-      }
-    }
-  } pads;
-  return pads.v[which];
-}
-
 // MSM_HIP_DEBUG_SYNC=1 (diagnostic): wait after every kernel of a launch and name it on stderr, so that a device fault is
 // pinned to a kernel.  Destroys all overlap; never set for measurements.
 inline bool debug_sync() {
@@ -416,9 +399,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
 
   // stitch + bucket reduce on the slot's reduce stream: few waves, long dependent chains
   HIP_TRY(ctx, hipStreamWaitEvent(rs, s.smvp_done, 0));
-  // occupancy caps of the two wide reduce-stream kernels (dynamic LDS they never touch): see reduce_lds_pad()
-  const unsigned pad_stitch = reduce_lds_pad(0), pad_rowcol = reduce_lds_pad(1);
-  hipLaunchKernelGGL(k_smvp_stitch, dim3(half / 256, w_count), dim3(256), pad_stitch, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails,
+  hipLaunchKernelGGL(k_smvp_stitch, dim3(half / 256, w_count), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails,
                      s.d_buckets, s.d_big_queue);
   AFTER_KERNEL(ctx, "k_smvp_stitch", rs);
   hipLaunchKernelGGL(k_smvp_stitch_big, dim3(256), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails, s.d_buckets,
@@ -435,7 +416,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   // serial run per thread before the LDS tree: 16 buckets when many windows are reduced at once (fewest wave-additions),
   // 4 for a few windows (shallowest); measured optimum for 16 and for 2 windows respectively
 #define ROWCOL(LOG_R, LOG_ROWS) \
-  hipLaunchKernelGGL((k_bpr_rowcol<LOG_R, LOG_ROWS>), dim3(bpr_rowcol_blocks<LOG_R, LOG_ROWS>(), w_count), dim3(256), pad_rowcol, rs, s.d_buckets, d_rows, d_cols)
+  hipLaunchKernelGGL((k_bpr_rowcol<LOG_R, LOG_ROWS>), dim3(bpr_rowcol_blocks<LOG_R, LOG_ROWS>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols)
   if (wbits == 16) {
     if (force_logr == 4 || (force_logr == 0 && w_count >= 8)) ROWCOL(4, 8);
     else if (force_logr == 2 || force_logr == 0) ROWCOL(2, 8);
