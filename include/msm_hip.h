@@ -230,6 +230,7 @@ int msm_hip_read_window_sums(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes);
  *      fq op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg ; a, b, out: n x 32 B
  *             5 mul, 6 sqr, 7 a*b + b*a, 8 (a+b)*2a, 9 (a+b)^2 through the SMVP's inline-assembly multipliers (fq29_asm.h)
  *      g1 op: 0 add, 1 double(a), 2 a + affine(b: n x 64 B) ; a, b, out: n x 96 B Jacobian
+ *             3 a + b - b + b, 4 a - b - b through the SMVP's signed-state mixed addition (g1_madd_w, csrc/g1.h)
  *      g1_mul_u32: out[i] = k[i] * a[i] (≙ double_and_add) ---- */
 int msm_hip_test_fq_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
 int msm_hip_test_g1_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);

@@ -437,7 +437,7 @@ class MsmContext:
         return out.raw[:32 * n]
 
     def g1_op(self, op, a, b=None):
-        code = {"add": 0, "double": 1, "add_affine": 2}[op]
+        code = {"add": 0, "double": 1, "add_affine": 2, "madd_w_pmp": 3, "madd_w_mm": 4}[op]
         n = len(a) // 96
         out = C.create_string_buffer(max(96 * n, 1))
         _check(lib().msm_hip_test_g1_op(self._h, code, a, b, out, n), "msm_hip_test_g1_op")

@@ -312,6 +312,17 @@ FQ_HD fq fq_from_mont(const fq& x) {  // x normal, value <= 84p
   return fq_canonical(fq_mul(x, one));
 }
 
+// y exact (limbs < 2^29), value <= p  ->  2p - y with lazy limbs (< 2^30), no borrow chain: fit for a multiplier operand
+FQ_HD fq fq_neg_lazy(const fq& y) {
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    FQ_ASSERT(FQ_2P_LAZY29[i] >= y.v[i], "fq_neg_lazy: limb borrow");
+    r.v[i] = FQ_2P_LAZY29[i] - y.v[i];
+  }
+  return r;
+}
+
 FQ_HD fq fq_neg_canonical(const fq& y) {  // y canonical in [0,p) -> p - y (or 0)
   uint32_t z = 0;
 #pragma unroll

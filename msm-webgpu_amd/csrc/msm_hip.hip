@@ -1074,8 +1074,8 @@ int msm_hip_test_fq_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t
 
 int msm_hip_test_g1_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
   if (n == 0) return MSM_HIP_OK;
-  if (op < 0 || op > 2 || (op != 1 && !b)) return MSM_HIP_ERR_INVALID_ARG;
-  const size_t b_bytes = op == 0 ? n * 96 : (op == 2 ? n * 64 : 0);
+  if (op < 0 || op > 4 || (op != 1 && !b)) return MSM_HIP_ERR_INVALID_ARG;
+  const size_t b_bytes = op == 0 ? n * 96 : (op >= 2 ? n * 64 : 0);
   uint8_t *da, *db, *dout;
   int rc = run_hook(ctx, a, n * 96, op == 1 ? nullptr : b, b_bytes, out, n * 96, da, db, dout);
   if (rc) return rc;

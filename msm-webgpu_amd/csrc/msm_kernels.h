@@ -783,6 +783,7 @@ __global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restri
   const uint32_t* vi = val_idxs + (size_t)lw * stride;
   const size_t rec = ((size_t)lw * chunks + c) * REC_WORDS;
   g1_xyzz acc = g1_identity();
+  bool wneg = false;  // sign carried by acc.y (g1_madd_w); applied when the accumulator is flushed
   // the point of entry t + 1 is requested before the addition of entry t starts, so that a gather that misses the
   // Infinity Cache (bases beyond 256 MiB) is covered by ~5 us of arithmetic instead of stalling the wave
   uint4 quad = *reinterpret_cast<const uint4*>(vi + begin);  // chunk starts are multiples of 4 entries
@@ -792,8 +793,7 @@ __global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restri
   ld8(bases + (size_t)(vnext & 0x7fffffffu) * 16 + 8, wy);
   for (uint32_t t = begin; t < end; t++) {
     const uint32_t v = vnext;
-    const fq px = fq_unpack(wx);
-    fq py = fq_unpack(wy);
+    const fq px = fq_unpack(wx), py = fq_unpack(wy);
     if (t + 1 < end) {
       const uint32_t k = (t + 1 - begin) & 3u;
       if (k == 0) quad = *reinterpret_cast<const uint4*>(vi + t + 1);
@@ -803,15 +803,16 @@ __global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restri
       ld8(pt + 8, wy);
     }
     if (t == run_end) {  // the run of slot s ended inside this chunk
-      if (run_begin >= begin) st_rec(buckets + ((size_t)lw * half + s) * REC_WORDS, acc);
-      else st_rec(heads + rec, acc);
+      if (run_begin >= begin) st_rec(buckets + ((size_t)lw * half + s) * REC_WORDS, g1_unsigned(acc, wneg));
+      else st_rec(heads + rec, g1_unsigned(acc, wneg));
       acc = g1_identity();
+      wneg = false;
       run_begin = run_end;
       do { s++; run_end = cp[s + 1]; } while (run_end == run_begin);  // next non-empty slot (exists: t < nw)
     }
-    if (v >> 31) py = fq_neg_canonical(py);
-    g1_madd(acc, px, py);
+    g1_madd_w(acc, wneg, px, py, (v >> 31) != 0u);  // bit 31: the digit is negative
   }
+  acc = g1_unsigned(acc, wneg);
   // last run of the chunk: complete only if it started here and ends exactly at or before `end`
   if (run_begin >= begin && run_end <= end) {
     st_rec(buckets + ((size_t)lw * half + s) * REC_WORDS, acc);
@@ -1380,10 +1381,22 @@ __global__ void __launch_bounds__(256) k_test_g1(int op, const uint32_t* __restr
     r = g1_add(p, ld_jacobian_plain(b + i * 24));
   } else if (op == 1) {
     r = g1_double(p);
-  } else {
+  } else if (op == 2) {
     const fq qx = fq_to_mont(ld_fq(b + i * 16)), qy = fq_to_mont(ld_fq(b + i * 16 + 8));
     g1_madd(p, qx, qy);
     r = p;
+  } else {  // the SMVP's signed-state form (g1_madd_w): 3: p + q - q + q ; 4: p - q - q  (every sign state, both digit signs)
+    const fq qx = fq_to_mont(ld_fq(b + i * 16)), qy = fq_to_mont(ld_fq(b + i * 16 + 8));
+    bool wneg = false;
+    if (op == 3) {
+      g1_madd_w(p, wneg, qx, qy, false);
+      g1_madd_w(p, wneg, qx, qy, true);
+      g1_madd_w(p, wneg, qx, qy, false);
+    } else {
+      g1_madd_w(p, wneg, qx, qy, true);
+      g1_madd_w(p, wneg, qx, qy, true);
+    }
+    r = g1_unsigned(p, wneg);
   }
   st_jacobian_plain(out + i * 24, r);
 }

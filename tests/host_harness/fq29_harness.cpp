@@ -55,6 +55,13 @@ void h_g1_madd_chain(const uint8_t* acc, const uint8_t* pts, size_t m, uint8_t* 
   for (size_t i = 0; i < m; i++) g1_madd(a, load_fq(pts + 64 * i), load_fq(pts + 64 * i + 32));
   store_jac(out, a);
 }
+// the SMVP's signed-state form: acc += (negs[i] ? -pts[i] : pts[i]) through g1_madd_w, sign applied at the end
+void h_g1_madd_w_chain(const uint8_t* acc, const uint8_t* pts, const uint8_t* negs, size_t m, uint8_t* out) {
+  g1_xyzz a = load_jac(acc);
+  bool wneg = false;
+  for (size_t i = 0; i < m; i++) g1_madd_w(a, wneg, load_fq(pts + 64 * i), load_fq(pts + 64 * i + 32), negs[i] != 0);
+  store_jac(out, g1_unsigned(a, wneg));
+}
 // op: 0 add, 1 double(a)
 void h_g1_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
   for (size_t i = 0; i < n; i++) {

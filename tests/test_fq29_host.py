@@ -108,3 +108,35 @@ def test_generated_headers_are_in_sync():
     for script, header in (("gen_constants.py", "bn254_constants.h"), ("gen_fq29_asm.py", "fq29_asm.h")):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)], capture_output=True, text=True, check=True).stdout
         assert out == open(os.path.join(ROOT, "msm-webgpu_amd", "csrc", header)).read(), header
+
+
+def test_signed_state_mixed_addition_chain(H):
+    # g1_madd_w (the SMVP's form: the accumulator keeps +-Y, the sign is applied at the flush) against affine big-integer
+    # arithmetic: random signs, the doubling and cancellation cases in both sign states, long chains (bounds asserted: -DFQ_CHECK)
+    r = rng(6)
+    pts = ref.sample_points(9, 40)
+    out = C.create_string_buffer(96)
+
+    def run(acc, chain, negs):
+        H.h_g1_madd_w_chain(jacobian_bytes(acc, r), ref.points_to_bytes(chain), bytes(negs), len(chain), out)
+        want = acc
+        for q, ng in zip(chain, negs):
+            want = ref.add(want, ref.neg(q) if ng else q)
+        assert cpu.to_affine64(out.raw) == ref.affine_to_bytes64(want), (negs,)
+
+    for trial in range(30):
+        k = r.randrange(1, 12)
+        run(None if trial % 3 == 0 else pts[trial], [pts[r.randrange(40)] for _ in range(k)], [r.randrange(2) for _ in range(k)])
+    a, b = pts[0], pts[1]
+    run(None, [a, a], [0, 0])            # P + P from the fresh (unsigned) state: doubling
+    run(None, [a, b, ref.add(a, b)], [0, 0, 0])   # doubling met in the signed state (after two steps W = -Y ... +Y)
+    run(None, [a, b, ref.add(a, b)], [0, 0, 1])   # cancellation in that state
+    run(None, [a, a], [0, 1])            # P - P
+    run(None, [a, a, b], [1, 0, 0])      # -P + P = identity, then a fresh start
+    run(b, [a, ref.add(a, b)], [0, 1])   # (b + a) - (a + b)
+    run(b, [a, ref.add(a, b)], [0, 0])   # (b + a) + (a + b): doubling with W = -Y
+    lp = cpu.sample_points(78, 4000)
+    negs = bytes(r.randrange(2) for _ in range(4000))
+    H.h_g1_madd_w_chain(bytes(96), lp, negs, 4000, out)
+    sc = b"".join(b32(ref.R - 1 if ng else 1) for ng in negs)
+    assert cpu.to_affine64(out.raw) == cpu.to_affine64(cpu.cpu_msm(lp, sc))

@@ -81,3 +81,17 @@ def test_assembly_multipliers_match_oracle(ctx, op):
     want = {"mul_asm": lambda: mul(a, b), "sqr_asm": lambda: mul(a, a), "mul2_asm": lambda: add(mul(a, b), mul(b, a)),
             "mul_asm_lazy": lambda: mul(add(a, b), add(a, a)), "sqr_asm_lazy": lambda: mul(add(a, b), add(a, b))}[op]()
     assert ctx.fq_op(op, a, b) == want
+
+
+def test_signed_state_mixed_addition(ctx):
+    # g1_madd_w, the SMVP's inner operation (W = +-Y state, lazily negated point, sign applied at the flush), every sign state
+    r = rng(17)
+    pts = _points(60, 34)
+    a = pts[:25] + [None, pts[7], ref.neg(pts[8]), pts[9], None]
+    q = pts[25:50] + [pts[6], pts[7], pts[8], ref.neg(pts[9]), pts[10]]
+    A = b"".join(jacobian_bytes(x, r) for x in a)
+    Q = ref.points_to_bytes(q)
+    got = affine64_list(ctx.g1_op("madd_w_pmp", A, Q))
+    assert got == [ref.affine_to_bytes64(ref.add(x, y)) for x, y in zip(a, q)]                      # a + q - q + q
+    got = affine64_list(ctx.g1_op("madd_w_mm", A, Q))
+    assert got == [ref.affine_to_bytes64(ref.add(ref.add(x, ref.neg(y)), ref.neg(y))) for x, y in zip(a, q)]  # a - q - q
