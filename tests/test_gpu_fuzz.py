@@ -12,9 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_fuzz_against_oracle(built, capsys):
     argv = sys.argv
-    sys.argv = ["fuzz_gpu.py", "40", "20261003"]
+    sys.argv = ["fuzz_gpu.py", "60", "20261004"]
     try:
         runpy.run_path(os.path.join(ROOT, "tools", "fuzz_gpu.py"), run_name="__main__")
     finally:
         sys.argv = argv
-    assert "fuzz ok: 40 cases" in capsys.readouterr().out
+    assert "fuzz ok: 60 cases" in capsys.readouterr().out

@@ -12,6 +12,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rnd = random.Random(seed)
 ctx = m.MsmContext(0)
+mg = {}  # lazily created msm_hip_mgpu handles by rank count (several contexts on this one GPU, pinned-buffer gather)
 R = ref.R
 special_n = [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8193, 16385, 32769, 65535, 65537]
 t0 = time.time()
@@ -44,8 +45,8 @@ for case in range(cases):
         sc = [base[i % max(1, n // 5)] for i in range(n)]
     sb = ref.scalars_to_bytes(sc)
     want = cpu.to_affine64(cpu.cpu_msm(points, sb))
-    ctx.set_bases(points)
-    mode = rnd.choice(["host", "device", "windows", "batch", "group", "hostbatch", "mont"])
+    mode = rnd.choice(["host", "device", "windows", "batch", "group", "hostbatch", "mont", "bits", "tables", "tables_batch", "hostpipe", "mgpu"])
+    ctx.set_bases(points, precompute=mode.startswith("tables"))
     if mode == "mont":
         # both inputs as R = 2^256 Montgomery words (MSM_HIP_BASES_MONT256, MSM_HIP_SCALARS_MONT256)
         PM, RM = ref.P, ref.R
@@ -57,8 +58,33 @@ for case in range(cases):
             got = ctx.msm(sm)
         finally:
             ctx.set_scalar_format(False)
-    elif mode == "host":
+    elif mode == "host" or mode == "tables":
         got = ctx.msm(sb)
+    elif mode == "bits":
+        # every window size, host and device scalars
+        bits = rnd.choice([12, 14, 16])
+        ctx.set_window_bits(bits)
+        try:
+            got = ctx.msm(sb) if rnd.random() < 0.5 else ctx.msm(torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda())
+            assert ctx.last_window_bits() == bits
+        finally:
+            ctx.set_window_bits(0)
+    elif mode == "tables_batch":
+        k = rnd.randrange(1, 7)
+        got = ctx.msm_batch(sb * k, n)[k - 1]
+    elif mode == "hostpipe":
+        # host scalars through the copy stream, three slots in flight
+        for slot in range(3):
+            ctx.launch_host(sb, slot)
+        outs = [ctx.finish(slot) for slot in range(3)]
+        assert outs[0] == outs[1] == outs[2]
+        got = outs[2]
+    elif mode == "mgpu":
+        world = rnd.choice([1, 2, 3, 5, 8])
+        if world not in mg:
+            mg[world] = m.MultiGpuMsm([0] * world, "host")
+        mg[world].set_bases(points)
+        got = mg[world].msm(sb) if rnd.random() < 0.6 else mg[world].msm_batch(sb + sb, n)[1]
     elif mode == "device":
         t = torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda()
         got = ctx.msm(t)
