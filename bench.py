@@ -179,6 +179,10 @@ def main():
     group1 = 1 if sharded else max(1, min(4, (1 << 20) // n))
     group1_scalars = torch.cat([scalar_sets[k & 1] for k in range(group1)], dim=0).contiguous() if group1 > 1 else None
 
+    # launches in flight on one GPU (4 result slots): 2 where one launch is one large MSM, 3 for grouped small MSMs, whose host
+    # combines (4 per launch) would otherwise sit between launches (measured: +5 % at 2^16, +3 % at 2^18, nothing at 2^20)
+    depth1 = max(1, min(4, int(os.environ.get("BENCH_PIPE_DEPTH", "0")) or (3 if group1 > 1 else 2)))
+
     def group_sizes(count, g):
         """`count` MSMs in ceil(count / g) launches of nearly equal size (a small remainder launch would run at the
         one-MSM-per-launch rate)."""
@@ -192,28 +196,28 @@ def main():
     def run_steps(count, record):
         """`count` MSMs; returns the last result.  N = 1 pipelines the host combine of MSM i with the device work of i+1."""
         result = None
-        if not sharded and group1 == 1:
-            ctx.launch(scalar_sets[0], 0)
-            for i in range(1, count):
-                ctx.launch(scalar_sets[i & 1], i & 1)
-                result = ctx.finish((i - 1) & 1)
-                if record:
-                    note_stages(w_local)
-            result = ctx.finish((count - 1) & 1)
-            if record:
-                note_stages(w_local)
-        elif not sharded:
-            # small MSMs (n < 2^19): up to 4 whole MSMs per launch, as msm_hip_run_batch_* does; same two-slot pipeline
+        if not sharded:
+            # one GPU: a launch holds one MSM (n >= 2^19) or up to `group1` whole small MSMs (as msm_hip_run_batch_* does); `depth`
+            # launches in flight over the engine's result slots, so that the host window combines (47 us per MSM) and the launch
+            # calls of one launch run under the device work of the others
             sizes = group_sizes(count, group1)
+            pending = []
             for k, gs in enumerate(sizes):
-                ctx.launch_batch(group1_scalars[: gs * n], n, k & 1)
-                if k:
-                    result = ctx.finish_batch((k - 1) & 1, sizes[k - 1])[-1]
+                slot = k % depth1
+                if group1 == 1:
+                    ctx.launch(scalar_sets[k & 1], slot)
+                else:
+                    ctx.launch_batch(group1_scalars[: gs * n], n, slot)
+                pending.append((slot, gs))
+                if len(pending) == depth1:
+                    slot0, gs0 = pending.pop(0)
+                    result = ctx.finish(slot0) if group1 == 1 else ctx.finish_batch(slot0, gs0)[-1]
                     if record:
-                        note_stages(sizes[k - 1] * w_local)
-            result = ctx.finish_batch((len(sizes) - 1) & 1, sizes[-1])[-1]
-            if record:
-                note_stages(sizes[-1] * w_local)
+                        note_stages(gs0 * w_local)
+            for slot0, gs0 in pending:
+                result = ctx.finish(slot0) if group1 == 1 else ctx.finish_batch(slot0, gs0)[-1]
+                if record:
+                    note_stages(gs0 * w_local)
         else:
             # windows sharded over the ranks; device work, RCCL all-gather, D2H and host combine all pipelined
             sizes = group_sizes(count, group)
@@ -342,7 +346,8 @@ def main():
         "config": {"workload": "2^%d BN254 G1 MSM, 16-bit signed-bucket windows, inputs resident in HBM" % args.logn,
                    "windows_per_gpu": w_local, "msms_per_launch": group if sharded else group1,
                    "parallelism": "windows/%d + RCCL all-gather" % world if sharded else "single GPU",
-                   "host_combine": "pipelined one MSM behind"},
+                   "launches_in_flight": pipe.depth if sharded else depth1,
+                   "host_combine": "pipelined behind the device work of the following launches"},
         "roofline": {"bound": "hbm", "kernel": "k_smvp_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                      "kernel_ms": smvp_avg_ms},
