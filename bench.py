@@ -320,13 +320,14 @@ def main():
     w_launch = max(smvp_windows)
     lane_mads_per_s = sum(n * w for w in smvp_windows) * MADS_PER_MIXED_ADD / (sum(smvp_ms) * 1e-3)
 
-    traffic = None
+    traffic, traffic_source = None, None
     try:
         pmc_name = "smvp_pmc_traffic.json" if args.logn == 20 else "smvp_pmc_traffic_logn%d.json" % args.logn
         with open(os.path.join(ROOT, "profiles", pmc_name)) as f:
             pmc = json.load(f)
         if pmc.get("logn") == args.logn and pmc.get("w_local") == w_launch:  # PMC bytes of one full 16-window launch
             traffic = pmc.get("hbm_bytes_per_launch")
+            traffic_source = "profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, calibrated (profiles/README.md); not measured in this run" % pmc_name
     except (OSError, ValueError):
         pass
 
@@ -349,7 +350,7 @@ def main():
                    "launches_in_flight": pipe.depth if sharded else depth1,
                    "host_combine": "pipelined behind the device work of the following launches"},
         "roofline": {"bound": "hbm", "kernel": "k_smvp_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": alg_bytes,
                      "kernel_ms": smvp_avg_ms},
         # beside (not instead of) the HBM figure: the kernel's multiply-add rate against the instruction's measured issue peak
         "roofline_valu": {"bound": "valu_issue", "kernel": "k_smvp_chunks", "unit": "T lane-mad/s (v_mad_u64_u32)",
