@@ -224,9 +224,9 @@ def main():
             inflight = []
             for k, gs in enumerate(sizes):
                 if group > 1:
-                    pipe.issue(group_scalars[: gs * n], n)
+                    pipe.issue(group_scalars[: gs * n], n, inputs_complete=True)  # sampled and synchronised before the timed region
                 else:
-                    pipe.issue(scalar_sets[k & 1])
+                    pipe.issue(scalar_sets[k & 1], inputs_complete=True)
                 inflight.append(gs)
                 if len(inflight) == pipe.depth:
                     result = pipe.complete()

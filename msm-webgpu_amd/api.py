@@ -300,13 +300,14 @@ class MsmContext:
                "msm_hip_launch_windows_device_bn254")
         self._keepalive[slot] = (t, out_dev)
 
-    def launch_windows_batch(self, scalars_dev, n, w_begin, w_end, slot, out_dev):
+    def launch_windows_batch(self, scalars_dev, n, w_begin, w_end, slot, out_dev, inputs_complete=False):
         """Several MSMs per launch: scalars_dev holds nvec contiguous vectors of n scalars (CUDA uint8 [nvec * n, 32]);
         `out_dev` (CUDA uint8 [nvec * (w_end - w_begin), 96], vector-major) receives the window sums.  nvec * windows <= 64; out_dev None keeps the sums in the slot (whole MSMs: finish_batch)."""
         t, rows = _as_device_u8(scalars_dev, 32, "scalars")
         if n <= 0 or rows % n:
             raise ValueError("scalars must hold a whole number of n-element vectors")
-        self._order_after_torch(t)
+        if not inputs_complete:  # True: the caller vouches that the scalars were complete before this call (no stream ordering needed)
+            self._order_after_torch(t)
         _check(lib().msm_hip_launch_windows_batch_device_bn254(self._h, t.data_ptr(), n, rows // n, w_begin, w_end, slot,
                                                                out_dev.data_ptr() if out_dev is not None else None),
                "msm_hip_launch_windows_batch_device_bn254")

@@ -153,8 +153,11 @@ class ShardedMsmPipeline:
         # stream / queue layout on a one-GPU box; needs an initialised process group)
         self.collective = world_size > 1 or (os.environ.get("MSM_SHARD_FORCE_COLLECTIVE") == "1" and dist.is_initialized())
 
-    def issue(self, scalars_dev, n=None):
-        """scalars_dev: one vector (CUDA uint8 [n, 32]) or, with `n` given, up to msms_per_issue contiguous vectors."""
+    def issue(self, scalars_dev, n=None, inputs_complete=False):
+        """scalars_dev: one vector (CUDA uint8 [n, 32]) or, with `n` given, up to msms_per_issue contiguous vectors.
+        inputs_complete: the scalars were complete (synchronised) before this call.  Otherwise the engine is ordered behind the
+        current torch stream -- which also carries the previous launches' gather and copies (below), so that launch i+1 then
+        starts only after launch i's gather: correct for scalars produced on that stream, but it serialises the pipeline."""
         assert self.issued - self.completed < self.depth, "pipeline full: call complete() first"
         slot = self.issued % self.SLOTS
         w_local = self.w_end - self.w_begin
@@ -164,7 +167,8 @@ class ShardedMsmPipeline:
         assert 1 <= nvec <= self.g and nvec * n == rows
         self.nvec[slot] = nvec
         if w_local > 0:
-            self.ctx.launch_windows_batch(scalars_dev, n, self.w_begin, self.w_end, slot, self.padded[slot][: nvec * w_local])
+            self.ctx.launch_windows_batch(scalars_dev, n, self.w_begin, self.w_end, slot, self.padded[slot][: nvec * w_local],
+                                          inputs_complete=inputs_complete)
             # gather + copies go to the CURRENT torch stream (normally the default stream): with GPU_MAX_HW_QUEUES=8 this
             # layout -- 3 engine streams, the default stream, RCCL's own -- keeps three launches in flight; a dedicated side
             # stream (or a 4th engine stream) was measured to collapse the pipeline to one at a time
