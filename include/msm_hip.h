@@ -69,6 +69,20 @@ typedef struct msm_hip_ctx msm_hip_ctx;
 int msm_hip_ctx_create(msm_hip_ctx** out, int device_id);
 void msm_hip_ctx_destroy(msm_hip_ctx* ctx);
 
+/* ---- other curves (the reference lists them as future work, README.md, and is hard-wired to BN254's Fq,
+ *      src/cuzk/msm.rs:37-43).  The curve is a property of the context: every entry point of this header works on the curve its
+ *      context was created for (their names keep the `_bn254` of the reference's only instantiation).  Supported besides BN254 G1:
+ *      Grumpkin, BN254's cycle partner (y^2 = x^3 - 17 over BN254's scalar field r; scalars modulo BN254's base field p) -- its
+ *      base field agrees with BN254's in the top 128 bits, so the same 9 x 29-bit lazy-limb arithmetic and the same kernels serve
+ *      both, instantiated once per curve (csrc/curve_select.h).  Wire formats are the same with the curve's own moduli. ---- */
+#define MSM_HIP_CURVE_BN254_G1 0
+#define MSM_HIP_CURVE_GRUMPKIN 1
+int msm_hip_ctx_create_curve(msm_hip_ctx** out, int device_id, int curve);
+int msm_hip_ctx_curve(const msm_hip_ctx* ctx);
+/* the context-free host helpers for a given curve (msm_hip_combine_windows_bn254 / msm_hip_g1_to_affine_bn254 are curve 0) */
+int msm_hip_combine_windows_curve(int curve, const uint8_t* window_sums_host, int num_windows, uint8_t out_xyz[96]);
+int msm_hip_g1_to_affine_curve(int curve, const uint8_t xyz[96], uint8_t out_xy[64]);
+
 /* ---- ordering contract for DEVICE inputs.  The engine works on its own non-blocking HIP streams, which are not ordered
  *      with the caller's streams (nor with the null stream).  Device scalars / bases handed to any *_device_* entry point
  *      must therefore be complete before the call -- or the caller names the stream that produces them:

@@ -17,6 +17,9 @@ import torch
 from . import build as _build
 
 P = 21888242871839275222246405745257275088696311157297823662689037894645226208583  # src/cuzk/msm.rs:39
+R_BN254 = 21888242871839275222246405745257275088548364400416034343698204186575808495617  # BN254's scalar field = Grumpkin's base field
+# curve of a context (include/msm_hip.h: MSM_HIP_CURVE_*): id and base-field modulus
+CURVES = {"bn254": (0, P), "grumpkin": (1, R_BN254)}
 NUM_WINDOWS = 16
 WINDOW_BITS = 16
 BUCKETS_PER_WINDOW = 1 << 15
@@ -44,6 +47,10 @@ def lib():
         L.msm_hip_strerror.argtypes = [i]
         L.msm_hip_abi_version.restype = i
         L.msm_hip_ctx_create.argtypes = [C.POINTER(vp), i]
+        L.msm_hip_ctx_create_curve.argtypes = [C.POINTER(vp), i, i]
+        L.msm_hip_ctx_curve.argtypes = [vp]
+        L.msm_hip_combine_windows_curve.argtypes = [i, u8p, i, u8p]
+        L.msm_hip_g1_to_affine_curve.argtypes = [i, u8p, u8p]
         L.msm_hip_ctx_destroy.argtypes = [vp]
         L.msm_hip_ctx_destroy.restype = None
         L.msm_hip_set_bases_bn254.argtypes = [vp, u8p, sz, C.c_uint32]
@@ -127,10 +134,11 @@ def scalars_to_bytes(scalars):
 class G1:
     """Result of an MSM: a Jacobian point (x, y, z), canonical integers, z = 0 <=> identity (≙ C::Curve)."""
 
-    __slots__ = ("xyz",)
+    __slots__ = ("xyz", "p")
 
-    def __init__(self, xyz):
+    def __init__(self, xyz, p=P):
         self.xyz = bytes(xyz)
+        self.p = p  # base-field modulus of the point's curve
         assert len(self.xyz) == 96
 
     def coords(self):
@@ -145,8 +153,8 @@ class G1:
         x, y, z = self.coords()
         if z == 0:
             return None
-        zi = pow(z, -1, P)
-        return (x * zi * zi % P, y * zi * zi * zi % P)
+        zi = pow(z, -1, self.p)
+        return (x * zi * zi % self.p, y * zi * zi * zi % self.p)
 
     def to_affine_bytes(self):
         """The 64-byte canonical affine encoding used for bit-exact comparison; 64 zero bytes for the identity."""
@@ -177,9 +185,11 @@ def _as_device_u8(t, row, what):
 class MsmContext:
     """Persistent engine on one GPU: stream, pooled buffers, resident bases (include/msm_hip.h)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, curve="bn254"):
         self._h = C.c_void_p()
-        _check(lib().msm_hip_ctx_create(C.byref(self._h), int(device)), "msm_hip_ctx_create")
+        self.curve = curve
+        self.curve_id, self.modulus = CURVES[curve]
+        _check(lib().msm_hip_ctx_create_curve(C.byref(self._h), int(device), self.curve_id), "msm_hip_ctx_create_curve")
         self.device = int(device)
         self.n_bases = 0
         self._keepalive = {}  # slot -> tensors the slot's launch still reads / writes; released when the slot is collected
@@ -235,7 +245,7 @@ class MsmContext:
             if len(b) % 32:
                 raise ValueError("scalars must be n x 32 bytes")
             _check(lib().msm_hip_run_bn254(self._h, b, len(b) // 32, out), "msm_hip_run_bn254")
-        return G1(out.raw)
+        return G1(out.raw, self.modulus)
 
     def msm_batch(self, scalars_dev, n):
         """`batch` MSMs over the resident bases: scalars_dev is a CUDA uint8 tensor of batch x n x 32 bytes (or host bytes
@@ -247,7 +257,7 @@ class MsmContext:
             batch = len(b) // (32 * n)
             out = C.create_string_buffer(96 * batch)
             _check(lib().msm_hip_run_batch_bn254(self._h, b, n, batch, out), "msm_hip_run_batch_bn254")
-            return [G1(out.raw[96 * k:96 * k + 96]) for k in range(batch)]
+            return [G1(out.raw[96 * k:96 * k + 96], self.modulus) for k in range(batch)]
         t, rows = _as_device_u8(scalars_dev, 32, "scalars")
         if n <= 0 or rows % n:
             raise ValueError("scalars must hold a whole number of n-element vectors")
@@ -255,7 +265,7 @@ class MsmContext:
         out = C.create_string_buffer(96 * batch)
         self._order_after_torch(t)
         _check(lib().msm_hip_run_batch_device_bn254(self._h, t.data_ptr(), n, batch, out), "msm_hip_run_batch_device_bn254")
-        return [G1(out.raw[96 * k:96 * k + 96]) for k in range(batch)]
+        return [G1(out.raw[96 * k:96 * k + 96], self.modulus) for k in range(batch)]
 
     def launch(self, scalars_dev, slot=0):
         """Enqueue the device work of one MSM into a result slot (0..3) and return at once."""
@@ -279,7 +289,7 @@ class MsmContext:
             _check(lib().msm_hip_finish_bn254(self._h, slot, out), "msm_hip_finish_bn254")
         finally:
             self._keepalive.pop(slot, None)
-        return G1(out.raw)
+        return G1(out.raw, self.modulus)
 
     # -- window shard (multi-GPU)
     def msm_windows(self, scalars_dev, w_begin, w_end, out_dev=None):
@@ -325,7 +335,7 @@ class MsmContext:
             _check(lib().msm_hip_finish_batch_bn254(self._h, slot, out), "msm_hip_finish_batch_bn254")
         finally:
             self._keepalive.pop(slot, None)
-        return [G1(out.raw[96 * k:96 * k + 96]) for k in range(nvec)]
+        return [G1(out.raw[96 * k:96 * k + 96], self.modulus) for k in range(nvec)]
 
     def slot_wait_stream(self, slot, stream=None):
         """Make a torch CUDA stream (default: the current one) wait, on the device, for the slot's results."""
@@ -341,14 +351,15 @@ class MsmContext:
             self._keepalive.pop(slot, None)
 
     @staticmethod
-    def combine_windows(window_sums):
+    def combine_windows(window_sums, curve="bn254"):
         """Host Horner over all window sums (bytes or uint8 tensor, num_windows x 96 B) -> G1."""
         if isinstance(window_sums, torch.Tensor):
             window_sums = window_sums.cpu().contiguous().numpy().tobytes()
         b = bytes(window_sums)
         out = C.create_string_buffer(96)
-        _check(lib().msm_hip_combine_windows_bn254(b, len(b) // 96, out), "msm_hip_combine_windows_bn254")
-        return G1(out.raw)
+        cid, p = CURVES[curve]
+        _check(lib().msm_hip_combine_windows_curve(cid, b, len(b) // 96, out), "msm_hip_combine_windows_curve")
+        return G1(out.raw, p)
 
     # -- synthetic inputs in HBM
     def sample_scalars(self, n, seed):

@@ -20,10 +20,12 @@
 //   "exact"   : limbs 0..7 < 2^29 exactly (unique)          (output of fq_mul / fq_sqr; value < 2p)
 //   "lazy"    : limbs < 2^30 + 16                           (fq_add of two normal values)
 //   fq_mul / fq_sqr accept lazy operands with value(a) * value(b) <= 169 p^2 and return exact, < 2p.
+#ifndef MSM_CURVE_UNIT  // stand-alone use instantiates BN254, once; inside a curve unit (curve_unit.h) the unit includes the parts
 #pragma once
+#include "curve_select.h"
+#include MSM_CURVE_CONSTANTS
+#endif
 #include <cstdint>
-
-#include "bn254_constants.h"
 
 #if defined(__HIPCC__)
 #define FQ_HD __host__ __device__ __forceinline__
@@ -45,18 +47,18 @@
 #define FQ_ASSERT(c, msg) ((void)0)
 #endif
 
-namespace bn254 {
+namespace MSM_FIELD_NS {
 
 struct fq {
   uint32_t v[9];
 };
 
-}  // namespace bn254
+}  // namespace MSM_FIELD_NS
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(FQ29_NO_ASM)
 #define FQ29_ASM 1
 #include "fq29_asm.h"  // fq_mul_asm / fq_sqr_asm: the multipliers as single inline-assembly blocks (tools/gen_fq29_asm.py)
 #endif
-namespace bn254 {
+namespace MSM_FIELD_NS {
 
 FQ_HD fq fq_zero() {
   fq r;
@@ -338,4 +340,4 @@ FQ_HD fq fq_neg_canonical(const fq& y) {  // y canonical in [0,p) -> p - y (or 0
   return z ? t : y;
 }
 
-}  // namespace bn254
+}  // namespace MSM_FIELD_NS

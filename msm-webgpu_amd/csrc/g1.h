@@ -10,10 +10,12 @@
 // Value bounds kept between operations (fq29.h conventions; all coordinates "normal"):
 //     X < 9p,  Y < 5p,  ZZ < 2p (exact),  ZZZ < 2p (exact)
 // Every fq_sub<K> below states the bound of its subtrahend in the trailing comment.
+#ifndef MSM_CURVE_UNIT
 #pragma once
 #include "fq29.h"
+#endif
 
-namespace bn254 {
+namespace MSM_FIELD_NS {
 
 struct g1_affine {  // Montgomery form, canonical
   fq x, y;
@@ -234,4 +236,4 @@ FQ_HD g1_xyzz g1_from_jacobian(const fq& X, const fq& Y, const fq& Z) {
   return r;
 }
 
-}  // namespace bn254
+}  // namespace MSM_FIELD_NS

@@ -4,13 +4,15 @@
 // (≙ src/cuzk/msm.rs:391-416, which the reference also runs on the host).  It is 240 dependent doublings --
 // a serial chain that one CPU core finishes in ~60 us while a single GPU lane would need milliseconds --
 // so it stays on the host by design (DESIGN.md "Window combine").  Not a fallback for any device stage.
+#ifndef MSM_CURVE_UNIT
 #pragma once
+#include "curve_select.h"
+#include MSM_CURVE_CONSTANTS
+#endif
 #include <cstdint>
 #include <cstring>
 
-#include "bn254_constants.h"
-
-namespace bn254 {
+namespace MSM_FIELD_NS {
 namespace host {
 
 typedef unsigned __int128 u128;
@@ -217,4 +219,4 @@ inline bool combine_windows(const uint8_t* sums96, int num_windows, int window_b
 }
 
 }  // namespace host
-}  // namespace bn254
+}  // namespace MSM_FIELD_NS

@@ -21,12 +21,60 @@
 #include <new>
 
 #include "../../include/msm_hip.h"
-#include "host_g1.h"
-#include "msm_kernels.h"
 
-using namespace msmk;
+// the arithmetic and the kernels, once per curve (csrc/curve_select.h)
+#define MSM_FIELD_NS bn254
+#define MSM_KERNEL_NS msmk
+#define MSM_CURVE_CONSTANTS "bn254_constants.h"
+#include "curve_unit.h"
+#undef MSM_FIELD_NS
+#undef MSM_KERNEL_NS
+#undef MSM_CURVE_CONSTANTS
+#define MSM_FIELD_NS grumpkin
+#define MSM_KERNEL_NS msmk_grumpkin
+#define MSM_CURVE_CONSTANTS "grumpkin_constants.h"
+#include "curve_unit.h"
+#undef MSM_FIELD_NS
+#undef MSM_KERNEL_NS
+#undef MSM_CURVE_CONSTANTS
+
+using namespace msmk;  // layout constants and the field-independent kernels (recode, sort) are taken from BN254's unit
 
 namespace {
+
+// What differs between the curves: the kernels that do field arithmetic, and the host's window combine.  A context holds one.
+struct CurveOps {
+  void (*convert_points)(const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t*);
+  void (*precompute_tables)(uint32_t*, size_t, size_t, int);
+  void (*scalars_from_mont256)(const uint32_t*, uint32_t*, size_t, uint32_t*);
+  void (*smvp_chunks)(const uint32_t*, const uint32_t*, const uint32_t*, size_t, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*,
+                      uint32_t*, uint32_t);
+  void (*smvp_stitch)(const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+  void (*smvp_stitch_big)(const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t);
+  void (*rowcol_4_8)(const uint32_t*, uint32_t*, uint32_t*);
+  void (*rowcol_2_8)(const uint32_t*, uint32_t*, uint32_t*);
+  void (*rowcol_3_8)(const uint32_t*, uint32_t*, uint32_t*);
+  void (*rowcol_4_6)(const uint32_t*, uint32_t*, uint32_t*);
+  void (*rowcol_2_6)(const uint32_t*, uint32_t*, uint32_t*);
+  void (*rowcol_2_4)(const uint32_t*, uint32_t*, uint32_t*);
+  void (*bpr_w256)(const uint32_t*, const uint32_t*, uint32_t*, int);
+  void (*bpr_final)(const uint32_t*, int, uint32_t*);
+  void (*sample_scalars)(uint64_t, size_t, uint32_t*);
+  void (*sample_points)(uint64_t, size_t, uint32_t*);
+  void (*export_buckets)(const uint32_t*, uint32_t*, size_t);
+  void (*test_fq)(int, const uint32_t*, const uint32_t*, uint32_t*, size_t);
+  void (*test_g1)(int, const uint32_t*, const uint32_t*, uint32_t*, size_t);
+  void (*test_g1_mul_u32)(const uint32_t*, const uint32_t*, uint32_t*, size_t);
+  bool (*combine_windows)(const uint8_t*, int, int, uint8_t*);
+  int (*to_affine64)(const uint8_t*, uint8_t*);
+};
+#define MSM_CURVE_OPS(K, F)                                                                                                              \
+  {K::k_convert_points, K::k_precompute_tables, K::k_scalars_from_mont256, K::k_smvp_chunks, K::k_smvp_stitch, K::k_smvp_stitch_big,       \
+   K::k_bpr_rowcol<4, 8>, K::k_bpr_rowcol<2, 8>, K::k_bpr_rowcol<3, 8>, K::k_bpr_rowcol<4, 6>, K::k_bpr_rowcol<2, 6>, K::k_bpr_rowcol<2, 4>, \
+   K::k_bpr_w256, K::k_bpr_final, K::k_sample_scalars, K::k_sample_points, K::k_export_buckets, K::k_test_fq, K::k_test_g1,                \
+   K::k_test_g1_mul_u32, F::host::combine_windows, F::host::to_affine64}
+const CurveOps CURVE_OPS[2] = {MSM_CURVE_OPS(msmk, bn254), MSM_CURVE_OPS(msmk_grumpkin, grumpkin)};
+#undef MSM_CURVE_OPS
 
 constexpr int N_MAIN_EVENTS = 7;  // boundaries of the 6 timed stages on the main stream
 constexpr uint32_t MAX_TILES = 1024;
@@ -69,6 +117,8 @@ struct Slot {
 
 struct msm_hip_ctx {
   int device = 0;
+  int curve = MSM_HIP_CURVE_BN254_G1;
+  const CurveOps* ops = &CURVE_OPS[0];
   hipStream_t stream = nullptr;         // main
   hipStream_t reduce_stream[NREDUCE] = {};  // bucket reduce + result copies
   int last_hip_error = 0;
@@ -359,7 +409,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   HIP_TRY(ctx, mark(0, false));
   if (ctx->scalar_format == MSM_HIP_SCALARS_MONT256) {  // Montgomery-form scalars: canonical copies first (part of stage 0)
     const size_t count = (size_t)nvec * n;
-    hipLaunchKernelGGL(k_scalars_from_mont256, dim3(blocks_for(count, 256)), dim3(256), 0, st, d_scalars, ctx->d_scalar_conv, count, d_err);
+    hipLaunchKernelGGL(ctx->ops->scalars_from_mont256, dim3(blocks_for(count, 256)), dim3(256), 0, st, d_scalars, ctx->d_scalar_conv, count, d_err);
     AFTER_KERNEL(ctx, "k_scalars_from_mont256", st);
     d_scalars = ctx->d_scalar_conv;
   }
@@ -391,7 +441,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
                      s.d_col_ptr, ctx->d_val, chunks, chunk_len, ctx->d_chunk_slot, part_hist);
   AFTER_KERNEL(ctx, "k_sort_fine", st);
   HIP_TRY(ctx, mark(4, true));
-  hipLaunchKernelGGL(k_smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, s.d_col_ptr, ctx->d_val, stride,
+  hipLaunchKernelGGL(ctx->ops->smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, s.d_col_ptr, ctx->d_val, stride,
                      chunks, chunk_len, ctx->d_chunk_slot, s.d_buckets, s.d_heads, s.d_tails, half);
   AFTER_KERNEL(ctx, "k_smvp_chunks", st);
   HIP_TRY(ctx, mark(5, true));
@@ -399,10 +449,10 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
 
   // stitch + bucket reduce on the slot's reduce stream: few waves, long dependent chains
   HIP_TRY(ctx, hipStreamWaitEvent(rs, s.smvp_done, 0));
-  hipLaunchKernelGGL(k_smvp_stitch, dim3(half / 256, w_count), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails,
+  hipLaunchKernelGGL(ctx->ops->smvp_stitch, dim3(half / 256, w_count), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails,
                      s.d_buckets, s.d_big_queue);
   AFTER_KERNEL(ctx, "k_smvp_stitch", rs);
-  hipLaunchKernelGGL(k_smvp_stitch_big, dim3(256), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails, s.d_buckets,
+  hipLaunchKernelGGL(ctx->ops->smvp_stitch_big, dim3(256), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails, s.d_buckets,
                      s.d_big_queue, s.d_done_blocks, half);
   AFTER_KERNEL(ctx, "k_smvp_stitch_big", rs);
   if (tl >= 2) {
@@ -416,7 +466,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   // serial run per thread before the LDS tree: 16 buckets when many windows are reduced at once (fewest wave-additions),
   // 4 for a few windows (shallowest); measured optimum for 16 and for 2 windows respectively
 #define ROWCOL(LOG_R, LOG_ROWS) \
-  hipLaunchKernelGGL((k_bpr_rowcol<LOG_R, LOG_ROWS>), dim3(bpr_rowcol_blocks<LOG_R, LOG_ROWS>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols)
+  hipLaunchKernelGGL(ctx->ops->rowcol_##LOG_R##_##LOG_ROWS, dim3(bpr_rowcol_blocks<LOG_R, LOG_ROWS>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols)
   if (wbits == 16) {
     if (force_logr == 4 || (force_logr == 0 && w_count >= 8)) ROWCOL(4, 8);
     else if (force_logr == 2 || force_logr == 0) ROWCOL(2, 8);
@@ -429,9 +479,9 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   }
 #undef ROWCOL
   AFTER_KERNEL(ctx, "k_bpr_rowcol", rs);
-  hipLaunchKernelGGL(k_bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts, (int)(half / BPR_COLS));
+  hipLaunchKernelGGL(ctx->ops->bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts, (int)(half / BPR_COLS));
   AFTER_KERNEL(ctx, "k_bpr_w256", rs);
-  hipLaunchKernelGGL(k_bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out);
+  hipLaunchKernelGGL(ctx->ops->bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out);
   AFTER_KERNEL(ctx, "k_bpr_final", rs);
   if (tl >= 2) HIP_TRY(ctx, hipEventRecord(s.red1, rs));
   if (to_host) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * 96, hipMemcpyDeviceToHost, rs));
@@ -516,7 +566,7 @@ int reserve_bases(msm_hip_ctx* ctx, size_t n, uint32_t flags) {
 int set_bases_from_device(msm_hip_ctx* ctx, const uint32_t* d_xy, size_t n, uint32_t flags) {
   if (n == 0) return MSM_HIP_OK;
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0, 4, ctx->stream));
-  hipLaunchKernelGGL(k_convert_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_xy, ctx->d_bases, n, flags, ctx->d_err);
+  hipLaunchKernelGGL(ctx->ops->convert_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_xy, ctx->d_bases, n, flags, ctx->d_err);
   HIP_TRY(ctx, hipGetLastError());
   uint32_t bits = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&bits, ctx->d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -524,19 +574,13 @@ int set_bases_from_device(msm_hip_ctx* ctx, const uint32_t* d_xy, size_t n, uint
   int rc = err_from_bits(bits);
   if (rc) return rc;
   if (flags & MSM_HIP_BASES_PRECOMPUTE) {  // tables 1 .. 15 behind the plain set: T_w[i] = 2^(16 w) P_i
-    hipLaunchKernelGGL(k_precompute_tables, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_bases, n, n, NWIN);
+    hipLaunchKernelGGL(ctx->ops->precompute_tables, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_bases, n, n, NWIN);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->precomputed = true;
   }
   ctx->n_bases = n;
   return MSM_HIP_OK;
-}
-
-__global__ void __launch_bounds__(256) k_export_buckets(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, size_t count) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  st_jacobian_plain(out + i * 24, ld_rec(buckets + i * REC_WORDS));
 }
 
 }  // namespace
@@ -600,9 +644,14 @@ const char* msm_hip_strerror(int code) {
 int msm_hip_last_hip_error(msm_hip_ctx* ctx) { return ctx ? ctx->last_hip_error : 0; }
 void* msm_hip_stream(msm_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
-int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
+int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) { return msm_hip_ctx_create_curve(out, device_id, MSM_HIP_CURVE_BN254_G1); }
+
+int msm_hip_ctx_curve(const msm_hip_ctx* ctx) { return ctx ? ctx->curve : MSM_HIP_ERR_INVALID_ARG; }
+
+int msm_hip_ctx_create_curve(msm_hip_ctx** out, int device_id, int curve) {
   if (!out) return MSM_HIP_ERR_INVALID_ARG;
   *out = nullptr;
+  if (curve != MSM_HIP_CURVE_BN254_G1 && curve != MSM_HIP_CURVE_GRUMPKIN) return MSM_HIP_ERR_INVALID_ARG;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MSM_HIP_ERR_NO_DEVICE;
   if (device_id < 0 || device_id >= count) return MSM_HIP_ERR_INVALID_ARG;
@@ -611,6 +660,8 @@ int msm_hip_ctx_create(msm_hip_ctx** out, int device_id) {
   msm_hip_ctx* ctx = new (std::nothrow) msm_hip_ctx();
   if (!ctx) return MSM_HIP_ERR_OUT_OF_MEMORY;
   ctx->device = device_id;
+  ctx->curve = curve;
+  ctx->ops = &CURVE_OPS[curve];
   if (const char* e = getenv("MSM_HIP_FINE_HIST_MIN_LOGN")) {  // tuning aid
     const int l = atoi(e);
     if (l >= 0 && l < 40) ctx->fine_hist_min_n = (size_t)1 << l;
@@ -785,7 +836,7 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   if (rc) return rc;
   auto t0 = std::chrono::steady_clock::now();
   for (int v = 0; v < s.nvec; v++)
-    if (!bn254::host::combine_windows(s.h_wsums + (size_t)v * nwin * 96, nwin, s.wbits, out_xyz + 96 * (size_t)v)) return MSM_HIP_ERR_HIP;
+    if (!ctx->ops->combine_windows(s.h_wsums + (size_t)v * nwin * 96, nwin, s.wbits, out_xyz + 96 * (size_t)v)) return MSM_HIP_ERR_HIP;
   ctx->stage_ms[8] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return MSM_HIP_OK;
 }
@@ -906,6 +957,20 @@ int msm_hip_g1_to_affine_bn254(const uint8_t xyz[96], uint8_t out_xy[64]) {
   return r < 0 ? MSM_HIP_ERR_NONCANONICAL : r;
 }
 
+int msm_hip_combine_windows_curve(int curve, const uint8_t* window_sums_host, int num_windows, uint8_t out_xyz[96]) {
+  if (curve != MSM_HIP_CURVE_BN254_G1 && curve != MSM_HIP_CURVE_GRUMPKIN) return MSM_HIP_ERR_INVALID_ARG;
+  if (!window_sums_host || !out_xyz || num_windows < 1 || num_windows > NWIN) return MSM_HIP_ERR_INVALID_ARG;
+  if (!CURVE_OPS[curve].combine_windows(window_sums_host, num_windows, WBITS, out_xyz)) return MSM_HIP_ERR_NONCANONICAL;
+  return MSM_HIP_OK;
+}
+
+int msm_hip_g1_to_affine_curve(int curve, const uint8_t xyz[96], uint8_t out_xy[64]) {
+  if (curve != MSM_HIP_CURVE_BN254_G1 && curve != MSM_HIP_CURVE_GRUMPKIN) return MSM_HIP_ERR_INVALID_ARG;
+  if (!xyz || !out_xy) return MSM_HIP_ERR_INVALID_ARG;
+  const int r = CURVE_OPS[curve].to_affine64(xyz, out_xy);
+  return r < 0 ? MSM_HIP_ERR_NONCANONICAL : r;
+}
+
 int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
   msm_hip_ctx* ctx = nullptr;
   int dev = 0;
@@ -922,7 +987,7 @@ int msm_hip_sample_scalars_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, voi
   if (!ctx || (!scalars_dev && n)) return MSM_HIP_ERR_INVALID_ARG;
   if (n == 0) return MSM_HIP_OK;
   ON_DEVICE(ctx);
-  hipLaunchKernelGGL(k_sample_scalars, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, seed, n, static_cast<uint32_t*>(scalars_dev));
+  hipLaunchKernelGGL(ctx->ops->sample_scalars, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, seed, n, static_cast<uint32_t*>(scalars_dev));
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MSM_HIP_OK;
@@ -932,7 +997,7 @@ int msm_hip_sample_points_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void
   if (!ctx || (!xy_dev && n)) return MSM_HIP_ERR_INVALID_ARG;
   if (n == 0) return MSM_HIP_OK;
   ON_DEVICE(ctx);
-  hipLaunchKernelGGL(k_sample_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, seed, n, static_cast<uint32_t*>(xy_dev));
+  hipLaunchKernelGGL(ctx->ops->sample_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, seed, n, static_cast<uint32_t*>(xy_dev));
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MSM_HIP_OK;
@@ -1031,7 +1096,7 @@ int msm_hip_read_buckets(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
   for (hipStream_t r : ctx->reduce_stream) HIP_TRY(ctx, hipStreamSynchronize(r));
   int rc = ensure_stage(ctx, count * 96);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_export_buckets, dim3(blocks_for(count, 256)), dim3(256), 0, ctx->stream, ctx->slot[ctx->last_slot].d_buckets,
+  hipLaunchKernelGGL(ctx->ops->export_buckets, dim3(blocks_for(count, 256)), dim3(256), 0, ctx->stream, ctx->slot[ctx->last_slot].d_buckets,
                      reinterpret_cast<uint32_t*>(ctx->d_stage), count);
   HIP_TRY(ctx, hipGetLastError());
   return read_back(ctx, out, ctx->d_stage, count * 96, cap_bytes);
@@ -1066,7 +1131,7 @@ int msm_hip_test_fq_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t
   uint8_t *da, *db, *dout;
   int rc = run_hook(ctx, a, n * 32, b, b ? n * 32 : 0, out, n * 32, da, db, dout);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_test_fq, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, op, (const uint32_t*)da, (const uint32_t*)db,
+  hipLaunchKernelGGL(ctx->ops->test_fq, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, op, (const uint32_t*)da, (const uint32_t*)db,
                      (uint32_t*)dout, n);
   HIP_TRY(ctx, hipGetLastError());
   return read_back(ctx, out, dout, n * 32, n * 32);
@@ -1079,7 +1144,7 @@ int msm_hip_test_g1_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t
   uint8_t *da, *db, *dout;
   int rc = run_hook(ctx, a, n * 96, op == 1 ? nullptr : b, b_bytes, out, n * 96, da, db, dout);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_test_g1, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, op, (const uint32_t*)da, (const uint32_t*)db,
+  hipLaunchKernelGGL(ctx->ops->test_g1, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, op, (const uint32_t*)da, (const uint32_t*)db,
                      (uint32_t*)dout, n);
   HIP_TRY(ctx, hipGetLastError());
   return read_back(ctx, out, dout, n * 96, n * 96);
@@ -1091,7 +1156,7 @@ int msm_hip_test_g1_mul_u32(msm_hip_ctx* ctx, const uint8_t* a, const uint32_t* 
   uint8_t *da, *db, *dout;
   int rc = run_hook(ctx, a, n * 96, reinterpret_cast<const uint8_t*>(k), n * 4, out, n * 96, da, db, dout);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_test_g1_mul_u32, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)da,
+  hipLaunchKernelGGL(ctx->ops->test_g1_mul_u32, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)da,
                      (const uint32_t*)db, (uint32_t*)dout, n);
   HIP_TRY(ctx, hipGetLastError());
   return read_back(ctx, out, dout, n * 96, n * 96);

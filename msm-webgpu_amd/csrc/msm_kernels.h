@@ -18,13 +18,14 @@
 // The reference keys its CSC rows by the biased digit (65536 rows per window, transpose.template.wgsl:47-73) and lets
 // the SMVP thread visit rows h+k and h-k (smvp.template.wgsl:55-92).  Here the sort key is the bucket slot itself
 // (|d| mod 2^15, 32768 rows) and the sign rides in bit 31 of the index, so one bucket is one contiguous run.
+#ifndef MSM_CURVE_UNIT
 #pragma once
+#include "g1.h"
+#endif
 #include <hip/hip_runtime.h>
 
-#include "g1.h"
-
-namespace msmk {
-using namespace bn254;
+namespace MSM_KERNEL_NS {
+using namespace MSM_FIELD_NS;
 
 constexpr int WBITS = 16;   // the reference's window (chunk_size, src/cuzk/msm.rs:79) and the unit of the window-sharding API
 constexpr int NWIN = 16;
@@ -88,10 +89,10 @@ __device__ __forceinline__ bool fq_equal_exact(const fq& a, const fq& b) {
   for (int i = 0; i < 9; i++) d |= a.v[i] ^ b.v[i];
   return d == 0;
 }
-__device__ __forceinline__ fq fq_three() {
+__device__ __forceinline__ fq fq_curve_b() {  // the curve constant b (y^2 = x^3 + b), Montgomery form
   fq r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.v[i] = FQ_THREE29[i];
+  for (int i = 0; i < 9; i++) r.v[i] = FQ_B29[i];
   return r;
 }
 
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(256) k_convert_points(const uint32_t* in, uint
   const fq y = m256 ? fq_from_mont256(fq_unpack(wy)) : fq_to_mont(fq_unpack(wy));
   if (flags & 1u) {
     const fq lhs = fq_canonical(fq_sqr(y));
-    const fq rhs = fq_canonical(fq_tidy(fq_add(fq_mul(fq_sqr(x), x), fq_three())));
+    const fq rhs = fq_canonical(fq_tidy(fq_add(fq_mul(fq_sqr(x), x), fq_curve_b())));
     if (!fq_equal_exact(lhs, rhs)) atomicOr(err, ERRBIT_NOT_ON_CURVE);
   }
   st_fq(out + i * 16, x);
@@ -1285,6 +1286,13 @@ __global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ p
   st_jacobian_plain(wsums + (size_t)w * 24, acc);
 }
 
+// bucket records -> Jacobian wire records (stage read-back for the parity tests)
+__global__ void __launch_bounds__(256) k_export_buckets(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, size_t count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  st_jacobian_plain(out + i * 24, ld_rec(buckets + i * REC_WORDS));
+}
+
 // ------------------------------------------------------------------------------------------------ samplers
 // deterministic synthetic inputs (≙ sample_scalars / sample_points, src/lib.rs:20-42, but seeded)
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -1318,13 +1326,47 @@ __global__ void __launch_bounds__(256) k_sample_scalars(uint64_t seed, size_t n,
   st8(out + i * 8, w);
 }
 
-__device__ __forceinline__ fq fq_sqrt_candidate(const fq& a) {  // a^((p+1)/4), a exact
+__device__ __constant__ uint32_t c_sqrt_t[8] = {FQ_SQRT_T_32[0], FQ_SQRT_T_32[1], FQ_SQRT_T_32[2], FQ_SQRT_T_32[3],
+                                                FQ_SQRT_T_32[4], FQ_SQRT_T_32[5], FQ_SQRT_T_32[6], FQ_SQRT_T_32[7]};
+__device__ __constant__ uint32_t c_sqrt_tp1h[8] = {FQ_SQRT_TP1H_32[0], FQ_SQRT_TP1H_32[1], FQ_SQRT_TP1H_32[2], FQ_SQRT_TP1H_32[3],
+                                                   FQ_SQRT_TP1H_32[4], FQ_SQRT_TP1H_32[5], FQ_SQRT_TP1H_32[6], FQ_SQRT_TP1H_32[7]};
+__device__ __forceinline__ fq fq_pow254(const fq& a, const uint32_t* e) {  // a^e, e < 2^254 (constant memory), a exact
   fq acc = fq_one();
   for (int bit = 253; bit >= 0; bit--) {
     acc = fq_sqr(acc);
-    if ((c_pp1d4[bit >> 5] >> (bit & 31)) & 1u) acc = fq_mul(acc, a);
+    if ((e[bit >> 5] >> (bit & 31)) & 1u) acc = fq_mul(acc, a);
   }
   return acc;
+}
+// a candidate square root of a (the caller checks y^2 == a).  p = 3 mod 4 (BN254 Fq): a^((p+1)/4).  Otherwise (Grumpkin's base
+// field, p - 1 = 2^28 t): Tonelli-Shanks with every loop bounded by the 2-adicity, so a non-residue just yields a wrong candidate.
+__device__ __forceinline__ fq fq_sqrt_candidate(const fq& a) {  // a exact
+  if constexpr (FQ_SQRT_S == 0) {
+    return fq_pow254(a, c_pp1d4);
+  } else {
+    fq x = fq_pow254(a, c_sqrt_tp1h), b = fq_pow254(a, c_sqrt_t), c;
+#pragma unroll
+    for (int i = 0; i < 9; i++) c.v[i] = FQ_SQRT_C0_29[i];
+    const fq one = fq_canonical(fq_one());
+    int m = FQ_SQRT_S;
+    for (int round = 0; round < FQ_SQRT_S; round++) {
+      if (fq_equal_exact(fq_canonical(b), one)) break;
+      int i = 0;  // least i with b^(2^i) == 1
+      fq q = b;
+      while (i < m && !fq_equal_exact(fq_canonical(q), one)) {
+        q = fq_sqr(q);
+        i++;
+      }
+      if (i >= m) break;  // not a square
+      fq bb = c;
+      for (int k = 0; k < m - i - 1; k++) bb = fq_sqr(bb);
+      x = fq_mul(x, bb);
+      c = fq_sqr(bb);
+      b = fq_mul(b, c);
+      m = i;
+    }
+    return x;
+  }
 }
 
 __global__ void __launch_bounds__(256) k_sample_points(uint64_t seed, size_t n, uint32_t* __restrict__ out) {
@@ -1335,7 +1377,7 @@ __global__ void __launch_bounds__(256) k_sample_points(uint64_t seed, size_t n, 
     draw256(seed, i, attempt, 2, wx);
     if (geq_modulus<0>(wx)) continue;
     const fq x = fq_to_mont(fq_unpack(wx));
-    const fq rhs = fq_canonical(fq_tidy(fq_add(fq_mul(fq_sqr(x), x), fq_three())));
+    const fq rhs = fq_canonical(fq_tidy(fq_add(fq_mul(fq_sqr(x), x), fq_curve_b())));
     const fq y = fq_sqrt_candidate(rhs);
     if (!fq_equal_exact(fq_canonical(fq_sqr(y)), rhs)) continue;
     fq yp = fq_from_mont(y);  // canonical integer
@@ -1408,4 +1450,4 @@ __global__ void __launch_bounds__(256) k_test_g1_mul_u32(const uint32_t* __restr
   st_jacobian_plain(out + i * 24, g1_mul_u32(ld_jacobian_plain(a + i * 24), k[i]));
 }
 
-}  // namespace msmk
+}  // namespace MSM_KERNEL_NS

@@ -11,9 +11,22 @@ typedef unsigned __int128 u128;
 /* ------------------------------------------------------------------------------------------------
  * Fq : 4 x 64-bit Montgomery, R = 2^256  (the in-memory form halo2curves uses)
  * ---------------------------------------------------------------------------------------------- */
+#ifndef ORACLE_GRUMPKIN
 static const uint64_t FQ_P[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
 static const uint64_t FR_R[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
 static const uint64_t FQ_N0 = 0x87d20782e4866389ull; /* -p^-1 mod 2^64 */
+#define CURVE_B_IS_MINUS 0
+#define CURVE_B_ABS 3 /* y^2 = x^3 + 3 */
+#else
+/* -DORACLE_GRUMPKIN: the same restatement over Grumpkin, BN254's cycle partner (SURVEY.md 8f-4 "other curves"): base field =
+ * BN254's scalar field r, scalar field = BN254's base field p, y^2 = x^3 - 17, generator (1, sqrt(-16)).  Only the moduli, the
+ * curve constant and the sampler's square root (r = 1 mod 4: Tonelli-Shanks) differ. */
+static const uint64_t FQ_P[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+static const uint64_t FR_R[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+static const uint64_t FQ_N0 = 0xc2e1f593efffffffull; /* -r^-1 mod 2^64 */
+#define CURVE_B_IS_MINUS 1
+#define CURVE_B_ABS 17 /* y^2 = x^3 - 17 */
+#endif
 
 static ofq FQ_R1, FQ_R2, FQ_ZERO, FQ_B3; /* R mod p, R^2 mod p, 0, 3*R mod p ; filled by init */
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
@@ -133,10 +146,10 @@ static void oracle_init(void) {
   FQ_R1 = t;
   for (int i = 0; i < 256; i++) fq_dbl(&t, &t);
   FQ_R2 = t;
-  ofq three = FQ_R1;
-  fq_add(&three, &three, &FQ_R1);
-  fq_add(&three, &three, &FQ_R1);
-  FQ_B3 = three;
+  ofq b = FQ_ZERO; /* the curve constant in Montgomery form (the name FQ_B3 is BN254's: b = 3) */
+  for (int i = 0; i < CURVE_B_ABS; i++) fq_add(&b, &b, &FQ_R1);
+  if (CURVE_B_IS_MINUS) fq_neg(&b, &b);
+  FQ_B3 = b;
 }
 static void ensure_init(void) { pthread_once(&g_once, oracle_init); }
 
@@ -731,6 +744,77 @@ void oracle_sample_scalars(uint64_t seed, size_t first, size_t n, uint8_t* out32
   }
 }
 
+/* square root in Fq for the samplers: y with y^2 = a, or 0 (return value) if a is not a square.
+ * p = 3 mod 4 (BN254 Fq): a^((p+1)/4).  Otherwise (Grumpkin's base field, p - 1 = 2^28 t): Tonelli-Shanks. */
+static int fq_sqrt(ofq* y, const ofq* a, const uint64_t e_p3[4]) {
+  ofq y2;
+  if ((FQ_P[0] & 3) == 3) {
+    fq_pow(y, a, e_p3);
+  } else {
+    /* p - 1 = 2^s t */
+    uint64_t t[4] = {FQ_P[0] - 1, FQ_P[1], FQ_P[2], FQ_P[3]};
+    int s = 0;
+    while (!(t[0] & 1)) {
+      for (int i = 0; i < 4; i++) t[i] = (t[i] >> 1) | (i < 3 ? t[i + 1] << 63 : 0);
+      s++;
+    }
+    uint64_t half[4]; /* (p - 1) / 2 */
+    {
+      uint64_t pm1[4] = {FQ_P[0] - 1, FQ_P[1], FQ_P[2], FQ_P[3]};
+      for (int i = 0; i < 4; i++) half[i] = (pm1[i] >> 1) | (i < 3 ? pm1[i + 1] << 63 : 0);
+    }
+    static ofq c0; /* z^t for the smallest non-residue z: a generator of the 2-Sylow subgroup */
+    static int have_c0 = 0;
+    if (!have_c0) {
+      ofq z = FQ_R1, e;
+      for (;;) {
+        fq_add(&z, &z, &FQ_R1); /* 2, 3, ... */
+        fq_pow(&e, &z, half);
+        if (!fq_eq(&e, &FQ_R1)) break;
+      }
+      fq_pow(&c0, &z, t);
+      have_c0 = 1;
+    }
+    ofq chk;
+    fq_pow(&chk, a, half);
+    if (!fq_eq(&chk, &FQ_R1) && !fq_is_zero(a)) return 0;
+    uint64_t tp1h[4]; /* (t + 1) / 2 */
+    {
+      u128 c = (u128)t[0] + 1;
+      uint64_t u[4];
+      u[0] = (uint64_t)c;
+      c >>= 64;
+      for (int i = 1; i < 4; i++) {
+        c += t[i];
+        u[i] = (uint64_t)c;
+        c >>= 64;
+      }
+      for (int i = 0; i < 4; i++) tp1h[i] = (u[i] >> 1) | (i < 3 ? u[i + 1] << 63 : 0);
+    }
+    ofq x, b, c = c0;
+    fq_pow(&x, a, tp1h);
+    fq_pow(&b, a, t);
+    int m = s;
+    while (!fq_eq(&b, &FQ_R1) && !fq_is_zero(&b)) {
+      int i = 0;
+      ofq q = b;
+      while (!fq_eq(&q, &FQ_R1)) {
+        fq_sqr(&q, &q);
+        i++;
+      }
+      ofq bb = c;
+      for (int k = 0; k < m - i - 1; k++) fq_sqr(&bb, &bb);
+      fq_mul(&x, &x, &bb);
+      fq_sqr(&c, &bb);
+      fq_mul(&b, &b, &c);
+      m = i;
+    }
+    *y = x;
+  }
+  fq_sqr(&y2, y);
+  return fq_eq(&y2, a);
+}
+
 void oracle_sample_points(uint64_t seed, size_t first, size_t n, uint8_t* out64) {
   ensure_init();
   /* (p + 1) / 4 */
@@ -759,9 +843,8 @@ void oracle_sample_points(uint64_t seed, size_t first, size_t n, uint8_t* out64)
       fq_sqr(&rhs, &x);
       fq_mul(&rhs, &rhs, &x);
       fq_add(&rhs, &rhs, &FQ_B3);
-      fq_pow(&y, &rhs, e);
-      fq_sqr(&y2, &y);
-      if (!fq_eq(&y2, &rhs)) continue;
+      (void)y2;
+      if (!fq_sqrt(&y, &rhs, e)) continue;
       uint8_t yb[32];
       fq_to_bytes(yb, &y);
       if ((unsigned)(yb[0] & 1) != (unsigned)((xb[0] >> 1) & 1)) {

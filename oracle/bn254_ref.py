@@ -175,14 +175,44 @@ def sample_scalar(seed, index):
         attempt += 1
 
 
+def sqrt_mod(a):
+    """A square root of a mod P, or None.  P = 3 mod 4 (BN254 Fq): a^((P+1)/4); otherwise Tonelli-Shanks (the Grumpkin
+    instance of this model, oracle/grumpkin_ref.py: P - 1 = 2^28 t)."""
+    a %= P
+    if P % 4 == 3:
+        y = pow(a, (P + 1) // 4, P)
+        return y if y * y % P == a else None
+    if a == 0:
+        return 0
+    if pow(a, (P - 1) // 2, P) != 1:
+        return None
+    t, s = P - 1, 0
+    while t % 2 == 0:
+        t //= 2
+        s += 1
+    z = 2
+    while pow(z, (P - 1) // 2, P) == 1:
+        z += 1
+    x, b, c, m = pow(a, (t + 1) // 2, P), pow(a, t, P), pow(z, t, P), s
+    while b != 1:
+        i, q = 0, b
+        while q != 1:
+            q = q * q % P
+            i += 1
+        bb = pow(c, 1 << (m - i - 1), P)
+        x, c = x * bb % P, bb * bb % P
+        b, m = b * c % P, i
+    return x
+
+
 def sample_point(seed, index):
     attempt = 0
     while True:
         x = _draw256(seed, index, attempt, 2)
         if x < P:
             rhs = (x * x * x + B) % P
-            y = pow(rhs, (P + 1) // 4, P)          # p = 3 mod 4
-            if y * y % P == rhs:
+            y = sqrt_mod(rhs)
+            if y is not None:
                 if (y & 1) != ((x >> 1) & 1):        # pick the root by a data-dependent bit
                     y = P - y
                 return (x, y)

@@ -4,7 +4,10 @@
 
 #include "g1.h"
 
-using namespace bn254;
+#ifndef HARNESS_FIELD_NS  // -DMSM_FIELD_NS=... -DMSM_CURVE_CONSTANTS=... -DHARNESS_FIELD_NS=...: the same harness for another curve
+#define HARNESS_FIELD_NS bn254
+#endif
+using namespace HARNESS_FIELD_NS;
 
 static fq load_fq(const uint8_t* b) {  // canonical LE bytes -> Montgomery fq
   uint32_t w[8];

@@ -105,8 +105,9 @@ def test_generated_headers_are_in_sync():
     # bn254_constants.h and fq29_asm.h are generated; the committed files must be what the generators emit
     import sys
 
-    for script, header in (("gen_constants.py", "bn254_constants.h"), ("gen_fq29_asm.py", "fq29_asm.h")):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)], capture_output=True, text=True, check=True).stdout
+    for script, args, header in (("gen_constants.py", [], "bn254_constants.h"), ("gen_constants.py", ["grumpkin"], "grumpkin_constants.h"),
+                                 ("gen_fq29_asm.py", [], "fq29_asm.h")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)] + args, capture_output=True, text=True, check=True).stdout
         assert out == open(os.path.join(ROOT, "msm-webgpu_amd", "csrc", header)).read(), header
 
 
@@ -140,3 +141,30 @@ def test_signed_state_mixed_addition_chain(H):
     H.h_g1_madd_w_chain(bytes(96), lp, negs, 4000, out)
     sc = b"".join(b32(ref.R - 1 if ng else 1) for ng in negs)
     assert cpu.to_affine64(out.raw) == cpu.to_affine64(cpu.cpu_msm(lp, sc))
+
+
+def test_host_arithmetic_instantiated_for_grumpkin(tmp_path_factory):
+    # the same headers compiled for the second curve (csrc/curve_select.h), bounds asserted, against the Grumpkin oracle
+    from oracle import cpu_grumpkin as cg
+    from oracle import grumpkin_ref as gr
+
+    so = str(tmp_path_factory.mktemp("fq29g") / "fq29_harness_grumpkin.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFQ_CHECK", "-fPIC", "-shared", "-DMSM_FIELD_NS=grumpkin", "-DMSM_KERNEL_NS=msmk_grumpkin",
+                           '-DMSM_CURVE_CONSTANTS="grumpkin_constants.h"', "-DHARNESS_FIELD_NS=grumpkin", "-I", os.path.join(ROOT, "msm-webgpu_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host_harness", "fq29_harness.cpp"), "-o", so])
+    Hg = C.CDLL(so)
+    r = rng(8)
+    vals = [0, 1, gr.P - 1, gr.P - 2, (1 << 253) - 1, 1 << 232] + [r.randrange(gr.P) for _ in range(2000)]
+    n = len(vals)
+    A = b"".join(b32(x) for x in vals)
+    B = b"".join(b32(vals[(i * 7 + 3) % n]) for i in range(n))
+    for op, name in enumerate(["add", "sub", "mul", "sqr", "neg"]):
+        out = C.create_string_buffer(32 * n)
+        Hg.h_fq_op(op, A, B, out, n)
+        assert out.raw == cg.fq_op(name, A, B), name
+    lp = cg.sample_points(79, 3000)
+    negs = bytes(r.randrange(2) for _ in range(3000))
+    out = C.create_string_buffer(96)
+    Hg.h_g1_madd_w_chain(bytes(96), lp, negs, 3000, out)
+    sc = b"".join(b32(gr.R - 1 if ng else 1) for ng in negs)
+    assert cg.to_affine64(out.raw) == cg.to_affine64(cg.cpu_msm(lp, sc))
