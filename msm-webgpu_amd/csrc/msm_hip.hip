@@ -50,7 +50,7 @@ struct CurveOps {
   void (*smvp_chunks)(const uint32_t*, const uint32_t*, const uint32_t*, size_t, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*,
                       uint32_t*, uint32_t);
   void (*smvp_stitch)(const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
-  void (*smvp_stitch_big)(const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t);
+  void (*smvp_stitch_big)(const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, const uint32_t*, uint32_t);
   void (*rowcol_4_8)(const uint32_t*, uint32_t*, uint32_t*);
   void (*rowcol_2_8)(const uint32_t*, uint32_t*, uint32_t*);
   void (*rowcol_3_8)(const uint32_t*, uint32_t*, uint32_t*);
@@ -58,7 +58,7 @@ struct CurveOps {
   void (*rowcol_2_6)(const uint32_t*, uint32_t*, uint32_t*);
   void (*rowcol_2_4)(const uint32_t*, uint32_t*, uint32_t*);
   void (*bpr_w256)(const uint32_t*, const uint32_t*, uint32_t*, int);
-  void (*bpr_final)(const uint32_t*, int, uint32_t*);
+  void (*bpr_final)(const uint32_t*, int, uint32_t*, uint32_t*);
   void (*sample_scalars)(uint64_t, size_t, uint32_t*);
   void (*sample_points)(uint64_t, size_t, uint32_t*);
   void (*export_buckets)(const uint32_t*, uint32_t*, size_t);
@@ -96,7 +96,6 @@ struct Slot {
   uint32_t* d_heads = nullptr;     // [W][chunks] XYZZ records: SMVP pieces of runs that cross chunk boundaries
   uint32_t* d_tails = nullptr;     // [W][chunks] XYZZ records
   uint32_t* d_big_queue = nullptr;    // [1 + STITCH_BIG_CAP] buckets with many pieces (skewed scalars), [0] = count
-  uint32_t* d_done_blocks = nullptr;  // block counter of k_smvp_stitch_big
   hipEvent_t ev[N_MAIN_EVENTS] = {};
   hipEvent_t red0 = nullptr, red1 = nullptr;  // bucket reduce begin / end on the reduce stream
   hipEvent_t smvp_done = nullptr;             // main -> reduce hand-off
@@ -256,13 +255,11 @@ int setup_slot(msm_hip_ctx* ctx, Slot& s) {
   if ((rc = dev_alloc(ctx, s.d_partials, (size_t)MAXLW * (256 + 256 + 3) * XYZZ_WORDS))) return rc;
   if ((rc = dev_alloc(ctx, s.d_col_ptr, (size_t)MAXLW * (HALF + 1)))) return rc;
   if ((rc = dev_alloc(ctx, s.d_big_queue, (size_t)STITCH_BIG_CAP + 1))) return rc;
-  if ((rc = dev_alloc(ctx, s.d_done_blocks, 1))) return rc;
   // zeroed on the stream that first reads them (the slot's reduce stream; the error word is first written on the main
   // stream, which waits for `done` below) -- not on the null stream, which the non-blocking streams do not order with
   hipStream_t rs = ctx->reduce_stream[(&s - ctx->slot) % NREDUCE];
   HIP_TRY(ctx, hipMemsetAsync(s.d_wsums, 0, WSUM_BYTES + 4, rs));
   HIP_TRY(ctx, hipMemsetAsync(s.d_big_queue, 0, 4, rs));
-  HIP_TRY(ctx, hipMemsetAsync(s.d_done_blocks, 0, 4, rs));
   if (!s.done) HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   if (!s.smvp_done) HIP_TRY(ctx, hipEventCreateWithFlags(&s.smvp_done, hipEventDisableTiming));
   if (!s.staged) HIP_TRY(ctx, hipEventCreateWithFlags(&s.staged, hipEventDisableTiming));
@@ -453,7 +450,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
                      s.d_buckets, s.d_big_queue);
   AFTER_KERNEL(ctx, "k_smvp_stitch", rs);
   hipLaunchKernelGGL(ctx->ops->smvp_stitch_big, dim3(256), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails, s.d_buckets,
-                     s.d_big_queue, s.d_done_blocks, half);
+                     s.d_big_queue, half);
   AFTER_KERNEL(ctx, "k_smvp_stitch_big", rs);
   if (tl >= 2) {
     HIP_TRY(ctx, hipEventRecord(s.ev[6], rs));
@@ -481,7 +478,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   AFTER_KERNEL(ctx, "k_bpr_rowcol", rs);
   hipLaunchKernelGGL(ctx->ops->bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts, (int)(half / BPR_COLS));
   AFTER_KERNEL(ctx, "k_bpr_w256", rs);
-  hipLaunchKernelGGL(ctx->ops->bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out);
+  hipLaunchKernelGGL(ctx->ops->bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue);
   AFTER_KERNEL(ctx, "k_bpr_final", rs);
   if (tl >= 2) HIP_TRY(ctx, hipEventRecord(s.red1, rs));
   if (to_host) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * 96, hipMemcpyDeviceToHost, rs));
@@ -698,7 +695,7 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   for (int k = 0; k < NSLOT; k++) {
     Slot& s = ctx->slot[k];
     if (s.h_wsums) (void)hipHostFree(s.h_wsums);
-    void* sbufs[] = {s.d_wsums, s.d_buckets, s.d_partials, s.d_col_ptr, s.d_heads, s.d_tails, s.d_big_queue, s.d_done_blocks, s.d_host_scalars};
+    void* sbufs[] = {s.d_wsums, s.d_buckets, s.d_partials, s.d_col_ptr, s.d_heads, s.d_tails, s.d_big_queue, s.d_host_scalars};
     for (void* b : sbufs)
       if (b) (void)hipFree(b);
     hipEvent_t evs[] = {s.done, s.smvp_done, s.staged, s.red0, s.red1};

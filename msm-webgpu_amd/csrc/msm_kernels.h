@@ -864,11 +864,12 @@ __global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict_
 }
 
 // Queued big buckets: one block per bucket (blocks stride over the queue); every thread adds a strided subset of the
-// pieces, then an LDS tree.  Block 0 resets the queue counter for the next MSM once every block has read it.
+// pieces, then an LDS tree.  The queue counter is reset for the slot's next launch by k_bpr_final, a later kernel of the same
+// stream (a last-block hand-off here would cost a __threadfence per launch, queue empty or not).
 __global__ void __launch_bounds__(256) k_smvp_stitch_big(const uint32_t* __restrict__ col_ptr, uint32_t chunks, uint32_t chunk_len,
                                                          const uint32_t* __restrict__ heads, const uint32_t* __restrict__ tails,
-                                                         uint32_t* __restrict__ buckets, uint32_t* __restrict__ big_queue,
-                                                         uint32_t* __restrict__ done_blocks, uint32_t half) {
+                                                         uint32_t* __restrict__ buckets, const uint32_t* __restrict__ big_queue,
+                                                         uint32_t half) {
   __shared__ uint32_t x[256 * XYZZ_WORDS];
   const int t = threadIdx.x;
   uint32_t count = big_queue[0];
@@ -891,15 +892,6 @@ __global__ void __launch_bounds__(256) k_smvp_stitch_big(const uint32_t* __restr
     }
     if (t == 0) st_rec(buckets + ((size_t)lw * half + s) * REC_WORDS, ld_xyzz(x));
     __syncthreads();
-  }
-  // last block out resets the queue for the next run
-  if (t == 0) {
-    __threadfence();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (atomicAdd(done_blocks, 1u) == gridDim.x - 1) {
-      big_queue[0] = 0;
-      *done_blocks = 0;
-    }
   }
 }
 
@@ -1277,8 +1269,10 @@ __global__ void __launch_bounds__(256) k_bpr_w256(const uint32_t* __restrict__ r
 
 // one lane per window: S = 128 * W(R) + W(C) + sum(C), emitted as canonical Jacobian bytes.  (Operands stay in registers
 // here, which measured faster than the cooperative LDS form: 52 vs 71 us.)
-__global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ parts, int w_count, uint32_t* __restrict__ wsums) {
+__global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ parts, int w_count, uint32_t* __restrict__ wsums,
+                                                  uint32_t* __restrict__ big_queue) {
   const int w = threadIdx.x;
+  if (w == 0) big_queue[0] = 0;  // the stitch's queue of big buckets, consumed earlier on this stream: empty for the next launch
   if (w >= w_count) return;
   g1_xyzz acc = ld_xyzz(parts + ((size_t)w * 3 + 0) * XYZZ_WORDS);
   for (int i = 0; i < 7; i++) acc = g1_double(acc);
