@@ -107,3 +107,21 @@ def test_mgpu_without_gpu_fails_loudly(built):
     with pytest.raises(m.MsmHipError) as e:
         m.MultiGpuMsm([0])
     assert e.value.code == -1
+
+
+def test_host_only_helpers_of_window_sizes_and_curves(built):
+    import msm_webgpu_amd as m
+    from oracle import cpu_grumpkin as cg
+
+    L = m.lib()
+    nw, nb = C.c_int(), C.c_int()
+    assert [(L.msm_hip_window_config(b, C.byref(nw), C.byref(nb)), nw.value, nb.value) for b in (12, 14, 16)] == [(0, 22, 2048), (0, 19, 8192), (0, 16, 32768)]
+    assert L.msm_hip_window_config(13, C.byref(nw), C.byref(nb)) == -2
+    # the host window combine for the second curve (no device involved): Horner over 16 arbitrary Grumpkin points
+    sums = cg.g1_scalar_mul(cg.sample_points(3, 16), cg.sample_scalars(4, 16))
+    got = m.MsmContext.combine_windows(sums, curve="grumpkin")
+    assert got.to_affine_bytes() == cg.to_affine64(cg.horner(sums))
+    out = C.create_string_buffer(96)
+    assert L.msm_hip_combine_windows_curve(2, sums, 16, out) == -2  # unknown curve
+    h = C.c_void_p()
+    assert L.msm_hip_ctx_create_curve(C.byref(h), 0, 7) == -2

@@ -143,3 +143,20 @@ def test_both_curves_side_by_side(gctx, ctx):
     gctx.set_bases(pb_gr)
     assert ctx.msm(sb).to_affine_bytes() == cpu_bn.to_affine64(cpu_bn.cpu_msm(pb_bn, sb))
     assert gctx.msm(sb).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb_gr, sb))
+
+
+def test_montgomery_word_formats(gctx):
+    # MSM_HIP_BASES_MONT256 / MSM_HIP_SCALARS_MONT256 with Grumpkin's moduli (base field r, scalar field p of BN254)
+    n = 500
+    points, scalars = cpu.sample_points(600, n), cpu.sample_scalars(601, n)
+    want = cpu.to_affine64(cpu.cpu_msm(points, scalars))
+    pm = b"".join(((x << 256) % P).to_bytes(32, "little") + ((y << 256) % P).to_bytes(32, "little") for x, y in ref.bytes_to_points(points))
+    sm = b"".join(((v << 256) % R).to_bytes(32, "little") for v in ref.bytes_to_scalars(scalars))
+    gctx.set_bases(pm, check_on_curve=True, mont256=True)
+    gctx.set_scalar_format(True)
+    try:
+        assert gctx.msm(sm).to_affine_bytes() == want
+    finally:
+        gctx.set_scalar_format(False)
+    gctx.set_bases(points)
+    assert gctx.msm(scalars).to_affine_bytes() == want
