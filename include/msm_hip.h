@@ -58,6 +58,14 @@ extern "C" {
                                           entry points (run, launch / finish, batch) then put all 16 windows of an MSM into ONE bucket
                                           set: one stitch + bucket reduce instead of 16, no window combine, up to 64 MSMs per launch.
                                           Same result.  The window-sharding entry points ignore the tables (table 0 is the plain set). */
+#define MSM_HIP_BASES_ENDOMORPHISM 8u  /* curve endomorphism (SURVEY.md 8f-3 "GLV endomorphism ... to halve scalar length"; the reference
+                                          uses full-length scalars, src/cuzk/msm.rs:79-82): also store phi(P_i) = (beta x_i, y_i) = lambda P_i
+                                          (2 x the base memory; at most 2^27 points).  Whole-MSM entry points then split every scalar
+                                          k = k1 + k2 lambda (mod r), |k1|, |k2| < 2^127, on the device and run the MSM over the 2n points
+                                          with HALF the windows (8 instead of 16 at 16 bits): the same bucket additions, half the buckets
+                                          to stitch / reduce and half the window sums to combine.  Same result.  Not combinable with
+                                          MSM_HIP_BASES_PRECOMPUTE; the window-sharding entry points ignore it (records 0 .. n-1 are the
+                                          plain set). */
 
 typedef struct msm_hip_ctx msm_hip_ctx;
 
@@ -115,6 +123,8 @@ int msm_hip_set_scalar_format(msm_hip_ctx* ctx, uint32_t format);
 int msm_hip_set_window_bits(msm_hip_ctx* ctx, int bits);
 int msm_hip_window_config(int bits, int* num_windows, int* buckets_per_window); /* host-only: the shape of a window size */
 int msm_hip_last_window_bits(msm_hip_ctx* ctx);                                 /* window size of the last launch       */
+int msm_hip_endomorphism_window_count(int bits); /* host-only: windows of a 127-bit half (MSM_HIP_BASES_ENDOMORPHISM): 8 / 10 / 11 */
+int msm_hip_uses_endomorphism(const msm_hip_ctx* ctx); /* 1: the resident bases were set with MSM_HIP_BASES_ENDOMORPHISM */
 /* how many whole MSMs of n points the batch entry points put through ONE launch (what msm_hip_launch_windows_batch_device_bn254
  * with w_begin = 0, w_end = 16, window_sums_dev = NULL should be given for best throughput): 1 from 2^20 points up, at most
  * MSM_HIP_MAX_LOCAL_WINDOWS / (windows of the size picked for n) below */

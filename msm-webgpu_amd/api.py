@@ -83,6 +83,8 @@ def lib():
         L.msm_hip_set_window_bits.argtypes = [vp, i]
         L.msm_hip_window_config.argtypes = [i, C.POINTER(i), C.POINTER(i)]
         L.msm_hip_last_window_bits.argtypes = [vp]
+        L.msm_hip_endomorphism_window_count.argtypes = [i]
+        L.msm_hip_uses_endomorphism.argtypes = [vp]
         L.msm_hip_batch_group_size.argtypes = [vp, sz]
         L.msm_hip_read_digits.argtypes = [vp, vp, sz]
         L.msm_hip_read_col_ptr.argtypes = [vp, vp, sz]
@@ -214,11 +216,13 @@ class MsmContext:
             pass
 
     # -- bases
-    def set_bases(self, points, check_on_curve=False, mont256=False, precompute=False):
+    def set_bases(self, points, check_on_curve=False, mont256=False, precompute=False, endomorphism=False):
         """points: bytes (host, n x 64 B wire format) or a CUDA uint8 tensor holding the same bytes.
         mont256: the coordinates are x * 2^256 mod p (4 x 64-bit Montgomery limbs, R = 2^256) instead of canonical integers.
-        precompute: fixed-base tables 2^(16 w) P_i (16 x the memory): whole MSMs then use one bucket set for all windows."""
-        flags = (1 if check_on_curve else 0) | (2 if mont256 else 0) | (4 if precompute else 0)
+        precompute: fixed-base tables 2^(16 w) P_i (16 x the memory): whole MSMs then use one bucket set for all windows.
+        endomorphism: also store phi(P_i) (2 x the memory): whole MSMs split every scalar into two 127-bit halves and need
+        half the windows."""
+        flags = (1 if check_on_curve else 0) | (2 if mont256 else 0) | (4 if precompute else 0) | (8 if endomorphism else 0)
         if isinstance(points, torch.Tensor) and points.is_cuda:
             t, n = _as_device_u8(points, 64, "points")
             self._order_after_torch(t)
@@ -402,6 +406,17 @@ class MsmContext:
         nw, nb = C.c_int(), C.c_int()
         _check(lib().msm_hip_window_config(int(bits), C.byref(nw), C.byref(nb)), "msm_hip_window_config")
         return nw.value, nb.value
+
+    @staticmethod
+    def endomorphism_window_count(bits):
+        """Windows of one 127-bit half at a window size (8 at 16 bits)."""
+        v = lib().msm_hip_endomorphism_window_count(int(bits))
+        if v < 0:
+            raise MsmHipError(v, "msm_hip_endomorphism_window_count")
+        return v
+
+    def uses_endomorphism(self):
+        return lib().msm_hip_uses_endomorphism(self._h) == 1
 
     # -- stage read-back (parity tests)
     def set_scalar_format(self, mont256):

@@ -5,5 +5,6 @@
 #include "fq29.h"
 #include "g1.h"
 #include "host_g1.h"
+#include "glv.h"
 #include "msm_kernels.h"
 #undef MSM_CURVE_UNIT

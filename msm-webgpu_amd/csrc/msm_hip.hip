@@ -46,6 +46,8 @@ namespace {
 struct CurveOps {
   void (*convert_points)(const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t*);
   void (*precompute_tables)(uint32_t*, size_t, size_t, int);
+  void (*endo_points)(uint32_t*, size_t);
+  void (*glv_split)(const uint32_t*, uint32_t*, size_t, int, uint32_t*);
   void (*scalars_from_mont256)(const uint32_t*, uint32_t*, size_t, uint32_t*);
   void (*smvp_chunks)(const uint32_t*, const uint32_t*, const uint32_t*, size_t, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*,
                       uint32_t*, uint32_t);
@@ -69,12 +71,19 @@ struct CurveOps {
   int (*to_affine64)(const uint8_t*, uint8_t*);
 };
 #define MSM_CURVE_OPS(K, F)                                                                                                              \
-  {K::k_convert_points, K::k_precompute_tables, K::k_scalars_from_mont256, K::k_smvp_chunks, K::k_smvp_stitch, K::k_smvp_stitch_big,       \
+  {K::k_convert_points, K::k_precompute_tables, K::k_endo_points, K::k_glv_split, K::k_scalars_from_mont256, K::k_smvp_chunks, K::k_smvp_stitch, K::k_smvp_stitch_big,       \
    K::k_bpr_rowcol<4, 8>, K::k_bpr_rowcol<2, 8>, K::k_bpr_rowcol<3, 8>, K::k_bpr_rowcol<4, 6>, K::k_bpr_rowcol<2, 6>, K::k_bpr_rowcol<2, 4>, \
    K::k_bpr_w256, K::k_bpr_final, K::k_sample_scalars, K::k_sample_points, K::k_export_buckets, K::k_test_fq, K::k_test_g1,                \
    K::k_test_g1_mul_u32, F::host::combine_windows, F::host::to_affine64}
 const CurveOps CURVE_OPS[2] = {MSM_CURVE_OPS(msmk, bn254), MSM_CURVE_OPS(msmk_grumpkin, grumpkin)};
 #undef MSM_CURVE_OPS
+
+// What a launch's local windows are made of
+enum LaunchMode {
+  MODE_PLAIN = 0,   // windows [w_begin, w_end) of 254-bit scalars over the n bases
+  MODE_TABLES = 1,  // fixed-base tables: all windows of a vector feed one bucket set (MSM_HIP_BASES_PRECOMPUTE)
+  MODE_HALVES = 2,  // endomorphism: 127-bit halves k1, k2 over the 2n points P_i, phi(P_i) (MSM_HIP_BASES_ENDOMORPHISM, csrc/glv.h)
+};
 
 constexpr int N_MAIN_EVENTS = 7;  // boundaries of the 6 timed stages on the main stream
 constexpr uint32_t MAX_TILES = 1024;
@@ -107,6 +116,7 @@ struct Slot {
   bool ready = false;                         // small buffers + events exist (slots are set up on first use)
   bool timed = false, pending = false, to_host = false;
   bool merged = false;                        // fixed-base launch: one bucket set (one window sum) per scalar vector
+  bool halves = false;                        // endomorphism launch: the windows are those of 127-bit halves
   int timing_level = 0;
   int w_begin = 0, w_count = 0, nvec = 1;  // windows [w_begin, w_begin + w_count) of nvec scalar vectors
   size_t n = 0;
@@ -125,6 +135,9 @@ struct msm_hip_ctx {
   uint32_t* d_bases = nullptr;  // n_bases x 16 words
   size_t n_bases = 0, cap_bases = 0;  // points per table; capacity in point records (16 x n_bases with fixed-base tables)
   bool precomputed = false;           // d_bases holds the 16 tables 2^(16 w) P_i (MSM_HIP_BASES_PRECOMPUTE)
+  bool endo = false;                  // d_bases holds phi(P_i) behind the n bases (MSM_HIP_BASES_ENDOMORPHISM)
+  uint32_t* d_halves = nullptr;       // the split scalars of one launch (main stream only): [vector][2n] x 4 words
+  size_t cap_halves = 0;              // in scalars
 
   hipStream_t copy_stream = nullptr;    // H2D of host scalars (created on first use by msm_hip_launch_bn254)
   hipEvent_t input_ready = nullptr;     // a caller's producer stream -> main stream (msm_hip_wait_stream)
@@ -330,11 +343,11 @@ int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, Slot& s) {
 // (0.70 vs 0.80 ms latency, 0.34 vs 0.40 ms pipelined), 16 bits from 2^13 up; 14 bits never wins and is kept as an explicit
 // choice (msm_hip_set_window_bits).  `nvec` whole MSMs must fit MAXLW local windows.  The window-sharding entry points always use
 // 16-bit windows: their w_begin / w_end index the reference's 16 windows.
-inline int pick_window_bits(const msm_hip_ctx* ctx, size_t n, int nvec) {
+inline int pick_window_bits(const msm_hip_ctx* ctx, size_t n, int nvec, bool halves = false) {
   static const int forced = [] { const char* e = getenv("MSM_HIP_WINDOW_BITS"); return e ? atoi(e) : 0; }();  // tuning aid
   int bits = ctx->window_bits ? ctx->window_bits : (forced == 12 || forced == 14 || forced == 16 ? forced : 0);
   if (!bits) bits = n <= ((size_t)1 << 12) ? 12 : 16;
-  while (bits < 16 && nvec * nwin_of(bits) > MAXLW) bits += 2;
+  while (bits < 16 && nvec * nwin_of(bits, halves) > MAXLW) bits += 2;
   return bits;
 }
 
@@ -370,22 +383,26 @@ int err_from_bits(uint32_t bits) {
 // Enqueue one MSM (windows [w_begin, w_begin + w_count)) into slot `s`.  Window sums (canonical Jacobian bytes) go to
 // `wsums_out` (device memory; the slot's own buffer when null); the error word and, if `to_host`, the window sums are
 // copied to the slot's pinned buffer.  Returns without waiting.
-int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count_vec, int nvec, int wbits, bool merge, Slot& s,
+int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count_vec, int nvec, int wbits, LaunchMode mode, Slot& s,
             uint32_t* wsums_out, bool to_host) {
+  const bool merge = mode == MODE_TABLES, halves = mode == MODE_HALVES;
   const uint32_t half = 1u << (wbits - 1);   // bucket slots per window
   const unsigned ncoarse = half / FINE;      // coarse bins that can hold entries
   // fixed-base tables (`merge`): the w_count_vec windows of a vector feed one bucket set -- one local window of up to
   // n * w_count_vec entries per vector -- whose entries index the tables (window w of point i = record w * n_bases + i)
   const size_t merge_nb = merge ? ctx->n_bases : 0;
-  const size_t n_entries = merge ? n * (size_t)w_count_vec : n;
+  // endomorphism (`halves`): the recode reads 2n halves of 16 B (k_glv_split) against 2n points -- P_i and, n_bases records
+  // further on, phi(P_i) -- in half as many windows
+  const size_t n_sc = halves ? 2 * n : n;  // inputs of the recode
+  const size_t n_entries = merge ? n * (size_t)w_count_vec : n_sc;
   // `nvec` scalar vectors (contiguous, n x 32 B each) share this launch: local window lw = v * w_count_vec + (w - w_begin);
   // everything after the two scalar-reading kernels only sees w_count = nvec * w_count_vec local windows
   const int w_count = merge ? nvec : nvec * w_count_vec;
   hipStream_t st = ctx->stream, rs = ctx->reduce_stream[(&s - ctx->slot) % NREDUCE];
   // tiles of scalars for the two global sort passes: >= 2048 scalars each, at most MAX_TILES of them
   uint32_t tile_len = 2048;
-  if ((n + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n + MAX_TILES - 1) / MAX_TILES) + 255) / 256 * 256);
-  const uint32_t tiles = (uint32_t)((n + tile_len - 1) / tile_len);
+  if ((n_sc + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n_sc + MAX_TILES - 1) / MAX_TILES) + 255) / 256 * 256);
+  const uint32_t tiles = (uint32_t)((n_sc + tile_len - 1) / tile_len);
   const uint32_t chunk_len = chunk_len_for(n_entries, w_count);
   const uint32_t chunks = chunks_for(n_entries, chunk_len);
   const size_t stride = stride_for(n_entries);
@@ -410,21 +427,34 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     AFTER_KERNEL(ctx, "k_scalars_from_mont256", st);
     d_scalars = ctx->d_scalar_conv;
   }
-#define LAUNCH_BY_WBITS(KERNEL, ...)                                                     \
+  if (halves) {  // k = k1 + k2 lambda: the halves of every vector (part of stage 0)
+    const size_t count = (size_t)nvec * n;
+    hipLaunchKernelGGL(ctx->ops->glv_split, dim3(blocks_for(count, 256)), dim3(256), 0, st, d_scalars, ctx->d_halves, n, nvec, d_err);
+    AFTER_KERNEL(ctx, "k_glv_split", st);
+    d_scalars = ctx->d_halves;
+  }
+#define LAUNCH_BY_WBITS_SW(KERNEL, SW, ...)                                              \
   do {                                                                                   \
-    if (wbits == 16) hipLaunchKernelGGL(KERNEL<16>, dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
-    else if (wbits == 14) hipLaunchKernelGGL(KERNEL<14>, dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
-    else hipLaunchKernelGGL(KERNEL<12>, dim3(tiles), dim3(256), 0, st, __VA_ARGS__);     \
+    if (wbits == 16) hipLaunchKernelGGL((KERNEL<16, SW>), dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
+    else if (wbits == 14) hipLaunchKernelGGL((KERNEL<14, SW>), dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<12, SW>), dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
   } while (0)
-  LAUNCH_BY_WBITS(k_count, d_scalars, n, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, digits, d_err, merge_nb);
+#define LAUNCH_BY_WBITS(KERNEL, ...)                           \
+  do {                                                         \
+    if (halves) LAUNCH_BY_WBITS_SW(KERNEL, 4, __VA_ARGS__);    \
+    else LAUNCH_BY_WBITS_SW(KERNEL, 8, __VA_ARGS__);           \
+  } while (0)
+  // (a vector's 2n halves take the room of its n scalars: the vector stride is n * 8 words either way)
+  LAUNCH_BY_WBITS(k_count, d_scalars, n_sc, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, digits, d_err, merge_nb);
   AFTER_KERNEL(ctx, "k_count", st);
   HIP_TRY(ctx, mark(1, false));
   hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total);  // all 128 bins: the scatter scans them
   AFTER_KERNEL(ctx, "k_scan_tiles", st);
   HIP_TRY(ctx, mark(2, false));
-  LAUNCH_BY_WBITS(k_scatter_coarse, d_scalars, n, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
-                  ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb);
+  LAUNCH_BY_WBITS(k_scatter_coarse, d_scalars, n_sc, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
+                  ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, (uint32_t)n, (uint32_t)(ctx->n_bases - n));
 #undef LAUNCH_BY_WBITS
+#undef LAUNCH_BY_WBITS_SW
   AFTER_KERNEL(ctx, "k_scatter_coarse", st);
   HIP_TRY(ctx, mark(3, false));
   const uint32_t* part_hist = nullptr;
@@ -492,12 +522,13 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   s.nvec = nvec;
   s.wbits = wbits;
   s.merged = merge;
+  s.halves = halves;
   s.n = n;
   s.timed = tl >= 1;
   s.timing_level = tl;
   s.pending = true;
   s.to_host = to_host;
-  ctx->last_n = n;
+  ctx->last_n = n_sc;
   ctx->last_w_count = w_count;
   ctx->last_wbits = wbits;
   ctx->last_slot = (int)(&s - ctx->slot);
@@ -545,11 +576,12 @@ constexpr size_t MAX_PRECOMPUTE_POINTS = (size_t)1 << 24;  // 16 tables: 16 GiB,
 
 int reserve_bases(msm_hip_ctx* ctx, size_t n, uint32_t flags) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const bool tables = (flags & MSM_HIP_BASES_PRECOMPUTE) != 0;
-  if (n > MAX_POINTS || (tables && n > MAX_PRECOMPUTE_POINTS)) return MSM_HIP_ERR_INVALID_ARG;
+  const bool tables = (flags & MSM_HIP_BASES_PRECOMPUTE) != 0, endo = (flags & MSM_HIP_BASES_ENDOMORPHISM) != 0;
+  if (n > MAX_POINTS || (tables && n > MAX_PRECOMPUTE_POINTS) || (endo && n > MAX_POINTS / 2) || (tables && endo)) return MSM_HIP_ERR_INVALID_ARG;
   ctx->n_bases = 0;
   ctx->precomputed = false;
-  const size_t records = tables ? n * NWIN : n;
+  ctx->endo = false;
+  const size_t records = tables ? n * NWIN : endo ? 2 * n : n;
   if (records > ctx->cap_bases) {
     ctx->cap_bases = 0;
     int rc = dev_alloc(ctx, ctx->d_bases, records * 16);
@@ -576,6 +608,12 @@ int set_bases_from_device(msm_hip_ctx* ctx, const uint32_t* d_xy, size_t n, uint
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->precomputed = true;
   }
+  if (flags & MSM_HIP_BASES_ENDOMORPHISM) {  // phi(P_i) = (beta x_i, y_i) behind the plain set
+    hipLaunchKernelGGL(ctx->ops->endo_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_bases, n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->endo = true;
+  }
   ctx->n_bases = n;
   return MSM_HIP_OK;
 }
@@ -586,8 +624,8 @@ namespace {
 // MSMs per launch of the batch runners: small MSMs cannot fill the GPU one at a time (kernel latencies dominate below
 // ~2^19 points), so up to MAXLW / NWIN = 4 of them -- at most about 2^20 points together -- share one kernel sequence
 size_t batch_group(msm_hip_ctx* ctx, size_t n, size_t batch) {
-  // 4 at 16 bits, 3 at 14, 2 at 12; with fixed-base tables every MSM is one local window
-  const size_t fit = ctx->precomputed ? (size_t)MAXLW : (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 1)));
+  // 4 at 16 bits, 3 at 14, 2 at 12 (twice that with the endomorphism's half-length scalars); with fixed-base tables every MSM is one local window
+  const size_t fit = ctx->precomputed ? (size_t)MAXLW : (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 1, ctx->endo), ctx->endo));
   size_t g = n ? ((size_t)1 << 20) / n : 1;
   if (g > fit) g = fit;
   if (g > batch) g = batch;
@@ -621,7 +659,7 @@ int run_batch_groups(msm_hip_ctx* ctx, size_t n, size_t batch, uint8_t* out_xyz,
 
 extern "C" {
 
-int msm_hip_abi_version(void) { return 4; }
+int msm_hip_abi_version(void) { return 5; }
 
 const char* msm_hip_strerror(int code) {
   switch (code) {
@@ -688,7 +726,7 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   for (hipStream_t r : ctx->reduce_stream)
     if (r) (void)hipStreamSynchronize(r);
-  void* bufs[] = {ctx->d_bases,   ctx->d_batch_stage, ctx->d_scalar_conv, ctx->d_part_hist, ctx->d_digits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
+  void* bufs[] = {ctx->d_bases,   ctx->d_halves, ctx->d_batch_stage, ctx->d_scalar_conv, ctx->d_part_hist, ctx->d_digits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
                   ctx->d_tmp_val, ctx->d_tmp_fine, ctx->d_val,    ctx->d_chunk_slot, ctx->d_err,       ctx->d_stage};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -743,10 +781,11 @@ int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, 
 namespace {
 // windows [w_begin, w_end) -- in units of `wbits`-bit windows -- of `nvec` scalar vectors into `slot`
 int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end, int wbits, int slot,
-                void* window_sums_dev, bool merge = false) {
+                void* window_sums_dev, LaunchMode mode = MODE_PLAIN) {
+  const bool merge = mode == MODE_TABLES, halves = mode == MODE_HALVES;
   int rc = check_run_args(ctx, scalars_dev, n);
   if (rc) return rc;
-  if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > nwin_of(wbits) || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
+  if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > nwin_of(wbits, halves) || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
   const int w_count = w_end - w_begin;
   const int w_local = merge ? nvec : nvec * w_count;  // bucket sets of the launch
   if (nvec < 1 || w_local > MAXLW) return MSM_HIP_ERR_INVALID_ARG;
@@ -760,6 +799,7 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
   s.nvec = nvec;
   s.wbits = wbits;
   s.merged = merge;
+  s.halves = halves;
   s.to_host = window_sums_dev == nullptr;
   if (n == 0) {  // identity window sums, nothing to compute
     s.pending = true;
@@ -771,14 +811,20 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
     }
     return MSM_HIP_OK;
   }
-  if ((rc = ensure_work(ctx, merge ? n * (size_t)w_count : n, w_local, wbits, s))) return rc;
+  if ((rc = ensure_work(ctx, merge ? n * (size_t)w_count : halves ? 2 * n : n, w_local, wbits, s))) return rc;
+  if (halves && (size_t)nvec * n > ctx->cap_halves) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cap_halves = 0;
+    if ((rc = dev_alloc(ctx, ctx->d_halves, (size_t)nvec * n * 8))) return rc;
+    ctx->cap_halves = (size_t)nvec * n;
+  }
   if (ctx->scalar_format == MSM_HIP_SCALARS_MONT256 && (size_t)nvec * n > ctx->cap_scalar_conv) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cap_scalar_conv = 0;
     if ((rc = dev_alloc(ctx, ctx->d_scalar_conv, (size_t)nvec * n * 8))) return rc;
     ctx->cap_scalar_conv = (size_t)nvec * n;
   }
-  return enqueue(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, nvec, wbits, merge, s,
+  return enqueue(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, nvec, wbits, mode, s,
                  static_cast<uint32_t*>(window_sums_dev), window_sums_dev == nullptr);
 }
 }  // namespace
@@ -790,7 +836,11 @@ int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scal
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
   // whole MSMs whose sums stay in the slot (finish / finish_batch combines them): the window size follows n
   if (w_begin == 0 && w_end == NWIN && window_sums_dev == nullptr && nvec >= 1 && ctx->precomputed && n > 0)
-    return launch_impl(ctx, scalars_dev, n, nvec, 0, NWIN, WBITS, slot, nullptr, true);  // fixed-base tables: one bucket set per vector
+    return launch_impl(ctx, scalars_dev, n, nvec, 0, NWIN, WBITS, slot, nullptr, MODE_TABLES);  // fixed-base tables: one bucket set per vector
+  if (w_begin == 0 && w_end == NWIN && window_sums_dev == nullptr && nvec >= 1 && ctx->endo && n > 0 && nvec * nwin_of(16, true) <= MAXLW) {
+    const int wbits = pick_window_bits(ctx, n, nvec, true);  // endomorphism: half-length scalars over 2n points
+    return launch_impl(ctx, scalars_dev, n, nvec, 0, nwin_of(wbits, true), wbits, slot, nullptr, MODE_HALVES);
+  }
   if (w_begin == 0 && w_end == NWIN && window_sums_dev == nullptr && nvec >= 1 && nvec * NWIN <= MAXLW) {
     const int wbits = pick_window_bits(ctx, n, nvec);
     return launch_impl(ctx, scalars_dev, n, nvec, 0, nwin_of(wbits), wbits, slot, nullptr);
@@ -826,8 +876,8 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   if (!ctx || !out_xyz || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   Slot& s = ctx->slot[slot];
   // fixed-base launches leave ONE sum per vector (every table already carries its power of two): nothing to combine but the copy
-  const int nwin = s.merged ? 1 : nwin_of(s.wbits);
-  if (!s.pending || !s.to_host || s.w_count != nwin_of(s.wbits)) return MSM_HIP_ERR_INVALID_ARG;
+  const int nwin = s.merged ? 1 : nwin_of(s.wbits, s.halves);
+  if (!s.pending || !s.to_host || s.w_count != nwin_of(s.wbits, s.halves)) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   int rc = wait_slot(ctx, s);
   if (rc) return rc;
@@ -1045,6 +1095,13 @@ int msm_hip_window_config(int bits, int* num_windows, int* buckets_per_window) {
 }
 
 int msm_hip_last_window_bits(msm_hip_ctx* ctx) { return ctx ? ctx->last_wbits : MSM_HIP_ERR_INVALID_ARG; }
+
+int msm_hip_endomorphism_window_count(int bits) {
+  if (bits != 12 && bits != 14 && bits != 16) return MSM_HIP_ERR_INVALID_ARG;
+  return nwin_of(bits, true);
+}
+
+int msm_hip_uses_endomorphism(const msm_hip_ctx* ctx) { return ctx ? (ctx->endo ? 1 : 0) : MSM_HIP_ERR_INVALID_ARG; }
 
 int msm_hip_batch_group_size(msm_hip_ctx* ctx, size_t n) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;

@@ -36,16 +36,20 @@ constexpr int HALF = 1 << (WBITS - 1);  // 32768 bucket slots per window at 16 b
 // 2^(C-1) bucket slots per window, NWIN = ceil(255 / C) windows (254-bit scalars + one bit for the recode's carry).
 // Small MSMs are dominated by the bucket reduce of 16 x 2^15 mostly empty buckets; a smaller C trades a few more
 // additions per point for 16 x / 4 x fewer buckets.  The host picks C from n (msm_hip.hip: pick_window_bits).
-template <int C>
+// SW = words per scalar the recode reads: 8 (a 254-bit scalar) or 4 (one 127-bit half of the endomorphism split, csrc/glv.h:
+// magnitude in bits 0 .. 126, sign in bit 127).
+template <int C, int SW = 8>
 struct WinCfg {
   static_assert(C >= 10 && C <= 16, "window bits");
+  static_assert(SW == 8 || SW == 4, "scalar words");
   static constexpr int BITS = C;
-  static constexpr int NWIN = (254 + C) / C;               // 16: 16, 14: 19, 12: 22
+  static constexpr int SBITS = SW == 8 ? 254 : 127;        // bits of the scalar (magnitude)
+  static constexpr int NWIN = (SBITS + C) / C;             // 16: 16 | 8, 14: 19 | 10, 12: 22 | 11
   static constexpr int HALF = 1 << (C - 1);                // bucket slots per window
   static constexpr int TBITS = NWIN * C;                   // bits of the biased scalar that carry digits
-  static constexpr int WORDS = (TBITS + 31) / 32;          // 8 (C = 16) or 9
+  static constexpr int WORDS = (TBITS + 31) / 32;          // 8 or 9 | 4 or 5
 };
-__host__ __device__ constexpr int nwin_of(int bits) { return (254 + bits) / bits; }
+__host__ __device__ constexpr int nwin_of(int bits, bool halves = false) { return ((halves ? 127 : 254) + bits) / bits; }
 
 __device__ __constant__ uint32_t c_pp1d4[8] = {FQ_PP1D4_32[0], FQ_PP1D4_32[1], FQ_PP1D4_32[2], FQ_PP1D4_32[3],
                                                FQ_PP1D4_32[4], FQ_PP1D4_32[5], FQ_PP1D4_32[6], FQ_PP1D4_32[7]};
@@ -164,6 +168,40 @@ __global__ void __launch_bounds__(256) k_convert_points(const uint32_t* in, uint
   st_fq(out + i * 16 + 8, y);
 }
 
+// The endomorphism's point half (csrc/glv.h): record n + i = phi(P_i) = (beta x_i, y_i) behind the n plain bases
+__global__ void __launch_bounds__(256) k_endo_points(uint32_t* __restrict__ bases, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fq beta;
+#pragma unroll
+  for (int k = 0; k < 9; k++) beta.v[k] = FQ_BETA29[k];
+  st_fq(bases + (n + i) * 16, fq_mul(ld_fq(bases + i * 16), beta));
+  const uint4* y = reinterpret_cast<const uint4*>(bases + i * 16 + 8);
+  uint4* o = reinterpret_cast<uint4*>(bases + (n + i) * 16 + 8);
+  o[0] = y[0];
+  o[1] = y[1];
+}
+
+// ... and its scalar half: vector v's n scalars -> 2n halves of 16 B, |k1| of scalar i at [v][i], |k2| at [v][n + i] (signs in
+// bit 127); the halves are then recoded like scalars of 4 words (k_count / k_scatter_coarse with SW = 4) against the 2n points
+__global__ void __launch_bounds__(256) k_glv_split(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ halves, size_t n, int nvec,
+                                                   uint32_t* __restrict__ err) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * (size_t)nvec) return;
+  const size_t v = idx / n, i = idx - v * n;
+  uint32_t k[8], h1[4], h2[4];
+  ld8(scalars + idx * 8, k);
+  // the input contract of the plain path: scalars that overflow the reference's 16-bit recode are rejected (test/utils.rs:150-152)
+  uint64_t c = 0;
+#pragma unroll
+  for (int w = 0; w < 8; w++) c = (c + k[w] + 0x80008000u) >> 32;
+  const bool ok = glv_split(k, h1, h2);
+  if (c != 0 || !ok) atomicOr(err, ERRBIT_SCALAR_CARRY);
+  uint32_t* o = halves + v * n * 8;
+  *reinterpret_cast<uint4*>(o + i * 4) = make_uint4(h1[0], h1[1], h1[2], h1[3]);
+  *reinterpret_cast<uint4*>(o + (n + i) * 4) = make_uint4(h2[0], h2[1], h2[2], h2[3]);
+}
+
 
 // Fixed-base tables (reference README.md "Future work": the Elastic-MSM precomputation trade-off): with
 // T_w[i] = 2^(16 w) P_i stored for every window, sum_i s_i P_i = sum_i sum_w d_{i,w} T_w[i] needs ONE bucket set for all
@@ -219,32 +257,45 @@ constexpr int FINE = HALF / NCOARSE;  // 256 slots per coarse bin
 // 105-112), and the carry out of bit 255 is its "final carry".  Each window's digit is then read independently.
 // The same for C-bit windows: the bias constant has bit C w + C - 1 set for every window w (word i of it below), the biased
 // scalar t has WinCfg<C>::WORDS words, and the recode overflows iff t has a bit at or above C * NWIN.
-template <int C>
+template <int C, int SW = 8>
 __host__ __device__ constexpr uint32_t bias_word(int i) {
   uint32_t v = 0;
-  for (int w = 0; w < WinCfg<C>::NWIN; w++) {
+  for (int w = 0; w < WinCfg<C, SW>::NWIN; w++) {
     const int bit = C * w + C - 1;
     if (bit / 32 == i) v |= 1u << (bit % 32);
   }
   return v;
 }
-template <int C>
-__device__ __forceinline__ uint32_t bias_scalar(const uint32_t s[8], uint32_t t[WinCfg<C>::WORDS]) {
-  constexpr int WORDS = WinCfg<C>::WORDS;
+template <int C, int SW = 8>
+__device__ __forceinline__ uint32_t bias_scalar(const uint32_t s[SW], uint32_t t[WinCfg<C, SW>::WORDS]) {
+  constexpr int WORDS = WinCfg<C, SW>::WORDS;
   uint64_t c = 0;
 #pragma unroll
   for (int i = 0; i < WORDS; i++) {
-    c += (uint64_t)(i < 8 ? s[i] : 0u) + bias_word<C>(i);
+    c += (uint64_t)(i < SW ? s[i] : 0u) + bias_word<C, SW>(i);
     t[i] = (uint32_t)c;
     c >>= 32;
   }
   // 1: the recode does not fit NWIN windows ("final carry is 1", test/utils.rs:150-152)
-  if constexpr (WinCfg<C>::TBITS == 32 * WORDS) return (uint32_t)c;
-  else return (t[WORDS - 1] >> (WinCfg<C>::TBITS - 32 * (WORDS - 1))) != 0u ? 1u : 0u;
+  if constexpr (WinCfg<C, SW>::TBITS == 32 * WORDS) return (uint32_t)c;
+  else return (t[WORDS - 1] >> (WinCfg<C, SW>::TBITS - 32 * (WORDS - 1))) != 0u ? 1u : 0u;
+}
+// the recode's input: a scalar (8 words) or one half of the endomorphism split (4 words; `neg` receives its sign)
+template <int SW>
+__device__ __forceinline__ void ld_scalar(const uint32_t* p, uint32_t s[SW], uint32_t& neg) {
+  if constexpr (SW == 8) {
+    ld8(p, s);
+    neg = 0;
+  } else {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    s[0] = a.x; s[1] = a.y; s[2] = a.z;
+    s[3] = a.w & 0x7fffffffu;
+    neg = a.w >> 31;
+  }
 }
 // biased digit b = d + 2^(C-1) of window w  ->  signed-magnitude code: sign << 15 | (|d| mod 2^(C-1))
 template <int C>
-__device__ __forceinline__ uint32_t code_of_window(const uint32_t t[WinCfg<C>::WORDS], int w) {
+__device__ __forceinline__ uint32_t code_of_window(const uint32_t* t, int w) {  // t: WinCfg<C, SW>::WORDS words
   constexpr uint32_t H = (uint32_t)WinCfg<C>::HALF;
   const int bit = C * w, i = bit >> 5, sh = bit & 31;
   uint32_t b = t[i] >> sh;
@@ -305,7 +356,7 @@ __global__ void __launch_bounds__(256) k_scalars_from_mont256(const uint32_t* __
 // `nvec` scalar vectors (vec_stride words apart) may share one launch: vector v, window w is handled as local window
 // lw = v * w_count + (w - w_begin), nvec * w_count <= MAXLW -- several MSMs over the same bases sorted, accumulated and reduced
 // by one kernel sequence (used by the window-sharded multi-GPU pipeline, where one MSM's share is too small to fill a GPU).
-template <int C>
+template <int C, int SW>
 __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles,
                                                int w_begin, int w_count, int nvec, size_t vec_stride,
                                                uint32_t* __restrict__ counts, uint16_t* __restrict__ digits_dbg,
@@ -322,21 +373,21 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
   for (int v = 0; v < nvec; v++) {
     const uint32_t* sv = scalars + (size_t)v * vec_stride;
     for (size_t i = base + tid; i < end; i += 256) {
-      uint32_t s[8], tb[WinCfg<C>::WORDS];
-      ld8(sv + i * 8, s);
-      bad |= bias_scalar<C>(s, tb);
-      if constexpr (C != 16) {  // the same input contract for every window size: scalars that overflow the reference's
-        uint32_t t16[8];        // 16-bit recode ("final carry is 1", test/utils.rs:150-152) are rejected
-        bad |= bias_scalar<16>(s, t16);
+      uint32_t s[SW], tb[WinCfg<C, SW>::WORDS], neg;
+      ld_scalar<SW>(sv + i * SW, s, neg);
+      bad |= bias_scalar<C, SW>(s, tb);
+      if constexpr (C != 16 && SW == 8) {  // the same input contract for every window size: scalars that overflow the reference's
+        uint32_t t16[8];                   // 16-bit recode ("final carry is 1", test/utils.rs:150-152) are rejected
+        bad |= bias_scalar<16>(s, t16);    // (halves: k_glv_split checks the scalar they come from)
       }
 #pragma unroll
-      for (int w = 0; w < WinCfg<C>::NWIN; w++) {
+      for (int w = 0; w < WinCfg<C, SW>::NWIN; w++) {
         const int lw = w - w_begin;
         if (lw >= 0 && lw < w_count) {
           const int le = merge_nb ? v : v * w_count + lw;
           const uint32_t code = code_of_window<C>(tb, w);
           if (code != 0) atomicAdd(&cnt[le * NCOARSE + ((code & 0x7fffu) >> 8)], 1u);
-          if (digits_dbg) digits_dbg[((size_t)v * w_count + lw) * n + i] = (uint16_t)code;
+          if (digits_dbg) digits_dbg[((size_t)v * w_count + lw) * n + i] = (uint16_t)(code ? code ^ (neg << 15) : 0u);
         }
       }
     }
@@ -394,13 +445,15 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* wa
 // addresses inside each (tile, bin) run instead of 64 unrelated 4-byte stores per wave instruction.
 constexpr int SCAT_SUB = 2048;  // scalars staged per block iteration (8 per thread)
 
-template <int C>
+template <int C, int SW>
 __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
                                                         uint32_t tiles, int w_begin, int w_count, int nvec, size_t vec_stride,
                                                         const uint32_t* __restrict__ counts,
                                                         const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr,
                                                         uint32_t* __restrict__ tmp_val,
-                                                        uint8_t* __restrict__ tmp_fine, size_t merge_nb) {
+                                                        uint8_t* __restrict__ tmp_fine, size_t merge_nb, uint32_t half_n, uint32_t half_shift) {
+  // SW = 4 (endomorphism halves): input j < half_n is k1 of scalar j and multiplies base j; input half_n + j is k2 and multiplies
+  // phi(P_j), stored half_shift = n_bases - half_n records further on than its position
   __shared__ uint32_t gpos[MAXLW * NCOARSE];  // global write cursor of every (window, coarse bin) run of this tile
   __shared__ uint32_t hist[NCOARSE];
   __shared__ uint32_t lstart[NCOARSE];
@@ -438,16 +491,20 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
   for (size_t sub = tile_base; sub < tile_end; sub += SCAT_SUB) {
     // this thread's 8 biased scalars stay in registers; every window's digit code is read from them
     const uint32_t* sv = scalars + (size_t)v * vec_stride;
-    uint32_t sc[8][WinCfg<C>::WORDS];
+    uint32_t sc[8][WinCfg<C, SW>::WORDS];
+    uint32_t negs = 0;  // bit j: scalar j is a negative half (its digits' signs are flipped)
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const size_t i = sub + (size_t)j * 256 + tid;
-      uint32_t raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // an all-zero scalar recodes to all-zero digits: no entries
-      if (i < tile_end) ld8(sv + i * 8, raw);
-      (void)bias_scalar<C>(raw, sc[j]);
+      uint32_t raw[SW], neg = 0;
+#pragma unroll
+      for (int k = 0; k < SW; k++) raw[k] = 0;  // an all-zero scalar recodes to all-zero digits: no entries
+      if (i < tile_end) ld_scalar<SW>(sv + i * SW, raw, neg);
+      negs |= neg << j;
+      (void)bias_scalar<C, SW>(raw, sc[j]);
     }
 #pragma unroll
-    for (int w = 0; w < WinCfg<C>::NWIN; w++) {
+    for (int w = 0; w < WinCfg<C, SW>::NWIN; w++) {
       if (w < w_begin || w >= w_begin + w_count) continue;  // block-uniform
       // fixed-base tables: window w of point i is table entry w * merge_nb + i, and all windows share local window v
       const int lw = merge_nb ? v : v * w_count + (w - w_begin);
@@ -472,7 +529,9 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
         if (code) {
           const uint32_t slot = code & 0x7fffu, bin = slot >> 8;
           const uint32_t e = lstart[bin] + rank[j];
-          st_val[e] = (idx_base + (uint32_t)(sub + (size_t)j * 256 + tid)) | ((code >> 15) << 31);
+          uint32_t pos = (uint32_t)(sub + (size_t)j * 256 + tid);
+          if constexpr (SW == 4) pos += pos >= half_n ? half_shift : 0u;
+          st_val[e] = (idx_base + pos) | (((code >> 15) ^ ((negs >> j) & 1u)) << 31);
           st_fine[e] = (uint8_t)(slot & 0xffu);
           st_dst[e] = gpos[lw * NCOARSE + bin] + rank[j];
         }

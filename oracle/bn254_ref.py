@@ -347,3 +347,61 @@ def msm_cuzk_model(points, scalars, word_size=16):
         buckets = cpu_smvp_signed(col_ptr, val, points, num_columns)
         sums.append(running_sum_bucket_reduction(buckets))
     return horner(sums, word_size)
+
+
+# ---------------------------------------------------------------------------------------------------
+# curve endomorphism ("GLV endomorphism ... to halve scalar length"; no counterpart in the reference, which
+# uses full-length scalars, src/cuzk/msm.rs:79-82).  phi(x, y) = (beta x, y) = lambda (x, y); k = k1 + k2 lambda (mod r).
+# Derived here from P, R, G alone, independently of tools/gen_constants.py; tests compare the two.
+# ---------------------------------------------------------------------------------------------------
+GLV_SHIFT = 320
+_glv_cache = {}
+
+
+def _cube_root_of_unity(mod):
+    g = 2
+    while pow(g, (mod - 1) // 3, mod) == 1:
+        g += 1
+    return pow(g, (mod - 1) // 3, mod)
+
+
+def glv_params():
+    """-> dict(beta, lam, v1, v2, g1, g2, s1, s2): beta / lambda paired on the generator; (v1, v2) the short lattice basis from
+    the extended Euclidean sequence of (r, lambda) around sqrt(r) with det = +r; g_i = round(2^320 |b| / r) and the signs of
+    c1 = round(k b2 / r), c2 = round(-k b1 / r)."""
+    key = (P, R, G)
+    if key in _glv_cache:
+        return _glv_cache[key]
+    beta = _cube_root_of_unity(P)
+    lam = _cube_root_of_unity(R)
+    if mul(lam, G) != (beta * G[0] % P, G[1]):
+        lam = lam * lam % R
+    assert mul(lam, G) == (beta * G[0] % P, G[1])
+    seq = [(R, 0), (lam, 1)]
+    while seq[-1][0]:
+        q = seq[-2][0] // seq[-1][0]
+        seq.append((seq[-2][0] - q * seq[-1][0], seq[-2][1] - q * seq[-1][1]))
+    l = max(i for i, (rem, _) in enumerate(seq) if rem * rem >= R)
+    v1 = (seq[l + 1][0], -seq[l + 1][1])
+    v2 = min([(seq[l][0], -seq[l][1]), (seq[l + 2][0], -seq[l + 2][1])], key=lambda v: v[0] * v[0] + v[1] * v[1])
+    if v1[0] * v2[1] - v2[0] * v1[1] < 0:
+        v2 = (-v2[0], -v2[1])
+    assert v1[0] * v2[1] - v2[0] * v1[1] == R
+    out = {"beta": beta, "lam": lam, "v1": v1, "v2": v2,
+           "g1": ((abs(v2[1]) << GLV_SHIFT) + R // 2) // R, "g2": ((abs(v1[1]) << GLV_SHIFT) + R // 2) // R,
+           "s1": 1 if v2[1] >= 0 else -1, "s2": 1 if -v1[1] >= 0 else -1}
+    _glv_cache[key] = out
+    return out
+
+
+def glv_split(k):
+    """-> (k1, k2), signed, with k = k1 + k2 lambda (mod r) -- the rounding is the engine's (csrc/glv.h): (k g + 2^319) >> 320."""
+    q = glv_params()
+    c1 = q["s1"] * ((k * q["g1"] + (1 << (GLV_SHIFT - 1))) >> GLV_SHIFT)
+    c2 = q["s2"] * ((k * q["g2"] + (1 << (GLV_SHIFT - 1))) >> GLV_SHIFT)
+    return k - c1 * q["v1"][0] - c2 * q["v2"][0], -c1 * q["v1"][1] - c2 * q["v2"][1]
+
+
+def endo(pt):
+    """phi(P) = (beta x, y) = lambda P"""
+    return None if pt is None else (glv_params()["beta"] * pt[0] % P, pt[1])

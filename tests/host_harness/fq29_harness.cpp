@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "g1.h"
+#include "glv.h"
 
 #ifndef HARNESS_FIELD_NS  // -DMSM_FIELD_NS=... -DMSM_CURVE_CONSTANTS=... -DHARNESS_FIELD_NS=...: the same harness for another curve
 #define HARNESS_FIELD_NS bn254
@@ -29,6 +30,25 @@ static void store_jac(uint8_t* b, const g1_xyzz& p) {
 }
 
 extern "C" {
+// scalar split of the curve endomorphism (csrc/glv.h): n x 32 B scalars -> n x (16 B half 1 | 16 B half 2), sign in bit 127;
+// returns the number of scalars whose halves did not fit
+size_t h_glv_split(const uint8_t* scalars, uint8_t* out, size_t n) {
+  size_t bad = 0;
+  for (size_t i = 0; i < n; i++) {
+    uint32_t k[8], h1[4], h2[4];
+    memcpy(k, scalars + 32 * i, 32);
+    if (!glv_split(k, h1, h2)) bad++;
+    memcpy(out + 32 * i, h1, 16);
+    memcpy(out + 32 * i + 16, h2, 16);
+  }
+  return bad;
+}
+// x -> beta x (the endomorphism's action on a point's x coordinate), canonical bytes
+void h_fq_mul_beta(const uint8_t* a, uint8_t* out, size_t n) {
+  fq beta;
+  for (int i = 0; i < 9; i++) beta.v[i] = FQ_BETA29[i];
+  for (size_t i = 0; i < n; i++) store_fq(out + 32 * i, fq_mul(load_fq(a + 32 * i), beta));
+}
 // op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg
 void h_fq_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
   for (size_t i = 0; i < n; i++) {

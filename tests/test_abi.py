@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported(built):
     assert len(names) >= 25
     for name in names:
         assert hasattr(L, name), name
-    assert L.msm_hip_abi_version() == 4
+    assert L.msm_hip_abi_version() == 5
     assert b"ok" == L.msm_hip_strerror(0)
 
 

@@ -143,6 +143,43 @@ def test_signed_state_mixed_addition_chain(H):
     assert cpu.to_affine64(out.raw) == cpu.to_affine64(cpu.cpu_msm(lp, sc))
 
 
+def _check_glv(Hx, m, seed):
+    # csrc/glv.h against the oracle's independently derived model: identical halves (same rounding rule), k = k1 + k2 lambda,
+    # and the magnitude bound the 8-window recode needs; edge scalars, non-canonical scalars up to 2^256 - 1
+    r = rng(seed)
+    q = m.glv_params()
+    ks = [0, 1, 2, m.R - 1, m.R, m.R + 1, (1 << 256) - 1, 1 << 255, q["lam"], m.R - q["lam"], (1 << 128) - 1, 1 << 127]
+    ks += [r.randrange(m.R) for _ in range(4000)] + [r.randrange(1 << 256) for _ in range(500)]
+    # scalars next to a rounding boundary of c1 / c2 (k ~ (j + 1/2) r / |b|)
+    for b in (abs(q["v1"][1]), abs(q["v2"][1])):
+        for _ in range(200):
+            j = r.randrange(b)
+            k0 = ((2 * j + 1) * m.R) // (2 * b)
+            ks += [k for k in (k0 - 1, k0, k0 + 1) if 0 <= k < 1 << 256]
+    out = C.create_string_buffer(32 * len(ks))
+    Hx.h_glv_split.restype = C.c_size_t
+    assert Hx.h_glv_split(b"".join(k.to_bytes(32, "little") for k in ks), out, len(ks)) == 0
+    for i, k in enumerate(ks):
+        got = []
+        for j in range(2):
+            v = int.from_bytes(out.raw[32 * i + 16 * j:32 * i + 16 * j + 16], "little")
+            mag = v & ((1 << 127) - 1)
+            assert mag < (1 << 127) - (1 << 112)
+            got.append(-mag if v >> 127 else mag)
+        assert tuple(got) == m.glv_split(k), hex(k)
+        assert (got[0] + got[1] * q["lam"] - k) % m.R == 0
+    xs = [r.randrange(m.P) for _ in range(50)]
+    o = C.create_string_buffer(32 * len(xs))
+    Hx.h_fq_mul_beta(b"".join(b32(x) for x in xs), o, len(xs))
+    assert o.raw == b"".join(b32(q["beta"] * x % m.P) for x in xs)
+    pt = m.sample_points(4, 3)[2]
+    assert m.mul(q["lam"], pt) == m.endo(pt)
+
+
+def test_endomorphism_scalar_split(H):
+    _check_glv(H, ref, 10)
+
+
 def test_host_arithmetic_instantiated_for_grumpkin(tmp_path_factory):
     # the same headers compiled for the second curve (csrc/curve_select.h), bounds asserted, against the Grumpkin oracle
     from oracle import cpu_grumpkin as cg
@@ -168,3 +205,4 @@ def test_host_arithmetic_instantiated_for_grumpkin(tmp_path_factory):
     Hg.h_g1_madd_w_chain(bytes(96), lp, negs, 3000, out)
     sc = b"".join(b32(gr.R - 1 if ng else 1) for ng in negs)
     assert cg.to_affine64(out.raw) == cg.to_affine64(cg.cpu_msm(lp, sc))
+    _check_glv(Hg, gr, 11)
