@@ -45,8 +45,8 @@ for case in range(cases):
         sc = [base[i % max(1, n // 5)] for i in range(n)]
     sb = ref.scalars_to_bytes(sc)
     want = cpu.to_affine64(cpu.cpu_msm(points, sb))
-    mode = rnd.choice(["host", "device", "windows", "batch", "group", "hostbatch", "mont", "bits", "tables", "tables_batch", "hostpipe", "mgpu"])
-    ctx.set_bases(points, precompute=mode.startswith("tables"))
+    mode = rnd.choice(["host", "device", "windows", "batch", "group", "hostbatch", "mont", "bits", "tables", "tables_batch", "hostpipe", "mgpu", "endo", "endo_batch"])
+    ctx.set_bases(points, precompute=mode.startswith("tables"), endomorphism=mode.startswith("endo"))
     if mode == "mont":
         # both inputs as R = 2^256 Montgomery words (MSM_HIP_BASES_MONT256, MSM_HIP_SCALARS_MONT256)
         PM, RM = ref.P, ref.R
@@ -69,6 +69,17 @@ for case in range(cases):
             assert ctx.last_window_bits() == bits
         finally:
             ctx.set_window_bits(0)
+    elif mode == "endo":
+        # endomorphism halves, every window size, host and device scalars
+        bits = rnd.choice([0, 12, 14, 16])
+        ctx.set_window_bits(bits)
+        try:
+            got = ctx.msm(sb) if rnd.random() < 0.5 else ctx.msm(torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda())
+        finally:
+            ctx.set_window_bits(0)
+    elif mode == "endo_batch":
+        k = rnd.randrange(1, 11)
+        got = ctx.msm_batch(sb * k, n)[k - 1]
     elif mode == "tables_batch":
         k = rnd.randrange(1, 7)
         got = ctx.msm_batch(sb * k, n)[k - 1]
