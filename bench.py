@@ -40,6 +40,7 @@ BUCKETS = 1 << 15
 
 
 def smvp_algorithmic_bytes(n, w_local):
+    """n entries per window at most (one per point the recode reads), w_local bucket sets"""
     return n * w_local * (64 + 4) + w_local * BUCKETS * 96
 
 
@@ -148,12 +149,22 @@ def main():
     # identical synthetic inputs on every rank (deterministic device sampler), resident in HBM
     points = ctx.sample_points(n, 0x6D736D5F0000 + args.logn)
     scalar_sets = [ctx.sample_scalars(n, 0x6D736D5F1000 + args.logn + 7 * i) for i in range(2)]
-    ctx.set_bases(points)
     w_begin, w_end = window_range(rank, world)
     w_local = w_end - w_begin
     # tuning aid (never a reported result): BENCH_EMULATE_WORLD=8 makes this single rank do the per-rank share of an
     # 8-rank run (2 windows) through the sharded pipeline; the MSM value is then NOT a whole-job figure
     emulate = int(os.environ.get("BENCH_EMULATE_WORLD", "0"))
+    sharded = world > 1 or force_sharded or emulate > 1
+    # how the resident bases are held (include/msm_hip.h; the result is the same group element in every mode):
+    #   endomorphism  P_i and phi(P_i): every scalar is split into two 127-bit halves on the device, 8 windows over 2n points
+    #                 (default on one GPU: the same bucket additions, half the buckets to reduce; 2 x the base memory)
+    #   plain         the reference's shape: 16 windows over n points (what the window-sharded multi-GPU path uses)
+    #   tables        fixed-base tables 2^(16 w) P_i: one bucket set per MSM (16 x the base memory)
+    bases_mode = os.environ.get("BENCH_BASES") or ("plain" if sharded else "endomorphism")
+    assert bases_mode in ("plain", "endomorphism", "tables") and (bases_mode == "plain" or not sharded)
+    ctx.set_bases(points, endomorphism=bases_mode == "endomorphism", precompute=bases_mode == "tables")
+    # the SMVP launch of one whole MSM: points the recode reads and bucket sets
+    smvp_n, smvp_w = {"plain": (n, NUM_WINDOWS), "endomorphism": (2 * n, NUM_WINDOWS // 2), "tables": (NUM_WINDOWS * n, 1)}[bases_mode]
 
     def sync_all():
         torch.cuda.synchronize()
@@ -162,7 +173,6 @@ def main():
         torch.cuda.synchronize()
 
     smvp_ms, smvp_windows = [], []
-    sharded = world > 1 or force_sharded or emulate > 1
     # window-sharded runs put the shares of several independent MSMs through one launch (as many as fit 16 local windows:
     # 8 MSMs x 2 windows at 8 GPUs) -- one kernel sequence and one RCCL all-gather per group; BENCH_MSMS_PER_LAUNCH overrides
     group = 1
@@ -176,7 +186,7 @@ def main():
         group_scalars = torch.cat([scalar_sets[k & 1] for k in range(group)], dim=0).contiguous() if group > 1 else None
 
     # single GPU, small MSMs: whole MSMs grouped per launch (vector k of a group is scalar set k & 1)
-    group1 = 1 if sharded else max(1, min(4, (1 << 20) // n))
+    group1 = 1 if sharded else max(1, min(ctx.batch_group_size(n), 8))
     group1_scalars = torch.cat([scalar_sets[k & 1] for k in range(group1)], dim=0).contiguous() if group1 > 1 else None
 
     # launches in flight on one GPU (4 result slots): 2 where one launch is one large MSM, 3 for grouped small MSMs, whose host
@@ -213,11 +223,11 @@ def main():
                     slot0, gs0 = pending.pop(0)
                     result = ctx.finish(slot0) if group1 == 1 else ctx.finish_batch(slot0, gs0)[-1]
                     if record:
-                        note_stages(gs0 * w_local)
+                        note_stages(gs0 * smvp_w)
             for slot0, gs0 in pending:
                 result = ctx.finish(slot0) if group1 == 1 else ctx.finish_batch(slot0, gs0)[-1]
                 if record:
-                    note_stages(gs0 * w_local)
+                    note_stages(gs0 * smvp_w)
         else:
             # windows sharded over the ranks; device work, RCCL all-gather, D2H and host combine all pipelined
             sizes = group_sizes(count, group)
@@ -315,17 +325,18 @@ def main():
     # roofline of the SMVP accumulate kernel: algorithmic bytes of all timed launches / their summed durations
     launches = len(smvp_ms)
     smvp_avg_ms = sum(smvp_ms) / launches
-    alg_bytes = sum(smvp_algorithmic_bytes(n, w) for w in smvp_windows) / launches
+    n_launch = n if sharded else smvp_n  # entries per bucket set
+    alg_bytes = sum(smvp_algorithmic_bytes(n_launch, w) for w in smvp_windows) / launches
     achieved = alg_bytes / (smvp_avg_ms * 1e-3) / 1e9
     w_launch = max(smvp_windows)
-    lane_mads_per_s = sum(n * w for w in smvp_windows) * MADS_PER_MIXED_ADD / (sum(smvp_ms) * 1e-3)
+    lane_mads_per_s = sum(n_launch * w for w in smvp_windows) * MADS_PER_MIXED_ADD / (sum(smvp_ms) * 1e-3)
 
     traffic, traffic_source = None, None
     try:
         pmc_name = "smvp_pmc_traffic.json" if args.logn == 20 else "smvp_pmc_traffic_logn%d.json" % args.logn
         with open(os.path.join(ROOT, "profiles", pmc_name)) as f:
             pmc = json.load(f)
-        if pmc.get("logn") == args.logn and pmc.get("w_local") == w_launch:  # PMC bytes of one full 16-window launch
+        if pmc.get("logn") == args.logn and pmc.get("w_local") == w_launch and pmc.get("bases", "plain") == bases_mode:  # one whole-MSM launch
             traffic = pmc.get("hbm_bytes_per_launch")
             traffic_source = "profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, calibrated (profiles/README.md); not measured in this run" % pmc_name
     except (OSError, ValueError):
@@ -345,7 +356,10 @@ def main():
         "dtype": "u32",
         "data": "synthetic",
         "config": {"workload": "2^%d BN254 G1 MSM, 16-bit signed-bucket windows, inputs resident in HBM" % args.logn,
-                   "windows_per_gpu": w_local, "msms_per_launch": group if sharded else group1,
+                   "bases": {"plain": "n points, 16 windows (the reference's shape)",
+                             "endomorphism": "P and phi(P) resident: scalars split into two 127-bit halves on the device, 8 windows over 2n points",
+                             "tables": "fixed-base tables 2^(16 w) P resident: one bucket set per MSM"}[bases_mode],
+                   "windows_per_gpu": w_local if sharded else smvp_w, "msms_per_launch": group if sharded else group1,
                    "parallelism": "windows/%d + RCCL all-gather" % world if sharded else "single GPU",
                    "launches_in_flight": pipe.depth if sharded else depth1,
                    "host_combine": "pipelined behind the device work of the following launches"},

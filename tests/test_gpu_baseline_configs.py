@@ -116,3 +116,32 @@ def test_config5_batch_64_x_2p18_shared_base(ctx):
         assert e - b == 8
         shares += ctx.msm_batch(sc[b * n:e * n], n)
     assert [g.to_affine_bytes() for g in shares] == [g.to_affine_bytes() for g in got]
+
+
+def test_configs_2_4_5_with_endomorphism_bases(ctx, inputs_2p20):
+    # the same real sizes with MSM_HIP_BASES_ENDOMORPHISM (what bench.py's single-GPU line runs): C2 against the oracle,
+    # C5's batch against the plain mode's results and the oracle, C4 against the plain mode (split-consistent above)
+    n, pts, sets, want = inputs_2p20
+    ctx.set_bases(pts, endomorphism=True)
+    for s, w in zip(sets, want):
+        assert ctx.msm(s).to_affine_bytes() == w
+    ctx.launch_host(_host(sets[0]), 0)
+    ctx.launch(sets[1], 1)
+    assert ctx.finish(0).to_affine_bytes() == want[0] and ctx.finish(1).to_affine_bytes() == want[1]
+
+    n5, batch = 1 << 18, 64
+    pts5 = ctx.sample_points(n5, 0xC5_0001)
+    sc5 = ctx.sample_scalars(n5 * batch, 0xC5_0002)
+    ctx.set_bases(pts5, endomorphism=True)
+    got = ctx.msm_batch(sc5, n5)
+    assert got[63].to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(_host(pts5), _host(sc5[63 * n5:]), THREADS))
+    ctx.set_bases(pts5)
+    assert [g.to_affine_bytes() for g in ctx.msm_batch(sc5, n5)] == [g.to_affine_bytes() for g in got]
+    del pts5, sc5
+
+    n4 = 1 << 24
+    pts4, sc4 = ctx.sample_points(n4, 0xC4_0001), ctx.sample_scalars(n4, 0xC4_0002)
+    ctx.set_bases(pts4, endomorphism=True)
+    whole = ctx.msm(sc4)
+    ctx.set_bases(pts4)
+    assert ctx.msm(sc4) == whole

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise a tools/profile_round.sh run: per-kernel averages of FETCH_SIZE / WRITE_SIZE (KiB, as rocprofv3 reports them),
 the calibration factors measured on known byte counts in this engine's access patterns, and the corrected HBM traffic of
-k_smvp_chunks per launch.  Usage: python tools/pmc_summarize.py gpurun_out/prof_<tag> <logn> <w_local> [out.json]"""
+k_smvp_chunks per launch.  Usage: python tools/pmc_summarize.py gpurun_out/prof_<tag> <logn> <w_local> [out.json] [bases]
+(bases = plain | endomorphism: with the endomorphism a launch has w_local = 8 bucket sets of 2 * 2^logn entries)"""
 import csv
 import glob
 import json
@@ -33,6 +34,7 @@ def kernel_stats(dirpath):
 def main():
     root, logn, w_local = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     out_json = sys.argv[4] if len(sys.argv) > 4 else None
+    bases = sys.argv[5] if len(sys.argv) > 5 else "plain"
     fetch, nfetch = per_kernel(os.path.join(root, "pmc_fetch"), "FETCH_SIZE")
     write, _ = per_kernel(os.path.join(root, "pmc_write"), "WRITE_SIZE")
     cfetch, _ = per_kernel(os.path.join(root, "cal_fetch"), "FETCH_SIZE")
@@ -54,12 +56,12 @@ def main():
         print("  %-28s FETCH_SIZE %12.1f  WRITE_SIZE %12.1f  avg_us %10.1f  calls %s" % (
             k.replace("msmk::", ""), fetch.get(k, 0), write.get(k, 0), st.get("avg_ns", 0) / 1e3, st.get("calls", "")))
     name = "msmk::k_smvp_chunks"
-    n = 1 << logn
+    n = (2 if bases == "endomorphism" else 1) << logn
     alg = n * w_local * 68 + w_local * 32768 * 96
     f_raw, w_raw = fetch.get(name, 0) * 1024, write.get(name, 0) * 1024
     f_corr = f_raw / cal["gather_64B_records"] if cal["gather_64B_records"] else None
     w_corr = w_raw / cal["scatter_160B_records"] if cal["scatter_160B_records"] else None
-    res = {"logn": logn, "w_local": w_local, "kernel": "k_smvp_chunks", "algorithmic_bytes": alg,
+    res = {"logn": logn, "w_local": w_local, "bases": bases, "kernel": "k_smvp_chunks", "algorithmic_bytes": alg,
            "fetch_bytes_reported": f_raw, "write_bytes_reported": w_raw,
            "fetch_calibration_gather64": cal["gather_64B_records"], "write_calibration_scatter160": cal["scatter_160B_records"],
            "fetch_bytes_corrected": f_corr, "write_bytes_corrected": w_corr,
