@@ -195,8 +195,14 @@ def main():
 
     def group_sizes(count, g):
         """`count` MSMs in ceil(count / g) launches of nearly equal size (a small remainder launch would run at the
-        one-MSM-per-launch rate)."""
+        one-MSM-per-launch rate).  One GPU, whole small MSMs per launch: full launches and the remainder LAST when it is at least
+        half a launch -- what follows the last launch's main-stream work (bucket reduce, host combines) is not hidden by a next
+        launch and is shorter for a smaller one (measured at 2^16, 20 MSMs: 0.293 vs 0.328 ms per MSM; no difference for the
+        window-sharded pipeline: 0.266 vs 0.264)."""
         k = -(-count // g)
+        rem = count % g
+        if not sharded and rem and 2 * rem >= g:
+            return [g] * (count // g) + [rem]
         return [count // k + (1 if i < count % k else 0) for i in range(k)]
 
     def note_stages(w_eff):
