@@ -91,9 +91,10 @@ class MsmContext {
   MsmContext(const MsmContext&) = delete;
   MsmContext& operator=(const MsmContext&) = delete;
 
-  void set_bases(const std::vector<G1Affine>& g, bool check_on_curve = false) {
+  void set_bases(const std::vector<G1Affine>& g, bool check_on_curve = false, uint32_t more_flags = 0) {
+    // more_flags: MSM_HIP_BASES_ENDOMORPHISM (half-length scalars, 2 x the base memory) or MSM_HIP_BASES_PRECOMPUTE (fixed-base tables)
     const std::vector<uint8_t> b = points_to_bytes(g);
-    check(msm_hip_set_bases_bn254(ctx_, b.data(), g.size(), check_on_curve ? MSM_HIP_CHECK_ON_CURVE : 0u), "msm_hip_set_bases_bn254");
+    check(msm_hip_set_bases_bn254(ctx_, b.data(), g.size(), (check_on_curve ? MSM_HIP_CHECK_ON_CURVE : 0u) | more_flags), "msm_hip_set_bases_bn254");
   }
   /// Raw forms for callers whose field elements already sit in memory as bytes: `flags` as in msm_hip_set_bases_bn254
   /// (e.g. MSM_HIP_BASES_MONT256 for 4 x 64-bit Montgomery limbs); scalars_mont256(true) switches the scalar format likewise.

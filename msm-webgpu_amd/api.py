@@ -509,9 +509,12 @@ class MultiGpuMsm:
     def uses_rccl(self):
         return lib().msm_hip_mgpu_uses_rccl(self._h) == 1
 
-    def set_bases(self, points, check_on_curve=False):
+    def set_bases(self, points, check_on_curve=False, endomorphism=False):
+        """Replicated on every device.  endomorphism: MSM_HIP_BASES_ENDOMORPHISM -- used by msm_batch (whole MSMs per device);
+        the window-sharded msm() runs the plain 16 windows."""
         b = bytes(points)
-        _check(lib().msm_hip_mgpu_set_bases_bn254(self._h, b, len(b) // 64, 1 if check_on_curve else 0), "msm_hip_mgpu_set_bases_bn254")
+        flags = (1 if check_on_curve else 0) | (8 if endomorphism else 0)
+        _check(lib().msm_hip_mgpu_set_bases_bn254(self._h, b, len(b) // 64, flags), "msm_hip_mgpu_set_bases_bn254")
         return len(b) // 64
 
     def msm(self, scalars):

@@ -45,6 +45,11 @@ int main(int argc, char** argv) {
   // many MSMs over the resident bases: [v, 0, v] -> [result, identity, result]
   const std::vector<G1> many = ctx.msm_batch({v, std::vector<Fr>(n), v});
   if (many.size() != 3 || many[0] != fast || many[2] != fast || !many[1].to_affine().infinity) return 5;
+  // the same bases with their endomorphism images (half-length scalars): same group element, compared projectively
+  ctx.set_bases(g, false, MSM_HIP_BASES_ENDOMORPHISM);
+  if (ctx.msm(v) != fast) return 6;
+  const std::vector<G1> many2 = ctx.msm_batch({v, v});
+  if (many2.size() != 2 || many2[0] != fast || many2[1] != fast) return 7;
   const G1Affine a = fast.to_affine();
   std::vector<uint8_t> got(64, 0);
   if (!a.infinity) {

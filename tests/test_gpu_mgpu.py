@@ -47,6 +47,10 @@ def test_mgpu_batch_of_whole_msms(data):
         for j in range(batch):
             assert got[j].to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points[: 64 * k], vecs[32 * k * j:32 * k * (j + 1)])), j
         assert mg.msm_batch(b"", k) == []
+        # endomorphism bases on every device: the batch path uses them, the window-sharded msm() runs the plain 16 windows
+        mg.set_bases(points[: 64 * k], endomorphism=True)
+        assert [g.to_affine_bytes() for g in mg.msm_batch(vecs, k)] == [g.to_affine_bytes() for g in got]
+        assert mg.msm(vecs[: 32 * k]).to_affine_bytes() == got[0].to_affine_bytes()
     finally:
         mg.close()
 
