@@ -207,8 +207,14 @@ int msm_hip_window_range(int rank, int world, int num, int* begin, int* end);
  * Returns 1 when the point is the identity (out zeroed), 0 otherwise, negative on error. */
 int msm_hip_g1_to_affine_bn254(const uint8_t xyz[96], uint8_t out_xy[64]);
 
-/* ---- one-shot: create context, set bases, run, destroy (≙ compute_msm as the reference calls it) ---- */
+/* ---- one-shot: context, set bases, run (≙ compute_msm as the reference calls it, src/cuzk/msm.rs:75-94), on the caller's current
+ *      device.  The library keeps the context it used (streams, device pools) for the next one-shot call on that device instead of
+ *      creating and destroying one per call as the reference does with its wgpu device (creation, first-use allocations and the frees
+ *      cost more than a 2^20 MSM); calls are serialised by a process-wide mutex, results do not depend on it.
+ *      msm_hip_oneshot_release() frees the kept contexts (call it before unloading the library or to return the device memory);
+ *      MSM_HIP_ONESHOT_KEEP=0 in the environment restores create / destroy per call. ---- */
 int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
+void msm_hip_oneshot_release(void);
 
 /* ---- synthetic inputs generated in HBM (≙ sample_scalars / sample_points, src/lib.rs:20-42, seeded):
  *      scalars uniform in [0, r) by rejection; points by try-and-increment on x (Curve::random does the same).

@@ -71,6 +71,8 @@ def lib():
         L.msm_hip_slot_sync.argtypes = [vp, i]
         L.msm_hip_combine_windows_bn254.argtypes = [u8p, i, u8p]
         L.msm_hip_msm_bn254_g1.argtypes = [u8p, u8p, sz, u8p]
+        L.msm_hip_oneshot_release.argtypes = []
+        L.msm_hip_oneshot_release.restype = None
         L.msm_hip_sample_scalars_device.argtypes = [vp, C.c_uint64, sz, vp]
         L.msm_hip_sample_points_device.argtypes = [vp, C.c_uint64, sz, vp]
         L.msm_hip_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i]

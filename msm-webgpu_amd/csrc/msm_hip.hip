@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "../../include/msm_hip.h"
@@ -1018,16 +1019,47 @@ int msm_hip_g1_to_affine_curve(int curve, const uint8_t xyz[96], uint8_t out_xy[
   return r < 0 ? MSM_HIP_ERR_NONCANONICAL : r;
 }
 
+// The one-shot keeps ONE context per device alive between calls (the reference creates and drops its wgpu device on every call,
+// src/cuzk/msm.rs:88-94; here that costs 0.3 ms of creation, ~1 ms of first-use allocations and 3.4 ms of hipFree per call --
+// more than the MSM).  Process-wide, mutex-protected (one-shot calls on one device are serialised, as a context requires);
+// msm_hip_oneshot_release() drops the kept contexts; MSM_HIP_ONESHOT_KEEP=0 restores create / destroy per call.
+namespace {
+constexpr int ONESHOT_MAX_DEVICES = 64;
+std::mutex g_oneshot_mutex;
+msm_hip_ctx* g_oneshot_ctx[ONESHOT_MAX_DEVICES] = {};
+inline bool oneshot_keep() {
+  static const bool v = [] { const char* e = getenv("MSM_HIP_ONESHOT_KEEP"); return !(e && e[0] == '0'); }();
+  return v;
+}
+}  // namespace
+
 int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
-  msm_hip_ctx* ctx = nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return MSM_HIP_ERR_NO_DEVICE;  // the caller's current device (0 unless it chose another)
-  int rc = msm_hip_ctx_create(&ctx, dev);
-  if (rc) return rc;
+  const bool keep = oneshot_keep() && dev >= 0 && dev < ONESHOT_MAX_DEVICES;
+  std::unique_lock<std::mutex> lock(g_oneshot_mutex, std::defer_lock);
+  msm_hip_ctx* ctx = nullptr;
+  int rc = MSM_HIP_OK;
+  if (keep) {
+    lock.lock();
+    ctx = g_oneshot_ctx[dev];
+  }
+  if (!ctx) {
+    if ((rc = msm_hip_ctx_create(&ctx, dev))) return rc;
+    if (keep) g_oneshot_ctx[dev] = ctx;
+  }
   rc = msm_hip_set_bases_bn254(ctx, xy_host, n, 0);
   if (!rc) rc = msm_hip_run_bn254(ctx, scalars_host, n, out_xyz);
-  msm_hip_ctx_destroy(ctx);
+  if (!keep) msm_hip_ctx_destroy(ctx);
   return rc;
+}
+
+void msm_hip_oneshot_release(void) {
+  std::lock_guard<std::mutex> lock(g_oneshot_mutex);
+  for (msm_hip_ctx*& c : g_oneshot_ctx) {
+    if (c) msm_hip_ctx_destroy(c);
+    c = nullptr;
+  }
 }
 
 int msm_hip_sample_scalars_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void* scalars_dev) {

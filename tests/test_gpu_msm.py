@@ -359,3 +359,22 @@ def test_inputs_produced_asynchronously_on_the_torch_stream(ctx):
             junk = torch.full((n, 32), 0xFF, dtype=torch.uint8, device=pts.device)  # ... to this (non-canonical scalars)
             del junk
         assert [ctx.finish(k) for k in range(3)] == want
+
+
+def test_one_shot_keeps_its_context_between_calls(built):
+    # msm_hip_msm_bn254_g1 ≙ compute_msm as the reference calls it (src/cuzk/msm.rs:75-94); the library keeps the context it used:
+    # different inputs and sizes (growing and shrinking) through the kept context, release, again
+    import ctypes as C
+
+    L = m.lib()
+    out = C.create_string_buffer(96)
+    for round_ in range(2):
+        for n, seed in ((300, 1), (5000, 2), (70000, 3), (17, 4), (5000, 2)):
+            points, scalars = cpu.sample_points(700 + seed, n), cpu.sample_scalars(800 + seed, n)
+            assert L.msm_hip_msm_bn254_g1(points, scalars, n, out) == 0
+            assert cpu.to_affine64(out.raw) == cpu.to_affine64(cpu.cpu_msm(points, scalars)), (round_, n)
+        # an input error leaves the kept context usable
+        assert L.msm_hip_msm_bn254_g1(cpu.sample_points(1, 2), b"\xff" * 64, 2, out) == -4
+        assert L.msm_hip_msm_bn254_g1(cpu.sample_points(1, 2), bytes(64), 2, out) == 0 and cpu.to_affine64(out.raw) == bytes(64)
+        L.msm_hip_oneshot_release()
+    L.msm_hip_oneshot_release()  # nothing kept: a no-op
