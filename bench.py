@@ -284,7 +284,7 @@ def main():
         latency_ms = sorted(lat)[len(lat) // 2]
 
     # timing scopes B and C of SURVEY.md section 8(d), informational (never `value`): B = scalars arrive from host memory
-    # (32 MiB H2D per MSM at 2^20), bases resident -- as the latency of one call and as the throughput of two slots alternating
+    # (32 MiB H2D per MSM at 2^20), bases resident -- as the latency of one call and as the throughput of three slots in rotation
     # (msm_hip_launch_bn254: the copy of MSM i+1 runs on the copy stream under the device work of MSM i); C = one-shot incl.
     # base upload (≙ the reference's compute_msm call shape): the first call also creates the context the library then keeps
     scope_ms = None
@@ -296,14 +296,15 @@ def main():
             t1 = time.perf_counter()
             ctx.msm(sb_host[i & 1])
             tb.append((time.perf_counter() - t1) * 1e3)
-        k = 12
-        ctx.launch_host(sb_host[0], 0)
+        k, slots = 24, 3  # three result slots in flight: the copy of MSM i+2 and the sort of i+1 under the SMVP of i
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(1, k):
-            ctx.launch_host(sb_host[i & 1], i & 1)
-            ctx.finish((i - 1) & 1)
-        ctx.finish((k - 1) & 1)
+        for i in range(k):
+            if i >= slots:
+                ctx.finish(i % slots)
+            ctx.launch_host(sb_host[i & 1], i % slots)
+        for i in range(k, k + slots):
+            ctx.finish(i % slots)
         b_pipe = (time.perf_counter() - t1) * 1e3 / k
         import ctypes
 
@@ -315,7 +316,7 @@ def main():
             tc.append((time.perf_counter() - t1) * 1e3)
             assert rc1 == 0, rc1
         m.lib().msm_hip_oneshot_release()
-        scope_ms = {"B_host_scalars_resident_bases_latency": sorted(tb)[2], "B_host_scalars_two_slots_pipelined": b_pipe,
+        scope_ms = {"B_host_scalars_resident_bases_latency": sorted(tb)[2], "B_host_scalars_three_slots_pipelined": b_pipe,
                     "C_one_shot_with_base_upload": sorted(tc[1:])[1], "C_one_shot_first_call": tc[0]}
 
     # sharded runs: check the gathered + combined result against this rank's own whole 16-window MSM (outside the timed region)
