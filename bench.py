@@ -256,6 +256,63 @@ def main():
                 inflight.pop(0)
         return result
 
+    # The scope measurements come BEFORE the timed region, the host-scalar pipeline (24 MSMs back to back) last: after an idle phase the
+    # GPU needs ~15 MSMs (~20 ms of this work) to reach its steady state -- with only the W = 5 warm-up steps behind an idle GPU the
+    # first half of a 20-step timed region runs ~8 % slow (tools/step_time_trend.py: first 20 MSMs 1.53 ms each after 5 warm-up steps,
+    # 1.46 after 20, 1.36 from the 21st on).  The W warm-up steps still directly precede the timed region ("pre_timed_activity" in the
+    # JSON line says what ran before them).
+    # timing scopes B and C of SURVEY.md section 8(d), informational (never `value`): B = scalars arrive from host memory
+    # (32 MiB H2D per MSM at 2^20), bases resident -- as the latency of one call and as the throughput of three slots in rotation
+    # (msm_hip_launch_bn254: the copy of MSM i+1 runs on the copy stream under the device work of MSM i); C = one-shot incl.
+    # base upload (≙ the reference's compute_msm call shape): the first call also creates the context the library then keeps
+    scope_ms = None
+    if world == 1 and emulate <= 1 and args.logn <= 22:
+        sb_host = [s.cpu().numpy().tobytes() for s in scalar_sets]
+        pb_host = points.cpu().numpy().tobytes()
+        import ctypes
+
+        one = ctypes.create_string_buffer(96)
+        tc = []
+        for _ in range(4):
+            t1 = time.perf_counter()
+            rc1 = m.lib().msm_hip_msm_bn254_g1(pb_host, sb_host[0], n, one)  # uploads the bases, runs; the library keeps its context
+            tc.append((time.perf_counter() - t1) * 1e3)
+            assert rc1 == 0, rc1
+        m.lib().msm_hip_oneshot_release()
+        tb = []
+        for i in range(5):
+            t1 = time.perf_counter()
+            ctx.msm(sb_host[i & 1])
+            tb.append((time.perf_counter() - t1) * 1e3)
+        k, slots = 24, 3  # three result slots in flight: the copy of MSM i+2 and the sort of i+1 under the SMVP of i
+        ctx.set_stage_timing(0)  # (the stage events of the latency runs above cost queue time between kernels)
+        for timed_pass in (False, True):  # the first pass brings the GPU out of its idle state
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(k):
+                if i >= slots:
+                    ctx.finish(i % slots)
+                ctx.launch_host(sb_host[i & 1], i % slots)
+            for i in range(k, k + slots):
+                ctx.finish(i % slots)
+            b_pipe = (time.perf_counter() - t1) * 1e3 / k
+        scope_ms = {"B_host_scalars_resident_bases_latency": sorted(tb)[2], "B_host_scalars_three_slots_pipelined": b_pipe,
+                    "C_one_shot_with_base_upload": sorted(tc[1:])[1], "C_one_shot_first_call": tc[0]}
+
+    # window-sharded runs: the latency of ONE MSM across the ranks (its window shares, the gather, the host combine; nothing in
+    # flight beside it) -- BASELINE config 3 as a single call -- median of 20, measured before the timed region for the same reason
+    sharded_latency_ms = None
+    if sharded:
+        ctx.set_stage_timing(0)
+        lat = []
+        for i in range(20):
+            sync_all()
+            t1 = time.perf_counter()
+            pipe.issue(scalar_sets[i & 1], inputs_complete=True)
+            pipe.complete()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        sharded_latency_ms = sorted(lat)[len(lat) // 2]
+
     # timed region: HIP events only around the SMVP accumulate kernel (the roofline figure); every extra stage event
     # costs queue time between kernels.  The per-stage breakdown comes from the un-pipelined latency runs below.
     ctx.set_stage_timing(1)
@@ -282,42 +339,6 @@ def main():
             lat.append((time.perf_counter() - t1) * 1e3)
             isolated = ctx.stage_ms()
         latency_ms = sorted(lat)[len(lat) // 2]
-
-    # timing scopes B and C of SURVEY.md section 8(d), informational (never `value`): B = scalars arrive from host memory
-    # (32 MiB H2D per MSM at 2^20), bases resident -- as the latency of one call and as the throughput of three slots in rotation
-    # (msm_hip_launch_bn254: the copy of MSM i+1 runs on the copy stream under the device work of MSM i); C = one-shot incl.
-    # base upload (≙ the reference's compute_msm call shape): the first call also creates the context the library then keeps
-    scope_ms = None
-    if world == 1 and emulate <= 1 and args.logn <= 22:
-        sb_host = [s.cpu().numpy().tobytes() for s in scalar_sets]
-        pb_host = points.cpu().numpy().tobytes()
-        tb = []
-        for i in range(5):
-            t1 = time.perf_counter()
-            ctx.msm(sb_host[i & 1])
-            tb.append((time.perf_counter() - t1) * 1e3)
-        k, slots = 24, 3  # three result slots in flight: the copy of MSM i+2 and the sort of i+1 under the SMVP of i
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(k):
-            if i >= slots:
-                ctx.finish(i % slots)
-            ctx.launch_host(sb_host[i & 1], i % slots)
-        for i in range(k, k + slots):
-            ctx.finish(i % slots)
-        b_pipe = (time.perf_counter() - t1) * 1e3 / k
-        import ctypes
-
-        one = ctypes.create_string_buffer(96)
-        tc = []
-        for _ in range(4):
-            t1 = time.perf_counter()
-            rc1 = m.lib().msm_hip_msm_bn254_g1(pb_host, sb_host[0], n, one)  # uploads the bases, runs; the library keeps its context
-            tc.append((time.perf_counter() - t1) * 1e3)
-            assert rc1 == 0, rc1
-        m.lib().msm_hip_oneshot_release()
-        scope_ms = {"B_host_scalars_resident_bases_latency": sorted(tb)[2], "B_host_scalars_three_slots_pipelined": b_pipe,
-                    "C_one_shot_with_base_upload": sorted(tc[1:])[1], "C_one_shot_first_call": tc[0]}
 
     # sharded runs: check the gathered + combined result against this rank's own whole 16-window MSM (outside the timed region)
     sharded_ok = None
@@ -383,9 +404,11 @@ def main():
         "dist_ranks": dist_ranks,
         "emulated_world": emulate if emulate > 1 else None,
         "sharded_result_equals_single_gpu": sharded_ok,
-        "latency_ms_single_msm": latency_ms,
+        "latency_ms_single_msm": latency_ms if not sharded else sharded_latency_ms,
         "stage_ms_single_msm": isolated,
         "scope_ms": scope_ms,
+        "pre_timed_activity": ("scope C and B measurements (4 one-shot calls, 5 + 2 x 24 host-scalar MSMs), then the W warm-up steps" if scope_ms
+                               else "20 single-MSM latency runs across the ranks, then the W warm-up steps" if sharded else "the W warm-up steps"),
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
