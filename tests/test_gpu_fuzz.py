@@ -18,3 +18,13 @@ def test_fuzz_against_oracle(built, capsys):
     finally:
         sys.argv = argv
     assert "fuzz ok: 60 cases" in capsys.readouterr().out
+
+
+def test_fuzz_against_oracle_second_curve(built, capsys):
+    argv = sys.argv
+    sys.argv = ["fuzz_gpu.py", "30", "20261005", "grumpkin"]
+    try:
+        runpy.run_path(os.path.join(ROOT, "tools", "fuzz_gpu.py"), run_name="__main__")
+    finally:
+        sys.argv = argv
+    assert "fuzz ok: 30 cases" in capsys.readouterr().out

@@ -1,17 +1,21 @@
 """Randomised differential test of the HIP engine against the CPU oracle: random sizes (tile / chunk / alignment edges),
 random scalar distributions (uniform, few distinct values, small values, zeros, equal), random window ranges.
-Usage: python tools/fuzz_gpu.py [cases] [seed]   (test infrastructure: uses the oracle)"""
+Usage: python tools/fuzz_gpu.py [cases] [seed] [bn254|grumpkin]   (test infrastructure: uses the oracle)"""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import msm_webgpu_amd as m
 from msm_webgpu_amd.sharding import window_range
-from oracle import cpu, bn254_ref as ref
-
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+curve = sys.argv[3] if len(sys.argv) > 3 else "bn254"
+if curve == "grumpkin":  # the second curve through the same entry points (its oracles: oracle/cpu_grumpkin.py, grumpkin_ref.py)
+    from oracle import cpu_grumpkin as cpu, grumpkin_ref as ref
+else:
+    from oracle import cpu, bn254_ref as ref
 rnd = random.Random(seed)
-ctx = m.MsmContext(0)
+ctx = m.MsmContext(0, curve=curve)
+combine = lambda sums: m.MsmContext.combine_windows(sums, curve=curve)
 mg = {}  # lazily created msm_hip_mgpu handles by rank count (several contexts on this one GPU, pinned-buffer gather)
 R = ref.R
 special_n = [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8193, 16385, 32769, 65535, 65537]
@@ -46,6 +50,8 @@ for case in range(cases):
     sb = ref.scalars_to_bytes(sc)
     want = cpu.to_affine64(cpu.cpu_msm(points, sb))
     mode = rnd.choice(["host", "device", "windows", "batch", "group", "hostbatch", "mont", "bits", "tables", "tables_batch", "hostpipe", "mgpu", "endo", "endo_batch"])
+    if mode == "mgpu" and curve != "bn254":
+        mode = "endo"  # the multi-GPU ABI is BN254-only
     ctx.set_bases(points, precompute=mode.startswith("tables"), endomorphism=mode.startswith("endo"))
     if mode == "mont":
         # both inputs as R = 2^256 Montgomery words (MSM_HIP_BASES_MONT256, MSM_HIP_SCALARS_MONT256)
@@ -120,15 +126,15 @@ for case in range(cases):
             ctx.launch_windows_batch(t, n, b, e, r % 4, out)
             ctx.slot_sync(r % 4)
             parts.append(out[pos * (e - b):(pos + 1) * (e - b)])
-        got = m.MsmContext.combine_windows(torch.cat(parts, dim=0))
+        got = combine(torch.cat(parts, dim=0))
     else:
         t = torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda()
         world = rnd.choice([2, 3, 4, 5, 8, 16])
         parts = [ctx.msm_windows(t, *window_range(r, world)) for r in range(world)]
-        got = m.MsmContext.combine_windows(torch.cat(parts, dim=0))
+        got = combine(torch.cat(parts, dim=0))
     if (case + 1) % 25 == 0:
         print("  %d cases ok, %.0f s" % (case + 1, time.time() - t0), flush=True)
     if got.to_affine_bytes() != want:
         print("MISMATCH case", case, "n", n, "kind", kind, "mode", mode, "seeds", pseed, sseed)
         sys.exit(1)
-print("fuzz ok: %d cases in %.1f s (seed %d)" % (cases, time.time() - t0, seed))
+print("fuzz ok: %d cases in %.1f s (seed %d, %s)" % (cases, time.time() - t0, seed, curve))
