@@ -116,8 +116,9 @@ int msm_hip_set_scalar_format(msm_hip_ctx* ctx, uint32_t format);
 
 /* ---- window size (the reference hard-codes chunk_size = 16 for n >= 2^16, src/cuzk/msm.rs:79-82).
  *      WHOLE-MSM entry points (run, launch, finish, batch) pick the signed-digit window from n: 12 bits (22 windows of 2^11 buckets)
- *      up to 2^12 points, 16 bits (16 windows of 2^15 buckets) beyond -- the measured optimum on MI355X; 14 bits (19 windows of 2^13
- *      buckets) is available as an explicit choice.  msm_hip_set_window_bits fixes the size (12, 14 or 16; 0 = by n).
+ *      up to 2^12 points, 16 bits (16 windows of 2^15 buckets) beyond -- the measured optimum on MI355X for one MSM per launch; launches
+ *      that carry several whole MSMs (the batch entry points) use 14 bits (19 windows of 2^13 buckets) up to 2^16 points.
+ *      msm_hip_set_window_bits fixes the size (12, 14 or 16; 0 = by n).
  *      The result is the same group element for every window size.  The window-sharding entry points below (w_begin / w_end) and
  *      msm_hip_combine_windows_bn254 always use the reference's 16-bit windows. ---- */
 int msm_hip_set_window_bits(msm_hip_ctx* ctx, int bits);

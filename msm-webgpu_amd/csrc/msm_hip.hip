@@ -342,12 +342,17 @@ int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, Slot& s) {
 // dependent group additions at ~7 us each), which does not shrink with the bucket count -- so smaller windows, which need more
 // windows (19 at 14 bits, 22 at 12), only win while the accumulation itself is negligible: 12 bits up to 2^12 points
 // (0.70 vs 0.80 ms latency, 0.34 vs 0.40 ms pipelined), 16 bits from 2^13 up; 14 bits never wins and is kept as an explicit
-// choice (msm_hip_set_window_bits).  `nvec` whole MSMs must fit MAXLW local windows.  The window-sharding entry points always use
-// 16-bit windows: their w_begin / w_end index the reference's 16 windows.
+// choice for ONE MSM per launch (msm_hip_set_window_bits).
+// Several whole MSMs per launch (the batch entry points; nvec > 1) are a different regime: 4 - 8 MSMs' bucket sets are stitched and
+// reduced side by side, so the work per bucket counts, not the depth of one reduce -- 14 bits (a quarter of the buckets for a
+// quarter more additions) wins up to 2^16 points, in both base modes (profiles/r02_window_bits_grouped.txt: 2^12 +41 %, 2^14 +29 %,
+// 2^16 +6 % with the endomorphism; +45 % / +50 % / +27 % plain; 16 bits from 2^17 up).
+// `nvec` whole MSMs must fit MAXLW local windows.  The window-sharding entry points always use 16-bit windows: their w_begin / w_end
+// index the reference's 16 windows.
 inline int pick_window_bits(const msm_hip_ctx* ctx, size_t n, int nvec, bool halves = false) {
   static const int forced = [] { const char* e = getenv("MSM_HIP_WINDOW_BITS"); return e ? atoi(e) : 0; }();  // tuning aid
   int bits = ctx->window_bits ? ctx->window_bits : (forced == 12 || forced == 14 || forced == 16 ? forced : 0);
-  if (!bits) bits = n <= ((size_t)1 << 12) ? 12 : 16;
+  if (!bits) bits = nvec > 1 ? (n <= ((size_t)1 << 16) ? 14 : 16) : (n <= ((size_t)1 << 12) ? 12 : 16);
   while (bits < 16 && nvec * nwin_of(bits, halves) > MAXLW) bits += 2;
   return bits;
 }
@@ -625,8 +630,9 @@ namespace {
 // MSMs per launch of the batch runners: small MSMs cannot fill the GPU one at a time (kernel latencies dominate below
 // ~2^19 points), so up to MAXLW / NWIN = 4 of them -- at most about 2^20 points together -- share one kernel sequence
 size_t batch_group(msm_hip_ctx* ctx, size_t n, size_t batch) {
-  // 4 at 16 bits, 3 at 14, 2 at 12 (twice that with the endomorphism's half-length scalars); with fixed-base tables every MSM is one local window
-  const size_t fit = ctx->precomputed ? (size_t)MAXLW : (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 1, ctx->endo), ctx->endo));
+  // 4 at 16 bits, 3 at 14, 2 at 12 (8 / 6 / 5 with the endomorphism's half-length scalars); with fixed-base tables every MSM is one local window
+  // (window size of a grouped launch: pick_window_bits with nvec > 1)
+  const size_t fit = ctx->precomputed ? (size_t)MAXLW : (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 2, ctx->endo), ctx->endo));
   size_t g = n ? ((size_t)1 << 20) / n : 1;
   if (g > fit) g = fit;
   if (g > batch) g = batch;

@@ -95,9 +95,23 @@ def test_automatic_choice_follows_n(ctx):
     # the window-sharding entry points keep the reference's 16-bit windows whatever n is
     ctx.msm_windows(sc[:1000].contiguous(), 3, 5)
     assert ctx.last_window_bits() == 16
+    # several whole MSMs per launch: 14 bits up to 2^16 points (profiles/r02_window_bits_grouped.txt), as many MSMs as fit 64 local windows
+    assert ctx.batch_group_size(2000) == 3 and ctx.batch_group_size(1 << 17) == 4
+    three = torch.cat([sc[:2000]] * 3, dim=0).contiguous()
+    ctx.launch_batch(three, 2000, 0)
+    assert ctx.last_window_bits() == 14
+    r3 = ctx.finish_batch(0, 3)
     # 4 whole MSMs in one launch only fit 16-bit windows: the launch falls back to them
     small = torch.cat([sc[:2000]] * 4, dim=0).contiguous()
     ctx.launch_batch(small, 2000, 0)
     assert ctx.last_window_bits() == 16
     r = ctx.finish_batch(0, 4)
-    assert r[0] == r[3] == ctx.msm(sc[:2000].contiguous())
+    assert r[0] == r[3] == r3[0] == r3[2] == ctx.msm(sc[:2000].contiguous())
+    # the same with the endomorphism's half-length scalars: 10 windows of 14 bits, 6 MSMs per launch
+    ctx.set_bases(pts, endomorphism=True)
+    assert ctx.batch_group_size(2000) == 6 and ctx.batch_group_size(1 << 17) == 8
+    six = torch.cat([sc[:2000]] * 6, dim=0).contiguous()
+    ctx.launch_batch(six, 2000, 1)
+    assert ctx.last_window_bits() == 14
+    assert ctx.finish_batch(1, 6)[5] == r[0]
+    ctx.set_bases(pts)
