@@ -868,7 +868,21 @@ __global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restri
       acc = g1_identity();
       wneg = false;
       run_begin = run_end;
-      do { s++; run_end = cp[s + 1]; } while (run_end == run_begin);  // next non-empty slot (exists: t < nw)
+      // next non-empty slot (exists: t < nw).  Usually the very next one; after a few empty slots switch to a binary search of the
+      // slot whose run contains entry t: a lane that walks thousands of empty slots with dependent loads (a few heavy buckets far
+      // apart: few distinct scalars, or the two halves of equal scalars) would hold up the whole kernel for milliseconds
+      int gap = 0;
+      do { s++; run_end = cp[s + 1]; } while (run_end == run_begin && ++gap < 8);
+      if (run_end == run_begin) {
+        uint32_t lo = s + 1, hi = half - 1;  // cp[hi + 1] = nw > t = run_begin
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (cp[mid + 1] > run_begin) hi = mid;
+          else lo = mid + 1;
+        }
+        s = lo;
+        run_end = cp[s + 1];
+      }
     }
     g1_madd_w(acc, wneg, px, py, (v >> 31) != 0u);  // bit 31: the digit is negative
   }

@@ -4,10 +4,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import msm_webgpu_amd as m
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+endo = len(sys.argv) > 2 and sys.argv[2] == "endomorphism"   # bases with their endomorphism images (8 windows over 2n points)
 n = 1 << logn
 ctx = m.MsmContext(0)
 pts = ctx.sample_points(n, 1)
-ctx.set_bases(pts)
+ctx.set_bases(pts, endomorphism=endo)
+print("bases:", "endomorphism" if endo else "plain")
 uni = ctx.sample_scalars(n, 2)
 ctx.msm(uni)
 s = 0x123456789ABCDEF013579BDF2468ACE0FEDCBA9876543210
