@@ -50,10 +50,10 @@ struct CurveOps {
   void (*endo_points)(uint32_t*, size_t);
   void (*glv_split)(const uint32_t*, uint32_t*, size_t, int, uint32_t*);
   void (*scalars_from_mont256)(const uint32_t*, uint32_t*, size_t, uint32_t*);
-  void (*smvp_chunks)(const uint32_t*, const uint32_t*, const uint32_t*, size_t, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*,
+  void (*smvp_chunks)(const uint32_t*, const uint32_t*, const uint32_t*, size_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*,
                       uint32_t*, uint32_t);
-  void (*smvp_stitch)(const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
-  void (*smvp_stitch_big)(const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+  void (*smvp_stitch)(const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+  void (*smvp_stitch_big)(const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t);
   void (*rowcol_4_8)(const uint32_t*, uint32_t*, uint32_t*);
   void (*rowcol_2_8)(const uint32_t*, uint32_t*, uint32_t*);
   void (*rowcol_3_8)(const uint32_t*, uint32_t*, uint32_t*);
@@ -105,7 +105,7 @@ struct Slot {
   uint32_t* d_col_ptr = nullptr;   // [W][32769] start of every bucket slot's run in the sorted entry list
   uint32_t* d_heads = nullptr;     // [W][chunks] XYZZ records: SMVP pieces of runs that cross chunk boundaries
   uint32_t* d_tails = nullptr;     // [W][chunks] XYZZ records
-  uint32_t* d_big_queue = nullptr;    // [1 + STITCH_BIG_CAP] buckets with many pieces (skewed scalars), [0] = count
+  uint32_t* d_big_queue = nullptr;    // buckets with many pieces (skewed scalars): [0] = count, items, arrival counters, scratch records (BIGQ_*)
   hipEvent_t ev[N_MAIN_EVENTS] = {};
   hipEvent_t red0 = nullptr, red1 = nullptr;  // bucket reduce begin / end on the reduce stream
   hipEvent_t smvp_done = nullptr;             // main -> reduce hand-off
@@ -268,12 +268,13 @@ int setup_slot(msm_hip_ctx* ctx, Slot& s) {
   if ((rc = dev_alloc(ctx, s.d_wsums, WSUM_BYTES + 4))) return rc;
   if ((rc = dev_alloc(ctx, s.d_partials, (size_t)MAXLW * (256 + 256 + 3) * XYZZ_WORDS))) return rc;
   if ((rc = dev_alloc(ctx, s.d_col_ptr, (size_t)MAXLW * (HALF + 1)))) return rc;
-  if ((rc = dev_alloc(ctx, s.d_big_queue, (size_t)STITCH_BIG_CAP + 1))) return rc;
+  if ((rc = dev_alloc(ctx, s.d_big_queue, BIGQ_WORDS))) return rc;
   // zeroed on the stream that first reads them (the slot's reduce stream; the error word is first written on the main
   // stream, which waits for `done` below) -- not on the null stream, which the non-blocking streams do not order with
   hipStream_t rs = ctx->reduce_stream[(&s - ctx->slot) % NREDUCE];
   HIP_TRY(ctx, hipMemsetAsync(s.d_wsums, 0, WSUM_BYTES + 4, rs));
   HIP_TRY(ctx, hipMemsetAsync(s.d_big_queue, 0, 4, rs));
+  HIP_TRY(ctx, hipMemsetAsync(s.d_big_queue + BIGQ_COUNTERS, 0, (size_t)STITCH_BLOCKS * 4, rs));
   if (!s.done) HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   if (!s.smvp_done) HIP_TRY(ctx, hipEventCreateWithFlags(&s.smvp_done, hipEventDisableTiming));
   if (!s.staged) HIP_TRY(ctx, hipEventCreateWithFlags(&s.staged, hipEventDisableTiming));
@@ -416,6 +417,8 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   uint16_t* digits = ctx->debug && !merge ? ctx->d_digits : nullptr;
   uint32_t* d_err = reinterpret_cast<uint32_t*>(s.d_wsums + WSUM_BYTES);
   if (!wsums_out) wsums_out = reinterpret_cast<uint32_t*>(s.d_wsums);
+  // the SMVP chunk length the device settles on for this launch (k_scatter_coarse -> fine sort, SMVP, stitch): a word of the slot
+  uint32_t* d_chunk_len = s.d_big_queue + BIGQ_CHUNK_LEN;
 
   // the slot's previous occupant (bucket reduce + copies on the reduce stream) must have drained; its error word was
   // re-zeroed at the end of that chain.  Stage events cost a few microseconds of queue time each, so only the ones the
@@ -458,7 +461,8 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   AFTER_KERNEL(ctx, "k_scan_tiles", st);
   HIP_TRY(ctx, mark(2, false));
   LAUNCH_BY_WBITS(k_scatter_coarse, d_scalars, n_sc, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
-                  ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, (uint32_t)n, (uint32_t)(ctx->n_bases - n));
+                  ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, (uint32_t)n, (uint32_t)(ctx->n_bases - n), chunks, chunk_len,
+                  d_chunk_len);
 #undef LAUNCH_BY_WBITS
 #undef LAUNCH_BY_WBITS_SW
   AFTER_KERNEL(ctx, "k_scatter_coarse", st);
@@ -471,21 +475,21 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     part_hist = ctx->d_part_hist;
   }
   hipLaunchKernelGGL(k_sort_fine, dim3(ncoarse, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
-                     s.d_col_ptr, ctx->d_val, chunks, chunk_len, ctx->d_chunk_slot, part_hist);
+                     s.d_col_ptr, ctx->d_val, chunks, d_chunk_len, ctx->d_chunk_slot, part_hist);
   AFTER_KERNEL(ctx, "k_sort_fine", st);
   HIP_TRY(ctx, mark(4, true));
   hipLaunchKernelGGL(ctx->ops->smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, s.d_col_ptr, ctx->d_val, stride,
-                     chunks, chunk_len, ctx->d_chunk_slot, s.d_buckets, s.d_heads, s.d_tails, half);
+                     chunks, d_chunk_len, ctx->d_chunk_slot, s.d_buckets, s.d_heads, s.d_tails, half);
   AFTER_KERNEL(ctx, "k_smvp_chunks", st);
   HIP_TRY(ctx, mark(5, true));
   HIP_TRY(ctx, hipEventRecord(s.smvp_done, st));
 
   // stitch + bucket reduce on the slot's reduce stream: few waves, long dependent chains
   HIP_TRY(ctx, hipStreamWaitEvent(rs, s.smvp_done, 0));
-  hipLaunchKernelGGL(ctx->ops->smvp_stitch, dim3(half / 256, w_count), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails,
+  hipLaunchKernelGGL(ctx->ops->smvp_stitch, dim3(half / 256, w_count), dim3(256), 0, rs, s.d_col_ptr, chunks, d_chunk_len, s.d_heads, s.d_tails,
                      s.d_buckets, s.d_big_queue);
   AFTER_KERNEL(ctx, "k_smvp_stitch", rs);
-  hipLaunchKernelGGL(ctx->ops->smvp_stitch_big, dim3(256), dim3(256), 0, rs, s.d_col_ptr, chunks, chunk_len, s.d_heads, s.d_tails, s.d_buckets,
+  hipLaunchKernelGGL(ctx->ops->smvp_stitch_big, dim3(STITCH_BLOCKS), dim3(256), 0, rs, s.d_col_ptr, chunks, s.d_heads, s.d_tails, s.d_buckets,
                      s.d_big_queue, half);
   AFTER_KERNEL(ctx, "k_smvp_stitch_big", rs);
   if (tl >= 2) {

@@ -440,6 +440,21 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* wa
   return x - v + add;
 }
 
+// The SMVP's chunk length is chosen on the DEVICE from the number of entries the sort actually produced: the host sizes the chunk
+// arrays and grids for n entries per window (`chunks` lanes of `host_len` entries), but zero digits produce no entry -- witness-like
+// scalar vectors (many zeros and ones) fill a fraction of that, and with the host's length most lanes would find nothing to do while
+// the rest carry full-length chunks.  Every kernel that uses the chunk structure (k_sort_fine's chunk table, k_smvp_chunks, the
+// stitch kernels) uses the same length: the largest window's entries spread over all `chunks` lanes.  It is computed ONCE per launch, by
+// workgroup 0 of k_scatter_coarse (which scans the windows' bin totals anyway), into a word of the launch's slot (`chunk_len_dev`);
+// the consumers load that one word (deriving it per workgroup from the 16 .. 64 window totals cost every SMVP workgroup a chain of
+// scalar loads at its start: +1 % on the whole MSM).
+constexpr int SMVP_CHUNK_MIN_ENTRIES = 8;
+__device__ __forceinline__ uint32_t smvp_chunk_len(uint32_t mx, uint32_t chunks, uint32_t host_len) {
+  uint32_t len = (uint32_t)(((uint64_t)mx + chunks - 1) / chunks);
+  len = (len + 3u) & ~3u;
+  if (len < (uint32_t)SMVP_CHUNK_MIN_ENTRIES) len = SMVP_CHUNK_MIN_ENTRIES;
+  return len < host_len ? len : host_len;
+}
 // Both scatter kernels stage their output through LDS: the block ranks its items per destination bin with LDS atomics,
 // lays them out bin-major in LDS, and writes them out in LDS order, so consecutive lanes store to consecutive global
 // addresses inside each (tile, bin) run instead of 64 unrelated 4-byte stores per wave instruction.
@@ -451,7 +466,8 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
                                                         const uint32_t* __restrict__ counts,
                                                         const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr,
                                                         uint32_t* __restrict__ tmp_val,
-                                                        uint8_t* __restrict__ tmp_fine, size_t merge_nb, uint32_t half_n, uint32_t half_shift) {
+                                                        uint8_t* __restrict__ tmp_fine, size_t merge_nb, uint32_t half_n, uint32_t half_shift,
+                                                        uint32_t chunks, uint32_t host_chunk_len, uint32_t* __restrict__ chunk_len_dev) {
   // SW = 4 (endomorphism halves): input j < half_n is k1 of scalar j and multiplies base j; input half_n + j is k2 and multiplies
   // phi(P_j), stored half_shift = n_bases - half_n records further on than its position
   __shared__ uint32_t gpos[MAXLW * NCOARSE];  // global write cursor of every (window, coarse bin) run of this tile
@@ -461,7 +477,10 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
   __shared__ uint32_t st_val[SCAT_SUB];
   __shared__ uint32_t st_dst[SCAT_SUB];
   __shared__ uint8_t st_fine[SCAT_SUB];
+  __shared__ uint32_t max_total;  // entries of the fullest local window (workgroup 0: -> chunk_len_dev)
   const int tid = threadIdx.x;
+  if (tid == 0) max_total = 0;
+  __syncthreads();
   // start of every (window, coarse bin): exclusive scan of the window's 128 bin totals -- a pair of waves per window, two
   // windows per step; workgroup 0 also publishes them as coarse_ptr[lw][0..128] for k_sort_fine
   const int w_eff = merge_nb ? nvec : nvec * w_count;  // local windows of all vectors of this launch
@@ -481,10 +500,14 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
     if (live) gpos[i] = incl - v + counts[((size_t)lw * tiles + blockIdx.x) * NCOARSE + bin];
     if (live && blockIdx.x == 0) {
       coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin] = incl - v;
-      if (bin == NCOARSE - 1) coarse_ptr[(size_t)lw * (NCOARSE + 1) + NCOARSE] = incl;
+      if (bin == NCOARSE - 1) {
+        coarse_ptr[(size_t)lw * (NCOARSE + 1) + NCOARSE] = incl;
+        atomicMax(&max_total, incl);
+      }
     }
     __syncthreads();
   }
+  if (blockIdx.x == 0 && tid == 0) *chunk_len_dev = smvp_chunk_len(max_total, chunks, host_chunk_len);
   const size_t tile_base = (size_t)blockIdx.x * tile_len;
   const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
   for (int v = 0; v < nvec; v++)
@@ -589,6 +612,7 @@ __device__ __forceinline__ void lds_count_only(uint32_t* counter, uint32_t key, 
 // its own offset inside every slot -- and then scatters only its sub-range.  Normal bins are handled by workgroup 0 alone
 // (the other FINE_SPLIT - 1 exit at once).
 constexpr int FINE_SPLIT = 8;
+
 constexpr uint32_t FINE_BIG = 8 * FINE_CHUNK;
 
 // Histograms of the FINE_SPLIT sub-ranges of every coarse bin that exceeds FINE_BIG (part_hist[lw][bin][part][256]); launched
@@ -623,8 +647,9 @@ __global__ void __launch_bounds__(256) k_fine_hist(const uint8_t* __restrict__ t
 
 __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ tmp_val, const uint8_t* __restrict__ tmp_fine, size_t stride,
                                                    const uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ col_ptr,
-                                                   uint32_t* __restrict__ val_idxs, uint32_t chunks, uint32_t chunk_len,
+                                                   uint32_t* __restrict__ val_idxs, uint32_t chunks, const uint32_t* __restrict__ chunk_len_dev,
                                                    uint32_t* __restrict__ chunk_slot, const uint32_t* __restrict__ part_hist) {
+  const uint32_t chunk_len = *chunk_len_dev;
   __shared__ uint32_t hist[FINE];
   __shared__ uint32_t before[FINE];  // entries of every slot in front of this workgroup's sub-range
   __shared__ uint32_t lstart[FINE];
@@ -788,7 +813,7 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
 // [SMVP_CHUNK_MIN, SMVP_CHUNK_MAX]) so that about SMVP_TARGET_LANES lanes exist (about two rounds of 3 waves per SIMD at 132 VGPRs, no scratch).  Runs that cross a chunk boundary leave a "tail" piece
 // (in the chunk where the run starts) and "head" pieces (in the chunks it continues into); k_smvp_stitch adds them.
 // Buckets and pieces are stored as raw XYZZ records (no multiplication on the flush path).
-constexpr int SMVP_CHUNK_MIN = 8;
+constexpr int SMVP_CHUNK_MIN = SMVP_CHUNK_MIN_ENTRIES;
 constexpr int SMVP_CHUNK_MAX = 1024;
 constexpr int SMVP_TARGET_LANES = 3 << 17;  // 1.5 x (256 CUs x 4 SIMDs x 4 waves x 64 lanes): measured optimum of SMVP + stitch
 constexpr int REC_WORDS = 40;  // 160 B record: 36 limbs, valid flag, 3 pad words; 16-byte aligned
@@ -827,9 +852,10 @@ __device__ __forceinline__ g1_xyzz ld_rec(const uint32_t* p) {
 
 __global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ col_ptr,
                                                      const uint32_t* __restrict__ val_idxs, size_t stride, uint32_t chunks,
-                                                     uint32_t chunk_len, const uint32_t* __restrict__ chunk_slot,
+                                                     const uint32_t* __restrict__ chunk_len_dev, const uint32_t* __restrict__ chunk_slot,
                                                      uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
                                                      uint32_t* __restrict__ tails, uint32_t half) {
+  const uint32_t chunk_len = *chunk_len_dev;
   const int lw = blockIdx.y;
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;
   const uint32_t* cp = col_ptr + (size_t)lw * (half + 1);
@@ -909,11 +935,12 @@ __device__ __forceinline__ void lds_add_pair(uint32_t* x, int dst, int src) {
 constexpr uint32_t STITCH_BIG = 32;
 constexpr uint32_t STITCH_BIG_CAP = 1 << 15;  // queue capacity; more big buckets than this fall back to the serial walk
 
-__global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict__ col_ptr, uint32_t chunks, uint32_t chunk_len,
+__global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict__ col_ptr, uint32_t chunks, const uint32_t* __restrict__ chunk_len_dev,
                                                      const uint32_t* __restrict__ heads, const uint32_t* __restrict__ tails,
                                                      uint32_t* __restrict__ buckets, uint32_t* __restrict__ big_queue) {
   const int lw = blockIdx.y;
   const uint32_t half = gridDim.x * 256;              // bucket slots per window: one lane per slot
+  const uint32_t chunk_len = *chunk_len_dev;
   const uint32_t s = blockIdx.x * 256 + threadIdx.x;  // < half by grid construction
   const uint32_t* cp = col_ptr + (size_t)lw * (half + 1);
   const uint32_t b = cp[s], e = cp[s + 1];
@@ -939,32 +966,110 @@ __global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict_
 // Queued big buckets: one block per bucket (blocks stride over the queue); every thread adds a strided subset of the
 // pieces, then an LDS tree.  The queue counter is reset for the slot's next launch by k_bpr_final, a later kernel of the same
 // stream (a last-block hand-off here would cost a __threadfence per launch, queue empty or not).
-__global__ void __launch_bounds__(256) k_smvp_stitch_big(const uint32_t* __restrict__ col_ptr, uint32_t chunks, uint32_t chunk_len,
+// HUGE buckets (>= STITCH_HUGE pieces: one value shared by a large part of the scalars -- the ones and small constants of witness
+// vectors, all-equal scalars) would keep their single workgroup busy for pieces / 256 dependent additions per thread while the rest
+// of the GPU idles: when the queue is short (<= 256 items) the huge ones are shared by STITCH_BLOCKS / (their number) workgroups
+// each; a workgroup leaves its partial sum in the slot's scratch records and the last one to arrive adds the partials
+// (device-scope fences: only on this rare path).
+// big_queue layout (words): [0] count, [1 .. CAP] items, [BIGQ_CHUNK_LEN] the launch's SMVP chunk length (smvp_chunk_len),
+// [BIGQ_COUNTERS ..] 256 arrival counters (zero between launches), [BIGQ_SCRATCH ..] 256 XYZZ records.
+constexpr uint32_t STITCH_HUGE = 1024;
+constexpr int STITCH_BLOCKS = 256;  // grid of k_smvp_stitch_big
+constexpr size_t BIGQ_CHUNK_LEN = STITCH_BIG_CAP + 1;
+constexpr size_t BIGQ_COUNTERS = STITCH_BIG_CAP + 4;
+constexpr size_t BIGQ_SCRATCH = BIGQ_COUNTERS + STITCH_BLOCKS;
+constexpr size_t BIGQ_WORDS = BIGQ_SCRATCH + (size_t)STITCH_BLOCKS * REC_WORDS;
+
+__global__ void __launch_bounds__(256) k_smvp_stitch_big(const uint32_t* __restrict__ col_ptr, uint32_t chunks,
                                                          const uint32_t* __restrict__ heads, const uint32_t* __restrict__ tails,
-                                                         uint32_t* __restrict__ buckets, const uint32_t* __restrict__ big_queue,
+                                                         uint32_t* __restrict__ buckets, uint32_t* big_queue,
                                                          uint32_t half) {
   __shared__ uint32_t x[256 * XYZZ_WORDS];
+  __shared__ uint32_t huge_flag[256], huge_list[256], wave_tot[4], s_nhuge, s_last;
   const int t = threadIdx.x;
   uint32_t count = big_queue[0];
   if (count > STITCH_BIG_CAP) count = STITCH_BIG_CAP;
-  for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+  if (count == 0) return;
+  const uint32_t chunk_len = big_queue[BIGQ_CHUNK_LEN];
+  // the pieces of queue item `item`: chunks c0 .. c1 of local window lw, bucket slot s
+  auto decode = [&](uint32_t item, uint32_t& lw, uint32_t& s, uint32_t& c0, uint32_t& c1) {
     const uint32_t code = big_queue[1 + item];
-    const uint32_t lw = code >> 16, s = code & 0xffffu;
+    lw = code >> 16;
+    s = code & 0xffffu;
     const uint32_t* cp = col_ptr + (size_t)lw * (half + 1);
-    const uint32_t c0 = cp[s] / chunk_len, c1 = (cp[s + 1] - 1) / chunk_len;
-    g1_xyzz acc = g1_identity();
-    for (uint32_t c = c0 + t; c <= c1; c += 256) {
-      const uint32_t* piece = (c == c0 ? tails : heads) + ((size_t)lw * chunks + c) * REC_WORDS;
-      acc = g1_add(acc, ld_rec(piece));
-    }
+    c0 = cp[s] / chunk_len;
+    c1 = (cp[s + 1] - 1) / chunk_len;
+  };
+  // block-wide sum of the per-thread accumulators -> x[0]
+  auto block_sum = [&](const g1_xyzz& acc) {
     st_xyzz(x + t * XYZZ_WORDS, acc);
     __syncthreads();
     for (int sft = 128; sft >= 1; sft >>= 1) {
       if (t < sft) lds_add_pair(x, t, t + sft);
       __syncthreads();
     }
+  };
+  // which items are huge (every workgroup computes the same list, in queue order)
+  const bool may_split = count <= 256 && gridDim.x == (unsigned)STITCH_BLOCKS;
+  uint32_t nhuge = 0;
+  if (may_split) {
+    uint32_t f = 0;
+    if ((uint32_t)t < count) {
+      uint32_t lw, s, c0, c1;
+      decode(t, lw, s, c0, c1);
+      f = c1 - c0 + 1 >= STITCH_HUGE ? 1u : 0u;
+    }
+    huge_flag[t] = f;
+    const uint32_t pos = block_excl_scan_256(f, wave_tot);
+    if (f) huge_list[pos] = (uint32_t)t;
+    if (t == 255) s_nhuge = pos + f;
+    __syncthreads();
+    nhuge = s_nhuge;
+  }
+  for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+    if (may_split && huge_flag[item]) continue;  // block-uniform
+    uint32_t lw, s, c0, c1;
+    decode(item, lw, s, c0, c1);
+    g1_xyzz acc = g1_identity();
+    for (uint32_t c = c0 + t; c <= c1; c += 256) {
+      const uint32_t* piece = (c == c0 ? tails : heads) + ((size_t)lw * chunks + c) * REC_WORDS;
+      acc = g1_add(acc, ld_rec(piece));
+    }
+    block_sum(acc);
     if (t == 0) st_rec(buckets + ((size_t)lw * half + s) * REC_WORDS, ld_xyzz(x));
     __syncthreads();
+  }
+  if (nhuge == 0) return;
+  const uint32_t per = (uint32_t)STITCH_BLOCKS / nhuge;  // workgroups per huge bucket, >= 1
+  const uint32_t hi = blockIdx.x / per, sub = blockIdx.x % per;
+  if (hi >= nhuge) return;
+  uint32_t lw, s, c0, c1;
+  decode(huge_list[hi], lw, s, c0, c1);
+  g1_xyzz acc = g1_identity();
+  for (uint32_t c = c0 + sub * 256 + t; c <= c1; c += per * 256) {
+    const uint32_t* piece = (c == c0 ? tails : heads) + ((size_t)lw * chunks + c) * REC_WORDS;
+    acc = g1_add(acc, ld_rec(piece));
+  }
+  block_sum(acc);
+  uint32_t* out = buckets + ((size_t)lw * half + s) * REC_WORDS;
+  if (per == 1) {
+    if (t == 0) st_rec(out, ld_xyzz(x));
+    return;
+  }
+  uint32_t* counters = big_queue + BIGQ_COUNTERS;
+  uint32_t* scratch = big_queue + BIGQ_SCRATCH;
+  if (t == 0) {
+    st_rec(scratch + (size_t)blockIdx.x * REC_WORDS, ld_xyzz(x));
+    __threadfence();  // the partial is visible device-wide before this workgroup is counted
+    s_last = atomicAdd(&counters[hi], 1u) == per - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();  // acquire: the other workgroups' partials
+  block_sum((uint32_t)t < per ? ld_rec(scratch + ((size_t)hi * per + t) * REC_WORDS) : g1_identity());
+  if (t == 0) {
+    st_rec(out, ld_xyzz(x));
+    counters[hi] = 0;  // ready for the slot's next launch
   }
 }
 
