@@ -213,6 +213,35 @@ def test_skewed_distributions_match_oracle(ctx, kind):
     assert ctx.msm(sb).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points, sb))
 
 
+@pytest.mark.parametrize("endo", [False, True], ids=["plain", "endomorphism"])
+@pytest.mark.parametrize("kind", ["3_values", "10_values", "20_values", "witness_like", "sparse_5_percent"])
+def test_heavy_buckets_and_sparse_vectors_at_2p17(ctx, kind, endo):
+    # the paths that only large skewed / sparse inputs reach ("Skewed and sparse scalars"):
+    #   buckets of >= 1024 pieces shared by several workgroups (3 values: 16 workgroups per bucket and the last-arrival hand-off;
+    #   10 values: more than 128 such buckets, one workgroup each; 20 values: a queue of > 256 items, no sharing),
+    #   the SMVP's jump across long gaps of empty slots, and the chunk length settled on the device from the real entry count
+    #   (witness-like: 40 % zeros, 30 % ones; 5 % non-zero)
+    n = 1 << 17
+    rnd = __import__("random").Random(11)
+    pts = ctx.sample_points(n, 150)
+    base = ref.bytes_to_scalars(ctx.sample_scalars(n, 151).cpu().numpy().tobytes())
+    if kind.endswith("_values"):
+        vals = base[: int(kind.split("_")[0])]
+        sc = [vals[rnd.randrange(len(vals))] for _ in range(n)]
+    elif kind == "witness_like":
+        sc = [0 if (u := rnd.random()) < 0.4 else 1 if u < 0.7 else base[i] for i in range(n)]
+    else:
+        sc = [base[i] if rnd.random() < 0.05 else 0 for i in range(n)]
+    pb, sb = pts.cpu().numpy().tobytes(), ref.scalars_to_bytes(sc)
+    ctx.set_bases(pts, endomorphism=endo)
+    try:
+        got = ctx.msm(sb)
+        assert got.to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb, sb, 8))
+        assert ctx.msm(sb) == got  # the arrival counters of the shared buckets are back at zero for the slot's next launch
+    finally:
+        ctx.set_bases(pts)
+
+
 def test_batch_over_shared_base(ctx):
     # BASELINE config 5 in miniature: many scalar vectors over one resident base, pipelined inside the library
     n, batch = 3000, 7
