@@ -288,7 +288,8 @@ int setup_slot(msm_hip_ctx* ctx, Slot& s) {
 }
 
 // make the pools fit a launch of `w_count` local windows (vectors x windows) over n points into slot `s` (not pending)
-int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, Slot& s) {
+// (`full_windows`: the windows of one whole MSM in the launch's mode -- the sort arrays are sized for at least that many)
+int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, int full_windows, Slot& s) {
   int rc;
   if ((rc = setup_slot(ctx, s))) return rc;
   const size_t need_recs = (size_t)w_count * chunks_for(n, chunk_len_for(n, w_count));
@@ -296,7 +297,7 @@ int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, Slot& s) {
   if (need_entries > ctx->cap_entries || need_recs > ctx->cap_chunk_slot || (ctx->debug && !ctx->d_digits)) {
     // growing the context-wide sort arrays (main stream only): nothing may still be running on them
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    size_t entries = stride_for(n) * NWIN;  // any single MSM over up to n points
+    size_t entries = stride_for(n) * (size_t)full_windows;  // any single MSM over up to n entries per window
     if (entries < need_entries) entries = need_entries;
     if (entries > ctx->cap_entries || (ctx->debug && !ctx->d_digits)) {
       if (entries < ctx->cap_entries) entries = ctx->cap_entries;
@@ -822,7 +823,8 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
     }
     return MSM_HIP_OK;
   }
-  if ((rc = ensure_work(ctx, merge ? n * (size_t)w_count : halves ? 2 * n : n, w_local, wbits, s))) return rc;
+  if ((rc = ensure_work(ctx, merge ? n * (size_t)w_count : halves ? 2 * n : n, w_local, wbits,
+                        merge ? 1 : halves ? nwin_of(wbits, true) : NWIN, s))) return rc;
   if (halves && (size_t)nvec * n > ctx->cap_halves) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cap_halves = 0;
