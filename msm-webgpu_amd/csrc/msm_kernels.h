@@ -4,7 +4,8 @@
 // (W = windows handled by this GPU, stride = n rounded up to 4):
 //
 //   bases      u32[n][16]            packed affine, Montgomery (R = 2^261), x || y, 64 B per point, resident
-//   scalars    u32[n][8]             canonical little-endian (wire format)
+//                                    (+ phi(P_i) as records n .. 2n-1 with the endomorphism, + 15 more tables with fixed-base tables)
+//   scalars    u32[n][8]             canonical little-endian (wire format)   (endomorphism: halves u32[2n][4], csrc/glv.h)
 //   counts     u32[W][tiles][128]    per-tile coarse-bin histogram, then prefix over tiles
 //   tmp_val    u32[W][stride]        point index | sign << 31, in coarse-bin order ; tmp_fine u8[W][stride] = slot & 255
 //   val_idxs   u32[W][stride]        point index | sign << 31, grouped by bucket slot
@@ -809,8 +810,10 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
 //   B[w][k] = sum_{d=+k} P - sum_{d=-k} P  (k >= 1),   B[w][0] = -sum_{d=-2^15} P
 // The reference gives one thread one bucket, so a wave runs as long as its fullest bucket.  Here every lane owns a
 // fixed-length chunk of `chunk_len` consecutive entries of the slot-sorted list -- equal work per lane whatever the bucket
-// sizes -- and flushes its accumulator whenever the slot changes.  The host picks chunk_len (a multiple of 4 in
-// [SMVP_CHUNK_MIN, SMVP_CHUNK_MAX]) so that about SMVP_TARGET_LANES lanes exist (about two rounds of 3 waves per SIMD at 132 VGPRs, no scratch).  Runs that cross a chunk boundary leave a "tail" piece
+// sizes -- and flushes its accumulator whenever the slot changes.  The host picks a chunk length (a multiple of 4 in
+// [SMVP_CHUNK_MIN, SMVP_CHUNK_MAX]) so that about SMVP_TARGET_LANES lanes exist for n entries per window (about two rounds of 3 waves
+// per SIMD at 168 VGPRs, no scratch) and sizes the chunk arrays and grids with it; the length actually used is settled on the device
+// from the entries the sort produced (smvp_chunk_len above: never longer than the host's).  Runs that cross a chunk boundary leave a "tail" piece
 // (in the chunk where the run starts) and "head" pieces (in the chunks it continues into); k_smvp_stitch adds them.
 // Buckets and pieces are stored as raw XYZZ records (no multiplication on the flush path).
 constexpr int SMVP_CHUNK_MIN = SMVP_CHUNK_MIN_ENTRIES;
