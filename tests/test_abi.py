@@ -125,3 +125,37 @@ def test_host_only_helpers_of_window_sizes_and_curves(built):
     assert L.msm_hip_combine_windows_curve(2, sums, 16, out) == -2  # unknown curve
     h = C.c_void_p()
     assert L.msm_hip_ctx_create_curve(C.byref(h), 0, 7) == -2
+
+
+def test_header_is_plain_c_and_links_from_c(built, tmp_path):
+    # the boundary is a C ABI: include/msm_hip.h compiles as strict C99 and a C program links against the library (what a cgo /
+    # Rust FFI binding relies on); host-only entry points run without a GPU
+    import subprocess
+
+    import msm_webgpu_amd as m
+
+    src = tmp_path / "c_caller.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "msm_hip.h"
+int main(void) {
+  int nw = 0, nb = 0, b = 0, e = 0;
+  unsigned char sums[96 * 16], out[96];
+  if (msm_hip_abi_version() != 5) return 1;
+  if (msm_hip_window_config(16, &nw, &nb) != MSM_HIP_OK || nw != 16 || nb != 32768) return 2;
+  if (msm_hip_endomorphism_window_count(16) != 8) return 3;
+  if (msm_hip_window_range(3, 8, 16, &b, &e) != MSM_HIP_OK || b != 6 || e != 8) return 4;
+  memset(sums, 0, sizeof sums);  /* 16 identity window sums combine to the identity */
+  if (msm_hip_combine_windows_bn254(sums, 16, out) != MSM_HIP_OK || out[64] != 0) return 5;
+  if (strcmp(msm_hip_strerror(MSM_HIP_ERR_NO_BASES), "bases not set") != 0) return 6;
+  msm_hip_oneshot_release();  /* nothing kept: a no-op */
+  puts("c caller ok");
+  return 0;
+}
+''')
+    exe = str(tmp_path / "c_caller")
+    so_dir = os.path.dirname(m.build())
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe,
+                           "-L", so_dir, "-lmsm_hip", "-Wl,-rpath," + so_dir])
+    assert "c caller ok" in subprocess.run([exe], capture_output=True, text=True, check=True).stdout
