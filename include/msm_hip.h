@@ -194,6 +194,7 @@ typedef struct msm_hip_mgpu msm_hip_mgpu;
 #define MSM_HIP_MGPU_GATHER_HOST 1u /* every device's sums leave through its slot's pinned buffer                        */
 #define MSM_HIP_MGPU_GATHER_RCCL 2u /* ncclAllGather; creation fails if RCCL cannot be initialised on these devices       */
 int msm_hip_mgpu_create(msm_hip_mgpu** out, const int* device_ids, int n_devices, uint32_t gather_flags);
+int msm_hip_mgpu_create_curve(msm_hip_mgpu** out, const int* device_ids, int n_devices, uint32_t gather_flags, int curve); /* MSM_HIP_CURVE_* */
 void msm_hip_mgpu_destroy(msm_hip_mgpu* m);
 int msm_hip_mgpu_device_count(const msm_hip_mgpu* m);
 int msm_hip_mgpu_uses_rccl(const msm_hip_mgpu* m);

@@ -98,6 +98,7 @@ def lib():
         L.msm_hip_test_g1_mul_u32.argtypes = [vp, u8p, vp, u8p, sz]
         L.msm_hip_last_hip_error.argtypes = [vp]
         L.msm_hip_mgpu_create.argtypes = [C.POINTER(vp), C.POINTER(i), i, C.c_uint32]
+        L.msm_hip_mgpu_create_curve.argtypes = [C.POINTER(vp), C.POINTER(i), i, C.c_uint32, i]
         L.msm_hip_mgpu_destroy.argtypes = [vp]
         L.msm_hip_mgpu_destroy.restype = None
         L.msm_hip_mgpu_device_count.argtypes = [vp]
@@ -487,10 +488,12 @@ class MultiGpuMsm:
 
     GATHER = {"auto": 0, "host": 1, "rccl": 2}
 
-    def __init__(self, device_ids, gather="auto"):
+    def __init__(self, device_ids, gather="auto", curve="bn254"):
         ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
         self._h = C.c_void_p()
-        _check(lib().msm_hip_mgpu_create(C.byref(self._h), ids, len(device_ids), self.GATHER[gather]), "msm_hip_mgpu_create")
+        self.curve = curve
+        self.modulus = CURVES[curve][1]
+        _check(lib().msm_hip_mgpu_create_curve(C.byref(self._h), ids, len(device_ids), self.GATHER[gather], CURVES[curve][0]), "msm_hip_mgpu_create_curve")
 
     def close(self):
         if self._h:
@@ -523,14 +526,14 @@ class MultiGpuMsm:
         b = bytes(scalars)
         out = C.create_string_buffer(96)
         _check(lib().msm_hip_mgpu_run_bn254(self._h, b, len(b) // 32, out), "msm_hip_mgpu_run_bn254")
-        return G1(out.raw)
+        return G1(out.raw, self.modulus)
 
     def msm_batch(self, scalars, n):
         b = bytes(scalars)
         batch = len(b) // (32 * n)
         out = C.create_string_buffer(max(96 * batch, 1))
         _check(lib().msm_hip_mgpu_run_batch_bn254(self._h, b, n, batch, out), "msm_hip_mgpu_run_batch_bn254")
-        return [G1(out.raw[96 * k:96 * k + 96]) for k in range(batch)]
+        return [G1(out.raw[96 * k:96 * k + 96], self.modulus) for k in range(batch)]
 
 
 def window_range_abi(rank, world, num=NUM_WINDOWS):

@@ -46,6 +46,7 @@ constexpr int NCCL_UINT8 = 1;  // ncclUint8 (rccl.h)
 }  // namespace
 
 struct msm_hip_mgpu {
+  int curve = MSM_HIP_CURVE_BN254_G1;
   int n = 0;
   int device[MGPU_MAX] = {};
   msm_hip_ctx* ctx[MGPU_MAX] = {};
@@ -100,16 +101,22 @@ void msm_hip_mgpu_destroy(msm_hip_mgpu* m) {
 }
 
 int msm_hip_mgpu_create(msm_hip_mgpu** out, const int* device_ids, int n_devices, uint32_t flags) {
+  return msm_hip_mgpu_create_curve(out, device_ids, n_devices, flags, MSM_HIP_CURVE_BN254_G1);
+}
+
+int msm_hip_mgpu_create_curve(msm_hip_mgpu** out, const int* device_ids, int n_devices, uint32_t flags, int curve) {
   if (!out) return MSM_HIP_ERR_INVALID_ARG;
   *out = nullptr;
   if (!device_ids || n_devices < 1 || n_devices > MGPU_MAX || flags > MSM_HIP_MGPU_GATHER_RCCL) return MSM_HIP_ERR_INVALID_ARG;
+  if (curve != MSM_HIP_CURVE_BN254_G1 && curve != MSM_HIP_CURVE_GRUMPKIN) return MSM_HIP_ERR_INVALID_ARG;
   msm_hip_mgpu* m = new (std::nothrow) msm_hip_mgpu();
   if (!m) return MSM_HIP_ERR_OUT_OF_MEMORY;
+  m->curve = curve;
   bool distinct = true;
   for (int d = 0; d < n_devices; d++) {
     m->device[d] = device_ids[d];
     for (int e = 0; e < d; e++) distinct = distinct && device_ids[e] != device_ids[d];
-    int rc = msm_hip_ctx_create(&m->ctx[d], device_ids[d]);
+    int rc = msm_hip_ctx_create_curve(&m->ctx[d], device_ids[d], curve);
     m->n = d + 1;
     if (rc) {
       m->n = d;  // ctx[d] was not created
@@ -205,7 +212,7 @@ int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t 
     if (rc) return rc;
   }
   // 3. ONE host window combine
-  return msm_hip_combine_windows_bn254(all, NWIN, out_xyz);
+  return msm_hip_combine_windows_curve(m->curve, all, NWIN, out_xyz);
 }
 
 int msm_hip_mgpu_run_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz) {

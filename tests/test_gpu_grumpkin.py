@@ -160,3 +160,21 @@ def test_montgomery_word_formats(gctx):
         gctx.set_scalar_format(False)
     gctx.set_bases(points)
     assert gctx.msm(scalars).to_affine_bytes() == want
+
+
+def test_multi_gpu_abi_on_the_second_curve(built):
+    # msm_hip_mgpu_create_curve: the in-process multi-GPU shape (window shares + gather + ONE combine; batches as whole MSMs) on
+    # Grumpkin -- several contexts on the one GPU, as tests/test_gpu_mgpu.py does for BN254
+    n = 20000
+    points, scalars = cpu.sample_points(950, n), cpu.sample_scalars(951, n)
+    want = cpu.to_affine64(cpu.cpu_msm(points, scalars, 8))
+    for ids, gather in (([0, 0, 0], "host"), ([0], "rccl")):
+        mg = m.MultiGpuMsm(ids, gather, curve="grumpkin")
+        try:
+            mg.set_bases(points, check_on_curve=True)
+            assert mg.msm(scalars).to_affine_bytes() == want
+            got = mg.msm_batch(scalars[: 32 * 6000] , 2000)
+            assert len(got) == 3
+            assert got[1].to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points[: 64 * 2000], scalars[32 * 2000: 32 * 4000]))
+        finally:
+            mg.close()
