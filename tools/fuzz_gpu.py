@@ -50,8 +50,6 @@ for case in range(cases):
     sb = ref.scalars_to_bytes(sc)
     want = cpu.to_affine64(cpu.cpu_msm(points, sb))
     mode = rnd.choice(["host", "device", "windows", "batch", "group", "hostbatch", "mont", "bits", "tables", "tables_batch", "hostpipe", "mgpu", "endo", "endo_batch"])
-    if mode == "mgpu" and curve != "bn254":
-        mode = "endo"  # the multi-GPU ABI is BN254-only
     ctx.set_bases(points, precompute=mode.startswith("tables"), endomorphism=mode.startswith("endo"))
     if mode == "mont":
         # both inputs as R = 2^256 Montgomery words (MSM_HIP_BASES_MONT256, MSM_HIP_SCALARS_MONT256)
@@ -99,7 +97,7 @@ for case in range(cases):
     elif mode == "mgpu":
         world = rnd.choice([1, 2, 3, 5, 8])
         if world not in mg:
-            mg[world] = m.MultiGpuMsm([0] * world, "host")
+            mg[world] = m.MultiGpuMsm([0] * world, "host", curve=curve)
         mg[world].set_bases(points)
         got = mg[world].msm(sb) if rnd.random() < 0.6 else mg[world].msm_batch(sb + sb, n)[1]
     elif mode == "device":
