@@ -106,6 +106,24 @@ FQ_HD fq fq_sub(const fq& a, const fq& b) {
   return fq_norm(t);
 }
 
+#if defined(FQ_CHECK)
+// host-only (tests/test_fq29_host.py): r has exact limbs; is its value below 2p?  A Montgomery product's result is < 2p exactly when
+// its operands respected value(a) * value(b) <= (2^261 / p) p^2 -- the contract every bound comment in g1.h relies on.
+inline bool fq_check_below_2p(const fq& r) {
+  uint32_t two_p[9];
+  uint64_t carry = 0;
+  for (int i = 0; i < 9; i++) {
+    const uint64_t t = 2ull * FQ_P29[i] + carry;
+    two_p[i] = (uint32_t)(i < 8 ? t & FQ_MASK : t);
+    carry = i < 8 ? t >> 29 : 0;
+  }
+  for (int i = 8; i >= 0; i--) {
+    if (r.v[i] != two_p[i]) return r.v[i] < two_p[i];
+  }
+  return false;
+}
+#endif
+
 // Montgomery product a*b/R mod p, R = 2^261.  Operand limbs <= 2^30 + 16; value(a)*value(b) <= 169 p^2.
 // Result exact (limbs < 2^29), value < 2p.
 FQ_HD fq fq_mul(const fq& a, const fq& b) {
@@ -133,6 +151,7 @@ FQ_HD fq fq_mul(const fq& a, const fq& b) {
   }
   r.v[8] = (uint32_t)c[17];
   FQ_ASSERT((c[17] >> 26) == 0, "fq_mul: result >= 2^258");
+  FQ_ASSERT(fq_check_below_2p(r), "fq_mul: result >= 2p (operand value bound violated)");
   return r;
 }
 
@@ -168,6 +187,7 @@ FQ_HD fq fq_mul2(const fq& a, const fq& b, const fq& c_, const fq& d) {
   }
   r.v[8] = (uint32_t)c[17];
   FQ_ASSERT((c[17] >> 26) == 0, "fq_mul2: result >= 2^258");
+  FQ_ASSERT(fq_check_below_2p(r), "fq_mul2: result >= 2p (operand value bound violated)");
   return r;
 }
 
@@ -205,6 +225,7 @@ FQ_HD fq fq_sqr(const fq& a) {
     c[k + 1] += c[k] >> 29;
   }
   r.v[8] = (uint32_t)c[17];
+  FQ_ASSERT(fq_check_below_2p(r), "fq_sqr: result >= 2p (operand value bound violated)");
   return r;
 }
 

@@ -85,6 +85,44 @@ void h_g1_madd_w_chain(const uint8_t* acc, const uint8_t* pts, const uint8_t* ne
   for (size_t i = 0; i < m; i++) g1_madd_w(a, wneg, load_fq(pts + 64 * i), load_fq(pts + 64 * i + 32), negs[i] != 0);
   store_jac(out, g1_unsigned(a, wneg));
 }
+// The value bounds g1.h promises between operations (X < 9p, Y < 5p, ZZ < 2p, ZZZ < 2p), pushed to their limits: the accumulator's
+// coordinates are raised by kx / ky / kz multiples of p (same residues, larger representatives) before each operation; every Montgomery
+// result is asserted below 2p (-DFQ_CHECK), i.e. the operand bounds of every multiplication in the formulas hold at the edge.
+static fq raise_by_p(fq x, int k) {
+  fq pp;
+  for (int i = 0; i < 9; i++) pp.v[i] = FQ_P29[i];
+  for (int j = 0; j < k; j++) x = fq_norm(fq_add(x, pp));
+  return x;
+}
+// op 0: g1_madd_w (sign state `wneg` on entry), 1: g1_madd, 2: g1_add (b raised too), 3: g1_double
+void h_g1_at_the_bounds(int op, const uint8_t* acc, const uint8_t* other, int neg, int wneg_in, int kx, int ky, int kz, uint8_t* out) {
+  g1_xyzz a = load_jac(acc);
+  if (!a.inf) {
+    a.x = raise_by_p(fq_canonical(a.x), kx);
+    a.y = raise_by_p(fq_canonical(a.y), ky);
+    a.zz = raise_by_p(fq_canonical(a.zz), kz);    // kz <= 1: exact limbs, < 2p
+    a.zzz = raise_by_p(fq_canonical(a.zzz), kz);
+  }
+  if (op == 0) {
+    bool wneg = wneg_in != 0;  // the accumulator then stands for (X, -Y): the caller passes the point it means negated
+    g1_madd_w(a, wneg, load_fq(other), load_fq(other + 32), neg != 0);
+    store_jac(out, g1_unsigned(a, wneg));
+  } else if (op == 1) {
+    g1_madd(a, load_fq(other), load_fq(other + 32));
+    store_jac(out, a);
+  } else if (op == 2) {
+    g1_xyzz b = load_jac(other);
+    if (!b.inf) {
+      b.x = raise_by_p(fq_canonical(b.x), kx);
+      b.y = raise_by_p(fq_canonical(b.y), ky);
+      b.zz = raise_by_p(fq_canonical(b.zz), kz);
+      b.zzz = raise_by_p(fq_canonical(b.zzz), kz);
+    }
+    store_jac(out, g1_add(a, b));
+  } else {
+    store_jac(out, g1_double(a));
+  }
+}
 // op: 0 add, 1 double(a)
 void h_g1_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
   for (size_t i = 0; i < n; i++) {

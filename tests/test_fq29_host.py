@@ -143,6 +143,51 @@ def test_signed_state_mixed_addition_chain(H):
     assert cpu.to_affine64(out.raw) == cpu.to_affine64(cpu.cpu_msm(lp, sc))
 
 
+def _check_bounds(Hx, m, seed):
+    # the formulas of g1.h with their inputs at the edge of the promised value bounds (X < 9p, Y < 5p, ZZ, ZZZ < 2p): larger
+    # representatives of the same residues must give the same points, and no multiplication may leave [0, 2p) (asserted in the harness)
+    r = rng(seed)
+    pts = m.sample_points(seed, 12)
+    out = C.create_string_buffer(96)
+
+    def jac(pt):
+        if pt is None:
+            return bytes(96)
+        z = r.randrange(1, m.P)
+        return b32(pt[0] * z * z % m.P) + b32(pt[1] * z * z * z % m.P) + b32(z)
+
+    def aff(raw):
+        x, y, z = (int.from_bytes(raw[k:k + 32], "little") for k in (0, 32, 64))
+        if z == 0:
+            return None
+        zi = pow(z, -1, m.P)
+        return (x * zi * zi % m.P, y * zi * zi * zi % m.P)
+
+    for trial in range(40):
+        a, b = pts[trial % 12], pts[(trial * 5 + 1) % 12]
+        for kx, ky, kz in ((8, 4, 1), (8, 0, 0), (0, 4, 1), (7, 3, 0), (0, 0, 0)):
+            neg = trial & 1
+            # op 0 with the sign state set: the stored Y stands for -Y, so the accumulator handed over is -a
+            for wneg in (0, 1):
+                Hx.h_g1_at_the_bounds(0, jac(m.neg(a) if wneg else a), m.points_to_bytes([b]), neg, wneg, kx, ky, kz, out)
+                assert aff(out.raw) == m.add(a, m.neg(b) if neg else b), (trial, kx, ky, kz, wneg)
+            Hx.h_g1_at_the_bounds(1, jac(a), m.points_to_bytes([b]), 0, 0, kx, ky, kz, out)
+            assert aff(out.raw) == m.add(a, b)
+            Hx.h_g1_at_the_bounds(2, jac(a), jac(b), 0, 0, kx, ky, kz, out)
+            assert aff(out.raw) == m.add(a, b)
+            Hx.h_g1_at_the_bounds(3, jac(a), None, 0, 0, kx, ky, kz, out)
+            assert aff(out.raw) == m.add(a, a)
+        # the special cases at the bounds: P + P and P - P through the mixed additions
+        Hx.h_g1_at_the_bounds(0, jac(a), m.points_to_bytes([a]), 0, 0, 8, 4, 1, out)
+        assert aff(out.raw) == m.add(a, a)
+        Hx.h_g1_at_the_bounds(0, jac(a), m.points_to_bytes([a]), 1, 0, 8, 4, 1, out)
+        assert aff(out.raw) is None
+
+
+def test_formulas_at_the_edge_of_their_value_bounds(H):
+    _check_bounds(H, ref, 12)
+
+
 def _check_glv(Hx, m, seed):
     # csrc/glv.h against the oracle's independently derived model: identical halves (same rounding rule), k = k1 + k2 lambda,
     # and the magnitude bound the 8-window recode needs; edge scalars, non-canonical scalars up to 2^256 - 1
@@ -206,3 +251,4 @@ def test_host_arithmetic_instantiated_for_grumpkin(tmp_path_factory):
     sc = b"".join(b32(gr.R - 1 if ng else 1) for ng in negs)
     assert cg.to_affine64(out.raw) == cg.to_affine64(cg.cpu_msm(lp, sc))
     _check_glv(Hg, gr, 11)
+    _check_bounds(Hg, gr, 13)
