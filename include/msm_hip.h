@@ -82,9 +82,15 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx);
  *      context was created for (their names keep the `_bn254` of the reference's only instantiation).  Supported besides BN254 G1:
  *      Grumpkin, BN254's cycle partner (y^2 = x^3 - 17 over BN254's scalar field r; scalars modulo BN254's base field p) -- its
  *      base field agrees with BN254's in the top 128 bits, so the same 9 x 29-bit lazy-limb arithmetic and the same kernels serve
- *      both, instantiated once per curve (csrc/curve_select.h).  Wire formats are the same with the curve's own moduli. ---- */
+ *      both, instantiated once per curve (csrc/curve_select.h); and the Pasta cycle, Pallas and Vesta (y^2 = x^3 + 5 over the
+ *      255-bit p with q points, resp. over q with p points; generators (-1, 2)) -- the reference's own dead second curve is Pallas
+ *      (src/naive/wgsl/pallas) -- whose moduli leave 2^261 / p = 127 instead of 169: enough for the formulas.
+ *      Wire formats are the same with the curve's own moduli. ---- */
 #define MSM_HIP_CURVE_BN254_G1 0
 #define MSM_HIP_CURVE_GRUMPKIN 1
+#define MSM_HIP_CURVE_PALLAS 2
+#define MSM_HIP_CURVE_VESTA 3
+#define MSM_HIP_NUM_CURVES 4
 int msm_hip_ctx_create_curve(msm_hip_ctx** out, int device_id, int curve);
 int msm_hip_ctx_curve(const msm_hip_ctx* ctx);
 /* the context-free host helpers for a given curve (msm_hip_combine_windows_bn254 / msm_hip_g1_to_affine_bn254 are curve 0) */

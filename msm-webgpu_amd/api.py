@@ -19,7 +19,9 @@ from . import build as _build
 P = 21888242871839275222246405745257275088696311157297823662689037894645226208583  # src/cuzk/msm.rs:39
 R_BN254 = 21888242871839275222246405745257275088548364400416034343698204186575808495617  # BN254's scalar field = Grumpkin's base field
 # curve of a context (include/msm_hip.h: MSM_HIP_CURVE_*): id and base-field modulus
-CURVES = {"bn254": (0, P), "grumpkin": (1, R_BN254)}
+PALLAS_P = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001  # Pallas' base field = Vesta's scalar field
+VESTA_P = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001   # Vesta's base field = Pallas' scalar field
+CURVES = {"bn254": (0, P), "grumpkin": (1, R_BN254), "pallas": (2, PALLAS_P), "vesta": (3, VESTA_P)}
 NUM_WINDOWS = 16
 WINDOW_BITS = 16
 BUCKETS_PER_WINDOW = 1 << 15

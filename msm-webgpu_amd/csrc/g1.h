@@ -10,6 +10,14 @@
 // Value bounds kept between operations (fq29.h conventions; all coordinates "normal"):
 //     X < 9p,  Y < 5p,  ZZ < 2p (exact),  ZZZ < 2p (exact)
 // Every fq_sub<K> below states the bound of its subtrahend in the trailing comment.
+// The products' operand bounds are written in units of p^2 beside each multiplication; a Montgomery product needs
+// value(a) value(b) <= FQ_HEADROOM p^2 (169 for BN254 / Grumpkin, 127 for the 255-bit Pallas / Vesta moduli) to return < 2p.  The
+// comments use the loose "< 2p" for every product's output; the one place where that is not enough for FQ_HEADROOM = 127 is P^2 in the
+// mixed additions ("144 p^2" with P < 12p).  The tight bound holds for every modulus: a product of operands with value(a) value(b) <= K p^2
+// is < (1 + K / FQ_HEADROOM) p, the stored bases are such products with K <= 1 (fq_to_mont, the endomorphism's beta x) or canonical,
+// ZZ / ZZZ are products with K <= 4, so U2 = px ZZ < 1.01 p, P = U2 - X + 10p < 11.02 p and P^2 <= 121.5 p^2 < 127 p^2.
+// tests/test_fq29_host.py builds these formulas for all four curves with every product's result asserted below 2p, on random chains
+// and with the inputs raised to the edge of the bounds above.
 #ifndef MSM_CURVE_UNIT
 #pragma once
 #include "fq29.h"

@@ -38,6 +38,20 @@
 #undef MSM_FIELD_NS
 #undef MSM_KERNEL_NS
 #undef MSM_CURVE_CONSTANTS
+#define MSM_FIELD_NS pallas
+#define MSM_KERNEL_NS msmk_pallas
+#define MSM_CURVE_CONSTANTS "pallas_constants.h"
+#include "curve_unit.h"
+#undef MSM_FIELD_NS
+#undef MSM_KERNEL_NS
+#undef MSM_CURVE_CONSTANTS
+#define MSM_FIELD_NS vesta
+#define MSM_KERNEL_NS msmk_vesta
+#define MSM_CURVE_CONSTANTS "vesta_constants.h"
+#include "curve_unit.h"
+#undef MSM_FIELD_NS
+#undef MSM_KERNEL_NS
+#undef MSM_CURVE_CONSTANTS
 
 using namespace msmk;  // layout constants and the field-independent kernels (recode, sort) are taken from BN254's unit
 
@@ -76,7 +90,8 @@ struct CurveOps {
    K::k_bpr_rowcol<4, 8>, K::k_bpr_rowcol<2, 8>, K::k_bpr_rowcol<3, 8>, K::k_bpr_rowcol<4, 6>, K::k_bpr_rowcol<2, 6>, K::k_bpr_rowcol<2, 4>, \
    K::k_bpr_w256, K::k_bpr_final, K::k_sample_scalars, K::k_sample_points, K::k_export_buckets, K::k_test_fq, K::k_test_g1,                \
    K::k_test_g1_mul_u32, F::host::combine_windows, F::host::to_affine64}
-const CurveOps CURVE_OPS[2] = {MSM_CURVE_OPS(msmk, bn254), MSM_CURVE_OPS(msmk_grumpkin, grumpkin)};
+const CurveOps CURVE_OPS[MSM_HIP_NUM_CURVES] = {MSM_CURVE_OPS(msmk, bn254), MSM_CURVE_OPS(msmk_grumpkin, grumpkin), MSM_CURVE_OPS(msmk_pallas, pallas),
+                                                MSM_CURVE_OPS(msmk_vesta, vesta)};
 #undef MSM_CURVE_OPS
 
 // What a launch's local windows are made of
@@ -698,7 +713,7 @@ int msm_hip_ctx_curve(const msm_hip_ctx* ctx) { return ctx ? ctx->curve : MSM_HI
 int msm_hip_ctx_create_curve(msm_hip_ctx** out, int device_id, int curve) {
   if (!out) return MSM_HIP_ERR_INVALID_ARG;
   *out = nullptr;
-  if (curve != MSM_HIP_CURVE_BN254_G1 && curve != MSM_HIP_CURVE_GRUMPKIN) return MSM_HIP_ERR_INVALID_ARG;
+  if (curve < 0 || curve >= MSM_HIP_NUM_CURVES) return MSM_HIP_ERR_INVALID_ARG;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MSM_HIP_ERR_NO_DEVICE;
   if (device_id < 0 || device_id >= count) return MSM_HIP_ERR_INVALID_ARG;
@@ -1018,14 +1033,14 @@ int msm_hip_g1_to_affine_bn254(const uint8_t xyz[96], uint8_t out_xy[64]) {
 }
 
 int msm_hip_combine_windows_curve(int curve, const uint8_t* window_sums_host, int num_windows, uint8_t out_xyz[96]) {
-  if (curve != MSM_HIP_CURVE_BN254_G1 && curve != MSM_HIP_CURVE_GRUMPKIN) return MSM_HIP_ERR_INVALID_ARG;
+  if (curve < 0 || curve >= MSM_HIP_NUM_CURVES) return MSM_HIP_ERR_INVALID_ARG;
   if (!window_sums_host || !out_xyz || num_windows < 1 || num_windows > NWIN) return MSM_HIP_ERR_INVALID_ARG;
   if (!CURVE_OPS[curve].combine_windows(window_sums_host, num_windows, WBITS, out_xyz)) return MSM_HIP_ERR_NONCANONICAL;
   return MSM_HIP_OK;
 }
 
 int msm_hip_g1_to_affine_curve(int curve, const uint8_t xyz[96], uint8_t out_xy[64]) {
-  if (curve != MSM_HIP_CURVE_BN254_G1 && curve != MSM_HIP_CURVE_GRUMPKIN) return MSM_HIP_ERR_INVALID_ARG;
+  if (curve < 0 || curve >= MSM_HIP_NUM_CURVES) return MSM_HIP_ERR_INVALID_ARG;
   if (!xyz || !out_xy) return MSM_HIP_ERR_INVALID_ARG;
   const int r = CURVE_OPS[curve].to_affine64(xyz, out_xy);
   return r < 0 ? MSM_HIP_ERR_NONCANONICAL : r;

@@ -210,10 +210,10 @@ __global__ void __launch_bounds__(256) k_glv_split(const uint32_t* __restrict__ 
 // bases[(w * nb + i)][16]: table w behind table w - 1; table 0 is the plain converted base set (so every entry point that does
 // not use the tables keeps working on the same buffer).  One thread per point: 16 doublings per table in XYZZ, then back to
 // affine (one inversion by Fermat, a^(p-2)).
-__device__ __constant__ uint32_t c_pm2[8] = {FQ_P32[0] - 2u, FQ_P32[1], FQ_P32[2], FQ_P32[3], FQ_P32[4], FQ_P32[5], FQ_P32[6], FQ_P32[7]};
+__device__ __constant__ uint32_t c_pm2[8] = {FQ_PM2_32[0], FQ_PM2_32[1], FQ_PM2_32[2], FQ_PM2_32[3], FQ_PM2_32[4], FQ_PM2_32[5], FQ_PM2_32[6], FQ_PM2_32[7]};
 __device__ __forceinline__ fq fq_inv(const fq& a) {  // a exact, nonzero; result exact, < 2p
   fq acc = fq_one();
-  for (int bit = 253; bit >= 0; bit--) {
+  for (int bit = 255; bit >= 0; bit--) {  // (leading zero bits of p - 2 only square the initial one)
     acc = fq_sqr(acc);
     if ((c_pm2[bit >> 5] >> (bit & 31)) & 1u) acc = fq_mul(acc, a);
   }

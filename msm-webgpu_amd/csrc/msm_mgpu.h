@@ -108,7 +108,7 @@ int msm_hip_mgpu_create_curve(msm_hip_mgpu** out, const int* device_ids, int n_d
   if (!out) return MSM_HIP_ERR_INVALID_ARG;
   *out = nullptr;
   if (!device_ids || n_devices < 1 || n_devices > MGPU_MAX || flags > MSM_HIP_MGPU_GATHER_RCCL) return MSM_HIP_ERR_INVALID_ARG;
-  if (curve != MSM_HIP_CURVE_BN254_G1 && curve != MSM_HIP_CURVE_GRUMPKIN) return MSM_HIP_ERR_INVALID_ARG;
+  if (curve < 0 || curve >= MSM_HIP_NUM_CURVES) return MSM_HIP_ERR_INVALID_ARG;
   msm_hip_mgpu* m = new (std::nothrow) msm_hip_mgpu();
   if (!m) return MSM_HIP_ERR_OUT_OF_MEMORY;
   m->curve = curve;

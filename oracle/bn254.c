@@ -11,13 +11,13 @@ typedef unsigned __int128 u128;
 /* ------------------------------------------------------------------------------------------------
  * Fq : 4 x 64-bit Montgomery, R = 2^256  (the in-memory form halo2curves uses)
  * ---------------------------------------------------------------------------------------------- */
-#ifndef ORACLE_GRUMPKIN
+#if !defined(ORACLE_GRUMPKIN) && !defined(ORACLE_PALLAS) && !defined(ORACLE_VESTA)
 static const uint64_t FQ_P[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
 static const uint64_t FR_R[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
 static const uint64_t FQ_N0 = 0x87d20782e4866389ull; /* -p^-1 mod 2^64 */
 #define CURVE_B_IS_MINUS 0
 #define CURVE_B_ABS 3 /* y^2 = x^3 + 3 */
-#else
+#elif defined(ORACLE_GRUMPKIN)
 /* -DORACLE_GRUMPKIN: the same restatement over Grumpkin, BN254's cycle partner (SURVEY.md 8f-4 "other curves"): base field =
  * BN254's scalar field r, scalar field = BN254's base field p, y^2 = x^3 - 17, generator (1, sqrt(-16)).  Only the moduli, the
  * curve constant and the sampler's square root (r = 1 mod 4: Tonelli-Shanks) differ. */
@@ -26,6 +26,21 @@ static const uint64_t FR_R[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0
 static const uint64_t FQ_N0 = 0xc2e1f593efffffffull; /* -r^-1 mod 2^64 */
 #define CURVE_B_IS_MINUS 1
 #define CURVE_B_ABS 17 /* y^2 = x^3 - 17 */
+#elif defined(ORACLE_PALLAS)
+/* -DORACLE_PALLAS / -DORACLE_VESTA: the Pasta cycle (the reference keeps dead Pallas shaders, src/naive/wgsl/pallas, and lists other
+ * curves as future work): 255-bit moduli p, q; Pallas: y^2 = x^3 + 5 over Fp with q points, Vesta: the same equation over Fq with p
+ * points; generators (-1, 2).  2-adicity 32: Tonelli-Shanks in the sampler. */
+static const uint64_t FQ_P[4] = {0x992d30ed00000001ull, 0x224698fc094cf91bull, 0x0000000000000000ull, 0x4000000000000000ull};
+static const uint64_t FR_R[4] = {0x8c46eb2100000001ull, 0x224698fc0994a8ddull, 0x0000000000000000ull, 0x4000000000000000ull};
+static const uint64_t FQ_N0 = 0x992d30ecffffffffull;
+#define CURVE_B_IS_MINUS 0
+#define CURVE_B_ABS 5
+#else /* ORACLE_VESTA */
+static const uint64_t FQ_P[4] = {0x8c46eb2100000001ull, 0x224698fc0994a8ddull, 0x0000000000000000ull, 0x4000000000000000ull};
+static const uint64_t FR_R[4] = {0x992d30ed00000001ull, 0x224698fc094cf91bull, 0x0000000000000000ull, 0x4000000000000000ull};
+static const uint64_t FQ_N0 = 0x8c46eb20ffffffffull;
+#define CURVE_B_IS_MINUS 0
+#define CURVE_B_ABS 5
 #endif
 
 static ofq FQ_R1, FQ_R2, FQ_ZERO, FQ_B3; /* R mod p, R^2 mod p, 0, 3*R mod p ; filled by init */
@@ -411,7 +426,9 @@ static int msm_window_bits(size_t n) {
 
 static void msm_serial(const ofq* bx, const ofq* by, const uint8_t* scalars, size_t n, og1* acc) {
   int c = msm_window_bits(n);
-  int nwin = 254 / c + 1; /* Fr::NUM_BITS = 254 */
+  int num_bits = 256; /* Fr::NUM_BITS: the bit length of the scalar modulus (254 for BN254 / Grumpkin, 255 for Pallas / Vesta) */
+  while (!((FR_R[(num_bits - 1) / 64] >> ((num_bits - 1) % 64)) & 1)) num_bits--;
+  int nwin = num_bits / c + 1;
   size_t nb = (size_t)1 << (c - 1);
   og1* buckets = (og1*)malloc(nb * sizeof(og1));
   g1_identity(acc);

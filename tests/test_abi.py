@@ -121,8 +121,13 @@ def test_host_only_helpers_of_window_sizes_and_curves(built):
     sums = cg.g1_scalar_mul(cg.sample_points(3, 16), cg.sample_scalars(4, 16))
     got = m.MsmContext.combine_windows(sums, curve="grumpkin")
     assert got.to_affine_bytes() == cg.to_affine64(cg.horner(sums))
+    # ... and for the Pasta curves (255-bit moduli in the host's 4 x 64-bit arithmetic)
+    for name in ("pallas", "vesta"):
+        cx = __import__("importlib").import_module("oracle.cpu_" + name)
+        sums_x = cx.g1_scalar_mul(cx.sample_points(5, 16), cx.sample_scalars(6, 16))
+        assert m.MsmContext.combine_windows(sums_x, curve=name).to_affine_bytes() == cx.to_affine64(cx.horner(sums_x)), name
     out = C.create_string_buffer(96)
-    assert L.msm_hip_combine_windows_curve(2, sums, 16, out) == -2  # unknown curve
+    assert L.msm_hip_combine_windows_curve(4, sums, 16, out) == -2  # unknown curve
     h = C.c_void_p()
     assert L.msm_hip_ctx_create_curve(C.byref(h), 0, 7) == -2
 

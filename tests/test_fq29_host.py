@@ -106,6 +106,7 @@ def test_generated_headers_are_in_sync():
     import sys
 
     for script, args, header in (("gen_constants.py", [], "bn254_constants.h"), ("gen_constants.py", ["grumpkin"], "grumpkin_constants.h"),
+                                 ("gen_constants.py", ["pallas"], "pallas_constants.h"), ("gen_constants.py", ["vesta"], "vesta_constants.h"),
                                  ("gen_fq29_asm.py", [], "fq29_asm.h")):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)] + args, capture_output=True, text=True, check=True).stdout
         assert out == open(os.path.join(ROOT, "msm-webgpu_amd", "csrc", header)).read(), header
@@ -252,3 +253,35 @@ def test_host_arithmetic_instantiated_for_grumpkin(tmp_path_factory):
     assert cg.to_affine64(out.raw) == cg.to_affine64(cg.cpu_msm(lp, sc))
     _check_glv(Hg, gr, 11)
     _check_bounds(Hg, gr, 13)
+
+
+@pytest.mark.parametrize("curve", ["pallas", "vesta"])
+def test_host_arithmetic_instantiated_for_the_pasta_curves(tmp_path_factory, curve):
+    # 255-bit moduli: 2^261 / p = 127 instead of 169.  The same headers, every limb bound and every Montgomery result (< 2p) asserted:
+    # field ops, a long signed-state accumulation, the formulas at the edge of their value bounds, the endomorphism split
+    import importlib
+
+    cx = importlib.import_module("oracle.cpu_" + curve)
+    rf = importlib.import_module("oracle." + curve + "_ref")
+    so = str(tmp_path_factory.mktemp("fq29" + curve) / ("fq29_harness_%s.so" % curve))
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFQ_CHECK", "-fPIC", "-shared", "-DMSM_FIELD_NS=" + curve, "-DMSM_KERNEL_NS=msmk_" + curve,
+                           '-DMSM_CURVE_CONSTANTS="%s_constants.h"' % curve, "-DHARNESS_FIELD_NS=" + curve, "-I", os.path.join(ROOT, "msm-webgpu_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host_harness", "fq29_harness.cpp"), "-o", so])
+    Hc = C.CDLL(so)
+    r = rng(20)
+    vals = [0, 1, rf.P - 1, rf.P - 2, (1 << 254) - 1, 1 << 254, 1 << 232] + [r.randrange(rf.P) for _ in range(2000)]
+    n = len(vals)
+    A = b"".join(b32(x) for x in vals)
+    B = b"".join(b32(vals[(i * 7 + 3) % n]) for i in range(n))
+    for op, name in enumerate(["add", "sub", "mul", "sqr", "neg"]):
+        out = C.create_string_buffer(32 * n)
+        Hc.h_fq_op(op, A, B, out, n)
+        assert out.raw == cx.fq_op(name, A, B), name
+    lp = cx.sample_points(81, 3000)
+    negs = bytes(r.randrange(2) for _ in range(3000))
+    out = C.create_string_buffer(96)
+    Hc.h_g1_madd_w_chain(bytes(96), lp, negs, 3000, out)
+    sc = b"".join(b32(rf.R - 1 if ng else 1) for ng in negs)
+    assert cx.to_affine64(out.raw) == cx.to_affine64(cx.cpu_msm(lp, sc))
+    _check_glv(Hc, rf, 21)
+    _check_bounds(Hc, rf, 22)

@@ -115,6 +115,13 @@ def analyse(name, lines):
 
 
 def compile_to_asm(extra):
+    """Device assembly of the product: the file the library's own build left behind when it is current (msm-webgpu_amd/build.py keeps the
+    compiler's intermediate files), else a fresh -S compile (minutes: every curve unit)."""
+    if not extra:
+        sys.path.insert(0, os.path.join(ROOT, "msm-webgpu_amd"))
+        import build as _b
+        if _b.device_asm_is_current():
+            return _b.DEVICE_ASM
     src = os.path.join(ROOT, "msm-webgpu_amd", "csrc", "msm_hip.hip")
     out = os.path.join(tempfile.mkdtemp(prefix="msm_hip_asm_"), "device.s")
     cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",

@@ -1,6 +1,6 @@
 """Randomised differential test of the HIP engine against the CPU oracle: random sizes (tile / chunk / alignment edges),
 random scalar distributions (uniform, few distinct values, small values, zeros, equal), random window ranges.
-Usage: python tools/fuzz_gpu.py [cases] [seed] [bn254|grumpkin]   (test infrastructure: uses the oracle)"""
+Usage: python tools/fuzz_gpu.py [cases] [seed] [bn254|grumpkin|pallas|vesta]   (test infrastructure: uses the oracle)"""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,8 +9,9 @@ from msm_webgpu_amd.sharding import window_range
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 curve = sys.argv[3] if len(sys.argv) > 3 else "bn254"
-if curve == "grumpkin":  # the second curve through the same entry points (its oracles: oracle/cpu_grumpkin.py, grumpkin_ref.py)
-    from oracle import cpu_grumpkin as cpu, grumpkin_ref as ref
+if curve != "bn254":  # another curve through the same entry points (its oracles: oracle/cpu_<curve>.py, <curve>_ref.py)
+    import importlib
+    cpu, ref = importlib.import_module("oracle.cpu_" + curve), importlib.import_module("oracle." + curve + "_ref")
 else:
     from oracle import cpu, bn254_ref as ref
 rnd = random.Random(seed)
