@@ -20,11 +20,12 @@ def test_fuzz_against_oracle(built, capsys):
     assert "fuzz ok: 60 cases" in capsys.readouterr().out
 
 
-def test_fuzz_against_oracle_second_curve(built, capsys):
+@pytest.mark.parametrize("curve,cases", [("grumpkin", 30), ("pallas", 12), ("vesta", 12)])
+def test_fuzz_against_oracle_other_curves(built, capsys, curve, cases):
     argv = sys.argv
-    sys.argv = ["fuzz_gpu.py", "30", "20261005", "grumpkin"]
+    sys.argv = ["fuzz_gpu.py", str(cases), "20261005", curve]
     try:
         runpy.run_path(os.path.join(ROOT, "tools", "fuzz_gpu.py"), run_name="__main__")
     finally:
         sys.argv = argv
-    assert "fuzz ok: 30 cases" in capsys.readouterr().out
+    assert "fuzz ok: %d cases" % cases in capsys.readouterr().out
