@@ -1,0 +1,40 @@
+"""The same engine on every curve it is built for: pipelined MSM time at 2^logn (endomorphism bases, two launches in flight, as
+bench.py's single-GPU line), single-MSM latency, SMVP kernel time; one result per curve checked bit-exactly against that curve's oracle.
+usage: curve_throughput.py [logn]   (test infrastructure: uses the oracle)"""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import msm_webgpu_amd as m
+
+logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+n = 1 << logn
+for curve in ("bn254", "grumpkin", "pallas", "vesta"):
+    cpu = importlib.import_module("oracle.cpu" if curve == "bn254" else "oracle.cpu_" + curve)
+    ctx = m.MsmContext(0, curve=curve)
+    pts, sc = ctx.sample_points(n, 1), [ctx.sample_scalars(n, 2 + i) for i in range(2)]
+    ctx.set_bases(pts, endomorphism=True)
+    ctx.set_stage_timing(1)
+    def run(k):
+        fl, last = [], None
+        for j in range(k):
+            if len(fl) == 2:
+                last = ctx.finish(fl.pop(0))
+            ctx.launch(sc[j & 1], j % 2)
+            fl.append(j % 2)
+        for s in fl:
+            last = ctx.finish(s)
+        return last
+    run(30)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = run(100)
+    torch.cuda.synchronize()
+    step = (time.perf_counter() - t0) * 10
+    smvp = ctx.stage_ms()["smvp"]
+    lat = []
+    for i in range(5):
+        torch.cuda.synchronize(); t1 = time.perf_counter(); ctx.msm(sc[i & 1]); lat.append((time.perf_counter() - t1) * 1e3)
+    want = cpu.to_affine64(cpu.cpu_msm(pts.cpu().numpy().tobytes(), sc[1].cpu().numpy().tobytes(), min(os.cpu_count() or 1, 32)))
+    print("%-9s 2^%d: %.4f ms per MSM pipelined (%.0f MSM/s), SMVP kernel %.3f ms, latency %.3f ms, bit-exact vs its oracle: %s"
+          % (curve, logn, step, 1e3 / step, smvp, sorted(lat)[2], last.to_affine_bytes() == want), flush=True)
+    ctx.close()
