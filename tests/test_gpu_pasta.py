@@ -130,6 +130,20 @@ def test_samplers_and_large_msm(cv):
     assert ctx.msm(eq).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb, eq, 8))
 
 
+def test_2p20_points_bit_exact(cv):
+    # BASELINE config 2's size on the other curves: plain and endomorphism bases against the multithreaded oracle
+    import os
+
+    name, ctx, cpu, ref = cv
+    n = 1 << 20
+    pts, sc = ctx.sample_points(n, 40), ctx.sample_scalars(n, 41)
+    want = cpu.to_affine64(cpu.cpu_msm(pts.cpu().numpy().tobytes(), sc.cpu().numpy().tobytes(), max(1, min(16, os.cpu_count() or 1))))
+    for endo in (False, True):
+        ctx.set_bases(pts, endomorphism=endo)
+        assert ctx.msm(sc).to_affine_bytes() == want, endo
+    ctx.set_bases(pts[:4].contiguous())
+
+
 def test_input_errors(cv):
     name, ctx, cpu, ref = cv
     pts = cpu.sample_points(38, 4)
