@@ -6,17 +6,22 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # MSM_HIP_SO: load (and build into) another file, e.g. a diagnostic variant next to the product library
 SO = os.environ.get("MSM_HIP_SO") or os.path.join(HERE, "libmsm_hip.so")
-SOURCES = ["msm_hip.hip", "msm_kernels.h", "g1.h", "fq29.h", "fq29_asm.h", "host_g1.h", "glv.h", "msm_mgpu.h", "curve_select.h", "curve_unit.h", "grumpkin_constants.h", "bn254_constants.h", "pallas_constants.h", "vesta_constants.h"]
+SOURCES = ["msm_hip.hip", "curve_grumpkin.hip", "curve_pallas.hip", "curve_vesta.hip", "curve_ops.h", "msm_kernels.h", "g1.h", "fq29.h", "fq29_asm.h", "host_g1.h", "glv.h", "msm_mgpu.h", "curve_select.h", "curve_unit.h", "grumpkin_constants.h", "bn254_constants.h", "pallas_constants.h", "vesta_constants.h"]
 HEADER = os.path.join(HERE, "..", "include", "msm_hip.h")
 TEMPS = os.path.join(HERE, "..", "build", "temps" if not os.environ.get("MSM_HIP_SO") else "temps_" + os.path.basename(SO))
-DEVICE_ASM = os.path.join(TEMPS, "msm_hip-hip-amdgcn-amd-amdhsa-gfx950.s")  # written by build()
+
+
+def device_asm_files():
+    """The device assembly of every translation unit, as build() leaves it behind."""
+    return [os.path.join(TEMPS, os.path.splitext(u)[0] + "-hip-amdgcn-amd-amdhsa-gfx950.s") for u in TRANSLATION_UNITS]
 
 
 def device_asm_is_current():
     """True if build() left the device assembly of the CURRENT sources behind (same staleness rule as the library itself)."""
-    if needs_build() or not os.path.exists(DEVICE_ASM):
+    if needs_build() or not all(os.path.exists(f) for f in device_asm_files()):
         return False
-    return os.path.getmtime(DEVICE_ASM) >= max(os.path.getmtime(os.path.join(CSRC, f)) for f in SOURCES if os.path.exists(os.path.join(CSRC, f)))
+    newest = max(os.path.getmtime(os.path.join(CSRC, f)) for f in SOURCES if os.path.exists(os.path.join(CSRC, f)))
+    return all(os.path.getmtime(f) >= newest for f in device_asm_files())
 
 
 def needs_build():
@@ -27,21 +32,37 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+TRANSLATION_UNITS = ["msm_hip.hip", "curve_grumpkin.hip", "curve_pallas.hip", "curve_vesta.hip"]  # host + BN254's unit; one per further curve
+
+
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -shared -fPIC csrc/msm_hip.hip -> msm-webgpu_amd/libmsm_hip.so"""
+    """hipcc --offload-arch=gfx950: every translation unit of csrc/ to an object (in parallel), then -shared -> msm-webgpu_amd/libmsm_hip.so"""
     if not force and not needs_build():
         return SO
+    from concurrent.futures import ThreadPoolExecutor
+
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # the compiler's intermediate files are kept (build/temps/, git-ignored): the device assembly among them is what the code-generation
     # gate reads (tools/check_long_branch_hazard.py, tests/test_codegen_hazards.py) instead of compiling everything a second time
     os.makedirs(TEMPS, exist_ok=True)
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-save-temps=cwd",
-           os.path.join(CSRC, "msm_hip.hip"), "-o", SO + ".tmp"]
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
     if os.environ.get("MSM_HIP_NO_ASM") == "1":  # the C++ multipliers everywhere (the inline-assembly ones are only in g1_madd)
-        cmd.insert(1, "-DFQ29_NO_ASM")
+        flags.append("-DFQ29_NO_ASM")
     if os.environ.get("MSM_HIP_ASM_EVERYWHERE") == "1":  # diagnostic: the inline-assembly multipliers in every kernel
-        cmd.insert(1, "-DFQ29_ASM_EVERYWHERE")
-    cmd[1:1] = os.environ.get("MSM_HIP_EXTRA_FLAGS", "").split()
+        flags.append("-DFQ29_ASM_EVERYWHERE")
+    flags += os.environ.get("MSM_HIP_EXTRA_FLAGS", "").split()
+
+    def compile_unit(name):
+        obj = os.path.join(TEMPS, os.path.splitext(name)[0] + ".o")
+        cmd = [hipcc] + flags + ["-save-temps=cwd", "-c", os.path.join(CSRC, name), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=TEMPS)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(TRANSLATION_UNITS), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_unit, TRANSLATION_UNITS))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "--hip-link"] + objs + ["-o", SO + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=TEMPS)

@@ -1,0 +1,48 @@
+// The table through which the host code (msm_hip.hip) reaches one curve's kernels and host arithmetic.  Every curve is compiled as its
+// own translation unit (curve_<name>.hip: csrc/curve_unit.h instantiated with that curve's constants; BN254's unit lives in msm_hip.hip
+// itself, which also takes the field-independent kernels and the layout constants from it) so that the units build in parallel; a unit
+// hands its table over through one accessor.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+// What differs between the curves: the kernels that do field arithmetic, and the host's window combine.  A context holds one.
+struct CurveOps {
+  void (*convert_points)(const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t*);
+  void (*precompute_tables)(uint32_t*, size_t, size_t, int);
+  void (*endo_points)(uint32_t*, size_t);
+  void (*glv_split)(const uint32_t*, uint32_t*, size_t, int, uint32_t*);
+  void (*scalars_from_mont256)(const uint32_t*, uint32_t*, size_t, uint32_t*);
+  void (*smvp_chunks)(const uint32_t*, const uint32_t*, const uint32_t*, size_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*,
+                      uint32_t*, uint32_t);
+  void (*smvp_stitch)(const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+  void (*smvp_stitch_big)(const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t);
+  void (*rowcol_4_8)(const uint32_t*, uint32_t*, uint32_t*);
+  void (*rowcol_2_8)(const uint32_t*, uint32_t*, uint32_t*);
+  void (*rowcol_3_8)(const uint32_t*, uint32_t*, uint32_t*);
+  void (*rowcol_4_6)(const uint32_t*, uint32_t*, uint32_t*);
+  void (*rowcol_2_6)(const uint32_t*, uint32_t*, uint32_t*);
+  void (*rowcol_2_4)(const uint32_t*, uint32_t*, uint32_t*);
+  void (*bpr_w256)(const uint32_t*, const uint32_t*, uint32_t*, int);
+  void (*bpr_final)(const uint32_t*, int, uint32_t*, uint32_t*);
+  void (*sample_scalars)(uint64_t, size_t, uint32_t*);
+  void (*sample_points)(uint64_t, size_t, uint32_t*);
+  void (*export_buckets)(const uint32_t*, uint32_t*, size_t);
+  void (*test_fq)(int, const uint32_t*, const uint32_t*, uint32_t*, size_t);
+  void (*test_g1)(int, const uint32_t*, const uint32_t*, uint32_t*, size_t);
+  void (*test_g1_mul_u32)(const uint32_t*, const uint32_t*, uint32_t*, size_t);
+  bool (*combine_windows)(const uint8_t*, int, int, uint8_t*);
+  int (*to_affine64)(const uint8_t*, uint8_t*);
+};
+#define MSM_CURVE_OPS(K, F)                                                                                                              \
+  {K::k_convert_points, K::k_precompute_tables, K::k_endo_points, K::k_glv_split, K::k_scalars_from_mont256, K::k_smvp_chunks, K::k_smvp_stitch, K::k_smvp_stitch_big,       \
+   K::k_bpr_rowcol<4, 8>, K::k_bpr_rowcol<2, 8>, K::k_bpr_rowcol<3, 8>, K::k_bpr_rowcol<4, 6>, K::k_bpr_rowcol<2, 6>, K::k_bpr_rowcol<2, 4>, \
+   K::k_bpr_w256, K::k_bpr_final, K::k_sample_scalars, K::k_sample_points, K::k_export_buckets, K::k_test_fq, K::k_test_g1,                \
+   K::k_test_g1_mul_u32, F::host::combine_windows, F::host::to_affine64}
+
+// accessors of the separately compiled units (hidden: not part of the C ABI)
+extern "C" {
+__attribute__((visibility("hidden"))) const CurveOps* msm_hip_curve_ops_grumpkin(void);
+__attribute__((visibility("hidden"))) const CurveOps* msm_hip_curve_ops_pallas(void);
+__attribute__((visibility("hidden"))) const CurveOps* msm_hip_curve_ops_vesta(void);
+}

@@ -22,32 +22,12 @@
 #include <new>
 
 #include "../../include/msm_hip.h"
+#include "curve_ops.h"
 
-// the arithmetic and the kernels, once per curve (csrc/curve_select.h)
+// the arithmetic and the kernels of BN254's unit (csrc/curve_select.h); the other curves' units are separate translation units (curve_ops.h)
 #define MSM_FIELD_NS bn254
 #define MSM_KERNEL_NS msmk
 #define MSM_CURVE_CONSTANTS "bn254_constants.h"
-#include "curve_unit.h"
-#undef MSM_FIELD_NS
-#undef MSM_KERNEL_NS
-#undef MSM_CURVE_CONSTANTS
-#define MSM_FIELD_NS grumpkin
-#define MSM_KERNEL_NS msmk_grumpkin
-#define MSM_CURVE_CONSTANTS "grumpkin_constants.h"
-#include "curve_unit.h"
-#undef MSM_FIELD_NS
-#undef MSM_KERNEL_NS
-#undef MSM_CURVE_CONSTANTS
-#define MSM_FIELD_NS pallas
-#define MSM_KERNEL_NS msmk_pallas
-#define MSM_CURVE_CONSTANTS "pallas_constants.h"
-#include "curve_unit.h"
-#undef MSM_FIELD_NS
-#undef MSM_KERNEL_NS
-#undef MSM_CURVE_CONSTANTS
-#define MSM_FIELD_NS vesta
-#define MSM_KERNEL_NS msmk_vesta
-#define MSM_CURVE_CONSTANTS "vesta_constants.h"
 #include "curve_unit.h"
 #undef MSM_FIELD_NS
 #undef MSM_KERNEL_NS
@@ -56,43 +36,16 @@
 using namespace msmk;  // layout constants and the field-independent kernels (recode, sort) are taken from BN254's unit
 
 namespace {
-
-// What differs between the curves: the kernels that do field arithmetic, and the host's window combine.  A context holds one.
-struct CurveOps {
-  void (*convert_points)(const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t*);
-  void (*precompute_tables)(uint32_t*, size_t, size_t, int);
-  void (*endo_points)(uint32_t*, size_t);
-  void (*glv_split)(const uint32_t*, uint32_t*, size_t, int, uint32_t*);
-  void (*scalars_from_mont256)(const uint32_t*, uint32_t*, size_t, uint32_t*);
-  void (*smvp_chunks)(const uint32_t*, const uint32_t*, const uint32_t*, size_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*,
-                      uint32_t*, uint32_t);
-  void (*smvp_stitch)(const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
-  void (*smvp_stitch_big)(const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t);
-  void (*rowcol_4_8)(const uint32_t*, uint32_t*, uint32_t*);
-  void (*rowcol_2_8)(const uint32_t*, uint32_t*, uint32_t*);
-  void (*rowcol_3_8)(const uint32_t*, uint32_t*, uint32_t*);
-  void (*rowcol_4_6)(const uint32_t*, uint32_t*, uint32_t*);
-  void (*rowcol_2_6)(const uint32_t*, uint32_t*, uint32_t*);
-  void (*rowcol_2_4)(const uint32_t*, uint32_t*, uint32_t*);
-  void (*bpr_w256)(const uint32_t*, const uint32_t*, uint32_t*, int);
-  void (*bpr_final)(const uint32_t*, int, uint32_t*, uint32_t*);
-  void (*sample_scalars)(uint64_t, size_t, uint32_t*);
-  void (*sample_points)(uint64_t, size_t, uint32_t*);
-  void (*export_buckets)(const uint32_t*, uint32_t*, size_t);
-  void (*test_fq)(int, const uint32_t*, const uint32_t*, uint32_t*, size_t);
-  void (*test_g1)(int, const uint32_t*, const uint32_t*, uint32_t*, size_t);
-  void (*test_g1_mul_u32)(const uint32_t*, const uint32_t*, uint32_t*, size_t);
-  bool (*combine_windows)(const uint8_t*, int, int, uint8_t*);
-  int (*to_affine64)(const uint8_t*, uint8_t*);
-};
-#define MSM_CURVE_OPS(K, F)                                                                                                              \
-  {K::k_convert_points, K::k_precompute_tables, K::k_endo_points, K::k_glv_split, K::k_scalars_from_mont256, K::k_smvp_chunks, K::k_smvp_stitch, K::k_smvp_stitch_big,       \
-   K::k_bpr_rowcol<4, 8>, K::k_bpr_rowcol<2, 8>, K::k_bpr_rowcol<3, 8>, K::k_bpr_rowcol<4, 6>, K::k_bpr_rowcol<2, 6>, K::k_bpr_rowcol<2, 4>, \
-   K::k_bpr_w256, K::k_bpr_final, K::k_sample_scalars, K::k_sample_points, K::k_export_buckets, K::k_test_fq, K::k_test_g1,                \
-   K::k_test_g1_mul_u32, F::host::combine_windows, F::host::to_affine64}
-const CurveOps CURVE_OPS[MSM_HIP_NUM_CURVES] = {MSM_CURVE_OPS(msmk, bn254), MSM_CURVE_OPS(msmk_grumpkin, grumpkin), MSM_CURVE_OPS(msmk_pallas, pallas),
-                                                MSM_CURVE_OPS(msmk_vesta, vesta)};
-#undef MSM_CURVE_OPS
+const CurveOps BN254_OPS = MSM_CURVE_OPS(msmk, bn254);
+// curve id (MSM_HIP_CURVE_*) -> its table
+inline const CurveOps* curve_ops(int curve) {
+  switch (curve) {
+    case MSM_HIP_CURVE_GRUMPKIN: return msm_hip_curve_ops_grumpkin();
+    case MSM_HIP_CURVE_PALLAS: return msm_hip_curve_ops_pallas();
+    case MSM_HIP_CURVE_VESTA: return msm_hip_curve_ops_vesta();
+    default: return &BN254_OPS;
+  }
+}
 
 // What a launch's local windows are made of
 enum LaunchMode {
@@ -143,7 +96,7 @@ struct Slot {
 struct msm_hip_ctx {
   int device = 0;
   int curve = MSM_HIP_CURVE_BN254_G1;
-  const CurveOps* ops = &CURVE_OPS[0];
+  const CurveOps* ops = nullptr;
   hipStream_t stream = nullptr;         // main
   hipStream_t reduce_stream[NREDUCE] = {};  // bucket reduce + result copies
   int last_hip_error = 0;
@@ -723,7 +676,7 @@ int msm_hip_ctx_create_curve(msm_hip_ctx** out, int device_id, int curve) {
   if (!ctx) return MSM_HIP_ERR_OUT_OF_MEMORY;
   ctx->device = device_id;
   ctx->curve = curve;
-  ctx->ops = &CURVE_OPS[curve];
+  ctx->ops = curve_ops(curve);
   if (const char* e = getenv("MSM_HIP_FINE_HIST_MIN_LOGN")) {  // tuning aid
     const int l = atoi(e);
     if (l >= 0 && l < 40) ctx->fine_hist_min_n = (size_t)1 << l;
@@ -1035,14 +988,14 @@ int msm_hip_g1_to_affine_bn254(const uint8_t xyz[96], uint8_t out_xy[64]) {
 int msm_hip_combine_windows_curve(int curve, const uint8_t* window_sums_host, int num_windows, uint8_t out_xyz[96]) {
   if (curve < 0 || curve >= MSM_HIP_NUM_CURVES) return MSM_HIP_ERR_INVALID_ARG;
   if (!window_sums_host || !out_xyz || num_windows < 1 || num_windows > NWIN) return MSM_HIP_ERR_INVALID_ARG;
-  if (!CURVE_OPS[curve].combine_windows(window_sums_host, num_windows, WBITS, out_xyz)) return MSM_HIP_ERR_NONCANONICAL;
+  if (!curve_ops(curve)->combine_windows(window_sums_host, num_windows, WBITS, out_xyz)) return MSM_HIP_ERR_NONCANONICAL;
   return MSM_HIP_OK;
 }
 
 int msm_hip_g1_to_affine_curve(int curve, const uint8_t xyz[96], uint8_t out_xy[64]) {
   if (curve < 0 || curve >= MSM_HIP_NUM_CURVES) return MSM_HIP_ERR_INVALID_ARG;
   if (!xyz || !out_xy) return MSM_HIP_ERR_INVALID_ARG;
-  const int r = CURVE_OPS[curve].to_affine64(xyz, out_xy);
+  const int r = curve_ops(curve)->to_affine64(xyz, out_xy);
   return r < 0 ? MSM_HIP_ERR_NONCANONICAL : r;
 }
 

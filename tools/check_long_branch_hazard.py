@@ -115,19 +115,22 @@ def analyse(name, lines):
 
 
 def compile_to_asm(extra):
-    """Device assembly of the product: the file the library's own build left behind when it is current (msm-webgpu_amd/build.py keeps the
-    compiler's intermediate files), else a fresh -S compile (minutes: every curve unit)."""
-    if not extra:
-        sys.path.insert(0, os.path.join(ROOT, "msm-webgpu_amd"))
-        import build as _b
-        if _b.device_asm_is_current():
-            return _b.DEVICE_ASM
-    src = os.path.join(ROOT, "msm-webgpu_amd", "csrc", "msm_hip.hip")
-    out = os.path.join(tempfile.mkdtemp(prefix="msm_hip_asm_"), "device.s")
-    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
-           src, "-o", out] + extra
-    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
-    return out
+    """Device assembly of the product, one file per translation unit: the files the library's own build left behind when they are
+    current (msm-webgpu_amd/build.py keeps the compiler's intermediate files), else fresh -S compiles (minutes)."""
+    sys.path.insert(0, os.path.join(ROOT, "msm-webgpu_amd"))
+    import build as _b
+
+    if not extra and _b.device_asm_is_current():
+        return _b.device_asm_files()
+    outdir = tempfile.mkdtemp(prefix="msm_hip_asm_")
+    outs = []
+    for unit in _b.TRANSLATION_UNITS:
+        out = os.path.join(outdir, os.path.splitext(unit)[0] + ".s")
+        cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+               os.path.join(ROOT, "msm-webgpu_amd", "csrc", unit), "-o", out] + extra
+        subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+        outs.append(out)
+    return outs
 
 
 def check_file(path):
@@ -141,13 +144,16 @@ def check_file(path):
 
 def main():
     args = sys.argv[1:]
-    path = args[0] if args and args[0].endswith(".s") else compile_to_asm(args)
-    long_branches, found = check_file(path)
-    print("%s: %d expanded long branches, %d with a scalar load in flight into their register pair" % (path, long_branches, len(found)))
-    for name, t, regs in found:
-        print("  HAZARD in %s: `%s` while s_load into s%s may be in flight" % (name, t, regs))
-    return 1 if found else 0
+    paths = [a for a in args if a.endswith(".s")] or compile_to_asm(args)
+    bad = 0
+    for path in paths:
+        long_branches, found = check_file(path)
+        print("%s: %d expanded long branches, %d with a scalar load in flight into their register pair" % (path, long_branches, len(found)))
+        for name, t, regs in found:
+            print("  HAZARD in %s: `%s` while s_load into s%s may be in flight" % (name, t, regs))
+        bad += len(found)
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":
-    raise SystemExit(main())
+    sys.exit(main())
