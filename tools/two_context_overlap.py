@@ -1,0 +1,32 @@
+"""Experiment: can the sort of one MSM run under the SMVP of another?  Two engine contexts on one GPU, their launches interleaved
+(each context keeps its own two launches in flight), against one context alone.  usage: two_context_overlap.py (MSM_HIP_SO selects the build)"""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # as bench.py: the engine streams of both contexts on their own hardware queues
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import msm_webgpu_amd as m
+n = 1 << 20
+ctxs = [m.MsmContext(0), m.MsmContext(0)]
+pts = ctxs[0].sample_points(n, 1)
+sc = [ctxs[0].sample_scalars(n, 2 + i) for i in range(2)]
+for c in ctxs:
+    c.set_bases(pts, endomorphism=True)
+    c.set_stage_timing(0)
+def run(cs, k, depth=2):
+    q = {id(c): [] for c in cs}
+    cnt = {id(c): 0 for c in cs}
+    for j in range(k):
+        c = cs[j % len(cs)]
+        slot = cnt[id(c)] % depth
+        cnt[id(c)] += 1
+        c.launch(sc[j & 1], slot)
+        q[id(c)].append(slot)
+        if len(q[id(c)]) == depth:
+            c.finish(q[id(c)].pop(0))
+    for c in cs:
+        for s0 in q[id(c)]:
+            c.finish(s0)
+for cs, name in ((ctxs[:1], "one context"), (ctxs, "two contexts interleaved")):
+    run(cs, 20)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); run(cs, 120); torch.cuda.synchronize()
+    print("%s [%s]: %.4f ms per MSM" % (name, os.path.basename(os.environ.get("MSM_HIP_SO", "product")), (time.perf_counter() - t0) / 120 * 1e3), flush=True)
