@@ -218,5 +218,23 @@ inline bool combine_windows(const uint8_t* sums96, int num_windows, int window_b
   return ok;
 }
 
+// The same with every window sum handed over as the bucket reduce's three parts (k_bpr_w256: S_w = 128 A + B + C, 3 x 96 B per window):
+// the last nine group operations of every window run here, at 0.2 us each, instead of in a lone GPU wave at 7 us each (k_bpr_final)
+inline bool combine_window_parts(const uint8_t* parts288, int num_windows, int window_bits, uint8_t out[96]) {
+  hg1 acc = hg1_identity();
+  bool ok = true;
+  for (int w = num_windows - 1; w >= 0; w--) {
+    for (int k = 0; k < window_bits; k++) acc = hg1_double(acc);
+    hg1 a, b, c;
+    ok &= hg1_from_bytes96(a, parts288 + 288 * (size_t)w);
+    ok &= hg1_from_bytes96(b, parts288 + 288 * (size_t)w + 96);
+    ok &= hg1_from_bytes96(c, parts288 + 288 * (size_t)w + 192);
+    for (int k = 0; k < 7; k++) a = hg1_double(a);  // 128 = the number of bucket columns (BPR_COLS)
+    acc = hg1_add(acc, hg1_add(a, hg1_add(b, c)));
+  }
+  hg1_to_bytes96(out, acc);
+  return ok;
+}
+
 }  // namespace host
 }  // namespace MSM_FIELD_NS

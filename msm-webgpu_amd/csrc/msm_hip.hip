@@ -56,7 +56,7 @@ enum LaunchMode {
 
 constexpr int N_MAIN_EVENTS = 7;  // boundaries of the 6 timed stages on the main stream
 constexpr uint32_t MAX_TILES = 1024;
-constexpr size_t WSUM_BYTES = (size_t)MAXLW * 96;
+constexpr size_t WSUM_BYTES = (size_t)MAXLW * 288;  // window sums (96 B each) or, for host-combined launches, their three parts
 constexpr int NSLOT = MSM_HIP_NUM_SLOTS;  // result slots
 constexpr int NREDUCE = 2;  // reduce streams (slot k uses stream k % NREDUCE): two bucket reduces may be in flight when the
                             // main-stream work of one MSM is shorter than its bucket reduce (few windows per GPU).  The context
@@ -86,6 +86,7 @@ struct Slot {
   bool timed = false, pending = false, to_host = false;
   bool merged = false;                        // fixed-base launch: one bucket set (one window sum) per scalar vector
   bool halves = false;                        // endomorphism launch: the windows are those of 127-bit halves
+  bool parts = false;                         // h_wsums holds three parts per window (k_bpr_parts_out): the host adds them up
   int timing_level = 0;
   int w_begin = 0, w_count = 0, nvec = 1;  // windows [w_begin, w_begin + w_count) of nvec scalar vectors
   size_t n = 0;
@@ -487,10 +488,22 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   AFTER_KERNEL(ctx, "k_bpr_rowcol", rs);
   hipLaunchKernelGGL(ctx->ops->bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts, (int)(half / BPR_COLS));
   AFTER_KERNEL(ctx, "k_bpr_w256", rs);
-  hipLaunchKernelGGL(ctx->ops->bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue);
-  AFTER_KERNEL(ctx, "k_bpr_final", rs);
+  // sums that the host combines anyway (finish / finish_batch) leave the device as their three parts per window: the last nine group
+  // operations of a window cost ~60 us in a lone wave (k_bpr_final) and 2 us on the host.  Sums that stay on the device (window shards
+  // for the gather) and debug read-backs get the finished sums.
+  // Only for launches that carry ONE scalar vector (where the latency is what counts: -4 % at 2^16, -2.5 % at 2^20): a grouped launch
+  // of 6 - 8 small MSMs would hand its host thread 0.13 ms more work per launch, and that thread is on the critical path there
+  // (2^16, 6 per launch: 0.170 -> 0.215 ms per MSM).
+  const bool parts_mode = to_host && nvec == 1 && !ctx->debug && wsums_out == reinterpret_cast<uint32_t*>(s.d_wsums);
+  if (parts_mode) {
+    hipLaunchKernelGGL(ctx->ops->bpr_parts_out, dim3((3 * w_count + 63) / 64), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue);
+    AFTER_KERNEL(ctx, "k_bpr_parts_out", rs);
+  } else {
+    hipLaunchKernelGGL(ctx->ops->bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue);
+    AFTER_KERNEL(ctx, "k_bpr_final", rs);
+  }
   if (tl >= 2) HIP_TRY(ctx, hipEventRecord(s.red1, rs));
-  if (to_host) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * 96, hipMemcpyDeviceToHost, rs));
+  if (to_host) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * (parts_mode ? 288 : 96), hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums + WSUM_BYTES, d_err, 4, hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipMemsetAsync(d_err, 0, 4, rs));  // ready for the slot's next occupant
   HIP_TRY(ctx, hipEventRecord(s.done, rs));
@@ -502,6 +515,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   s.wbits = wbits;
   s.merged = merge;
   s.halves = halves;
+  s.parts = parts_mode;
   s.n = n;
   s.timed = tl >= 1;
   s.timing_level = tl;
@@ -780,6 +794,7 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
   s.wbits = wbits;
   s.merged = merge;
   s.halves = halves;
+  s.parts = false;
   s.to_host = window_sums_dev == nullptr;
   if (n == 0) {  // identity window sums, nothing to compute
     s.pending = true;
@@ -863,8 +878,11 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   int rc = wait_slot(ctx, s);
   if (rc) return rc;
   auto t0 = std::chrono::steady_clock::now();
-  for (int v = 0; v < s.nvec; v++)
-    if (!ctx->ops->combine_windows(s.h_wsums + (size_t)v * nwin * 96, nwin, s.wbits, out_xyz + 96 * (size_t)v)) return MSM_HIP_ERR_HIP;
+  for (int v = 0; v < s.nvec; v++) {
+    const bool ok = s.parts ? ctx->ops->combine_window_parts(s.h_wsums + (size_t)v * nwin * 288, nwin, s.wbits, out_xyz + 96 * (size_t)v)
+                            : ctx->ops->combine_windows(s.h_wsums + (size_t)v * nwin * 96, nwin, s.wbits, out_xyz + 96 * (size_t)v);
+    if (!ok) return MSM_HIP_ERR_HIP;
+  }
   ctx->stage_ms[8] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return MSM_HIP_OK;
 }

@@ -1461,6 +1461,17 @@ __global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ p
   st_jacobian_plain(wsums + (size_t)w * 24, acc);
 }
 
+// ... or, for launches whose sums go to the host anyway: the three parts of every window as canonical Jacobian bytes (3 x 96 B per
+// window), one lane per part; the host adds them up (host_g1.h: combine_window_parts) -- nine dependent group operations less on the
+// latency path of every MSM (k_bpr_final: ~60 us)
+__global__ void __launch_bounds__(64) k_bpr_parts_out(const uint32_t* __restrict__ parts, int w_count, uint32_t* __restrict__ out,
+                                                      uint32_t* __restrict__ big_queue) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t == 0) big_queue[0] = 0;  // as k_bpr_final
+  if (t >= 3 * w_count) return;
+  st_jacobian_plain(out + (size_t)t * 24, ld_xyzz(parts + (size_t)t * XYZZ_WORDS));
+}
+
 // bucket records -> Jacobian wire records (stage read-back for the parity tests)
 __global__ void __launch_bounds__(256) k_export_buckets(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, size_t count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -172,7 +172,8 @@ int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t 
     return rc;
   }
   // 2. gather the window sums
-  uint8_t all[NWIN * 96];
+  uint8_t all[NWIN * 288];
+  bool parts = false;  // the pinned-buffer path receives every window sum as its three parts (Slot::parts): the host adds them up
   if (m->rccl) {
     // in stream order behind each device's bucket reduce: one all-gather over all devices, then device 0's copy to the host
     bool ok = m->api.GroupStart() == 0;
@@ -207,11 +208,16 @@ int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t 
       if (r && !rc) rc = r;
       int b, e;
       (void)msm_hip_window_range(d, G, NWIN, &b, &e);
-      memcpy(all + (size_t)b * 96, m->ctx[d]->slot[0].h_wsums, (size_t)(e - b) * 96);
+      const Slot& sl = m->ctx[d]->slot[0];
+      if (d == 0) parts = sl.parts;
+      if (sl.parts != parts) return MSM_HIP_ERR_HIP;  // (all contexts share the debug setting: cannot happen)
+      const size_t rec = parts ? 288 : 96;
+      memcpy(all + (size_t)b * rec, sl.h_wsums, (size_t)(e - b) * rec);
     }
     if (rc) return rc;
   }
   // 3. ONE host window combine
+  if (parts) return curve_ops(m->curve)->combine_window_parts(all, NWIN, WBITS, out_xyz) ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
   return msm_hip_combine_windows_curve(m->curve, all, NWIN, out_xyz);
 }
 
