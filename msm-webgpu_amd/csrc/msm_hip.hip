@@ -475,9 +475,12 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
 #define ROWCOL(LOG_R, LOG_ROWS) \
   hipLaunchKernelGGL(ctx->ops->rowcol_##LOG_R##_##LOG_ROWS, dim3(bpr_rowcol_blocks<LOG_R, LOG_ROWS>(), w_count), dim3(256), 0, rs, s.d_buckets, d_rows, d_cols)
   if (wbits == 16) {
-    if (force_logr == 4 || (force_logr == 0 && w_count >= 8)) ROWCOL(4, 8);
-    else if (force_logr == 2 || force_logr == 0) ROWCOL(2, 8);
-    else ROWCOL(3, 8);
+    // one small MSM alone in its launch (8 half-length windows, up to 2^18 points): 8 buckets per thread -- its latency is what counts
+    // (-4 % at 2^16, -2.6 % at 2^18; the same setting costs grouped launches 3 - 16 % and a pipelined 2^20 MSM 0.5 %)
+    const bool small_single = nvec == 1 && w_count == 8 && n_entries <= ((size_t)1 << 19);
+    if (force_logr == 4 || (force_logr == 0 && w_count >= 8 && !small_single)) ROWCOL(4, 8);
+    else if (force_logr == 3 || (force_logr == 0 && small_single)) ROWCOL(3, 8);
+    else ROWCOL(2, 8);
   } else if (wbits == 14) {  // 64 rows x 128 columns
     if (force_logr == 4 || (force_logr == 0 && w_count > 2 * nwin_of(14))) ROWCOL(4, 6);
     else ROWCOL(2, 6);
