@@ -145,3 +145,27 @@ def test_configs_2_4_5_with_endomorphism_bases(ctx, inputs_2p20):
     whole = ctx.msm(sc4)
     ctx.set_bases(pts4)
     assert ctx.msm(sc4) == whole
+
+
+@pytest.mark.parametrize("endo", [False, True], ids=["plain", "endomorphism"])
+def test_config2_size_with_skewed_and_sparse_scalars(ctx, inputs_2p20, endo):
+    # 2^20 points with the scalar distributions that reach the rare paths at full scale: every scalar equal (one bucket of 2^20 entries
+    # per window: 24 k pieces stitched by 16 workgroups each), a witness-like vector (40 % zeros, 30 % ones: the device-side chunk length),
+    # three distinct values (far-apart heavy buckets: the SMVP's jump across empty slots)
+    n, pts, sets, _ = inputs_2p20
+    pb = _host(pts)
+    s = 0x123456789ABCDEF013579BDF2468ACE0FEDCBA9876543210
+    eq = torch.tensor(list(s.to_bytes(32, "little")), dtype=torch.uint8, device=pts.device).repeat(n, 1).contiguous()
+    gen = torch.Generator(device=pts.device)
+    gen.manual_seed(7)
+    sel = torch.rand(n, device=pts.device, generator=gen)
+    wit = sets[0].clone()
+    wit[sel < 0.7] = 0
+    wit[(sel >= 0.4) & (sel < 0.7), 0] = 1
+    three = sets[1][:3].repeat((n + 2) // 3, 1)[:n].contiguous()
+    ctx.set_bases(pts, endomorphism=endo)
+    try:
+        for name, sc in (("all equal", eq), ("witness-like", wit), ("three values", three)):
+            assert ctx.msm(sc).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb, _host(sc), THREADS)), name
+    finally:
+        ctx.set_bases(pts)
