@@ -250,7 +250,8 @@ void* msm_hip_stream(msm_hip_ctx* ctx);
  *      val_idxs  : u32[num_windows_run][n]    point index | sign << 31, grouped by slot (order within a slot is
  *                  unspecified)                                 cf. transpose.template.wgsl:66-73
  *      buckets   : [num_windows_run][32768] x 96 B Jacobian canonical LE, slot k as smvp.template.wgsl:94
- *      windows   : [num_windows_run] x 96 B Jacobian canonical LE
+ *      windows   : [num_windows_run] x 96 B Jacobian canonical LE (a single-MSM launch whose sums the host combines leaves the
+ *                  bucket reduce's three parts per window on the device, S_w = 128 A + B + C: the read-back folds them)
  * ---- */
 /* digit-code planes are only materialised for read-back when enabled here (the sort recomputes digits on the fly) */
 int msm_hip_set_debug(msm_hip_ctx* ctx, int keep_digit_planes);

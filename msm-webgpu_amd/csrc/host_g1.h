@@ -236,5 +236,19 @@ inline bool combine_window_parts(const uint8_t* parts288, int num_windows, int w
   return ok;
 }
 
+// ... and one window at a time: S_w = 128 A + B + C as a 96-byte Jacobian record (the stage read-back of a launch that left parts)
+inline bool fold_window_parts(const uint8_t* parts288, int num_windows, uint8_t* sums96) {
+  bool ok = true;
+  for (int w = 0; w < num_windows; w++) {
+    hg1 a, b, c;
+    ok &= hg1_from_bytes96(a, parts288 + 288 * (size_t)w);
+    ok &= hg1_from_bytes96(b, parts288 + 288 * (size_t)w + 96);
+    ok &= hg1_from_bytes96(c, parts288 + 288 * (size_t)w + 192);
+    for (int k = 0; k < 7; k++) a = hg1_double(a);
+    hg1_to_bytes96(sums96 + 96 * (size_t)w, hg1_add(a, hg1_add(b, c)));
+  }
+  return ok;
+}
+
 }  // namespace host
 }  // namespace MSM_FIELD_NS

@@ -1191,7 +1191,15 @@ int msm_hip_read_buckets(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
 
 int msm_hip_read_window_sums(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
-  return read_back(ctx, out, ctx->slot[ctx->last_slot].d_wsums, (size_t)ctx->last_w_count * 96, cap_bytes);
+  const Slot& s = ctx->slot[ctx->last_slot];
+  if (!s.parts) return read_back(ctx, out, s.d_wsums, (size_t)ctx->last_w_count * 96, cap_bytes);
+  // the last launch handed its window sums to the host as three parts per window (k_bpr_parts_out): fold them here
+  const size_t w = (size_t)ctx->last_w_count;
+  if (!out || w * 96 > cap_bytes || w > (size_t)MAXLW) return MSM_HIP_ERR_INVALID_ARG;
+  uint8_t parts[(size_t)MAXLW * 288];
+  int rc = read_back(ctx, parts, s.d_wsums, w * 288, sizeof parts);
+  if (rc) return rc;
+  return ctx->ops->fold_window_parts(parts, (int)w, out) ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
 }
 
 // ---- op hooks -------------------------------------------------------------------------------------------------------

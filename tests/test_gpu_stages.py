@@ -95,3 +95,19 @@ def test_bucket_reduction_matches_cpu_models(run):
 def test_horner_of_window_sums_is_the_result(run):
     assert cpu.to_affine64(cpu.horner(run["wsums"].tobytes(), run["bits"])) == run["result"].to_affine_bytes()
     assert run["result"].to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(run["points"], run["scalars"]))
+
+
+def test_window_sums_read_back_after_a_plain_launch(ctx):
+    """Without debug a single-MSM launch leaves the bucket reduce's three parts per window on the device
+    (k_bpr_parts_out); msm_hip_read_window_sums folds them into the documented 96-byte records."""
+    n = 5000
+    points, scalars = cpu.sample_points(62, n), cpu.sample_scalars(63, n)
+    ctx.set_bases(points)
+    ctx.set_window_bits(16)
+    try:
+        result = ctx.msm(scalars)
+        wsums = ctx.read_window_sums(16)
+    finally:
+        ctx.set_window_bits(0)
+    assert cpu.to_affine64(cpu.horner(wsums.tobytes(), 16)) == result.to_affine_bytes()
+    assert result.to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points, scalars))

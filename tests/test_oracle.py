@@ -112,3 +112,31 @@ def test_oracle_reproduces_golden(case):
     assert cpu.to_affine64(cpu.cpu_msm(points, scalars)).hex() == case["expected_affine"]
     if len(scalars) // 32 <= 5000:
         assert cpu.to_affine64(cpu.msm_cuzk_model(points, scalars)).hex() == case["expected_affine"]
+
+
+def test_reference_known_answers_pasta():
+    """The Pallas constants the reference holds (its dead second curve): 16-bit limbs of p, BASE_M and U in
+    /root/reference/src/naive/wgsl/pallas/field.wgsl:4-6,18-24, the decimal p, q, base_m, u and the identity p = 2^254 + u in
+    src/naive/utils/bigint.rs:38-75, the hex modulus in src/naive/utils/files.rs:26 -- both Pasta oracles are pinned to them."""
+    from oracle import cpu_pallas, cpu_vesta, pallas_ref, vesta_ref
+
+    fp = int("28948022309329048855892746252171976963363056481941560715954676764349967630337")   # bigint.rs:38
+    fq = int("28948022309329048855892746252171976963363056481941647379679742748393362948097")   # bigint.rs:39
+    base_m = int("115792089237316195423570985008687907853087743403514885215096460958426388758524")  # bigint.rs:40
+    u = int("45560315531419706090280762371685220353")                                           # bigint.rs:59
+    assert fp == (1 << 254) + u and (4 * ((1 << 254) - u)) % (1 << 256) == base_m                # bigint.rs:60-64
+    assert fp == 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001             # files.rs:26
+    assert ref.to_words_le(fp, 16, 16) == [1, 0, 12525, 39213, 63771, 2380, 39164, 8774, 0, 0, 0, 0, 0, 0, 0, 16384]   # field.wgsl:5, bigint.rs:72
+    assert ref.to_words_le(fq, 16, 16) == [1, 0, 60193, 35910, 43229, 2452, 39164, 8774, 0, 0, 0, 0, 0, 0, 0, 16384]   # bigint.rs:73
+    assert ref.to_words_le(base_m, 16, 16) == [65532, 65535, 15435, 39755, 7057, 56012, 39951, 30437] + [65535] * 8    # field.wgsl:18-20, bigint.rs:74
+    assert ref.to_words_le(u, 16, 16) == [1, 0, 12525, 39213, 63771, 2380, 39164, 8774, 0, 0, 0, 0, 0, 0, 0, 0]        # field.wgsl:22-24, bigint.rs:75
+    # the moduli both oracle models and both C builds actually compute with
+    assert (pallas_ref.P, pallas_ref.R) == (fp, fq) and (vesta_ref.P, vesta_ref.R) == (fq, fp)
+    cp, cv = cpu_pallas.constants(), cpu_vesta.constants()
+    assert (cp["p"], cp["r"]) == (fp, fq) and (cv["p"], cv["r"]) == (fq, fp)
+    assert cp["R_mod_p"] == (1 << 256) % fp and cv["R_mod_p"] == (1 << 256) % fq
+    # the group orders: q G = infinity on Pallas, p G = infinity on Vesta (generator (-1, 2)), and (order - 1) G = -G
+    for cpu_c, model, order in ((cpu_pallas, pallas_ref, fq), (cpu_vesta, vesta_ref, fp)):
+        G = model.points_to_bytes([model.G])
+        assert cpu_c.to_affine64(cpu_c.g1_scalar_mul(G, order.to_bytes(32, "little"))) == bytes(64)
+        assert cpu_c.to_affine64(cpu_c.g1_scalar_mul(G, (order - 1).to_bytes(32, "little"))) == model.affine_to_bytes64((model.P - 1, model.P - 2))
