@@ -39,9 +39,9 @@ NUM_WINDOWS = 16
 BUCKETS = 1 << 15
 
 
-def smvp_algorithmic_bytes(n, w_local):
-    """n entries per window at most (one per point the recode reads), w_local bucket sets"""
-    return n * w_local * (64 + 4) + w_local * BUCKETS * 96
+def smvp_algorithmic_bytes(n, w_local, buckets=BUCKETS):
+    """n entries per window at most (one per point the recode reads), w_local bucket sets of `buckets` buckets"""
+    return n * w_local * (64 + 4) + w_local * buckets * 96
 
 
 def self_launch(n_ranks):
@@ -49,6 +49,7 @@ def self_launch(n_ranks):
     child per GPU with the torch.distributed environment set, lets rank 0 print the JSON line on the shared stdout, and
     exits with the worst child status.  A failing rank takes the others down (killed by PID) instead of leaving them in a
     collective."""
+    import signal
     import socket
     import subprocess
 
@@ -56,24 +57,117 @@ def self_launch(n_ranks):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(n_ranks):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    deadline = time.monotonic() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "1500"))  # a rank stuck in a collective ends the run
+
+    def on_signal(signum, frame):  # SIGTERM / SIGINT: the GPU-holding children go with the parent
+        raise KeyboardInterrupt
+
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
     worst = 0
-    pending = set(range(n_ranks))
-    while pending:
-        for r in sorted(pending):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            pending.discard(r)
-            if rc != 0:
-                worst = worst or rc
-                for q in pending:
-                    procs[q].kill()
-        time.sleep(0.05)
+    try:
+        for r in range(n_ranks):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        pending = set(range(n_ranks))
+        while pending:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0:
+                    worst = worst or rc
+                    for q in pending:
+                        procs[q].kill()
+            if pending and time.monotonic() > deadline:
+                sys.stderr.write("bench.py: ranks %s still running at the deadline, killing them\n" % sorted(pending))
+                worst = worst or 124
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        worst = worst or 130
+    finally:
+        for pr in procs:  # whatever happened: no child outlives the launcher (killed by PID, then reaped)
+            if pr.poll() is None:
+                pr.kill()
+        for pr in procs:
+            try:
+                pr.wait(timeout=30)
+            except Exception:
+                pass
+        for sig, h in old.items():
+            signal.signal(sig, h)
     return worst
+
+
+def native_mgpu_main(args):
+    """BENCH_MGPU_NATIVE=1: the same window-sharded workload through the in-process multi-GPU C ABI (msm_hip_mgpu_launch_batch_device_bn254 /
+    msm_hip_mgpu_finish_batch_bn254: one host process, one engine context and one persistent host thread per GPU, one ncclAllGather per
+    launch, host combines on the library's pool) instead of one process per GPU over torch.distributed -- so that the path a Rust caller
+    gets can be timed next to the one the driver measures.  BENCH_MGPU_IDS=0,0,0,0,0,0,0,0 rehearses it with several contexts on one GPU
+    (pinned-buffer gather; the contexts then SHARE that GPU, so the figure is a one-GPU total, not a scaling result)."""
+    import torch
+
+    import msm_webgpu_amd as m
+
+    ids = [int(x) for x in os.environ.get("BENCH_MGPU_IDS", ",".join(str(d) for d in range(args.gpus))).split(",")]
+    distinct = len(set(ids)) == len(ids)
+    n = 1 << args.logn
+    bases_mode = os.environ.get("BENCH_BASES") or "endomorphism"
+    ctx0 = m.MsmContext(ids[0])
+    points = ctx0.sample_points(n, 0x6D736D5F0000 + args.logn)
+    mg = m.MultiGpuMsm(ids, "auto" if distinct else "host")
+    mg.set_bases(points.cpu().numpy().tobytes(), endomorphism=bases_mode == "endomorphism")
+    full = mg.group_size
+    group = int(os.environ.get("BENCH_MSMS_PER_LAUNCH", "0")) or max(1, min(full, -(-args.steps // 5)))
+    per_dev = {}
+    for d in set(ids):  # identical synthetic scalars resident on every device (the deterministic device sampler)
+        c = ctx0 if d == ids[0] else m.MsmContext(d)
+        sets = [c.sample_scalars(n, 0x6D736D5F1000 + args.logn + 7 * i) for i in range(2)]
+        per_dev[d] = torch.cat([sets[k & 1] for k in range(group)], dim=0).contiguous()
+        if c is not ctx0:
+            c.close()
+    scal = [per_dev[d] for d in ids]
+    depth = max(1, min(3, int(os.environ.get("BENCH_PIPE_DEPTH", "3"))))
+
+    def run_steps(count):
+        k = -(-count // group)
+        sizes = [count // k + (1 if i < count % k else 0) for i in range(k)]
+        pending, last = [], None
+        for i, gs in enumerate(sizes):
+            slot = i % (depth + 1)
+            mg.launch_batch([t[: gs * n] for t in scal], n, slot)
+            pending.append((slot, gs))
+            if len(pending) == depth:
+                s0, g0 = pending.pop(0)
+                last = mg.finish_batch(s0, g0)
+        for s0, g0 in pending:
+            last = mg.finish_batch(s0, g0)
+        return last
+
+    run_steps(int(os.environ.get("BENCH_STEADY_MSMS", "40")))
+    run_steps(max(args.warmup, 1))
+    for d in set(ids):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    last = run_steps(args.steps)
+    for d in set(ids):
+        torch.cuda.synchronize(d)
+    elapsed = time.perf_counter() - t0
+    ctx0.set_bases(points, endomorphism=bases_mode == "endomorphism")
+    sets0 = [ctx0.sample_scalars(n, 0x6D736D5F1000 + args.logn + 7 * i) for i in range(2)]
+    ok = bool(ctx0.msm(sets0[(len(last) - 1) & 1]) == last[-1])
+    print(json.dumps({"metric": "BN254 MSM/s at 2^%d points" % args.logn, "value": args.steps / elapsed, "unit": "MSM/s", "n_gpus": len(ids),
+                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+                      "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                      "config": {"workload": "2^%d BN254 G1 MSM, 16-bit signed-bucket windows, inputs resident in HBM" % args.logn,
+                                 "parallelism": "in-process msm_hip_mgpu_*: %s windows over %d contexts, %s gather" % (
+                                     "8 half-length" if bases_mode == "endomorphism" else "16", len(ids), "RCCL" if mg.uses_rccl else "pinned-buffer"),
+                                 "device_ids": ids, "msms_per_launch": group, "launches_in_flight": depth},
+                      "sharded_result_equals_single_gpu": ok, "native_mgpu": True}))
+    mg.close()
+    ctx0.close()
 
 
 def main():
@@ -86,6 +180,8 @@ def main():
     ap.add_argument("--cpu-sample-logn", type=int, default=None, help="bounded CPU sample size (default: min(logn, 20))")
     args = ap.parse_args()
 
+    if os.environ.get("BENCH_MGPU_NATIVE") == "1" and "RANK" not in os.environ:
+        return native_mgpu_main(args)
     if args.gpus > 1 and "RANK" not in os.environ:  # no launcher around us: be the launcher
         raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,6 +204,8 @@ def main():
         dist.all_gather(ids, torch.tensor([rank], dtype=torch.int32))
         if os.environ["BENCH_DRY_RUN"] == "fail_last" and rank == world - 1:
             raise SystemExit(3)
+        if os.environ["BENCH_DRY_RUN"] == "hang_last" and rank == world - 1:
+            time.sleep(600)  # a rank that never returns: the self-launcher's deadline must end the run
         dist.barrier()
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "dist_backend": "gloo", "dist_ranks": sorted(int(t.item()) for t in ids)}))
@@ -149,8 +247,6 @@ def main():
     # identical synthetic inputs on every rank (deterministic device sampler), resident in HBM
     points = ctx.sample_points(n, 0x6D736D5F0000 + args.logn)
     scalar_sets = [ctx.sample_scalars(n, 0x6D736D5F1000 + args.logn + 7 * i) for i in range(2)]
-    w_begin, w_end = window_range(rank, world)
-    w_local = w_end - w_begin
     # tuning aid (never a reported result): BENCH_EMULATE_WORLD=8 makes this single rank do the per-rank share of an
     # 8-rank run (2 windows) through the sharded pipeline; the MSM value is then NOT a whole-job figure
     emulate = int(os.environ.get("BENCH_EMULATE_WORLD", "0"))
@@ -160,11 +256,23 @@ def main():
     #                 (default on one GPU: the same bucket additions, half the buckets to reduce; 2 x the base memory)
     #   plain         the reference's shape: 16 windows over n points (what the window-sharded multi-GPU path uses)
     #   tables        fixed-base tables 2^(16 w) P_i: one bucket set per MSM (16 x the base memory)
-    bases_mode = os.environ.get("BENCH_BASES") or ("plain" if sharded else "endomorphism")
-    assert bases_mode in ("plain", "endomorphism", "tables") and (bases_mode == "plain" or not sharded)
+    #   (window-sharded runs: endomorphism = the ranks share the 8 half-length windows, one per rank at 8 GPUs)
+    bases_mode = os.environ.get("BENCH_BASES") or "endomorphism"
+    assert bases_mode in ("plain", "endomorphism", "tables") and (bases_mode != "tables" or not sharded)
     ctx.set_bases(points, endomorphism=bases_mode == "endomorphism", precompute=bases_mode == "tables")
-    # the SMVP launch of one whole MSM: points the recode reads and bucket sets
-    smvp_n, smvp_w = {"plain": (n, NUM_WINDOWS), "endomorphism": (2 * n, NUM_WINDOWS // 2), "tables": (NUM_WINDOWS * n, 1)}[bases_mode]
+    halves = bases_mode == "endomorphism"
+    shard_windows = NUM_WINDOWS // 2 if halves else NUM_WINDOWS  # the windows the ranks share
+    w_begin, w_end = window_range(rank, world, shard_windows)
+    w_local = w_end - w_begin
+
+    def smvp_shape(bits):
+        """(inputs per bucket set, bucket sets, buckets per set) of one whole MSM's SMVP launch at a window size"""
+        nwin, buckets = m.MsmContext.window_config(bits)
+        if bases_mode == "endomorphism":
+            return 2 * n, m.MsmContext.endomorphism_window_count(bits), buckets
+        if bases_mode == "tables":
+            return NUM_WINDOWS * n, 1, buckets
+        return n, nwin, buckets
 
     def sync_all():
         torch.cuda.synchronize()
@@ -172,15 +280,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    smvp_ms, smvp_windows = [], []
-    # window-sharded runs put the shares of several independent MSMs through one launch (as many as fit 16 local windows:
-    # 8 MSMs x 2 windows at 8 GPUs) -- one kernel sequence and one RCCL all-gather per group; BENCH_MSMS_PER_LAUNCH overrides
+    smvp_ms, smvp_windows, smvp_bits = [], [], []
+    # window-sharded runs put the shares of several independent MSMs through one launch (as many as make up one MSM's worth of
+    # bucket sets: 8 MSMs x 2 windows -- or x 1 half-length window -- at 8 GPUs): one kernel sequence and one RCCL all-gather per
+    # group.  A short run (the driver's --steps 20) takes smaller groups so that at least ~5 launches exist: with three launches
+    # of 7 the pipeline (3 in flight) never reaches its steady state and the whole last launch's reduce + gather + combine is
+    # exposed.  BENCH_MSMS_PER_LAUNCH overrides.
     group = 1
     pipe = None
     if sharded:
-        group = int(os.environ.get("BENCH_MSMS_PER_LAUNCH", "0")) or msms_per_launch(emulate if emulate > 1 else world)
+        full = msms_per_launch(emulate if emulate > 1 else world, shard_windows)
+        group = int(os.environ.get("BENCH_MSMS_PER_LAUNCH", "0")) or max(1, min(full, -(-args.steps // 5)))
         pipe = ShardedMsmPipeline(ctx, rank, world, depth=int(os.environ.get("BENCH_PIPE_DEPTH", "3")), msms_per_issue=group,
-                                  emulate_world=emulate)
+                                  emulate_world=emulate, halves=halves)
         w_local = pipe.w_end - pipe.w_begin
         # vector k of a group is scalar set k & 1
         group_scalars = torch.cat([scalar_sets[k & 1] for k in range(group)], dim=0).contiguous() if group > 1 else None
@@ -205,9 +317,12 @@ def main():
             return [g] * (count // g) + [rem]
         return [count // k + (1 if i < count % k else 0) for i in range(k)]
 
-    def note_stages(w_eff):
+    def note_stages(nvec):
+        """one finished launch of `nvec` MSMs (or MSM shares): its SMVP kernel time, bucket sets and window size"""
         smvp_ms.append(ctx.stage_ms()["smvp"])
-        smvp_windows.append(w_eff)
+        bits = ctx.last_window_bits()
+        smvp_bits.append(bits)
+        smvp_windows.append(nvec * (w_local if sharded else smvp_shape(bits)[1]))
 
     def run_steps(count, record):
         """`count` MSMs; returns the last result.  N = 1 pipelines the host combine of MSM i with the device work of i+1."""
@@ -229,11 +344,11 @@ def main():
                     slot0, gs0 = pending.pop(0)
                     result = ctx.finish(slot0) if group1 == 1 else ctx.finish_batch(slot0, gs0)[-1]
                     if record:
-                        note_stages(gs0 * smvp_w)
+                        note_stages(gs0)
             for slot0, gs0 in pending:
                 result = ctx.finish(slot0) if group1 == 1 else ctx.finish_batch(slot0, gs0)[-1]
                 if record:
-                    note_stages(gs0 * smvp_w)
+                    note_stages(gs0)
         else:
             # windows sharded over the ranks; device work, RCCL all-gather, D2H and host combine all pipelined
             sizes = group_sizes(count, group)
@@ -247,12 +362,12 @@ def main():
                 if len(inflight) == pipe.depth:
                     result = pipe.complete()
                     if record:
-                        note_stages(inflight[0] * w_local)
+                        note_stages(inflight[0])
                     inflight.pop(0)
             while inflight:
                 result = pipe.complete()
                 if record:
-                    note_stages(inflight[0] * w_local)
+                    note_stages(inflight[0])
                 inflight.pop(0)
         return result
 
@@ -265,6 +380,24 @@ def main():
     # (32 MiB H2D per MSM at 2^20), bases resident -- as the latency of one call and as the throughput of three slots in rotation
     # (msm_hip_launch_bn254: the copy of MSM i+1 runs on the copy stream under the device work of MSM i); C = one-shot incl.
     # base upload (≙ the reference's compute_msm call shape): the first call also creates the context the library then keeps
+    pre_timed_msms = 0  # MSMs (or MSM shares) this process has run before the timed region starts
+
+    # The same measurement under the literal protocol first: W warm-up steps on a GPU that has done nothing but sample the inputs,
+    # then K timed steps.  Reported beside `value` as `value_cold_protocol`; the GPU is still in its post-idle ramp there.
+    ctx.set_stage_timing(1)
+    run_steps(max(args.warmup, 1), False)
+    sync_all()
+    t0 = time.perf_counter()
+    run_steps(args.steps, False)
+    sync_all()
+    cold_elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([cold_elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        cold_elapsed = float(t.item())
+    pre_timed_msms += max(args.warmup, 1) + args.steps
+    ctx.set_stage_timing(2)
+
     scope_ms = None
     if world == 1 and emulate <= 1 and args.logn <= 22:
         sb_host = [s.cpu().numpy().tobytes() for s in scalar_sets]
@@ -298,6 +431,7 @@ def main():
             b_pipe = (time.perf_counter() - t1) * 1e3 / k
         scope_ms = {"B_host_scalars_resident_bases_latency": sorted(tb)[2], "B_host_scalars_three_slots_pipelined": b_pipe,
                     "C_one_shot_with_base_upload": sorted(tc[1:])[1], "C_one_shot_first_call": tc[0]}
+        pre_timed_msms += 4 + 5 + 2 * k
 
     # window-sharded runs: the latency of ONE MSM across the ranks (its window shares, the gather, the host combine; nothing in
     # flight beside it) -- BASELINE config 3 as a single call -- median of 20, measured before the timed region for the same reason
@@ -312,11 +446,18 @@ def main():
             pipe.complete()
             lat.append((time.perf_counter() - t1) * 1e3)
         sharded_latency_ms = sorted(lat)[len(lat) // 2]
+        pre_timed_msms += 20
 
     # timed region: HIP events only around the SMVP accumulate kernel (the roofline figure); every extra stage event
     # costs queue time between kernels.  The per-stage breakdown comes from the un-pipelined latency runs below.
+    # Steady state is made explicit: whatever informational blocks ran above (they differ with the size and the rank count), at least
+    # BENCH_STEADY_MSMS (default 40) steps of the timed workload itself run back to back right before the W warm-up steps.
     ctx.set_stage_timing(1)
+    steady = max(0, int(os.environ.get("BENCH_STEADY_MSMS", "40")))
+    if steady:
+        run_steps(steady, False)
     run_steps(max(args.warmup, 1), False)
+    pre_timed_msms += steady + max(args.warmup, 1)
     sync_all()
     t0 = time.perf_counter()
     last = run_steps(args.steps, True)
@@ -352,13 +493,25 @@ def main():
 
     ms_per_step = elapsed * 1e3 / args.steps
     # roofline of the SMVP accumulate kernel: algorithmic bytes of all timed launches / their summed durations
+    # (geometry of every timed launch from the window size the engine reports for it: grouped small MSMs run 14-bit windows)
     launches = len(smvp_ms)
     smvp_avg_ms = sum(smvp_ms) / launches
-    n_launch = n if sharded else smvp_n  # entries per bucket set
-    alg_bytes = sum(smvp_algorithmic_bytes(n_launch, w) for w in smvp_windows) / launches
+    n_of = lambda bits: (2 * n if halves else n) if sharded else smvp_shape(bits)[0]  # inputs per bucket set
+    alg_bytes = sum(smvp_algorithmic_bytes(n_of(b), w, 1 << (b - 1)) for w, b in zip(smvp_windows, smvp_bits)) / launches
     achieved = alg_bytes / (smvp_avg_ms * 1e-3) / 1e9
     w_launch = max(smvp_windows)
-    lane_mads_per_s = sum(n_launch * w for w in smvp_windows) * MADS_PER_MIXED_ADD / (sum(smvp_ms) * 1e-3)
+    lane_mads_per_s = sum(n_of(b) * w for w, b in zip(smvp_windows, smvp_bits)) * MADS_PER_MIXED_ADD / (sum(smvp_ms) * 1e-3)
+    bits_main = max(set(smvp_bits), key=smvp_bits.count)
+    # the rocprofv3 --kernel-trace --stats average of the same kernel in the same command, when this round's profile is committed
+    kernel_ms_rocprof, rocprof_source = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "rocprof_kernel_ms.json")) as f:
+            rp = json.load(f)
+        key = "logn%d_%s_%s" % (args.logn, bases_mode, "w%d" % w_local if sharded else "single")
+        if key in rp:
+            kernel_ms_rocprof, rocprof_source = rp[key]["k_smvp_chunks_avg_ms"], rp[key]["source"]
+    except (OSError, ValueError, KeyError):
+        pass
 
     traffic, traffic_source = None, None
     try:
@@ -374,6 +527,7 @@ def main():
     out = {
         "metric": "BN254 MSM/s at 2^%d points" % args.logn,
         "value": args.steps / elapsed,
+        "value_cold_protocol": args.steps / cold_elapsed,
         "unit": "MSM/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -388,13 +542,14 @@ def main():
                    "bases": {"plain": "n points, 16 windows (the reference's shape)",
                              "endomorphism": "P and phi(P) resident: scalars split into two 127-bit halves on the device, 8 windows over 2n points",
                              "tables": "fixed-base tables 2^(16 w) P resident: one bucket set per MSM"}[bases_mode],
-                   "windows_per_gpu": w_local if sharded else smvp_w, "msms_per_launch": group if sharded else group1,
-                   "parallelism": "windows/%d + RCCL all-gather" % world if sharded else "single GPU",
+                   "window_bits": bits_main,
+                   "windows_per_gpu": w_local if sharded else smvp_shape(bits_main)[1], "msms_per_launch": group if sharded else group1,
+                   "parallelism": "%s windows/%d + RCCL all-gather" % ("8 half-length" if halves else "16", world) if sharded else "single GPU",
                    "launches_in_flight": pipe.depth if sharded else depth1,
                    "host_combine": "pipelined behind the device work of the following launches"},
         "roofline": {"bound": "hbm", "kernel": "k_smvp_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": alg_bytes,
-                     "kernel_ms": smvp_avg_ms},
+                     "kernel_ms": smvp_avg_ms, "kernel_ms_rocprof": kernel_ms_rocprof, "kernel_ms_rocprof_source": rocprof_source},
         # beside (not instead of) the HBM figure: the kernel's multiply-add rate against the instruction's measured issue peak
         "roofline_valu": {"bound": "valu_issue", "kernel": "k_smvp_chunks", "unit": "T lane-mad/s (v_mad_u64_u32)",
                           "achieved": lane_mads_per_s / 1e12, "peak": VALU_PEAK_LANE_MADS / 1e12, "frac": lane_mads_per_s / VALU_PEAK_LANE_MADS},
@@ -407,8 +562,12 @@ def main():
         "latency_ms_single_msm": latency_ms if not sharded else sharded_latency_ms,
         "stage_ms_single_msm": isolated,
         "scope_ms": scope_ms,
-        "pre_timed_activity": ("scope C and B measurements (4 one-shot calls, 5 + 2 x 24 host-scalar MSMs), then the W warm-up steps" if scope_ms
-                               else "20 single-MSM latency runs across the ranks, then the W warm-up steps" if sharded else "the W warm-up steps"),
+        "ms_per_step_cold_protocol": cold_elapsed * 1e3 / args.steps,
+        "pre_timed_msms": pre_timed_msms,
+        "pre_timed_activity": "W + K steps under the literal protocol (value_cold_protocol); " +
+                              ("scope C and B measurements (4 one-shot calls, 5 + 2 x 24 host-scalar MSMs); " if scope_ms
+                               else "20 single-MSM latency runs across the ranks; " if sharded else "") +
+                              "%d steady-state steps; the W warm-up steps" % steady,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -182,10 +182,20 @@ int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_de
 int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin,
                                               int w_end, int slot, void* window_sums_dev);
 int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz);
+/* the same for a context whose bases were set with MSM_HIP_BASES_ENDOMORPHISM: HALF-length windows [hw_begin, hw_end) of the 8 that the
+ * 127-bit halves k1, k2 of every scalar have (k = k1 + k2 lambda; the MSM runs over the 2n points P_i, phi(P_i)): at 8 GPUs one such window
+ * per rank instead of two full-length ones -- the same bucket additions, half the buckets to stitch and reduce.  The 8 sums S_hw combine like
+ * any window sums: result = sum_hw 2^(16 hw) S_hw (msm_hip_combine_windows_bn254 with num_windows = 8).  Anchor: the reference runs 16
+ * full-length windows, src/cuzk/msm.rs:79-82. */
+int msm_hip_launch_half_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int hw_begin,
+                                                   int hw_end, int slot, void* window_sums_dev);
 int msm_hip_slot_wait_stream(msm_hip_ctx* ctx, int slot, void* hip_stream);
 int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot);
 /* result = sum_w 2^(16 w) * S_w over num_windows records (host memory): src/cuzk/msm.rs:411-416 */
 int msm_hip_combine_windows_bn254(const uint8_t* window_sums_host, int num_windows, uint8_t out_xyz[96]);
+/* the same for `nvec` MSMs at once (window_sums_host: nvec x num_windows x 96 B, out_xyz: nvec x 96 B): the independent Horner chains
+ * (~47 us each) run side by side on a small pool of host threads the library keeps (MSM_HIP_COMBINE_THREADS=1: serially) */
+int msm_hip_combine_windows_batch_curve(int curve, const uint8_t* window_sums_host, int num_windows, int nvec, uint8_t* out_xyz);
 
 /* ---- multi-GPU in ONE host process (BASELINE.json north star: "independent Pippenger windows shard across the 8 GPUs of one
  *      node with a final RCCL gather/reduce of partial sums over xGMI"; the reference is single-device, src/cuzk/msm.rs:88-94).
@@ -206,6 +216,21 @@ int msm_hip_mgpu_device_count(const msm_hip_mgpu* m);
 int msm_hip_mgpu_uses_rccl(const msm_hip_mgpu* m);
 int msm_hip_mgpu_set_bases_bn254(msm_hip_mgpu* m, const uint8_t* xy_host, size_t n, uint32_t flags);
 int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
+/* The throughput form of the same (what a Rust caller that holds many (points, scalars) jobs drives, src/lib.rs:76-82; the reference creates
+ * its device per call, src/cuzk/msm.rs:88-94): `nvec` scalar vectors share ONE launch -- device d runs its window range of every vector in one
+ * kernel sequence (a single MSM's share, 2 of 16 windows at 8 GPUs, cannot fill a GPU) into result slot `slot` (0 .. MSM_HIP_NUM_SLOTS-1) of its
+ * context, and ONE all-gather per launch follows in stream order.  `launch` returns at once: every device has a persistent host thread that
+ * issues its calls, so several slots can be in flight.  `finish` waits for the slot and writes nvec x 96 B results (one host window combine
+ * per MSM, side by side on the host pool).  nvec x (windows per device) <= MSM_HIP_MAX_LOCAL_WINDOWS; msm_hip_mgpu_group_size() is the nvec
+ * that fills a device (8 at 8 GPUs).  With bases set with MSM_HIP_BASES_ENDOMORPHISM the shares are the 8 half-length windows.
+ *   _bn254         : scalars in host memory (nvec x n x 32 B); every device uploads all of them (PCIe-bound: the latency form).  The buffer
+ *                    must stay untouched until finish.
+ *   _device_bn254  : scalars_dev[d] = the same nvec x n x 32 B already resident on device d (complete before the call; alive until finish).
+ * A failing launch is reported by finish, which always leaves the slot free. */
+int msm_hip_mgpu_launch_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, int nvec, int slot);
+int msm_hip_mgpu_launch_batch_device_bn254(msm_hip_mgpu* m, const void* const* scalars_dev, size_t n, int nvec, int slot);
+int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz);
+int msm_hip_mgpu_group_size(const msm_hip_mgpu* m);
 int msm_hip_mgpu_run_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz);
 /* contiguous balanced partition of [0, num) over `world` ranks (the first num % world ranks take one more): the window ranges of
  * msm_hip_mgpu_run_bn254 and the MSM ranges of msm_hip_mgpu_run_batch_bn254; host-only */

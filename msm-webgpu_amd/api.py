@@ -62,6 +62,8 @@ def lib():
         L.msm_hip_run_batch_bn254.argtypes = [vp, u8p, sz, sz, u8p]
         L.msm_hip_launch_windows_batch_device_bn254.argtypes = [vp, vp, sz, i, i, i, i, vp]
         L.msm_hip_finish_batch_bn254.argtypes = [vp, i, u8p]
+        L.msm_hip_launch_half_windows_batch_device_bn254.argtypes = [vp, vp, sz, i, i, i, i, vp]
+        L.msm_hip_combine_windows_batch_curve.argtypes = [i, vp, i, i, u8p]
         L.msm_hip_run_batch_device_bn254.argtypes = [vp, vp, sz, sz, u8p]
         L.msm_hip_launch_device_bn254.argtypes = [vp, vp, sz, i]
         L.msm_hip_launch_bn254.argtypes = [vp, u8p, sz, i]
@@ -108,6 +110,10 @@ def lib():
         L.msm_hip_mgpu_set_bases_bn254.argtypes = [vp, u8p, sz, C.c_uint32]
         L.msm_hip_mgpu_run_bn254.argtypes = [vp, u8p, sz, u8p]
         L.msm_hip_mgpu_run_batch_bn254.argtypes = [vp, u8p, sz, sz, u8p]
+        L.msm_hip_mgpu_launch_batch_bn254.argtypes = [vp, u8p, sz, i, i]
+        L.msm_hip_mgpu_launch_batch_device_bn254.argtypes = [vp, C.POINTER(vp), sz, i, i]
+        L.msm_hip_mgpu_finish_batch_bn254.argtypes = [vp, i, u8p]
+        L.msm_hip_mgpu_group_size.argtypes = [vp]
         L.msm_hip_window_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
         _lib = L
     return _lib
@@ -332,6 +338,19 @@ class MsmContext:
                "msm_hip_launch_windows_batch_device_bn254")
         self._keepalive[slot] = (t, out_dev)
 
+    def launch_half_windows_batch(self, scalars_dev, n, hw_begin, hw_end, slot, out_dev, inputs_complete=False):
+        """launch_windows_batch over the 8 HALF-length windows of a context whose bases carry their endomorphism images
+        (msm_hip_launch_half_windows_batch_device_bn254): `out_dev` receives nvec * (hw_end - hw_begin) sums, vector-major."""
+        t, rows = _as_device_u8(scalars_dev, 32, "scalars")
+        if n <= 0 or rows % n:
+            raise ValueError("scalars must hold a whole number of n-element vectors")
+        if not inputs_complete:
+            self._order_after_torch(t)
+        _check(lib().msm_hip_launch_half_windows_batch_device_bn254(self._h, t.data_ptr(), n, rows // n, hw_begin, hw_end, slot,
+                                                                    out_dev.data_ptr() if out_dev is not None else None),
+               "msm_hip_launch_half_windows_batch_device_bn254")
+        self._keepalive[slot] = (t, out_dev)
+
     def launch_batch(self, scalars_dev, n, slot=0):
         """Enqueue up to 4 WHOLE MSMs (contiguous scalar vectors, CUDA uint8 [nvec * n, 32]) as one launch; finish_batch collects."""
         self.launch_windows_batch(scalars_dev, n, 0, NUM_WINDOWS, slot, None)
@@ -369,6 +388,21 @@ class MsmContext:
         cid, p = CURVES[curve]
         _check(lib().msm_hip_combine_windows_curve(cid, b, len(b) // 96, out), "msm_hip_combine_windows_curve")
         return G1(out.raw, p)
+
+    @staticmethod
+    def combine_windows_batch(window_sums, num_windows, curve="bn254"):
+        """Host Horner for several MSMs at once: window_sums holds nvec x num_windows x 96 B (bytes, numpy uint8 array or CPU tensor);
+        the chains run side by side on the library's host pool.  -> [G1, ...]"""
+        if isinstance(window_sums, torch.Tensor):
+            window_sums = window_sums.contiguous().numpy()
+        a = np.ascontiguousarray(np.frombuffer(window_sums, dtype=np.uint8) if isinstance(window_sums, (bytes, bytearray)) else window_sums, dtype=np.uint8)
+        nvec = a.size // (96 * num_windows)
+        if nvec * 96 * num_windows != a.size:
+            raise ValueError("window sums must be nvec x num_windows x 96 bytes")
+        out = C.create_string_buffer(max(96 * nvec, 1))
+        cid, p = CURVES[curve]
+        _check(lib().msm_hip_combine_windows_batch_curve(cid, a.ctypes.data, num_windows, nvec, out), "msm_hip_combine_windows_batch_curve")
+        return [G1(out.raw[96 * k:96 * k + 96], p) for k in range(nvec)]
 
     # -- synthetic inputs in HBM
     def sample_scalars(self, n, seed):
@@ -517,8 +551,8 @@ class MultiGpuMsm:
         return lib().msm_hip_mgpu_uses_rccl(self._h) == 1
 
     def set_bases(self, points, check_on_curve=False, endomorphism=False):
-        """Replicated on every device.  endomorphism: MSM_HIP_BASES_ENDOMORPHISM -- used by msm_batch (whole MSMs per device);
-        the window-sharded msm() runs the plain 16 windows."""
+        """Replicated on every device.  endomorphism: MSM_HIP_BASES_ENDOMORPHISM -- msm_batch runs whole MSMs over the 2n points, and
+        the window-sharded calls shard the 8 half-length windows."""
         b = bytes(points)
         flags = (1 if check_on_curve else 0) | (8 if endomorphism else 0)
         _check(lib().msm_hip_mgpu_set_bases_bn254(self._h, b, len(b) // 64, flags), "msm_hip_mgpu_set_bases_bn254")
@@ -536,6 +570,41 @@ class MultiGpuMsm:
         out = C.create_string_buffer(max(96 * batch, 1))
         _check(lib().msm_hip_mgpu_run_batch_bn254(self._h, b, n, batch, out), "msm_hip_mgpu_run_batch_bn254")
         return [G1(out.raw[96 * k:96 * k + 96], self.modulus) for k in range(batch)]
+
+    # -- window-sharded launches of several MSMs, asynchronous (the throughput form)
+    @property
+    def group_size(self):
+        """MSMs per launch that fill a device (msm_hip_mgpu_group_size): 16 / windows per device (8 with endomorphism bases)."""
+        return lib().msm_hip_mgpu_group_size(self._h)
+
+    def launch_batch(self, scalars, n, slot=0):
+        """`scalars`: nvec x n x 32 B of host bytes (every device uploads them), or a list with one CUDA uint8 tensor per device
+        holding the same bytes.  Returns nvec; finish_batch(slot, nvec) collects."""
+        if isinstance(scalars, (list, tuple)):
+            ts = [_as_device_u8(t, 32, "scalars")[0] for t in scalars]
+            rows = ts[0].numel() // 32
+            if n <= 0 or rows % n or any(t.numel() != ts[0].numel() for t in ts):
+                raise ValueError("every device needs the same whole number of n-element vectors")
+            ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+            _check(lib().msm_hip_mgpu_launch_batch_device_bn254(self._h, ptrs, n, rows // n, slot), "msm_hip_mgpu_launch_batch_device_bn254")
+            self._keep = getattr(self, "_keep", {})
+            self._keep[slot] = ts
+            return rows // n
+        b = bytes(scalars)
+        if n <= 0 or len(b) % (32 * n):
+            raise ValueError("scalars must hold a whole number of n-element vectors")
+        self._keep = getattr(self, "_keep", {})
+        self._keep[slot] = b  # the library reads the buffer until finish
+        _check(lib().msm_hip_mgpu_launch_batch_bn254(self._h, b, n, len(b) // (32 * n), slot), "msm_hip_mgpu_launch_batch_bn254")
+        return len(b) // (32 * n)
+
+    def finish_batch(self, slot, nvec):
+        out = C.create_string_buffer(96 * nvec)
+        try:
+            _check(lib().msm_hip_mgpu_finish_batch_bn254(self._h, slot, out), "msm_hip_mgpu_finish_batch_bn254")
+        finally:
+            getattr(self, "_keep", {}).pop(slot, None)
+        return [G1(out.raw[96 * k:96 * k + 96], self.modulus) for k in range(nvec)]
 
 
 def window_range_abi(rank, world, num=NUM_WINDOWS):

@@ -23,6 +23,7 @@
 
 #include "../../include/msm_hip.h"
 #include "curve_ops.h"
+#include "host_pool.h"
 
 // the arithmetic and the kernels of BN254's unit (csrc/curve_select.h); the other curves' units are separate translation units (curve_ops.h)
 #define MSM_FIELD_NS bn254
@@ -116,7 +117,9 @@ struct msm_hip_ctx {
   size_t cap_chunk_slot = 0;  // capacity (records) of d_chunk_slot
   uint8_t* d_batch_stage = nullptr;   // staging ring (NSLOT vectors) of msm_hip_run_batch_bn254, allocated on first use
   size_t cap_batch_stage = 0;
-  uint16_t* d_digits = nullptr;  // digit-code planes, only written when debug read-back is enabled
+  uint16_t* d_digits = nullptr;  // digit-code planes [local window][n]: debug read-back, or the input of the second sort pass (k_scatter_planes)
+  uint64_t* d_negbits = nullptr; // with the planes of a launch: one sign bit per input of every vector
+  size_t cap_planes = 0;         // capacity (u16 entries) of d_digits; d_negbits holds cap_planes / 64 + MAXLW words
   bool debug = false;
   int timing_level = 2;  // 0: no stage events, 1: only around the SMVP kernel, 2: every stage boundary
   uint32_t* d_counts = nullptr;      // [W][tiles][128]
@@ -258,23 +261,31 @@ int setup_slot(msm_hip_ctx* ctx, Slot& s) {
 
 // make the pools fit a launch of `w_count` local windows (vectors x windows) over n points into slot `s` (not pending)
 // (`full_windows`: the windows of one whole MSM in the launch's mode -- the sort arrays are sized for at least that many)
-int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, int full_windows, Slot& s) {
+int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, int full_windows, Slot& s, bool planes) {
   int rc;
   if ((rc = setup_slot(ctx, s))) return rc;
   const size_t need_recs = (size_t)w_count * chunks_for(n, chunk_len_for(n, w_count));
   const size_t need_entries = stride_for(n) * (size_t)w_count;
-  if (need_entries > ctx->cap_entries || need_recs > ctx->cap_chunk_slot || (ctx->debug && !ctx->d_digits)) {
+  if ((planes || ctx->debug) && need_entries > ctx->cap_planes) {  // digit planes (main stream only, like the sort arrays)
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    size_t entries = stride_for(n) * (size_t)full_windows;
+    if (entries < need_entries) entries = need_entries;
+    if (entries < ctx->cap_entries) entries = ctx->cap_entries;
+    ctx->cap_planes = 0;
+    if ((rc = dev_alloc(ctx, ctx->d_digits, entries))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->d_negbits, entries / 64 + MAXLW))) return rc;
+    ctx->cap_planes = entries;
+  }
+  if (need_entries > ctx->cap_entries || need_recs > ctx->cap_chunk_slot) {
     // growing the context-wide sort arrays (main stream only): nothing may still be running on them
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     size_t entries = stride_for(n) * (size_t)full_windows;  // any single MSM over up to n entries per window
     if (entries < need_entries) entries = need_entries;
-    if (entries > ctx->cap_entries || (ctx->debug && !ctx->d_digits)) {
-      if (entries < ctx->cap_entries) entries = ctx->cap_entries;
+    if (entries > ctx->cap_entries) {
       ctx->cap_entries = 0;
       if ((rc = dev_alloc(ctx, ctx->d_tmp_val, entries))) return rc;
       if ((rc = dev_alloc(ctx, ctx->d_tmp_fine, entries))) return rc;
       if ((rc = dev_alloc(ctx, ctx->d_val, entries))) return rc;
-      if (ctx->debug && (rc = dev_alloc(ctx, ctx->d_digits, entries))) return rc;
       ctx->cap_entries = entries;
     }
     size_t recs = piece_records_for(n);
@@ -357,6 +368,18 @@ int err_from_bits(uint32_t bits) {
   return MSM_HIP_OK;
 }
 
+// Does a launch's second sort pass read digit planes left by the first (k_scatter_planes) instead of the scalars again?  Yes for window
+// shares -- at most PLANES_MAX_W of a vector's windows (8 GPUs: 2 of 16, or 1 of 8 half-length windows): 2 B per (input, window) instead
+// of 32 B per scalar, and no scalars held in registers.  Not for fixed-base tables (one bucket set per vector) and not while the debug
+// read-back wants the planes in its own format.  MSM_HIP_PLANES_MAX_W overrides the limit (0: never; tuning aid).
+inline bool use_planes(const msm_hip_ctx* ctx, LaunchMode mode, int w_count_vec, int wbits) {
+  static const int max_w = [] { const char* e = getenv("MSM_HIP_PLANES_MAX_W"); return e ? atoi(e) : 8; }();
+  static const bool whole = [] { const char* e = getenv("MSM_HIP_PLANES_WHOLE"); return e && e[0] == '1'; }();  // A/B aid: whole MSMs too
+  if (mode == MODE_TABLES || ctx->debug) return false;
+  if (whole) return true;
+  return w_count_vec <= max_w && w_count_vec < nwin_of(wbits, mode == MODE_HALVES);
+}
+
 // Enqueue one MSM (windows [w_begin, w_begin + w_count)) into slot `s`.  Window sums (canonical Jacobian bytes) go to
 // `wsums_out` (device memory; the slot's own buffer when null); the error word and, if `to_host`, the window sums are
 // copied to the slot's pinned buffer.  Returns without waiting.
@@ -385,6 +408,8 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   const size_t stride = stride_for(n_entries);
   ctx->last_stride = stride;
   uint16_t* digits = ctx->debug && !merge ? ctx->d_digits : nullptr;
+  // window shares (a few of a scalar's windows per vector): the first pass leaves digit planes, the second reads them (k_scatter_planes)
+  const bool planes = use_planes(ctx, mode, w_count_vec, wbits);
   uint32_t* d_err = reinterpret_cast<uint32_t*>(s.d_wsums + WSUM_BYTES);
   if (!wsums_out) wsums_out = reinterpret_cast<uint32_t*>(s.d_wsums);
   // the SMVP chunk length the device settles on for this launch (k_scatter_coarse -> fine sort, SMVP, stitch): a word of the slot
@@ -424,15 +449,22 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     else LAUNCH_BY_WBITS_SW(KERNEL, 8, __VA_ARGS__);           \
   } while (0)
   // (a vector's 2n halves take the room of its n scalars: the vector stride is n * 8 words either way)
-  LAUNCH_BY_WBITS(k_count, d_scalars, n_sc, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, digits, d_err, merge_nb);
+  LAUNCH_BY_WBITS(k_count, d_scalars, n_sc, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, planes ? ctx->d_digits : digits,
+                  planes ? ctx->d_negbits : nullptr, d_err, merge_nb);
   AFTER_KERNEL(ctx, "k_count", st);
   HIP_TRY(ctx, mark(1, false));
   hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total);  // all 128 bins: the scatter scans them
   AFTER_KERNEL(ctx, "k_scan_tiles", st);
   HIP_TRY(ctx, mark(2, false));
-  LAUNCH_BY_WBITS(k_scatter_coarse, d_scalars, n_sc, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
-                  ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, (uint32_t)n, (uint32_t)(ctx->n_bases - n), chunks, chunk_len,
-                  d_chunk_len);
+  if (planes) {
+    hipLaunchKernelGGL(k_scatter_planes, dim3(tiles), dim3(256), 0, st, ctx->d_digits, ctx->d_negbits, n_sc, stride, tile_len, tiles, w_count, w_count_vec,
+                       ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, halves ? (uint32_t)n : 0xffffffffu,
+                       halves ? (uint32_t)(ctx->n_bases - n) : 0u, chunks, chunk_len, d_chunk_len);
+  } else {
+    LAUNCH_BY_WBITS(k_scatter_coarse, d_scalars, n_sc, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
+                    ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, (uint32_t)n, (uint32_t)(ctx->n_bases - n), chunks, chunk_len,
+                    d_chunk_len);
+  }
 #undef LAUNCH_BY_WBITS
 #undef LAUNCH_BY_WBITS_SW
   AFTER_KERNEL(ctx, "k_scatter_coarse", st);
@@ -656,7 +688,7 @@ int run_batch_groups(msm_hip_ctx* ctx, size_t n, size_t batch, uint8_t* out_xyz,
 
 extern "C" {
 
-int msm_hip_abi_version(void) { return 5; }
+int msm_hip_abi_version(void) { return 6; }
 
 const char* msm_hip_strerror(int code) {
   switch (code) {
@@ -723,7 +755,7 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   for (hipStream_t r : ctx->reduce_stream)
     if (r) (void)hipStreamSynchronize(r);
-  void* bufs[] = {ctx->d_bases,   ctx->d_halves, ctx->d_batch_stage, ctx->d_scalar_conv, ctx->d_part_hist, ctx->d_digits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
+  void* bufs[] = {ctx->d_bases,   ctx->d_halves, ctx->d_batch_stage, ctx->d_scalar_conv, ctx->d_part_hist, ctx->d_digits, ctx->d_negbits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
                   ctx->d_tmp_val, ctx->d_tmp_fine, ctx->d_val,    ctx->d_chunk_slot, ctx->d_err,       ctx->d_stage};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -810,7 +842,7 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
     return MSM_HIP_OK;
   }
   if ((rc = ensure_work(ctx, merge ? n * (size_t)w_count : halves ? 2 * n : n, w_local, wbits,
-                        merge ? 1 : halves ? nwin_of(wbits, true) : NWIN, s))) return rc;
+                        merge ? 1 : halves ? nwin_of(wbits, true) : NWIN, s, use_planes(ctx, mode, w_count, wbits)))) return rc;
   if (halves && (size_t)nvec * n > ctx->cap_halves) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cap_halves = 0;
@@ -847,6 +879,13 @@ int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scal
   return launch_impl(ctx, scalars_dev, n, nvec, w_begin, w_end, WBITS, slot, window_sums_dev);
 }
 
+int msm_hip_launch_half_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int hw_begin, int hw_end,
+                                                   int slot, void* window_sums_dev) {
+  if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  if (!ctx->endo && ctx->n_bases) return MSM_HIP_ERR_INVALID_ARG;  // needs bases set with MSM_HIP_BASES_ENDOMORPHISM
+  return launch_impl(ctx, scalars_dev, n, nvec, hw_begin, hw_end, WBITS, slot, window_sums_dev, MODE_HALVES);
+}
+
 int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot,
                                         void* window_sums_dev) {
   return msm_hip_launch_windows_batch_device_bn254(ctx, scalars_dev, n, 1, w_begin, w_end, slot, window_sums_dev);
@@ -881,11 +920,13 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   int rc = wait_slot(ctx, s);
   if (rc) return rc;
   auto t0 = std::chrono::steady_clock::now();
-  for (int v = 0; v < s.nvec; v++) {
+  std::atomic<bool> all_ok{true};
+  combine_pool().run(s.nvec, [&](int v) {  // one independent Horner chain per MSM of the launch: side by side when there are several
     const bool ok = s.parts ? ctx->ops->combine_window_parts(s.h_wsums + (size_t)v * nwin * 288, nwin, s.wbits, out_xyz + 96 * (size_t)v)
                             : ctx->ops->combine_windows(s.h_wsums + (size_t)v * nwin * 96, nwin, s.wbits, out_xyz + 96 * (size_t)v);
-    if (!ok) return MSM_HIP_ERR_HIP;
-  }
+    if (!ok) all_ok = false;
+  });
+  if (!all_ok) return MSM_HIP_ERR_HIP;
   ctx->stage_ms[8] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return MSM_HIP_OK;
 }
@@ -998,6 +1039,18 @@ int msm_hip_combine_windows_bn254(const uint8_t* window_sums_host, int num_windo
   if (!window_sums_host || !out_xyz || num_windows < 1 || num_windows > NWIN) return MSM_HIP_ERR_INVALID_ARG;
   if (!bn254::host::combine_windows(window_sums_host, num_windows, WBITS, out_xyz)) return MSM_HIP_ERR_NONCANONICAL;
   return MSM_HIP_OK;
+}
+
+int msm_hip_combine_windows_batch_curve(int curve, const uint8_t* window_sums_host, int num_windows, int nvec, uint8_t* out_xyz) {
+  if (curve < 0 || curve >= MSM_HIP_NUM_CURVES) return MSM_HIP_ERR_INVALID_ARG;
+  if (!window_sums_host || !out_xyz || num_windows < 1 || num_windows > NWIN || nvec < 0) return MSM_HIP_ERR_INVALID_ARG;
+  const CurveOps* ops = curve_ops(curve);
+  std::atomic<bool> ok{true};
+  // independent Horner chains (47 us each on one core): side by side on the combine pool when there are several
+  combine_pool().run(nvec, [&](int v) {
+    if (!ops->combine_windows(window_sums_host + (size_t)v * num_windows * 96, num_windows, WBITS, out_xyz + (size_t)v * 96)) ok = false;
+  });
+  return ok ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
 }
 
 int msm_hip_g1_to_affine_bn254(const uint8_t xyz[96], uint8_t out_xy[64]) {

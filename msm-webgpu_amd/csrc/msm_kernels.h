@@ -357,10 +357,17 @@ __global__ void __launch_bounds__(256) k_scalars_from_mont256(const uint32_t* __
 // `nvec` scalar vectors (vec_stride words apart) may share one launch: vector v, window w is handled as local window
 // lw = v * w_count + (w - w_begin), nvec * w_count <= MAXLW -- several MSMs over the same bases sorted, accumulated and reduced
 // by one kernel sequence (used by the window-sharded multi-GPU pipeline, where one MSM's share is too small to fill a GPU).
+//
+// Digit planes.  `planes` (may be null) receives every local window's digit code, u16 planes[lw][n]:
+//   negbits == null  (debug read-back, msm_hip_read_digits): the half's sign folded into bit 15;
+//   negbits != null  (the launch's second pass reads the planes instead of the scalars, k_scatter_planes): the raw code, and the
+//                    signs of a vector's inputs as one bit each, negbits[v][n / 64 rounded up] (all zero for 8-word scalars).
+// A rank of a window-sharded run needs 1 - 4 of a scalar's 16 digits: its second pass then reads 2 - 8 B per scalar instead of 32,
+// and keeps no scalar in registers (the scalar-reading scatter holds 8 biased scalars per thread: 282 VGPRs at 16 bits).
 template <int C, int SW>
 __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles,
                                                int w_begin, int w_count, int nvec, size_t vec_stride,
-                                               uint32_t* __restrict__ counts, uint16_t* __restrict__ digits_dbg,
+                                               uint32_t* __restrict__ counts, uint16_t* __restrict__ planes, uint64_t* __restrict__ negbits,
                                                uint32_t* __restrict__ err, size_t merge_nb) {
   // merge_nb != 0 (fixed-base tables, see k_precompute_tables): every window of vector v feeds ONE bucket set, local window v
   __shared__ uint32_t cnt[MAXLW * NCOARSE];
@@ -370,17 +377,27 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * tile_len;
   const size_t end = base + tile_len < n ? base + tile_len : n;
+  const size_t neg_words = (n + 63) / 64;
   uint32_t bad = 0;
   for (int v = 0; v < nvec; v++) {
     const uint32_t* sv = scalars + (size_t)v * vec_stride;
-    for (size_t i = base + tid; i < end; i += 256) {
-      uint32_t s[SW], tb[WinCfg<C, SW>::WORDS], neg;
-      ld_scalar<SW>(sv + i * SW, s, neg);
+    for (size_t i0 = base; i0 < end; i0 += 256) {  // (tile_len is a multiple of 256: a wave's 64 inputs share one word of negbits)
+      const size_t i = i0 + tid;
+      const bool valid = i < end;
+      uint32_t s[SW], tb[WinCfg<C, SW>::WORDS], neg = 0;
+#pragma unroll
+      for (int k = 0; k < SW; k++) s[k] = 0;  // an all-zero scalar recodes to all-zero digits
+      if (valid) ld_scalar<SW>(sv + i * SW, s, neg);
       bad |= bias_scalar<C, SW>(s, tb);
       if constexpr (C != 16 && SW == 8) {  // the same input contract for every window size: scalars that overflow the reference's
         uint32_t t16[8];                   // 16-bit recode ("final carry is 1", test/utils.rs:150-152) are rejected
         bad |= bias_scalar<16>(s, t16);    // (halves: k_glv_split checks the scalar they come from)
       }
+      if (negbits) {
+        const unsigned long long nb = __ballot(neg != 0u);
+        if ((tid & 63) == 0 && i < end) negbits[(size_t)v * neg_words + i / 64] = nb;
+      }
+      if (!valid) continue;
 #pragma unroll
       for (int w = 0; w < WinCfg<C, SW>::NWIN; w++) {
         const int lw = w - w_begin;
@@ -388,7 +405,7 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
           const int le = merge_nb ? v : v * w_count + lw;
           const uint32_t code = code_of_window<C>(tb, w);
           if (code != 0) atomicAdd(&cnt[le * NCOARSE + ((code & 0x7fffu) >> 8)], 1u);
-          if (digits_dbg) digits_dbg[((size_t)v * w_count + lw) * n + i] = (uint16_t)(code ? code ^ (neg << 15) : 0u);
+          if (planes) planes[((size_t)v * w_count + lw) * n + i] = (uint16_t)(negbits ? code : (code ? code ^ (neg << 15) : 0u));
         }
       }
     }
@@ -563,6 +580,103 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
       __syncthreads();
       uint32_t* ov = tmp_val + (size_t)lw * stride;
       uint8_t* of = tmp_fine + (size_t)lw * stride;
+      for (uint32_t e = tid; e < total; e += 256) {
+        const uint32_t d = st_dst[e];
+        ov[d] = st_val[e];
+        of[d] = st_fine[e];
+      }
+      if (tid < NCOARSE) gpos[lw * NCOARSE + tid] += hist[tid];
+      __syncthreads();
+    }
+  }
+}
+
+// The second pass of a launch whose first pass left digit planes (k_count with negbits != null): the same LDS-ranked, LDS-staged
+// scatter as k_scatter_coarse, reading 2 B per (input, local window) from the planes.  No scalar arithmetic and no scalars in
+// registers.  `w_eff` local windows of `w_count_vec` windows per scalar vector; input `pos` of a vector is scalar / half `pos`,
+// its sign bit `pos` of the vector's negbits; inputs from half_n on multiply the record half_shift further on (endomorphism).
+__global__ void __launch_bounds__(256) k_scatter_planes(const uint16_t* __restrict__ planes, const uint64_t* __restrict__ negbits, size_t n,
+                                                        size_t stride, uint32_t tile_len, uint32_t tiles, int w_eff, int w_count_vec,
+                                                        const uint32_t* __restrict__ counts, const uint32_t* __restrict__ bin_total,
+                                                        uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ tmp_val,
+                                                        uint8_t* __restrict__ tmp_fine, uint32_t half_n, uint32_t half_shift,
+                                                        uint32_t chunks, uint32_t host_chunk_len, uint32_t* __restrict__ chunk_len_dev) {
+  __shared__ uint32_t gpos[MAXLW * NCOARSE];
+  __shared__ uint32_t hist[NCOARSE];
+  __shared__ uint32_t lstart[NCOARSE];
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t st_val[SCAT_SUB];
+  __shared__ uint32_t st_dst[SCAT_SUB];
+  __shared__ uint8_t st_fine[SCAT_SUB];
+  __shared__ uint32_t max_total;
+  const int tid = threadIdx.x;
+  if (tid == 0) max_total = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < w_eff * NCOARSE; i0 += 256) {  // bin starts of every local window: as k_scatter_coarse
+    const int i = i0 + tid, lw = i / NCOARSE, bin = i % NCOARSE, lane = tid & 63;
+    const bool live = i < w_eff * NCOARSE;
+    const uint32_t v = live ? bin_total[i] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[tid >> 6] = x;
+    __syncthreads();
+    const uint32_t incl = x + ((tid >> 6) & 1 ? wave_tot[(tid >> 6) - 1] : 0u);
+    if (live) gpos[i] = incl - v + counts[((size_t)lw * tiles + blockIdx.x) * NCOARSE + bin];
+    if (live && blockIdx.x == 0) {
+      coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin] = incl - v;
+      if (bin == NCOARSE - 1) {
+        coarse_ptr[(size_t)lw * (NCOARSE + 1) + NCOARSE] = incl;
+        atomicMax(&max_total, incl);
+      }
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && tid == 0) *chunk_len_dev = smvp_chunk_len(max_total, chunks, host_chunk_len);
+  const size_t tile_base = (size_t)blockIdx.x * tile_len;
+  const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
+  const size_t neg_words = (n + 63) / 64;
+  for (int lw = 0; lw < w_eff; lw++) {
+    const uint16_t* pl = planes + (size_t)lw * n;
+    const uint64_t* nb = negbits + (size_t)(lw / w_count_vec) * neg_words;
+    uint32_t* ov = tmp_val + (size_t)lw * stride;
+    uint8_t* of = tmp_fine + (size_t)lw * stride;
+    for (size_t sub = tile_base; sub < tile_end; sub += SCAT_SUB) {
+      uint32_t code[8];
+      uint32_t negs = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const size_t i = sub + (size_t)j * 256 + tid;
+        code[j] = i < tile_end ? pl[i] : 0u;
+        if (i < tile_end) negs |= (uint32_t)((nb[i / 64] >> (i & 63)) & 1ull) << j;  // (i - lane is a multiple of 64: one word per wave)
+      }
+      if (tid < NCOARSE) hist[tid] = 0;
+      __syncthreads();
+      uint32_t rank[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) rank[j] = code[j] ? atomicAdd(&hist[(code[j] & 0x7fffu) >> 8], 1u) : 0u;
+      __syncthreads();
+      const uint32_t mine = tid < NCOARSE ? hist[tid] : 0u;
+      const uint32_t excl = block_excl_scan_256(mine, wave_tot);
+      if (tid < NCOARSE) lstart[tid] = excl;
+      __syncthreads();
+      const uint32_t total = lstart[NCOARSE - 1] + hist[NCOARSE - 1];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (code[j]) {
+          const uint32_t slot = code[j] & 0x7fffu, bin = slot >> 8;
+          const uint32_t e = lstart[bin] + rank[j];
+          uint32_t pos = (uint32_t)(sub + (size_t)j * 256 + tid);
+          pos += pos >= half_n ? half_shift : 0u;
+          st_val[e] = pos | (((code[j] >> 15) ^ ((negs >> j) & 1u)) << 31);
+          st_fine[e] = (uint8_t)(slot & 0xffu);
+          st_dst[e] = gpos[lw * NCOARSE + bin] + rank[j];
+        }
+      }
+      __syncthreads();
       for (uint32_t e = tid; e < total; e += 256) {
         const uint32_t d = st_dst[e];
         ov[d] = st_val[e];

@@ -2,15 +2,23 @@
 //
 // The reference is single-device (src/cuzk/msm.rs:88-94 creates one wgpu device per call); BASELINE.json's north star shards
 // the independent Pippenger windows over the GPUs of a node "with a final RCCL gather/reduce of partial sums over xGMI".
-//   one MSM      : device d computes the window sums of its contiguous window range (msm_hip_window_range; bases replicated,
-//                  every device gets all scalars), the ranges' sums are gathered -- ncclAllGather of per x 96 B per device over
-//                  RCCL (librccl is loaded at run time), or through each slot's pinned result buffer -- and the host window
-//                  combine (src/cuzk/msm.rs:411-416) runs ONCE.
-//   many MSMs    : whole MSMs are dealt out contiguously (BASELINE config 5); no exchange at all.
+//
+//   window-sharded launches (msm_hip_mgpu_launch_batch_* / msm_hip_mgpu_finish_batch_bn254; msm_hip_mgpu_run_bn254 = one vector, slot 0):
+//     device d computes the window sums of ITS window range for every scalar vector of the launch -- `nvec` MSMs' shares go through
+//     one kernel sequence per device, because one MSM's share (2 of 16 windows at 8 GPUs) cannot fill a GPU -- into result slot
+//     `slot` of its context; the shares are gathered with ONE ncclAllGather per launch, in stream order behind each device's bucket
+//     reduce (librccl is loaded at run time), or through the slots' pinned buffers; one host window combine per MSM
+//     (src/cuzk/msm.rs:411-416), spread over the host pool.  With endomorphism bases the windows are the 8 half-length ones.
+//     Launches are asynchronous: every device has a persistent host thread that issues its HIP / RCCL calls, so the caller can keep
+//     several result slots in flight (launch k + 1 and k + 2 run while launch k is gathered and combined).
+//   many whole MSMs (msm_hip_mgpu_run_batch_bn254): dealt out contiguously (BASELINE config 5); no exchange at all.
 // Included by msm_hip.hip (same translation unit: it uses the context internals).
 #pragma once
 #include <dlfcn.h>
 
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -43,6 +51,69 @@ struct RcclApi {
 };
 constexpr int NCCL_UINT8 = 1;  // ncclUint8 (rccl.h)
 
+// One persistent host thread per device: runs the closures posted to it in order.  H2D copies from pageable memory block their
+// thread, and a launch is ~100 us of HIP calls: with a thread per device the devices' uploads and launches proceed side by side,
+// and the caller's thread stays free (round 2 spawned the threads per call).
+class DeviceWorker {
+ public:
+  DeviceWorker() : th_([this] { loop(); }) {}
+  ~DeviceWorker() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    th_.join();
+  }
+  uint64_t post(std::function<void()> f) {  // returns the ticket wait() takes
+    std::lock_guard<std::mutex> lk(mu_);
+    q_.push_back(std::move(f));
+    cv_.notify_all();
+    return ++posted_;
+  }
+  void wait(uint64_t ticket) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return done_ >= ticket; });
+  }
+
+ private:
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+      if (q_.empty()) return;  // stop requested and nothing left to run
+      std::function<void()> f = std::move(q_.front());
+      q_.pop_front();
+      lk.unlock();
+      f();
+      lk.lock();
+      done_++;
+      cv_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> q_;
+  uint64_t posted_ = 0, done_ = 0;
+  bool stop_ = false;
+  std::thread th_;  // last: the thread starts when every other member exists
+};
+
+// what a result slot of the multi-GPU object holds between launch and finish
+struct MgpuSlot {
+  bool pending = false;
+  int nvec = 0;
+  size_t n = 0;
+  bool halves = false;           // the windows are the 8 half-length ones (endomorphism bases)
+  uint64_t ticket[MGPU_MAX] = {};  // the launch job of every device
+  int rc[MGPU_MAX] = {};           // ... and its status
+  bool launched[MGPU_MAX] = {};    // the device's context slot holds an unfinished launch
+  uint8_t* d_send[MGPU_MAX] = {};    // MAXLW x 96 B: this device's window sums [nvec][its windows], then padding
+  uint8_t* d_gather[MGPU_MAX] = {};  // n x MAXLW x 96 B: every device's block after the all-gather
+  uint8_t* h_gather = nullptr;       // pinned copy of device 0's gather buffer
+  hipEvent_t gathered = nullptr;     // device 0: h_gather is complete
+};
+
 }  // namespace
 
 struct msm_hip_mgpu {
@@ -50,26 +121,98 @@ struct msm_hip_mgpu {
   int n = 0;
   int device[MGPU_MAX] = {};
   msm_hip_ctx* ctx[MGPU_MAX] = {};
+  DeviceWorker* worker[MGPU_MAX] = {};
   bool rccl = false;
+  bool endo = false;  // the resident bases carry their endomorphism images: window-sharded launches use the 8 half-length windows
   RcclApi api;
   void* comm[MGPU_MAX] = {};
-  uint8_t* d_send[MGPU_MAX] = {};    // per x 96 B: this device's window sums, padded to the largest share
-  uint8_t* d_gather[MGPU_MAX] = {};  // n x per x 96 B: every device's sums after the all-gather
-  uint8_t* h_gather = nullptr;       // pinned copy of device 0's gather buffer
+  hipStream_t gather_stream[MGPU_MAX] = {};  // the collective and the copy to the host: behind the slot's bucket reduce, beside the next one
+  MgpuSlot slot[NSLOT];
 };
 
-// run f(d) for every device on its own host thread (device 0 on the caller's): H2D copies from pageable memory block their
-// thread, so the devices' uploads and launches proceed side by side
 namespace {
+// run f(d) for every device on its worker thread and wait for all of them
 template <typename F>
 int mgpu_for_each(msm_hip_mgpu* m, F f) {
-  std::vector<int> rc(m->n, MSM_HIP_OK);
-  std::vector<std::thread> th;
-  for (int d = 1; d < m->n; d++) th.emplace_back([&, d] { rc[d] = f(d); });
-  rc[0] = f(0);
-  for (std::thread& t : th) t.join();
+  int rc[MGPU_MAX] = {};
+  uint64_t ticket[MGPU_MAX];
+  for (int d = 0; d < m->n; d++) ticket[d] = m->worker[d]->post([&rc, &f, d] { rc[d] = f(d); });
+  for (int d = 0; d < m->n; d++) m->worker[d]->wait(ticket[d]);
   for (int d = 0; d < m->n; d++)
     if (rc[d]) return rc[d];
+  return MSM_HIP_OK;
+}
+
+inline int mgpu_windows(const msm_hip_mgpu* m, bool halves) { return halves ? nwin_of(WBITS, true) : NWIN; }
+inline int mgpu_per(const msm_hip_mgpu* m, bool halves) { return (mgpu_windows(m, halves) + m->n - 1) / m->n; }
+
+// device d's part of a window-sharded launch (on its worker thread): scalars up (host variant), its window range of every vector
+// into context slot `k`, then -- RCCL -- its call of the launch's all-gather, in stream order behind the slot
+int mgpu_launch_on_device(msm_hip_mgpu* m, int d, int k, const void* scalars, bool host_scalars, size_t n, int nvec) {
+  MgpuSlot& ms = m->slot[k];
+  msm_hip_ctx* ctx = m->ctx[d];
+  const bool halves = ms.halves;
+  const int W = mgpu_windows(m, halves), rows = nvec * mgpu_per(m, halves);
+  int b, e;
+  (void)msm_hip_window_range(d, m->n, W, &b, &e);
+  int rc = MSM_HIP_OK;
+  if (e > b) {
+    const void* dev = scalars;
+    if (host_scalars) {  // all vectors of the launch into the slot's staging buffer, on the copy stream
+      ON_DEVICE(ctx);
+      Slot& s = ctx->slot[k];
+      if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;
+      if ((rc = setup_slot(ctx, s))) return rc;
+      if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+      const size_t count = (size_t)nvec * n;
+      if (count > s.cap_host_scalars) {
+        s.cap_host_scalars = 0;
+        if ((rc = dev_alloc(ctx, s.d_host_scalars, count * 8))) return rc;
+        s.cap_host_scalars = count;
+      }
+      HIP_TRY(ctx, hipMemcpyAsync(s.d_host_scalars, scalars, count * 32, hipMemcpyHostToDevice, ctx->copy_stream));
+      HIP_TRY(ctx, hipEventRecord(s.staged, ctx->copy_stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.staged, 0));
+      dev = s.d_host_scalars;
+    }
+    void* sums = m->rccl ? ms.d_send[d] : nullptr;  // host gather: the sums leave through the context slot's pinned buffer
+    rc = launch_impl(ctx, dev, n, nvec, b, e, WBITS, k, sums, halves ? MODE_HALVES : MODE_PLAIN);
+    if (rc) return rc;
+    ms.launched[d] = true;
+  }
+  if (m->rccl) {
+    ON_DEVICE(ctx);
+    hipStream_t gs = m->gather_stream[d];
+    if (e > b) HIP_TRY(ctx, hipStreamWaitEvent(gs, ctx->slot[k].done, 0));
+    if (m->api.AllGather(ms.d_send[d], ms.d_gather[d], (size_t)rows * 96, NCCL_UINT8, m->comm[d], gs) != 0) return MSM_HIP_ERR_HIP;
+    if (d == 0) {
+      HIP_TRY(ctx, hipMemcpyAsync(ms.h_gather, ms.d_gather[0], (size_t)m->n * rows * 96, hipMemcpyDeviceToHost, gs));
+      HIP_TRY(ctx, hipEventRecord(ms.gathered, gs));
+    }
+  }
+  return MSM_HIP_OK;
+}
+
+int mgpu_launch(msm_hip_mgpu* m, const void* const* per_device, const void* host, bool is_host, size_t n, int nvec, int k) {
+  if (!m || k < 0 || k >= NSLOT || nvec < 1 || n > MAX_POINTS) return MSM_HIP_ERR_INVALID_ARG;
+  MgpuSlot& ms = m->slot[k];
+  if (ms.pending) return MSM_HIP_ERR_SLOT_BUSY;
+  const bool halves = m->endo;
+  if (nvec * mgpu_per(m, halves) > MAXLW) return MSM_HIP_ERR_INVALID_ARG;
+  if (n && m->ctx[0]->n_bases == 0) return MSM_HIP_ERR_NO_BASES;
+  if (n > m->ctx[0]->n_bases) return MSM_HIP_ERR_INVALID_ARG;
+  ms.pending = true;
+  ms.nvec = nvec;
+  ms.n = n;
+  ms.halves = halves;
+  for (int d = 0; d < m->n; d++) {
+    ms.launched[d] = false;
+    ms.rc[d] = MSM_HIP_OK;
+    const void* sc = is_host ? host : per_device[d];
+    ms.ticket[d] = m->worker[d]->post([m, d, k, sc, is_host, n, nvec] {
+      m->slot[k].rc[d] = n ? mgpu_launch_on_device(m, d, k, sc, is_host, n, nvec) : MSM_HIP_OK;
+    });
+  }
   return MSM_HIP_OK;
 }
 
@@ -87,16 +230,34 @@ int msm_hip_window_range(int rank, int world, int num_windows, int* w_begin, int
 
 void msm_hip_mgpu_destroy(msm_hip_mgpu* m) {
   if (!m) return;
+  for (int k = 0; k < NSLOT; k++)  // unfinished launches: their jobs must have run before anything is torn down
+    if (m->slot[k].pending)
+      for (int d = 0; d < m->n; d++)
+        if (m->worker[d]) m->worker[d]->wait(m->slot[k].ticket[d]);
+  for (int d = 0; d < m->n; d++) {
+    delete m->worker[d];  // (runs what is still queued, then joins)
+    m->worker[d] = nullptr;
+  }
+  for (int d = 0; d < m->n; d++)  // every device's part of the collectives still in flight, before any communicator goes
+    if (m->ctx[d] && m->gather_stream[d]) {
+      DeviceGuard guard(m->device[d]);
+      (void)hipStreamSynchronize(m->gather_stream[d]);
+    }
   for (int d = 0; d < m->n; d++) {
     if (m->ctx[d]) {
       DeviceGuard guard(m->device[d]);
       if (m->comm[d]) (void)m->api.CommDestroy(m->comm[d]);
-      if (m->d_send[d]) (void)hipFree(m->d_send[d]);
-      if (m->d_gather[d]) (void)hipFree(m->d_gather[d]);
+      for (MgpuSlot& ms : m->slot) {
+        if (ms.d_send[d]) (void)hipFree(ms.d_send[d]);
+        if (ms.d_gather[d]) (void)hipFree(ms.d_gather[d]);
+        if (d == 0 && ms.gathered) (void)hipEventDestroy(ms.gathered);
+      }
+      if (m->gather_stream[d]) (void)hipStreamDestroy(m->gather_stream[d]);
     }
     msm_hip_ctx_destroy(m->ctx[d]);
   }
-  if (m->h_gather) (void)hipHostFree(m->h_gather);
+  for (MgpuSlot& ms : m->slot)
+    if (ms.h_gather) (void)hipHostFree(ms.h_gather);
   delete m;
 }
 
@@ -123,19 +284,30 @@ int msm_hip_mgpu_create_curve(msm_hip_mgpu** out, const int* device_ids, int n_d
       msm_hip_mgpu_destroy(m);
       return rc;
     }
+    m->worker[d] = new (std::nothrow) DeviceWorker();
+    if (!m->worker[d]) {
+      msm_hip_mgpu_destroy(m);
+      return MSM_HIP_ERR_OUT_OF_MEMORY;
+    }
   }
   // gather transport: RCCL when asked for, or by default when there is more than one (distinct) device and librccl loads
   const bool want_rccl = flags == MSM_HIP_MGPU_GATHER_RCCL || (flags == MSM_HIP_MGPU_GATHER_AUTO && n_devices > 1 && distinct);
   if (want_rccl) {
     bool ok = distinct && m->api.load() && m->api.CommInitAll(m->comm, n_devices, m->device) == 0;
-    const int per = (NWIN + n_devices - 1) / n_devices;
     for (int d = 0; ok && d < n_devices; d++) {
       DeviceGuard guard(m->device[d]);
-      ok = guard.ok && hipMalloc((void**)&m->d_send[d], (size_t)per * 96) == hipSuccess &&
-           hipMalloc((void**)&m->d_gather[d], (size_t)n_devices * per * 96) == hipSuccess &&
-           hipMemset(m->d_send[d], 0, (size_t)per * 96) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+      ok = guard.ok && hipStreamCreateWithFlags(&m->gather_stream[d], hipStreamNonBlocking) == hipSuccess;
+      for (int k = 0; ok && k < NSLOT; k++) {
+        MgpuSlot& ms = m->slot[k];
+        ok = hipMalloc((void**)&ms.d_send[d], (size_t)MAXLW * 96) == hipSuccess &&
+             hipMalloc((void**)&ms.d_gather[d], (size_t)n_devices * MAXLW * 96) == hipSuccess &&
+             hipMemset(ms.d_send[d], 0, (size_t)MAXLW * 96) == hipSuccess;
+        if (ok && d == 0) ok = hipEventCreateWithFlags(&ms.gathered, hipEventDisableTiming) == hipSuccess;
+      }
+      ok = ok && hipDeviceSynchronize() == hipSuccess;
     }
-    ok = ok && hipHostMalloc((void**)&m->h_gather, (size_t)n_devices * per * 96, hipHostMallocDefault) == hipSuccess;
+    for (int k = 0; ok && k < NSLOT; k++)
+      ok = hipHostMalloc((void**)&m->slot[k].h_gather, (size_t)n_devices * MAXLW * 96, hipHostMallocDefault) == hipSuccess;
     if (!ok && flags == MSM_HIP_MGPU_GATHER_RCCL) {
       msm_hip_mgpu_destroy(m);
       return MSM_HIP_ERR_HIP;
@@ -151,7 +323,86 @@ int msm_hip_mgpu_uses_rccl(const msm_hip_mgpu* m) { return m ? (m->rccl ? 1 : 0)
 
 int msm_hip_mgpu_set_bases_bn254(msm_hip_mgpu* m, const uint8_t* xy_host, size_t n, uint32_t flags) {
   if (!m || (!xy_host && n)) return MSM_HIP_ERR_INVALID_ARG;
-  return mgpu_for_each(m, [&](int d) { return msm_hip_set_bases_bn254(m->ctx[d], xy_host, n, flags); });  // replicated
+  for (const MgpuSlot& ms : m->slot)
+    if (ms.pending) return MSM_HIP_ERR_SLOT_BUSY;
+  const int rc = mgpu_for_each(m, [&](int d) { return msm_hip_set_bases_bn254(m->ctx[d], xy_host, n, flags); });  // replicated
+  m->endo = !rc && n && (flags & MSM_HIP_BASES_ENDOMORPHISM) != 0;
+  return rc;
+}
+
+int msm_hip_mgpu_group_size(const msm_hip_mgpu* m) {
+  if (!m) return MSM_HIP_ERR_INVALID_ARG;
+  const int per = mgpu_per(m, m->endo);
+  int g = (m->endo ? 8 : 16) / per;  // as many MSMs' shares as make up one MSM's worth of bucket sets per device
+  return g < 1 ? 1 : g;
+}
+
+int msm_hip_mgpu_launch_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, int nvec, int slot) {
+  if (!scalars_host && n) return MSM_HIP_ERR_INVALID_ARG;
+  return mgpu_launch(m, nullptr, scalars_host, true, n, nvec, slot);
+}
+
+int msm_hip_mgpu_launch_batch_device_bn254(msm_hip_mgpu* m, const void* const* scalars_dev, size_t n, int nvec, int slot) {
+  if (!m || !scalars_dev) return MSM_HIP_ERR_INVALID_ARG;
+  for (int d = 0; d < m->n; d++)
+    if (!scalars_dev[d] && n) return MSM_HIP_ERR_INVALID_ARG;
+  return mgpu_launch(m, scalars_dev, nullptr, false, n, nvec, slot);
+}
+
+int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz) {
+  if (!m || !out_xyz || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
+  MgpuSlot& ms = m->slot[slot];
+  if (!ms.pending) return MSM_HIP_ERR_INVALID_ARG;
+  const int G = m->n, nvec = ms.nvec, W = mgpu_windows(m, ms.halves), rows = nvec * mgpu_per(m, ms.halves);
+  int rc = MSM_HIP_OK;
+  // 1. every device's launch job has run; the first failure is the launch's status
+  for (int d = 0; d < G; d++) {
+    m->worker[d]->wait(ms.ticket[d]);
+    if (ms.rc[d] && !rc) rc = ms.rc[d];
+  }
+  // 2. the gather is complete (RCCL: device 0's copy of the gathered blocks; every device's part of the collective with it)
+  bool hip_ok = true;
+  if (m->rccl && !rc && ms.n) {
+    DeviceGuard guard(m->device[0]);
+    hip_ok = guard.ok && hipEventSynchronize(ms.gathered) == hipSuccess;
+  }
+  // 3. collect every context slot (error words; leaves the slots free whatever happened)
+  bool parts = false;
+  for (int d = 0; d < G; d++) {
+    if (!ms.launched[d]) continue;
+    const int r = msm_hip_slot_sync(m->ctx[d], slot);
+    if (r && !rc) rc = r;
+    parts = parts || m->ctx[d]->slot[slot].parts;
+  }
+  if (m->rccl)  // a later launch may reuse the slot's send / gather buffers: the devices' collectives have left them
+    for (int d = 1; d < G; d++) {
+      DeviceGuard guard(m->device[d]);
+      if (!guard.ok || hipStreamSynchronize(m->gather_stream[d]) != hipSuccess) hip_ok = false;
+    }
+  ms.pending = false;
+  if (rc) return rc;
+  if (!hip_ok) return MSM_HIP_ERR_HIP;
+  if (ms.n == 0) {  // nothing was launched anywhere
+    memset(out_xyz, 0, (size_t)nvec * 96);
+    return MSM_HIP_OK;
+  }
+  // 4. one host window combine per MSM, side by side on the host pool
+  const size_t rec = parts ? 288 : 96;
+  const CurveOps* ops = curve_ops(m->curve);
+  std::atomic<bool> ok{true};
+  combine_pool().run(nvec, [&](int v) {
+    uint8_t all[NWIN * 288];
+    for (int d = 0; d < G; d++) {
+      int b, e;
+      (void)msm_hip_window_range(d, G, W, &b, &e);
+      if (e == b) continue;
+      const uint8_t* block = m->rccl ? ms.h_gather + (size_t)d * rows * 96 : m->ctx[d]->slot[slot].h_wsums;
+      memcpy(all + (size_t)b * rec, block + (size_t)v * (e - b) * rec, (size_t)(e - b) * rec);
+    }
+    const bool good = parts ? ops->combine_window_parts(all, W, WBITS, out_xyz + (size_t)v * 96) : ops->combine_windows(all, W, WBITS, out_xyz + (size_t)v * 96);
+    if (!good) ok = false;
+  });
+  return ok ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
 }
 
 int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
@@ -160,70 +411,16 @@ int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t 
     memset(out_xyz, 0, 96);
     return MSM_HIP_OK;
   }
-  const int G = m->n, per = (NWIN + G - 1) / G;
-  // 1. every device: all scalars up, its own window range through the pipeline (slot 0)
-  int rc = mgpu_for_each(m, [&](int d) {
-    int b, e;
-    (void)msm_hip_window_range(d, G, NWIN, &b, &e);
-    return launch_host_windows(m->ctx[d], scalars_host, n, b, e, 0, m->rccl ? m->d_send[d] : nullptr);
-  });
-  if (rc) {
-    for (int d = 0; d < G; d++) drain_slots(m->ctx[d]);
-    return rc;
-  }
-  // 2. gather the window sums
-  uint8_t all[NWIN * 288];
-  bool parts = false;  // the pinned-buffer path receives every window sum as its three parts (Slot::parts): the host adds them up
-  if (m->rccl) {
-    // in stream order behind each device's bucket reduce: one all-gather over all devices, then device 0's copy to the host
-    bool ok = m->api.GroupStart() == 0;
-    for (int d = 0; ok && d < G; d++) {
-      DeviceGuard guard(m->device[d]);
-      ok = guard.ok && m->api.AllGather(m->d_send[d], m->d_gather[d], (size_t)per * 96, NCCL_UINT8, m->comm[d], m->ctx[d]->reduce_stream[0]) == 0;
-    }
-    ok = (m->api.GroupEnd() == 0) && ok;
-    if (ok) {
-      DeviceGuard guard(m->device[0]);
-      ok = guard.ok && hipMemcpyAsync(m->h_gather, m->d_gather[0], (size_t)G * per * 96, hipMemcpyDeviceToHost, m->ctx[0]->reduce_stream[0]) == hipSuccess &&
-           hipStreamSynchronize(m->ctx[0]->reduce_stream[0]) == hipSuccess;
-    }
-    for (int d = 0; d < G; d++) {  // error words; also leaves every slot collected
-      const int r = msm_hip_slot_sync(m->ctx[d], 0);
-      if (r && !rc) rc = r;
-      if (d > 0) {
-        DeviceGuard guard(m->device[d]);
-        if (hipStreamSynchronize(m->ctx[d]->reduce_stream[0]) != hipSuccess) ok = false;  // its part of the collective
-      }
-    }
-    if (rc) return rc;
-    if (!ok) return MSM_HIP_ERR_HIP;
-    for (int d = 0; d < G; d++) {
-      int b, e;
-      (void)msm_hip_window_range(d, G, NWIN, &b, &e);
-      memcpy(all + (size_t)b * 96, m->h_gather + (size_t)d * per * 96, (size_t)(e - b) * 96);
-    }
-  } else {
-    for (int d = 0; d < G; d++) {
-      const int r = msm_hip_slot_sync(m->ctx[d], 0);
-      if (r && !rc) rc = r;
-      int b, e;
-      (void)msm_hip_window_range(d, G, NWIN, &b, &e);
-      const Slot& sl = m->ctx[d]->slot[0];
-      if (d == 0) parts = sl.parts;
-      if (sl.parts != parts) return MSM_HIP_ERR_HIP;  // (all contexts share the debug setting: cannot happen)
-      const size_t rec = parts ? 288 : 96;
-      memcpy(all + (size_t)b * rec, sl.h_wsums, (size_t)(e - b) * rec);
-    }
-    if (rc) return rc;
-  }
-  // 3. ONE host window combine
-  if (parts) return curve_ops(m->curve)->combine_window_parts(all, NWIN, WBITS, out_xyz) ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
-  return msm_hip_combine_windows_curve(m->curve, all, NWIN, out_xyz);
+  int rc = msm_hip_mgpu_launch_batch_bn254(m, scalars_host, n, 1, 0);
+  if (rc) return rc;
+  return msm_hip_mgpu_finish_batch_bn254(m, 0, out_xyz);
 }
 
 int msm_hip_mgpu_run_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz) {
   if (!m || (!out_xyz && batch) || (!scalars_host && n && batch)) return MSM_HIP_ERR_INVALID_ARG;
   if (batch > (size_t)1 << 30) return MSM_HIP_ERR_INVALID_ARG;
+  for (const MgpuSlot& ms : m->slot)
+    if (ms.pending) return MSM_HIP_ERR_SLOT_BUSY;
   return mgpu_for_each(m, [&](int d) {
     int b, e;
     (void)msm_hip_window_range(d, m->n, (int)batch, &b, &e);

@@ -8,6 +8,7 @@ addition is not an RCCL reduction operator, hence gather + local combine rather 
 """
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -111,6 +112,20 @@ def group_window_rows(gathered, v, world_size, num_windows=NUM_WINDOWS, window_r
     return torch.cat(rows, dim=0)
 
 
+def gathered_window_sums(host, nvec, world_size, num_windows=NUM_WINDOWS):
+    """host: numpy uint8 [world, rows, 96], the all-gathered blocks of one launch (rank r's block holds [nvec][its windows] records,
+    vector-major, then padding).  Returns a contiguous uint8 array [nvec, num_windows, 96]: every MSM's window sums in window order --
+    the input of ONE msm_hip_combine_windows_batch_curve call for the whole launch."""
+    if num_windows % world_size == 0:  # equal shares: one transpose
+        per = num_windows // world_size
+        return np.ascontiguousarray(host[:, : nvec * per].reshape(world_size, nvec, per, 96).transpose(1, 0, 2, 3)).reshape(nvec, num_windows, 96)
+    out = np.empty((nvec, num_windows, 96), dtype=np.uint8)
+    for r in range(world_size):
+        b, e = window_range(r, world_size, num_windows)
+        out[:, b:e] = host[r, : nvec * (e - b)].reshape(nvec, e - b, 96)
+    return out
+
+
 class ShardedMsmPipeline:
     """Back-to-back window-sharded MSMs with everything asynchronous: rank-local device work (result slots and
     main/reduce HIP streams inside the engine), the RCCL all-gather on the torch stream (ordered after the slot by a device-side
@@ -126,9 +141,14 @@ class ShardedMsmPipeline:
 
     SLOTS = 4
 
-    def __init__(self, ctx, rank, world_size, group=None, num_windows=NUM_WINDOWS, depth=3, msms_per_issue=1, emulate_world=0):
+    def __init__(self, ctx, rank, world_size, group=None, num_windows=None, depth=3, msms_per_issue=1, emulate_world=0, halves=False):
+        """halves: the context's bases carry their endomorphism images (set_bases(..., endomorphism=True)); the ranks then share the 8
+        HALF-length windows of the 2n-point problem (msm_hip_launch_half_windows_batch_device_bn254) instead of the 16 full-length ones."""
         assert 1 <= depth < self.SLOTS
         self.depth = depth
+        self.halves = halves
+        if num_windows is None:
+            num_windows = NUM_WINDOWS // 2 if halves else NUM_WINDOWS
         self.ctx, self.rank, self.world, self.group, self.num_windows = ctx, rank, world_size, group, num_windows
         self.w_begin, self.w_end = window_range(rank, world_size, num_windows)
         self.per = max_windows_per_rank(world_size, num_windows)
@@ -145,6 +165,7 @@ class ShardedMsmPipeline:
         self.padded = [torch.zeros((rows, 96), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
         self.gathered = [torch.empty((world_size, rows, 96), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
         self.host = [torch.empty((world_size, rows, 96), dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
+        self.host_np = [h.numpy() for h in self.host]  # views of the pinned buffers
         self.copied = [torch.cuda.Event() for _ in range(self.SLOTS)]
         self.nvec = [1] * self.SLOTS
         self.issued = 0
@@ -167,8 +188,8 @@ class ShardedMsmPipeline:
         assert 1 <= nvec <= self.g and nvec * n == rows
         self.nvec[slot] = nvec
         if w_local > 0:
-            self.ctx.launch_windows_batch(scalars_dev, n, self.w_begin, self.w_end, slot, self.padded[slot][: nvec * w_local],
-                                          inputs_complete=inputs_complete)
+            launch = self.ctx.launch_half_windows_batch if self.halves else self.ctx.launch_windows_batch
+            launch(scalars_dev, n, self.w_begin, self.w_end, slot, self.padded[slot][: nvec * w_local], inputs_complete=inputs_complete)
             # gather + copies go to the CURRENT torch stream (normally the default stream): with GPU_MAX_HW_QUEUES=8 this
             # layout -- 3 engine streams, the default stream, RCCL's own -- keeps three launches in flight; a dedicated side
             # stream (or a 4th engine stream) was measured to collapse the pipeline to one at a time
@@ -189,11 +210,19 @@ class ShardedMsmPipeline:
             self.copied[slot].synchronize()
             if self.w_end > self.w_begin:
                 self.ctx.slot_sync(slot)
-            nvec = self.nvec[slot]
-            out = []
-            ranges = [(self.w_begin, self.w_end)] if self.emulate else None
-            for v in range(nvec):
-                out.append(MsmContext.combine_windows(group_window_rows(self.host[slot], v, self.world, self.num_windows, ranges)))
+            out = self._combine(slot, self.nvec[slot])
         finally:
             self.completed += 1
         return out if self.g > 1 else out[0]
+
+    def _combine(self, slot, nvec):
+        """The launch's window sums (pinned host buffer: rank r's block holds [nvec][its windows] records) -> one G1 per MSM.
+        All Horner chains of the launch go through ONE library call (host pool: side by side)."""
+        host = self.host_np[slot]
+        if self.emulate:  # partial sums over this rank's windows only (tuning aid)
+            nw = self.w_end - self.w_begin
+            sums = np.ascontiguousarray(host[0, : nvec * nw])
+        else:
+            nw = self.num_windows
+            sums = gathered_window_sums(host, nvec, self.world, nw)
+        return MsmContext.combine_windows_batch(sums, nw, self.ctx.curve)

@@ -33,3 +33,9 @@ def test_under_an_external_launcher_it_does_not_relaunch():
     r = _run(["--gpus", "1"], BENCH_DRY_RUN="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT="29611")
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["dist_ranks"] == [0]
+
+
+def test_self_launch_deadline_ends_a_hung_rank():
+    # a rank that never comes back (stuck in a collective): the launcher kills the ranks at its deadline and reports failure
+    r = _run(["--gpus", "2"], BENCH_DRY_RUN="hang_last", BENCH_LAUNCH_TIMEOUT_S="20")
+    assert r.returncode == 124, (r.returncode, r.stderr[-1000:])

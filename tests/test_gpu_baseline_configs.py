@@ -77,6 +77,61 @@ def test_config3_2p20_window_shares_of_8_ranks(ctx, inputs_2p20):
         assert m.MsmContext.combine_windows(torch.cat(parts, dim=0)).to_affine_bytes() == want[0], world
 
 
+def test_config3_2p20_half_window_shares_with_endomorphism_bases(ctx, inputs_2p20):
+    """C3 with MSM_HIP_BASES_ENDOMORPHISM: the ranks share the 8 half-length windows of the 2n-point problem (one per rank at 8 GPUs,
+    8 MSMs per launch; reference shape: 16 full-length windows, src/cuzk/msm.rs:79-82) -- gathered in rank order, 8 sums per MSM."""
+    from msm_webgpu_amd.sharding import gathered_window_sums
+
+    n, pts, sets, want = inputs_2p20
+    ctx.set_bases(pts, endomorphism=True)
+    try:
+        for world, g in ((8, 8), (4, 4), (3, 2)):
+            per = -(-8 // world)
+            batch = torch.cat([sets[k & 1] for k in range(g)], dim=0).contiguous()
+            gathered = torch.zeros((world, g * per, 96), dtype=torch.uint8, device=batch.device)
+            for rank in range(world):
+                b, e = window_range(rank, world, 8)
+                ctx.launch_half_windows_batch(batch, n, b, e, rank % 3, gathered[rank][: g * (e - b)])
+                ctx.slot_sync(rank % 3)
+            got = m.MsmContext.combine_windows_batch(gathered_window_sums(gathered.cpu().numpy(), g, world, 8), 8)
+            assert [r.to_affine_bytes() for r in got] == [want[v & 1] for v in range(g)], world
+        # the plain 16-window shares keep working on the same bases (records 0 .. n-1 are the plain set)
+        parts = [ctx.msm_windows(sets[0], *window_range(r, 8)) for r in range(8)]
+        assert m.MsmContext.combine_windows(torch.cat(parts, dim=0)).to_affine_bytes() == want[0]
+        with pytest.raises(m.MsmHipError):  # half-window range out of [0, 8]
+            ctx.launch_half_windows_batch(sets[0], n, 4, 9, 0, gathered[0])
+    finally:
+        ctx.set_bases(pts)
+    with pytest.raises(m.MsmHipError):  # bases without their endomorphism images
+        ctx.launch_half_windows_batch(sets[0], n, 0, 1, 0, gathered[0])
+
+
+@pytest.mark.parametrize("endo", [False, True], ids=["plain", "endomorphism"])
+def test_config3_2p20_through_the_multi_gpu_abi(inputs_2p20, endo):
+    """C3 through msm_hip_mgpu_launch_batch_* / finish_batch (8 contexts on the one GPU, pinned-buffer gather): 8 MSMs' window shares
+    per launch, several launches in flight, device-resident and host scalars; the Rust caller's shape (src/lib.rs:76-82)."""
+    n, pts, sets, want = inputs_2p20
+    mg = m.MultiGpuMsm([0] * 8, "host")
+    try:
+        mg.set_bases(_host(pts), endomorphism=endo)
+        g = mg.group_size
+        assert g == 8
+        batch = torch.cat([sets[k & 1] for k in range(g)], dim=0).contiguous()
+        per_device = [batch] * 8  # one pointer per device (here: the same GPU)
+        for k in range(3):  # three launches in flight over three result slots
+            assert mg.launch_batch(per_device, n, k) == g
+        for k in range(3):
+            got = mg.finish_batch(k, g)
+            assert [r.to_affine_bytes() for r in got] == [want[v & 1] for v in range(g)], k
+        # host scalars, fewer vectors than a full group, a slot reused
+        hb = _host(batch[: 3 * n])
+        assert mg.launch_batch(hb, n, 1) == 3
+        assert [r.to_affine_bytes() for r in mg.finish_batch(1, 3)] == [want[0], want[1], want[0]]
+        assert mg.msm(_host(sets[1])).to_affine_bytes() == want[1]  # the synchronous call = one vector through slot 0
+    finally:
+        mg.close()
+
+
 def test_config4_2p24_single_gpu(ctx):
     n = 1 << 24
     pts, sc = ctx.sample_points(n, 0xC4_0001), ctx.sample_scalars(n, 0xC4_0002)

@@ -201,3 +201,43 @@ def test_grumpkin(built):
                 assert cg.to_affine64(cg.cpu_msm(eq_points, eq_scalars)) == want
     finally:
         g.close()
+
+
+def test_sharded_pipeline_over_half_length_windows(ctx):
+    """ShardedMsmPipeline(halves=True): the ranks share the 8 half-length windows (msm_hip_launch_half_windows_batch_device_bn254).
+    One rank doing all 8 gives whole results; the emulated share of an 8-rank run (1 window, 8 MSMs per launch) gives the partial sums
+    the plain problem's stage model predicts for that window."""
+    import torch
+
+    import msm_webgpu_amd as m
+    from msm_webgpu_amd.sharding import ShardedMsmPipeline, msms_per_launch
+
+    n = 7000
+    points = cpu.sample_points(95, n)
+    vecs_host = [cpu.sample_scalars(96 + k, n) for k in range(8)]
+    want = [cpu.to_affine64(cpu.cpu_msm(points, s)) for s in vecs_host]
+    dev = torch.device("cuda", ctx.device)
+    vecs = [torch.frombuffer(bytearray(s), dtype=torch.uint8).view(n, 32).to(dev) for s in vecs_host]
+    ctx.set_bases(points, endomorphism=True)
+    try:
+        pipe = ShardedMsmPipeline(ctx, 0, 1, halves=True, msms_per_issue=8)
+        assert pipe.num_windows == 8 and (pipe.w_begin, pipe.w_end) == (0, 8)
+        batch = torch.cat(vecs, dim=0).contiguous()
+        pipe.issue(batch, n)
+        pipe.issue(batch[: 3 * n], n)
+        got, got3 = pipe.complete(), pipe.complete()
+        assert [g.to_affine_bytes() for g in got] == want and [g.to_affine_bytes() for g in got3] == want[:3]
+        assert msms_per_launch(8, 8) == 8
+        # one rank's share of an 8-rank run: half-length window 0 of 8 MSMs per launch
+        pipe8 = ShardedMsmPipeline(ctx, 0, 1, halves=True, msms_per_issue=8, emulate_world=8)
+        assert (pipe8.w_begin, pipe8.w_end) == (0, 1)
+        pipe8.issue(batch, n)
+        part = pipe8.complete()
+        out = torch.empty((8, 96), dtype=torch.uint8, device=dev)
+        ctx.launch_half_windows_batch(batch, n, 0, 1, 3, out)
+        ctx.slot_sync(3)
+        host = out.cpu()
+        for k in range(8):
+            assert part[k] == m.MsmContext.combine_windows(host[k:k + 1]), k
+    finally:
+        ctx.set_bases(points)

@@ -55,6 +55,66 @@ def test_mgpu_batch_of_whole_msms(data):
         mg.close()
 
 
+@pytest.mark.parametrize("ids,gather,endo", [([0], "rccl", False), ([0], "rccl", True), ([0, 0, 0], "host", False), ([0] * 5, "host", True),
+                                             ([0] * 16, "host", True)])
+def test_mgpu_grouped_asynchronous_launches(data, ids, gather, endo):
+    """msm_hip_mgpu_launch_batch_* / finish_batch: several MSMs' window shares per launch, slots in flight, errors reported by finish
+    and every slot left free; uneven shares (3 and 5 devices), more devices than half-length windows (16 > 8: some devices idle)."""
+    n, points, scalars, want = data
+    other = cpu.sample_scalars(903, n)
+    want_other = cpu.to_affine64(cpu.cpu_msm(points, other, 8))
+    mg = m.MultiGpuMsm(ids, gather)
+    try:
+        mg.set_bases(points, endomorphism=endo)
+        g = mg.group_size
+        assert g == max(1, (8 if endo else 16) // -(-(8 if endo else 16) // len(ids)))
+        nv = min(g, 3)
+        vecs = (scalars, other, scalars)[:nv]
+        wants = (want, want_other, want)[:nv]
+        for k in range(4):
+            assert mg.launch_batch(b"".join(vecs), n, k) == nv
+        with pytest.raises(m.MsmHipError) as e:  # slot still in flight
+            mg.launch_batch(scalars, n, 2)
+        assert e.value.code == -8
+        for k in (2, 0, 3, 1):  # any order
+            assert [r.to_affine_bytes() for r in mg.finish_batch(k, nv)] == list(wants)
+        with pytest.raises(m.MsmHipError):  # nothing pending
+            mg.finish_batch(0, 1)
+        # a non-canonical scalar in one vector: finish reports it, the slot and every context stay usable
+        mg.launch_batch(scalars[:32] + b"\xff" * 32, 2, 1)
+        mg.launch_batch(scalars, n, 2)
+        with pytest.raises(m.MsmHipError) as e:
+            mg.finish_batch(1, 1)
+        assert e.value.code == -4
+        assert mg.finish_batch(2, 1)[0].to_affine_bytes() == want
+        mg.launch_batch(other, n, 1)
+        assert mg.finish_batch(1, 1)[0].to_affine_bytes() == want_other
+    finally:
+        mg.close()
+
+
+def test_mgpu_two_distinct_devices_over_rccl(data):
+    """The in-process RCCL gather on two real GPUs (skipped on a one-GPU box; the driver's multi-GPU node runs it)."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    n, points, scalars, want = data
+    for endo in (False, True):
+        mg = m.MultiGpuMsm([0, 1], "rccl")
+        try:
+            assert mg.uses_rccl
+            mg.set_bases(points, endomorphism=endo)
+            assert mg.msm(scalars).to_affine_bytes() == want
+            g = mg.group_size
+            for k in range(3):
+                mg.launch_batch(scalars * g, n, k)
+            for k in range(3):
+                assert all(r.to_affine_bytes() == want for r in mg.finish_batch(k, g))
+        finally:
+            mg.close()
+
+
 def test_mgpu_bad_arguments():
     with pytest.raises(m.MsmHipError) as e:
         m.MultiGpuMsm([])

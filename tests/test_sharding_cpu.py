@@ -161,3 +161,30 @@ def test_grouped_launch_layout_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in got)
+
+
+@pytest.mark.parametrize("world,num_windows", [(1, 16), (2, 16), (3, 16), (8, 16), (16, 16), (2, 8), (3, 8), (8, 8)])
+def test_gathered_blocks_to_per_msm_window_sums(built, world, num_windows):
+    """The layout step of ShardedMsmPipeline.complete (16 full-length windows, or the 8 half-length ones of endomorphism bases) and the
+    one-call batch combine behind it (msm_hip_combine_windows_batch_curve, host only)."""
+    import msm_webgpu_amd as m
+    from msm_webgpu_amd.sharding import gathered_window_sums, max_windows_per_rank, window_range
+
+    nvec = 3
+    per = max_windows_per_rank(world, num_windows)
+    recs = cpu.g1_scalar_mul(cpu.sample_points(5, nvec * num_windows), cpu.sample_scalars(6, nvec * num_windows))  # arbitrary group elements
+    rec = lambda v, w: recs[96 * (v * num_windows + w):96 * (v * num_windows + w) + 96]
+    host = np.zeros((world, nvec * per + 2, 96), dtype=np.uint8)  # (+2: a block may be longer than what the launch filled)
+    for r in range(world):
+        b, e = window_range(r, world, num_windows)
+        for v in range(nvec):
+            for w in range(b, e):
+                host[r, v * (e - b) + (w - b)] = np.frombuffer(rec(v, w), dtype=np.uint8)
+    sums = gathered_window_sums(host, nvec, world, num_windows)
+    assert sums.shape == (nvec, num_windows, 96) and sums.tobytes() == recs
+    got = m.MsmContext.combine_windows_batch(sums, num_windows)
+    for v in range(nvec):
+        want = cpu.horner(recs[96 * num_windows * v:96 * num_windows * (v + 1)])
+        assert got[v].to_affine_bytes() == cpu.to_affine64(want)
+        assert m.MsmContext.combine_windows(recs[96 * num_windows * v:96 * num_windows * (v + 1)]).to_affine_bytes() == cpu.to_affine64(want)
+    assert m.MsmContext.combine_windows_batch(b"", num_windows) == []
