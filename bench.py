@@ -114,13 +114,13 @@ def native_mgpu_main(args):
     ids = [int(x) for x in os.environ.get("BENCH_MGPU_IDS", ",".join(str(d) for d in range(args.gpus))).split(",")]
     distinct = len(set(ids)) == len(ids)
     n = 1 << args.logn
-    bases_mode = os.environ.get("BENCH_BASES") or "endomorphism"
+    bases_mode = os.environ.get("BENCH_BASES") or "plain"
     ctx0 = m.MsmContext(ids[0])
     points = ctx0.sample_points(n, 0x6D736D5F0000 + args.logn)
     mg = m.MultiGpuMsm(ids, "auto" if distinct else "host")
     mg.set_bases(points.cpu().numpy().tobytes(), endomorphism=bases_mode == "endomorphism")
     full = mg.group_size
-    group = int(os.environ.get("BENCH_MSMS_PER_LAUNCH", "0")) or max(1, min(full, -(-args.steps // 5)))
+    group = int(os.environ.get("BENCH_MSMS_PER_LAUNCH", "0")) or full
     per_dev = {}
     for d in set(ids):  # identical synthetic scalars resident on every device (the deterministic device sampler)
         c = ctx0 if d == ids[0] else m.MsmContext(d)
@@ -254,10 +254,11 @@ def main():
     # how the resident bases are held (include/msm_hip.h; the result is the same group element in every mode):
     #   endomorphism  P_i and phi(P_i): every scalar is split into two 127-bit halves on the device, 8 windows over 2n points
     #                 (default on one GPU: the same bucket additions, half the buckets to reduce; 2 x the base memory)
-    #   plain         the reference's shape: 16 windows over n points (what the window-sharded multi-GPU path uses)
+    #   plain         the reference's shape: 16 windows over n points
     #   tables        fixed-base tables 2^(16 w) P_i: one bucket set per MSM (16 x the base memory)
-    #   (window-sharded runs: endomorphism = the ranks share the 8 half-length windows, one per rank at 8 GPUs)
-    bases_mode = os.environ.get("BENCH_BASES") or "endomorphism"
+    #   (window-sharded runs: plain by default -- with endomorphism bases the ranks share the 8 half-length windows, one per rank at
+    #    8 GPUs, measured 8 % slower per MSM than two full-length windows per rank: every rank splits every scalar, profiles/r03_share_ab.txt)
+    bases_mode = os.environ.get("BENCH_BASES") or ("plain" if sharded else "endomorphism")
     assert bases_mode in ("plain", "endomorphism", "tables") and (bases_mode != "tables" or not sharded)
     ctx.set_bases(points, endomorphism=bases_mode == "endomorphism", precompute=bases_mode == "tables")
     halves = bases_mode == "endomorphism"
@@ -283,14 +284,14 @@ def main():
     smvp_ms, smvp_windows, smvp_bits = [], [], []
     # window-sharded runs put the shares of several independent MSMs through one launch (as many as make up one MSM's worth of
     # bucket sets: 8 MSMs x 2 windows -- or x 1 half-length window -- at 8 GPUs): one kernel sequence and one RCCL all-gather per
-    # group.  A short run (the driver's --steps 20) takes smaller groups so that at least ~5 launches exist: with three launches
-    # of 7 the pipeline (3 in flight) never reaches its steady state and the whole last launch's reduce + gather + combine is
-    # exposed.  BENCH_MSMS_PER_LAUNCH overrides.
+    # group.  (Smaller groups for a short run -- 5 launches of 4 instead of 3 of 7 at the driver's --steps 20 -- were measured and lose:
+    # 0.235 vs 0.221 ms per MSM, profiles/r03_share_ab.txt; a launch's fixed costs outweigh the shorter exposed tail.)
+    # BENCH_MSMS_PER_LAUNCH overrides.
     group = 1
     pipe = None
     if sharded:
         full = msms_per_launch(emulate if emulate > 1 else world, shard_windows)
-        group = int(os.environ.get("BENCH_MSMS_PER_LAUNCH", "0")) or max(1, min(full, -(-args.steps // 5)))
+        group = int(os.environ.get("BENCH_MSMS_PER_LAUNCH", "0")) or full
         pipe = ShardedMsmPipeline(ctx, rank, world, depth=int(os.environ.get("BENCH_PIPE_DEPTH", "3")), msms_per_issue=group,
                                   emulate_world=emulate, halves=halves)
         w_local = pipe.w_end - pipe.w_begin

@@ -276,7 +276,7 @@ void* msm_hip_stream(msm_hip_ctx* ctx);
  *                  unspecified)                                 cf. transpose.template.wgsl:66-73
  *      buckets   : [num_windows_run][32768] x 96 B Jacobian canonical LE, slot k as smvp.template.wgsl:94
  *      windows   : [num_windows_run] x 96 B Jacobian canonical LE (a single-MSM launch whose sums the host combines leaves the
- *                  bucket reduce's three parts per window on the device, S_w = 128 A + B + C: the read-back folds them)
+ *                  bucket reduce's 16 bit-plane sums per window on the device, k_bpr_planes: the read-back finishes them)
  * ---- */
 /* digit-code planes are only materialised for read-back when enabled here (the sort recomputes digits on the fly) */
 int msm_hip_set_debug(msm_hip_ctx* ctx, int keep_digit_planes);

@@ -25,7 +25,7 @@ struct CurveOps {
   void (*rowcol_2_4)(const uint32_t*, uint32_t*, uint32_t*);
   void (*bpr_w256)(const uint32_t*, const uint32_t*, uint32_t*, int);
   void (*bpr_final)(const uint32_t*, int, uint32_t*, uint32_t*);
-  void (*bpr_parts_out)(const uint32_t*, int, uint32_t*, uint32_t*);
+  void (*bpr_planes)(const uint32_t*, const uint32_t*, uint32_t*, int, uint32_t*);
   void (*sample_scalars)(uint64_t, size_t, uint32_t*);
   void (*sample_points)(uint64_t, size_t, uint32_t*);
   void (*export_buckets)(const uint32_t*, uint32_t*, size_t);
@@ -33,15 +33,14 @@ struct CurveOps {
   void (*test_g1)(int, const uint32_t*, const uint32_t*, uint32_t*, size_t);
   void (*test_g1_mul_u32)(const uint32_t*, const uint32_t*, uint32_t*, size_t);
   bool (*combine_windows)(const uint8_t*, int, int, uint8_t*);
-  bool (*combine_window_parts)(const uint8_t*, int, int, uint8_t*);
-  bool (*fold_window_parts)(const uint8_t*, int, uint8_t*);
+  bool (*window_from_planes)(const uint8_t*, uint8_t*);
   int (*to_affine64)(const uint8_t*, uint8_t*);
 };
 #define MSM_CURVE_OPS(K, F)                                                                                                              \
   {K::k_convert_points, K::k_precompute_tables, K::k_endo_points, K::k_glv_split, K::k_scalars_from_mont256, K::k_smvp_chunks, K::k_smvp_stitch, K::k_smvp_stitch_big,       \
    K::k_bpr_rowcol<4, 8>, K::k_bpr_rowcol<2, 8>, K::k_bpr_rowcol<3, 8>, K::k_bpr_rowcol<4, 6>, K::k_bpr_rowcol<2, 6>, K::k_bpr_rowcol<2, 4>, \
-   K::k_bpr_w256, K::k_bpr_final, K::k_bpr_parts_out, K::k_sample_scalars, K::k_sample_points, K::k_export_buckets, K::k_test_fq, K::k_test_g1,                \
-   K::k_test_g1_mul_u32, F::host::combine_windows, F::host::combine_window_parts, F::host::fold_window_parts, F::host::to_affine64}
+   K::k_bpr_w256, K::k_bpr_final, K::k_bpr_planes, K::k_sample_scalars, K::k_sample_points, K::k_export_buckets, K::k_test_fq, K::k_test_g1,                \
+   K::k_test_g1_mul_u32, F::host::combine_windows, F::host::window_from_planes, F::host::to_affine64}
 
 // accessors of the separately compiled units (hidden: not part of the C ABI)
 extern "C" {

@@ -253,6 +253,23 @@ FQ_HD fq fq_sqr_fast(const fq& a) {
 #endif
 }
 
+// ... and with the result written over one operand (a = a b ; c = a b + c d): on the device the assembly block produces result limb j in
+// the register of the operand's limb j, which is dead by then -- a loop-carried accumulator is updated without a copy back
+FQ_HD void fq_mul_fast_ip(fq& a, const fq& b) {
+#if defined(FQ29_ASM)
+  fq_mul_ip_asm(a, b);
+#else
+  a = fq_mul(a, b);
+#endif
+}
+FQ_HD void fq_mul2_fast_ip(const fq& a, const fq& b, fq& c_, const fq& d) {
+#if defined(FQ29_ASM)
+  fq_mul2_ip_asm(a, b, c_, d);
+#else
+  c_ = fq_mul2(a, b, c_, d);
+#endif
+}
+
 // x exact and < 2p  ->  true iff x == 0 (mod p)
 FQ_HD bool fq_is_zero_exact(const fq& x) {
   uint32_t z = 0, e = 0;

@@ -133,9 +133,13 @@ FQ_HD void g1_madd(g1_xyzz& a, const fq& px, const fq& py) {
 //   when the accumulator is flushed (g1_unsigned).  Saves ~60 of the ~2270 VALU instructions of a step.
 // `sneg`: the digit is negative (the point enters as -P).
 FQ_HD void g1_madd_w(g1_xyzz& a, bool& wneg, const fq& px, const fq& py, bool sneg) {
-  if (a.inf) {
-    a = g1_from_affine(px, sneg ? fq_neg_canonical(py) : py);
-    wneg = false;
+  if (a.inf) {  // the first point of a run: W = py with the digit's sign as the state -- no negation (zz, zzz of an empty accumulator are don't-care)
+    a.x = px;
+    a.y = py;
+    a.zz = fq_one();
+    a.zzz = fq_one();
+    a.inf = false;
+    wneg = sneg;
     return;
   }
   const bool negp = sneg == wneg;                        // -sigma s = -1
@@ -163,16 +167,48 @@ FQ_HD void g1_madd_w(g1_xyzz& a, bool& wneg, const fq& px, const fq& py, bool sn
   const fq RR = fq_sqr_fast(Rw);                        // 49 p^2
   const fq X3 = fq_sub<7>(RR, fq_add(PPP, fq_dbl(Q)));  // PPP + 2Q < 6p     -> X3 < 9p
   const fq T = fq_sub<10>(Q, X3);                       // X3 < 9p           -> T < 12p
-  a.y = fq_mul2_fast(Rw, T, a.y, PPP);                  // 84 + 10 p^2, one reduction -> -sigma Y3 < 2p (R' lazy, the others normal)
+  // the three products that update a loop-carried coordinate write their result over it (fq_mul_fast_ip: no copy back)
+  fq_mul2_fast_ip(Rw, T, a.y, PPP);                     // 84 + 10 p^2, one reduction -> -sigma Y3 < 2p (R' lazy, the others normal)
   a.x = X3;
-  a.zz = fq_mul_fast(a.zz, PP);
-  a.zzz = fq_mul_fast(a.zzz, PPP);
+  fq_mul_fast_ip(a.zz, PP);
+  fq_mul_fast_ip(a.zzz, PPP);
   wneg = !wneg;
+}
+// The SMVP loop's form of g1_madd_w: `a` is not empty.  Every product is computed unconditionally and the loop-carried coordinates are
+// updated in place, so the hot path has no merge of alternative results (each merge costs a register copy per limb).  Returns 0, or --
+// same x coordinate, the products above are void -- 1: the sum is 2 (+-P), 2: the sum is the identity; the caller repairs `a` (rare).
+FQ_HD int g1_madd_w_hot(g1_xyzz& a, bool& wneg, const fq& px, const fq& py, bool sneg) {
+  const bool negp = sneg == wneg;                        // -sigma s = -1
+  fq pye;                                               // (-sigma s) py: py itself or 2p - py (lazy limbs < 2^30)
+  {
+    const fq n = fq_neg_lazy(py);
+#pragma unroll
+    for (int i = 0; i < 9; i++) pye.v[i] = negp ? n.v[i] : py.v[i];
+  }
+  const fq U2 = fq_mul_fast(px, a.zz);                  // < 2p
+  const fq S2 = fq_mul_fast(pye, a.zzz);                // 2p * 2p           -> < 2p, exact
+  const fq P = fq_sub<10>(U2, a.x);                     // X < 9p            -> P < 12p
+  const fq Rw = fq_add(a.y, S2);                        // W < 5p (normal)   -> R' < 7p, lazy limbs
+  const fq PP = fq_sqr_fast(P);                         // 144 p^2
+  int status = 0;
+  if ((PP.v[0] == 0u || PP.v[0] == FQ_P29[0]) && fq_is_zero_exact(PP))  // same x: P = Q or P = -Q (the lowest limb filters first)
+    status = fq_is_zero_exact(fq_tidy(Rw)) ? 1 : 2;
+  const fq PPP = fq_mul_fast(P, PP);                    // 24 p^2
+  const fq Q = fq_mul_fast(a.x, PP);                    // 18 p^2
+  const fq RR = fq_sqr_fast(Rw);                        // 49 p^2
+  const fq X3 = fq_sub<7>(RR, fq_add(PPP, fq_dbl(Q)));  // PPP + 2Q < 6p     -> X3 < 9p
+  const fq T = fq_sub<10>(Q, X3);                       // X3 < 9p           -> T < 12p
+  fq_mul2_fast_ip(Rw, T, a.y, PPP);                     // 84 + 10 p^2, one reduction -> -sigma Y3 < 2p
+  a.x = X3;
+  fq_mul_fast_ip(a.zz, PP);
+  fq_mul_fast_ip(a.zzz, PPP);
+  wneg = !wneg;
+  return status;
 }
 // the accumulator of g1_madd_w with its sign applied: a plain XYZZ point (Y < 5p, normal)
 FQ_HD g1_xyzz g1_unsigned(const g1_xyzz& a, bool wneg) {
   g1_xyzz r = a;
-  if (wneg && !a.inf) r.y = fq_sub<3>(fq_zero(), a.y);  // wneg only after a multiplication: W < 2p -> -W < 3p
+  if (wneg && !a.inf) r.y = fq_sub<3>(fq_zero(), a.y);  // wneg only with W a product's result or a canonical y: W < 2p -> -W < 3p
   return r;
 }
 

@@ -57,7 +57,9 @@ enum LaunchMode {
 
 constexpr int N_MAIN_EVENTS = 7;  // boundaries of the 6 timed stages on the main stream
 constexpr uint32_t MAX_TILES = 1024;
-constexpr size_t WSUM_BYTES = (size_t)MAXLW * 288;  // window sums (96 B each) or, for host-combined launches, their three parts
+constexpr size_t PLANE_BYTES = (size_t)PLANES_PER_WINDOW * 96;  // a window's bit-plane sums (k_bpr_planes)
+constexpr size_t WSUM_BYTES = (size_t)24 * PLANE_BYTES;  // MAXLW window sums (96 B each) or, for one host-combined MSM, the plane sums of its <= 22 windows
+static_assert(WSUM_BYTES >= (size_t)MAXLW * 96, "window-sum buffer");
 constexpr int NSLOT = MSM_HIP_NUM_SLOTS;  // result slots
 constexpr int NREDUCE = 2;  // reduce streams (slot k uses stream k % NREDUCE): two bucket reduces may be in flight when the
                             // main-stream work of one MSM is shorter than its bucket reduce (few windows per GPU).  The context
@@ -87,7 +89,7 @@ struct Slot {
   bool timed = false, pending = false, to_host = false;
   bool merged = false;                        // fixed-base launch: one bucket set (one window sum) per scalar vector
   bool halves = false;                        // endomorphism launch: the windows are those of 127-bit halves
-  bool parts = false;                         // h_wsums holds three parts per window (k_bpr_parts_out): the host adds them up
+  bool parts = false;                         // h_wsums holds the bit-plane sums of every window (k_bpr_planes): the host finishes the window sums
   int timing_level = 0;
   int w_begin = 0, w_count = 0, nvec = 1;  // windows [w_begin, w_begin + w_count) of nvec scalar vectors
   size_t n = 0;
@@ -521,24 +523,23 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   }
 #undef ROWCOL
   AFTER_KERNEL(ctx, "k_bpr_rowcol", rs);
-  hipLaunchKernelGGL(ctx->ops->bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts, (int)(half / BPR_COLS));
-  AFTER_KERNEL(ctx, "k_bpr_w256", rs);
-  // sums that the host combines anyway (finish / finish_batch) leave the device as their three parts per window: the last nine group
-  // operations of a window cost ~60 us in a lone wave (k_bpr_final) and 2 us on the host.  Sums that stay on the device (window shards
-  // for the gather) and debug read-backs get the finished sums.
-  // Only for launches that carry ONE scalar vector (where the latency is what counts: -4 % at 2^16, -2.5 % at 2^20): a grouped launch
-  // of 6 - 8 small MSMs would hand its host thread 0.13 ms more work per launch, and that thread is on the critical path there
-  // (2^16, 6 per launch: 0.170 -> 0.215 ms per MSM).
-  const bool parts_mode = to_host && nvec == 1 && !ctx->debug && wsums_out == reinterpret_cast<uint32_t*>(s.d_wsums);
+  // A launch that carries ONE MSM whose sums the host combines anyway (finish): the narrow end of the reduction -- ~25 dependent group
+  // operations at ~7 us each in k_bpr_w256 / k_bpr_final -- is replaced by 16 independent masked tree sums per window (k_bpr_planes, 8 deep)
+  // and 29 operations per window on the host (0.3 us each).  Sums that stay on the device (window shards for the gather), grouped launches
+  // (their host thread is on the critical path: several MSMs' worth of host work per launch) and debug read-backs get finished sums.
+  const bool parts_mode = to_host && nvec == 1 && !ctx->debug && wsums_out == reinterpret_cast<uint32_t*>(s.d_wsums) && w_count <= 24;
   if (parts_mode) {
-    hipLaunchKernelGGL(ctx->ops->bpr_parts_out, dim3((3 * w_count + 63) / 64), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue);
-    AFTER_KERNEL(ctx, "k_bpr_parts_out", rs);
+    hipLaunchKernelGGL(ctx->ops->bpr_planes, dim3(PLANES_PER_WINDOW, w_count), dim3(256), 0, rs, d_rows, d_cols, wsums_out, (int)(half / BPR_COLS),
+                       s.d_big_queue);
+    AFTER_KERNEL(ctx, "k_bpr_planes", rs);
   } else {
+    hipLaunchKernelGGL(ctx->ops->bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts, (int)(half / BPR_COLS));
+    AFTER_KERNEL(ctx, "k_bpr_w256", rs);
     hipLaunchKernelGGL(ctx->ops->bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue);
     AFTER_KERNEL(ctx, "k_bpr_final", rs);
   }
   if (tl >= 2) HIP_TRY(ctx, hipEventRecord(s.red1, rs));
-  if (to_host) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * (parts_mode ? 288 : 96), hipMemcpyDeviceToHost, rs));
+  if (to_host) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * (parts_mode ? PLANE_BYTES : 96), hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums + WSUM_BYTES, d_err, 4, hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipMemsetAsync(d_err, 0, 4, rs));  // ready for the slot's next occupant
   HIP_TRY(ctx, hipEventRecord(s.done, rs));
@@ -921,11 +922,17 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   if (rc) return rc;
   auto t0 = std::chrono::steady_clock::now();
   std::atomic<bool> all_ok{true};
-  combine_pool().run(s.nvec, [&](int v) {  // one independent Horner chain per MSM of the launch: side by side when there are several
-    const bool ok = s.parts ? ctx->ops->combine_window_parts(s.h_wsums + (size_t)v * nwin * 288, nwin, s.wbits, out_xyz + 96 * (size_t)v)
-                            : ctx->ops->combine_windows(s.h_wsums + (size_t)v * nwin * 96, nwin, s.wbits, out_xyz + 96 * (size_t)v);
-    if (!ok) all_ok = false;
-  });
+  if (s.parts) {  // one MSM, its windows as bit-plane sums: the windows' positional sums side by side, then the Horner chain over them
+    uint8_t sums[24 * 96];
+    combine_pool().run(nwin, [&](int w) {
+      if (!ctx->ops->window_from_planes(s.h_wsums + (size_t)w * PLANE_BYTES, sums + 96 * (size_t)w)) all_ok = false;
+    });
+    if (!ctx->ops->combine_windows(sums, nwin, s.wbits, out_xyz)) all_ok = false;
+  } else {
+    combine_pool().run(s.nvec, [&](int v) {  // one independent Horner chain per MSM of the launch: side by side when there are several
+      if (!ctx->ops->combine_windows(s.h_wsums + (size_t)v * nwin * 96, nwin, s.wbits, out_xyz + 96 * (size_t)v)) all_ok = false;
+    });
+  }
   if (!all_ok) return MSM_HIP_ERR_HIP;
   ctx->stage_ms[8] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return MSM_HIP_OK;
@@ -1246,13 +1253,15 @@ int msm_hip_read_window_sums(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
   const Slot& s = ctx->slot[ctx->last_slot];
   if (!s.parts) return read_back(ctx, out, s.d_wsums, (size_t)ctx->last_w_count * 96, cap_bytes);
-  // the last launch handed its window sums to the host as three parts per window (k_bpr_parts_out): fold them here
+  // the last launch handed its window sums to the host as bit-plane sums (k_bpr_planes): finish them here
   const size_t w = (size_t)ctx->last_w_count;
-  if (!out || w * 96 > cap_bytes || w > (size_t)MAXLW) return MSM_HIP_ERR_INVALID_ARG;
-  uint8_t parts[(size_t)MAXLW * 288];
-  int rc = read_back(ctx, parts, s.d_wsums, w * 288, sizeof parts);
+  if (!out || w * 96 > cap_bytes || w > 24) return MSM_HIP_ERR_INVALID_ARG;
+  uint8_t planes[WSUM_BYTES];
+  int rc = read_back(ctx, planes, s.d_wsums, w * PLANE_BYTES, sizeof planes);
   if (rc) return rc;
-  return ctx->ops->fold_window_parts(parts, (int)w, out) ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
+  bool ok = true;
+  for (size_t k = 0; k < w; k++) ok &= ctx->ops->window_from_planes(planes + k * PLANE_BYTES, out + k * 96);
+  return ok ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
 }
 
 // ---- op hooks -------------------------------------------------------------------------------------------------------

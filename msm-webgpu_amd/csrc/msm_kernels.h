@@ -967,6 +967,33 @@ __device__ __forceinline__ g1_xyzz ld_rec(const uint32_t* p) {
   return a;
 }
 
+// Assignments to the SMVP loop's accumulator from its rare paths (a run's first point; the repair after a doubling).  On the device they
+// are written as moves INTO the accumulator's own registers (read-write operands): a plain assignment makes every coordinate a merge of
+// two values at the end of the branch, and the register allocator then keeps the merged value in the rare path's registers -- the hot
+// path, which updates the coordinates in place, pays a copy per limb and iteration to get there and back (measured: 36 + 18 v_mov).
+__device__ __forceinline__ void smvp_set(fq& dst, const fq& src) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) asm("v_mov_b32 %0, %1" : "+v"(dst.v[i]) : "v"(src.v[i]));
+}
+__device__ __forceinline__ void smvp_set_one(fq& dst) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) asm("v_mov_b32 %0, %1" : "+v"(dst.v[i]) : "s"(FQ_ONE29[i]));
+}
+__device__ __forceinline__ void smvp_restart(g1_xyzz& acc, const fq& px, const fq& py) {
+  smvp_set(acc.x, px);
+  smvp_set(acc.y, py);
+  smvp_set_one(acc.zz);
+  smvp_set_one(acc.zzz);
+  acc.inf = false;
+}
+__device__ __forceinline__ void smvp_assign(g1_xyzz& acc, const g1_xyzz& src) {
+  smvp_set(acc.x, src.x);
+  smvp_set(acc.y, src.y);
+  smvp_set(acc.zz, src.zz);
+  smvp_set(acc.zzz, src.zzz);
+  acc.inf = src.inf;
+}
+
 __global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ col_ptr,
                                                      const uint32_t* __restrict__ val_idxs, size_t stride, uint32_t chunks,
                                                      const uint32_t* __restrict__ chunk_len_dev, const uint32_t* __restrict__ chunk_slot,
@@ -987,29 +1014,39 @@ __global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restri
   const size_t rec = ((size_t)lw * chunks + c) * REC_WORDS;
   g1_xyzz acc = g1_identity();
   bool wneg = false;  // sign carried by acc.y (g1_madd_w); applied when the accumulator is flushed
-  // the point of entry t + 1 is requested before the addition of entry t starts, so that a gather that misses the
-  // Infinity Cache (bases beyond 256 MiB) is covered by ~5 us of arithmetic instead of stalling the wave
-  uint4 quad = *reinterpret_cast<const uint4*>(vi + begin);  // chunk starts are multiples of 4 entries
-  uint32_t vnext = quad.x;
+  // Two entries ahead: the index of entry t + 2 and the point of entry t + 1 are requested before the addition of entry t starts, so that
+  // a gather that misses the Infinity Cache (bases beyond 256 MiB) is covered by ~4 us of arithmetic instead of stalling the wave.  Both
+  // loads are unconditional (clamped to the chunk's last entry): a conditional load makes every prefetch register a merge of old and
+  // new value, i.e. a copy per register and iteration.
+  const uint32_t last = end - 1;
+  uint32_t vnext = vi[begin];
+  uint32_t vnn = vi[begin + 1 < end ? begin + 1 : last];
   uint32_t wx[8], wy[8];
   ld8(bases + (size_t)(vnext & 0x7fffffffu) * 16, wx);
   ld8(bases + (size_t)(vnext & 0x7fffffffu) * 16 + 8, wy);
   for (uint32_t t = begin; t < end; t++) {
     const uint32_t v = vnext;
-    const fq px = fq_unpack(wx), py = fq_unpack(wy);
-    if (t + 1 < end) {
-      const uint32_t k = (t + 1 - begin) & 3u;
-      if (k == 0) quad = *reinterpret_cast<const uint4*>(vi + t + 1);
-      vnext = k == 0 ? quad.x : (k == 1 ? quad.y : (k == 2 ? quad.z : quad.w));
+    fq px = fq_unpack(wx), py = fq_unpack(wy);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the loads below stay behind the unpacking (the limbs are pinned in front of this point): they can then reuse the registers of
+    // wx / wy; hoisted above it they need a second set and 16 copies per iteration
+    asm volatile("" : "+v"(px.v[0]), "+v"(px.v[1]), "+v"(px.v[2]), "+v"(px.v[3]), "+v"(px.v[4]), "+v"(px.v[5]), "+v"(px.v[6]), "+v"(px.v[7]), "+v"(px.v[8]),
+                      "+v"(py.v[0]), "+v"(py.v[1]), "+v"(py.v[2]), "+v"(py.v[3]), "+v"(py.v[4]), "+v"(py.v[5]), "+v"(py.v[6]), "+v"(py.v[7]), "+v"(py.v[8])
+                 :
+                 : "memory");
+#endif
+    vnext = vnn;
+    vnn = vi[t + 2 < end ? t + 2 : last];
+    {
       const uint32_t* pt = bases + (size_t)(vnext & 0x7fffffffu) * 16;
       ld8(pt, wx);
       ld8(pt + 8, wy);
     }
+    const bool sneg = (v >> 31) != 0u;  // bit 31: the digit is negative
     if (t == run_end) {  // the run of slot s ended inside this chunk
       if (run_begin >= begin) st_rec(buckets + ((size_t)lw * half + s) * REC_WORDS, g1_unsigned(acc, wneg));
       else st_rec(heads + rec, g1_unsigned(acc, wneg));
-      acc = g1_identity();
-      wneg = false;
+      acc.inf = true;  // (the coordinates of an empty accumulator are never read: no need to zero 36 registers)
       run_begin = run_end;
       // next non-empty slot (exists: t < nw).  Usually the very next one; after a few empty slots switch to a binary search of the
       // slot whose run contains entry t: a lane that walks thousands of empty slots with dependent loads (a few heavy buckets far
@@ -1027,7 +1064,22 @@ __global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restri
         run_end = cp[s + 1];
       }
     }
-    g1_madd_w(acc, wneg, px, py, (v >> 31) != 0u);  // bit 31: the digit is negative
+    if (acc.inf) {  // the first point of a run: W = y with the digit's sign as the state -- no negation, no arithmetic
+      smvp_restart(acc, px, py);
+      wneg = sneg;
+    } else {
+      const int status = g1_madd_w_hot(acc, wneg, px, py, sneg);
+      if (status) {  // the point met itself or its negative in the accumulator (duplicate bases): repair, from the point read again
+        wneg = false;
+        if (status == 1) {
+          const uint32_t* pt = bases + (size_t)(v & 0x7fffffffu) * 16;
+          const fq qy = ld_fq(pt + 8);
+          smvp_assign(acc, g1_double_affine(ld_fq(pt), sneg ? fq_neg_canonical(qy) : qy));
+        } else {
+          acc.inf = true;
+        }
+      }
+    }
   }
   acc = g1_unsigned(acc, wneg);
   // last run of the chunk: complete only if it started here and ends exactly at or before `end`
@@ -1575,15 +1627,39 @@ __global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ p
   st_jacobian_plain(wsums + (size_t)w * 24, acc);
 }
 
-// ... or, for launches whose sums go to the host anyway: the three parts of every window as canonical Jacobian bytes (3 x 96 B per
-// window), one lane per part; the host adds them up (host_g1.h: combine_window_parts) -- nine dependent group operations less on the
-// latency path of every MSM (k_bpr_final: ~60 us)
-__global__ void __launch_bounds__(64) k_bpr_parts_out(const uint32_t* __restrict__ parts, int w_count, uint32_t* __restrict__ out,
-                                                      uint32_t* __restrict__ big_queue) {
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t == 0) big_queue[0] = 0;  // as k_bpr_final
-  if (t >= 3 * w_count) return;
-  st_jacobian_plain(out + (size_t)t * 24, ld_xyzz(parts + (size_t)t * XYZZ_WORDS));
+// ... or, for a launch whose sums go to the host anyway (one MSM per launch: its LATENCY is what counts): the narrow end of the reduction
+// is not done here at all.  W(X) = sum_i i X_i = sum_b 2^b P_b with the PLAIN bit-plane sums P_b = sum_{i: bit b of i set} X_i -- eight
+// (rows) + seven (columns) + the column total = PLANES_PER_WINDOW masked tree sums per window, all independent and 8 additions deep,
+// instead of k_bpr_w256's ~16 dependent levels and k_bpr_final's 9 operations in a lone wave (~200 us together); the positional
+// combination S_w = sum_b 2^(b+7) PR_b + sum_b 2^b PC_b + TC is 29 group operations per window on the host (host_g1.h:
+// window_sum_from_planes, ~8 us; the windows side by side on the host pool).
+// Grid (PLANES_PER_WINDOW, windows); plane 0 .. 7: row bit b, 8 .. 14: column bit b - 8, 15: column total.  out[w][plane] x 96 B Jacobian.
+constexpr int PLANES_PER_WINDOW = 16;
+__global__ void __launch_bounds__(256) k_bpr_planes(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ cols, uint32_t* __restrict__ out,
+                                                    int nrows, uint32_t* __restrict__ big_queue) {
+  __shared__ uint32_t x[256 * XYZZ_WORDS];
+  const int w = blockIdx.y, plane = blockIdx.x, t = threadIdx.x;
+  if (w == 0 && plane == 0 && t == 0) big_queue[0] = 0;  // as k_bpr_final: the stitch's queue is empty for the slot's next launch
+  const bool is_row = plane < 8;
+  const int bit = is_row ? plane : plane - 8;  // 7 for the column total: bit 7 of a column index is never set -> handled by `all`
+  const bool all = plane == PLANES_PER_WINDOW - 1;
+  const int count = is_row ? nrows : BPR_COLS;
+  const bool take = t < count && (all || ((t >> bit) & 1));
+  const uint32_t* src = is_row ? rows + ((size_t)w * BPR_ROWS + t) * XYZZ_WORDS : cols + ((size_t)w * 256 + t) * XYZZ_WORDS;
+  // first level straight from memory: thread t < 128 adds elements t and t + 128 (both masked)
+  g1_xyzz acc = g1_identity();
+  if (t < 128) {
+    if (take) acc = ld_xyzz(src);
+    const int u = t + 128;
+    if (u < count && (all || ((u >> bit) & 1))) acc = g1_add(acc, ld_xyzz(src + (size_t)128 * XYZZ_WORDS));
+    st_xyzz(x + t * XYZZ_WORDS, acc);
+  }
+  __syncthreads();
+  for (int sft = 64; sft >= 1; sft >>= 1) {
+    if (t < sft) lds_add_pair(x, t, t + sft);
+    __syncthreads();
+  }
+  if (t == 0) st_jacobian_plain(out + ((size_t)w * PLANES_PER_WINDOW + plane) * 24, ld_xyzz(x));
 }
 
 // bucket records -> Jacobian wire records (stage read-back for the parity tests)

@@ -387,11 +387,11 @@ int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz)
     return MSM_HIP_OK;
   }
   // 4. one host window combine per MSM, side by side on the host pool
-  const size_t rec = parts ? 288 : 96;
+  const size_t rec = parts ? PLANE_BYTES : 96;  // (one vector per launch through the pinned buffers: the windows arrive as bit-plane sums)
   const CurveOps* ops = curve_ops(m->curve);
   std::atomic<bool> ok{true};
   combine_pool().run(nvec, [&](int v) {
-    uint8_t all[NWIN * 288];
+    uint8_t all[NWIN * PLANE_BYTES], sums[NWIN * 96];
     for (int d = 0; d < G; d++) {
       int b, e;
       (void)msm_hip_window_range(d, G, W, &b, &e);
@@ -399,8 +399,13 @@ int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz)
       const uint8_t* block = m->rccl ? ms.h_gather + (size_t)d * rows * 96 : m->ctx[d]->slot[slot].h_wsums;
       memcpy(all + (size_t)b * rec, block + (size_t)v * (e - b) * rec, (size_t)(e - b) * rec);
     }
-    const bool good = parts ? ops->combine_window_parts(all, W, WBITS, out_xyz + (size_t)v * 96) : ops->combine_windows(all, W, WBITS, out_xyz + (size_t)v * 96);
-    if (!good) ok = false;
+    const uint8_t* records = all;
+    if (parts) {
+      for (int w = 0; w < W; w++)
+        if (!ops->window_from_planes(all + (size_t)w * PLANE_BYTES, sums + 96 * (size_t)w)) ok = false;
+      records = sums;
+    }
+    if (!ops->combine_windows(records, W, WBITS, out_xyz + (size_t)v * 96)) ok = false;
   });
   return ok ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
 }

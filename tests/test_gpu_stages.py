@@ -98,8 +98,8 @@ def test_horner_of_window_sums_is_the_result(run):
 
 
 def test_window_sums_read_back_after_a_plain_launch(ctx):
-    """Without debug a single-MSM launch leaves the bucket reduce's three parts per window on the device
-    (k_bpr_parts_out); msm_hip_read_window_sums folds them into the documented 96-byte records."""
+    """Without debug a single-MSM launch leaves the bucket reduce's bit-plane sums on the device (k_bpr_planes: the host finishes
+    the window sums); msm_hip_read_window_sums turns them into the documented 96-byte records."""
     n = 5000
     points, scalars = cpu.sample_points(62, n), cpu.sample_scalars(63, n)
     ctx.set_bases(points)

@@ -21,8 +21,10 @@ S0 = 86            # s[86:94] = p limbs, s95 = n0
 acc, acclo = "v[%d:%d]" % (ACC, ACC + 1), "v%d" % ACC
 
 
-def block(kind):
-    """kind: 'mul' (a*b), 'mul2' (a*b + c*d), 'sqr' (a*a; operand list a, a2 = 2a)"""
+def block(kind, inplace=None):
+    """kind: 'mul' (a*b), 'mul2' (a*b + c*d), 'sqr' (a*a; operand list a, a2 = 2a).
+    inplace: name of the operand ('a' for mul, 'c' for mul2) whose registers receive the result: result limb j is column 9 + j, and
+    limb j of the first factor of a product is last read in column j + 8, so the register is free by then; the m[k] are scratch."""
     L = []
     first = True
 
@@ -55,9 +57,10 @@ def block(kind):
             L.append("v_and_b32 %%[m%d], 0x%x, %%[m%d]" % (k, MASK, k))
             mad("%%[m%d]" % k, "%[p0]")
         elif k < 17:
-            L.append("v_and_b32 %%[m%d], 0x%x, %s" % (k - 9, MASK, acclo))   # result limb k-9 reuses the register of m[k-9]
+            dst = "%%[m%d]" % (k - 9) if not inplace else "%%[%s%d]" % (inplace, k - 9)
+            L.append("v_and_b32 %s, 0x%x, %s" % (dst, MASK, acclo))   # result limb k-9 reuses the register of m[k-9] (or of the in-place operand)
         else:
-            L.append("v_mov_b32 %%[m8], %s" % acclo)
+            L.append("v_mov_b32 %s, %s" % ("%[m8]" if not inplace else "%%[%s8]" % inplace, acclo))
         if k < 17:
             L.append("v_lshrrev_b64 %s, 29, %s" % (acc, acc))
     return L
@@ -94,6 +97,33 @@ def emit(name, kind):
     print()
 
 
+def emit_inplace(name, kind):
+    """a = a * b   /   c = a * b + c * d : the result overwrites one operand (no copy back into a loop-carried accumulator)"""
+    ip = "a" if kind == "mul" else "c"
+    lines = block(kind, ip)
+    tmps = ", ".join('[m%d] "=&v"(m[%d])' % (i, i) for i in range(9))
+    if kind == "mul":
+        io = ", ".join('[a%d] "+v"(a.v[%d])' % (i, i) for i in range(9))
+        ins = ", ".join('[b%d] "v"(b.v[%d])' % (i, i) for i in range(9))
+        sig = "fq& a, const fq& b"
+    else:
+        io = ", ".join('[c%d] "+v"(c_.v[%d])' % (i, i) for i in range(9))
+        ins = ", ".join('[%s%d] "v"(%s.v[%d])' % (n, i, n, i) for n in "abd" for i in range(9))
+        sig = "const fq& a, const fq& b, fq& c_, const fq& d"
+    ins += ", " + ", ".join('[p%d] "s"(FQ_P29[%d])' % (j, j) for j in range(9)) + ', [n0] "s"(FQ_N0_29)'
+    clob = ['"vcc"', '"v%d"' % ACC, '"v%d"' % (ACC + 1)]
+    print("__device__ __forceinline__ void %s(%s) {" % (name, sig))
+    print("  uint32_t m[9];")
+    print("  asm(")
+    for ln in lines:
+        print('      "%s\\n"' % ln)
+    print("      : %s, %s" % (io, tmps))
+    print("      : %s" % ins)
+    print("      : %s);" % ", ".join(clob))
+    print("}")
+    print()
+
+
 print("// GENERATED by tools/gen_fq29_asm.py -- do not edit.  gfx950 inline-assembly forms of fq_mul / fq_sqr (see that script).")
 print("// (no include guard: included by fq29.h once per curve unit, inside the unit's field namespace; the blocks take p's limbs and n0")
 print("//  as operands from that namespace's constants)")
@@ -101,4 +131,6 @@ print("namespace MSM_FIELD_NS {")
 emit("fq_mul_asm", "mul")
 emit("fq_sqr_asm", "sqr")
 emit("fq_mul2_asm", "mul2")
+emit_inplace("fq_mul_ip_asm", "mul")
+emit_inplace("fq_mul2_ip_asm", "mul2")
 print("}  // namespace MSM_FIELD_NS")
