@@ -90,7 +90,11 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx);
 #define MSM_HIP_CURVE_GRUMPKIN 1
 #define MSM_HIP_CURVE_PALLAS 2
 #define MSM_HIP_CURVE_VESTA 3
-#define MSM_HIP_NUM_CURVES 4
+#define MSM_HIP_CURVE_BLS12_381 4 /* G1: y^2 = x^3 + 4 over the 381-bit p, scalars modulo the 255-bit r.  Coordinates are 48 bytes on this curve's wire:
+                                     points n x 96 B (x || y), results and window sums 144 B Jacobian records (x || y || z), scalars 32 B as everywhere;
+                                     every `[96]` / `[64]` / "x 96 B" of this header reads 144 / 96 for such a context.  Device arithmetic: 14 limbs of
+                                     28 bits (csrc/curve_bls12_381.hip).  All modes (window sizes, fixed-base tables, endomorphism, shards, batches). */
+#define MSM_HIP_NUM_CURVES 5
 int msm_hip_ctx_create_curve(msm_hip_ctx** out, int device_id, int curve);
 int msm_hip_ctx_curve(const msm_hip_ctx* ctx);
 /* the context-free host helpers for a given curve (msm_hip_combine_windows_bn254 / msm_hip_g1_to_affine_bn254 are curve 0) */

@@ -21,7 +21,13 @@ R_BN254 = 2188824287183927522224640574525727508854836440041603434369820418657580
 # curve of a context (include/msm_hip.h: MSM_HIP_CURVE_*): id and base-field modulus
 PALLAS_P = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001  # Pallas' base field = Vesta's scalar field
 VESTA_P = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001   # Vesta's base field = Pallas' scalar field
-CURVES = {"bn254": (0, P), "grumpkin": (1, R_BN254), "pallas": (2, PALLAS_P), "vesta": (3, VESTA_P)}
+BLS12_381_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+CURVES = {"bn254": (0, P), "grumpkin": (1, R_BN254), "pallas": (2, PALLAS_P), "vesta": (3, VESTA_P), "bls12_381": (4, BLS12_381_P)}
+
+
+def coord_bytes(curve):
+    """Bytes of a coordinate on a curve's wire: 32, or 48 for BLS12-381 (points 2 x, Jacobian records 3 x that)."""
+    return 48 if curve == "bls12_381" else 32
 NUM_WINDOWS = 16
 WINDOW_BITS = 16
 BUCKETS_PER_WINDOW = 1 << 15
@@ -152,11 +158,11 @@ class G1:
     def __init__(self, xyz, p=P):
         self.xyz = bytes(xyz)
         self.p = p  # base-field modulus of the point's curve
-        assert len(self.xyz) == 96
+        assert len(self.xyz) in (96, 144)  # 3 coordinates of 32 bytes (48: BLS12-381)
 
     def coords(self):
-        b = self.xyz
-        return tuple(int.from_bytes(b[k:k + 32], "little") for k in (0, 32, 64))
+        b, cb = self.xyz, len(self.xyz) // 3
+        return tuple(int.from_bytes(b[k:k + cb], "little") for k in (0, cb, 2 * cb))
 
     def is_identity(self):
         return self.coords()[2] == 0
@@ -171,10 +177,10 @@ class G1:
 
     def to_affine_bytes(self):
         """The 64-byte canonical affine encoding used for bit-exact comparison; 64 zero bytes for the identity."""
-        a = self.to_affine()
+        a, cb = self.to_affine(), len(self.xyz) // 3
         if a is None:
-            return bytes(64)
-        return a[0].to_bytes(32, "little") + a[1].to_bytes(32, "little")
+            return bytes(2 * cb)
+        return a[0].to_bytes(cb, "little") + a[1].to_bytes(cb, "little")
 
     def __eq__(self, other):  # projective equality, as G1's PartialEq (src/lib.rs:166)
         return isinstance(other, G1) and self.to_affine() == other.to_affine()
@@ -202,6 +208,8 @@ class MsmContext:
         self._h = C.c_void_p()
         self.curve = curve
         self.curve_id, self.modulus = CURVES[curve]
+        self.cb = coord_bytes(curve)  # bytes per coordinate; a point is pb = 2 cb, a Jacobian record jb = 3 cb
+        self.pb, self.jb = 2 * self.cb, 3 * self.cb
         _check(lib().msm_hip_ctx_create_curve(C.byref(self._h), int(device), self.curve_id), "msm_hip_ctx_create_curve")
         self.device = int(device)
         self.n_bases = 0
@@ -235,14 +243,14 @@ class MsmContext:
         half the windows."""
         flags = (1 if check_on_curve else 0) | (2 if mont256 else 0) | (4 if precompute else 0) | (8 if endomorphism else 0)
         if isinstance(points, torch.Tensor) and points.is_cuda:
-            t, n = _as_device_u8(points, 64, "points")
+            t, n = _as_device_u8(points, self.pb, "points")
             self._order_after_torch(t)
             _check(lib().msm_hip_set_bases_device_bn254(self._h, t.data_ptr(), n, flags), "msm_hip_set_bases_device_bn254")
         else:
             b = bytes(points)
-            if len(b) % 64:
+            if len(b) % self.pb:
                 raise ValueError("points must be n x 64 bytes")
-            n = len(b) // 64
+            n = len(b) // self.pb
             _check(lib().msm_hip_set_bases_bn254(self._h, b, n, flags), "msm_hip_set_bases_bn254")
         self.n_bases = n
         return n
@@ -250,7 +258,7 @@ class MsmContext:
     # -- whole MSM
     def msm(self, scalars):
         """sum_i scalars[i] * bases[i] -> G1.  scalars: bytes (n x 32 B) or CUDA uint8 tensor."""
-        out = C.create_string_buffer(96)
+        out = C.create_string_buffer(self.jb)
         if isinstance(scalars, torch.Tensor) and scalars.is_cuda:
             t, n = _as_device_u8(scalars, 32, "scalars")
             self._order_after_torch(t)
@@ -270,17 +278,17 @@ class MsmContext:
             if n <= 0 or len(b) % (32 * n):
                 raise ValueError("scalars must hold a whole number of n-element vectors")
             batch = len(b) // (32 * n)
-            out = C.create_string_buffer(96 * batch)
+            out = C.create_string_buffer(self.jb * batch)
             _check(lib().msm_hip_run_batch_bn254(self._h, b, n, batch, out), "msm_hip_run_batch_bn254")
-            return [G1(out.raw[96 * k:96 * k + 96], self.modulus) for k in range(batch)]
+            return [G1(out.raw[self.jb * k:self.jb * (k + 1)], self.modulus) for k in range(batch)]
         t, rows = _as_device_u8(scalars_dev, 32, "scalars")
         if n <= 0 or rows % n:
             raise ValueError("scalars must hold a whole number of n-element vectors")
         batch = rows // n
-        out = C.create_string_buffer(96 * batch)
+        out = C.create_string_buffer(self.jb * batch)
         self._order_after_torch(t)
         _check(lib().msm_hip_run_batch_device_bn254(self._h, t.data_ptr(), n, batch, out), "msm_hip_run_batch_device_bn254")
-        return [G1(out.raw[96 * k:96 * k + 96], self.modulus) for k in range(batch)]
+        return [G1(out.raw[self.jb * k:self.jb * (k + 1)], self.modulus) for k in range(batch)]
 
     def launch(self, scalars_dev, slot=0):
         """Enqueue the device work of one MSM into a result slot (0..3) and return at once."""
@@ -299,7 +307,7 @@ class MsmContext:
 
     def finish(self, slot=0):
         """Wait for the slot's device work, run the host window combine, return G1."""
-        out = C.create_string_buffer(96)
+        out = C.create_string_buffer(self.jb)
         try:
             _check(lib().msm_hip_finish_bn254(self._h, slot, out), "msm_hip_finish_bn254")
         finally:
@@ -311,7 +319,7 @@ class MsmContext:
         """Window sums S_w, w in [w_begin, w_end), as a CUDA uint8 tensor [(w_end - w_begin), 96]."""
         t, n = _as_device_u8(scalars_dev, 32, "scalars")
         if out_dev is None:
-            out_dev = torch.empty((w_end - w_begin, 96), dtype=torch.uint8, device=t.device)
+            out_dev = torch.empty((w_end - w_begin, self.jb), dtype=torch.uint8, device=t.device)
         self._order_after_torch(t)
         _check(lib().msm_hip_run_windows_device_bn254(self._h, t.data_ptr(), n, w_begin, w_end, out_dev.data_ptr()),
                "msm_hip_run_windows_device_bn254")
@@ -358,12 +366,12 @@ class MsmContext:
 
     def finish_batch(self, slot, nvec):
         """Wait for a launch_batch slot, run the host window combines, return the list of G1 results."""
-        out = C.create_string_buffer(96 * nvec)
+        out = C.create_string_buffer(self.jb * nvec)
         try:
             _check(lib().msm_hip_finish_batch_bn254(self._h, slot, out), "msm_hip_finish_batch_bn254")
         finally:
             self._keepalive.pop(slot, None)
-        return [G1(out.raw[96 * k:96 * k + 96], self.modulus) for k in range(nvec)]
+        return [G1(out.raw[self.jb * k:self.jb * (k + 1)], self.modulus) for k in range(nvec)]
 
     def slot_wait_stream(self, slot, stream=None):
         """Make a torch CUDA stream (default: the current one) wait, on the device, for the slot's results."""
@@ -384,9 +392,10 @@ class MsmContext:
         if isinstance(window_sums, torch.Tensor):
             window_sums = window_sums.cpu().contiguous().numpy().tobytes()
         b = bytes(window_sums)
-        out = C.create_string_buffer(96)
+        jb = 3 * coord_bytes(curve)
+        out = C.create_string_buffer(jb)
         cid, p = CURVES[curve]
-        _check(lib().msm_hip_combine_windows_curve(cid, b, len(b) // 96, out), "msm_hip_combine_windows_curve")
+        _check(lib().msm_hip_combine_windows_curve(cid, b, len(b) // jb, out), "msm_hip_combine_windows_curve")
         return G1(out.raw, p)
 
     @staticmethod
@@ -396,13 +405,14 @@ class MsmContext:
         if isinstance(window_sums, torch.Tensor):
             window_sums = window_sums.contiguous().numpy()
         a = np.ascontiguousarray(np.frombuffer(window_sums, dtype=np.uint8) if isinstance(window_sums, (bytes, bytearray)) else window_sums, dtype=np.uint8)
-        nvec = a.size // (96 * num_windows)
-        if nvec * 96 * num_windows != a.size:
-            raise ValueError("window sums must be nvec x num_windows x 96 bytes")
-        out = C.create_string_buffer(max(96 * nvec, 1))
+        jb = 3 * coord_bytes(curve)
+        nvec = a.size // (jb * num_windows)
+        if nvec * jb * num_windows != a.size:
+            raise ValueError("window sums must be nvec x num_windows x %d bytes" % jb)
+        out = C.create_string_buffer(max(jb * nvec, 1))
         cid, p = CURVES[curve]
         _check(lib().msm_hip_combine_windows_batch_curve(cid, a.ctypes.data, num_windows, nvec, out), "msm_hip_combine_windows_batch_curve")
-        return [G1(out.raw[96 * k:96 * k + 96], p) for k in range(nvec)]
+        return [G1(out.raw[jb * k:jb * (k + 1)], p) for k in range(nvec)]
 
     # -- synthetic inputs in HBM
     def sample_scalars(self, n, seed):
@@ -411,7 +421,7 @@ class MsmContext:
         return t
 
     def sample_points(self, n, seed):
-        t = torch.empty((n, 64), dtype=torch.uint8, device="cuda:%d" % self.device)
+        t = torch.empty((n, self.pb), dtype=torch.uint8, device="cuda:%d" % self.device)
         _check(lib().msm_hip_sample_points_device(self._h, seed, n, t.data_ptr()), "msm_hip_sample_points_device")
         return t
 
@@ -484,12 +494,12 @@ class MsmContext:
         return a
 
     def read_buckets(self, w_count=NUM_WINDOWS, buckets=BUCKETS_PER_WINDOW):
-        a = np.empty((w_count, buckets, 96), dtype=np.uint8)
+        a = np.empty((w_count, buckets, self.jb), dtype=np.uint8)
         _check(lib().msm_hip_read_buckets(self._h, a.ctypes.data, a.size), "msm_hip_read_buckets")
         return a
 
     def read_window_sums(self, w_count=NUM_WINDOWS):
-        a = np.empty((w_count, 96), dtype=np.uint8)
+        a = np.empty((w_count, self.jb), dtype=np.uint8)
         _check(lib().msm_hip_read_window_sums(self._h, a.ctypes.data, a.size), "msm_hip_read_window_sums")
         return a
 
@@ -497,24 +507,24 @@ class MsmContext:
     def fq_op(self, op, a, b=None):
         code = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "neg": 4, "mul_asm": 5, "sqr_asm": 6, "mul2_asm": 7, "mul_asm_lazy": 8,
                 "sqr_asm_lazy": 9}[op]
-        n = len(a) // 32
-        out = C.create_string_buffer(max(32 * n, 1))
+        n = len(a) // self.cb
+        out = C.create_string_buffer(max(self.cb * n, 1))
         _check(lib().msm_hip_test_fq_op(self._h, code, a, b, out, n), "msm_hip_test_fq_op")
-        return out.raw[:32 * n]
+        return out.raw[:self.cb * n]
 
     def g1_op(self, op, a, b=None):
         code = {"add": 0, "double": 1, "add_affine": 2, "madd_w_pmp": 3, "madd_w_mm": 4}[op]
-        n = len(a) // 96
-        out = C.create_string_buffer(max(96 * n, 1))
+        n = len(a) // self.jb
+        out = C.create_string_buffer(max(self.jb * n, 1))
         _check(lib().msm_hip_test_g1_op(self._h, code, a, b, out, n), "msm_hip_test_g1_op")
-        return out.raw[:96 * n]
+        return out.raw[:self.jb * n]
 
     def g1_mul_u32(self, a, ks):
-        n = len(a) // 96
+        n = len(a) // self.jb
         k = np.ascontiguousarray(ks, dtype=np.uint32)
-        out = C.create_string_buffer(max(96 * n, 1))
+        out = C.create_string_buffer(max(self.jb * n, 1))
         _check(lib().msm_hip_test_g1_mul_u32(self._h, a, k.ctypes.data, out, n), "msm_hip_test_g1_mul_u32")
-        return out.raw[:96 * n]
+        return out.raw[:self.jb * n]
 
 
 class MultiGpuMsm:
@@ -529,6 +539,8 @@ class MultiGpuMsm:
         self._h = C.c_void_p()
         self.curve = curve
         self.modulus = CURVES[curve][1]
+        self.cb = coord_bytes(curve)
+        self.pb, self.jb = 2 * self.cb, 3 * self.cb
         _check(lib().msm_hip_mgpu_create_curve(C.byref(self._h), ids, len(device_ids), self.GATHER[gather], CURVES[curve][0]), "msm_hip_mgpu_create_curve")
 
     def close(self):
@@ -555,21 +567,21 @@ class MultiGpuMsm:
         the window-sharded calls shard the 8 half-length windows."""
         b = bytes(points)
         flags = (1 if check_on_curve else 0) | (8 if endomorphism else 0)
-        _check(lib().msm_hip_mgpu_set_bases_bn254(self._h, b, len(b) // 64, flags), "msm_hip_mgpu_set_bases_bn254")
-        return len(b) // 64
+        _check(lib().msm_hip_mgpu_set_bases_bn254(self._h, b, len(b) // self.pb, flags), "msm_hip_mgpu_set_bases_bn254")
+        return len(b) // self.pb
 
     def msm(self, scalars):
         b = bytes(scalars)
-        out = C.create_string_buffer(96)
+        out = C.create_string_buffer(self.jb)
         _check(lib().msm_hip_mgpu_run_bn254(self._h, b, len(b) // 32, out), "msm_hip_mgpu_run_bn254")
         return G1(out.raw, self.modulus)
 
     def msm_batch(self, scalars, n):
         b = bytes(scalars)
         batch = len(b) // (32 * n)
-        out = C.create_string_buffer(max(96 * batch, 1))
+        out = C.create_string_buffer(max(self.jb * batch, 1))
         _check(lib().msm_hip_mgpu_run_batch_bn254(self._h, b, n, batch, out), "msm_hip_mgpu_run_batch_bn254")
-        return [G1(out.raw[96 * k:96 * k + 96], self.modulus) for k in range(batch)]
+        return [G1(out.raw[self.jb * k:self.jb * (k + 1)], self.modulus) for k in range(batch)]
 
     # -- window-sharded launches of several MSMs, asynchronous (the throughput form)
     @property
@@ -599,12 +611,12 @@ class MultiGpuMsm:
         return len(b) // (32 * n)
 
     def finish_batch(self, slot, nvec):
-        out = C.create_string_buffer(96 * nvec)
+        out = C.create_string_buffer(self.jb * nvec)
         try:
             _check(lib().msm_hip_mgpu_finish_batch_bn254(self._h, slot, out), "msm_hip_mgpu_finish_batch_bn254")
         finally:
             getattr(self, "_keep", {}).pop(slot, None)
-        return [G1(out.raw[96 * k:96 * k + 96], self.modulus) for k in range(nvec)]
+        return [G1(out.raw[self.jb * k:self.jb * (k + 1)], self.modulus) for k in range(nvec)]
 
 
 def window_range_abi(rank, world, num=NUM_WINDOWS):

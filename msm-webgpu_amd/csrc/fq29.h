@@ -14,6 +14,10 @@
 // uses 20 x 13-bit limbs because WGSL has no 64-bit integers; only its semantics (Montgomery product,
 // add, sub mod p) are kept here.
 //
+// The limb layout is a parameter of the curve unit (FQ_LIMBS limbs of FQ_LIMB_BITS bits, FQ_WORDS packed 32-bit words per element,
+// from the generated constants): 9 x 29 bits for the 254 / 255-bit fields, 14 x 28 bits for BLS12-381's 381-bit field (28 x 2^58 partial
+// products and lazy squares must still fit a 64-bit column: 14 limbs of 29 bits do not).  The comments below quote the 9 x 29 numbers.
+//
 // Conventions
 //   value(x)  = sum_i x.v[i] * 2^(29 i)
 //   "normal"  : limbs 0..7 < 2^29 + 8, top limb small       (output of fq_sub / fq_norm)
@@ -50,26 +54,30 @@
 namespace MSM_FIELD_NS {
 
 struct fq {
-  uint32_t v[9];
+  uint32_t v[FQ_LIMBS];
 };
+constexpr int FQ_L = FQ_LIMBS, FQ_W = FQ_LIMB_BITS;  // short names for the loops below
 
 }  // namespace MSM_FIELD_NS
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(FQ29_NO_ASM)
 #define FQ29_ASM 1
-#include "fq29_asm.h"  // fq_mul_asm / fq_sqr_asm: the multipliers as single inline-assembly blocks (tools/gen_fq29_asm.py)
+#ifndef MSM_FQ_ASM_HEADER
+#define MSM_FQ_ASM_HEADER "fq29_asm.h"  // 9 x 29-bit limbs; a unit with another limb layout names its own generated file
+#endif
+#include MSM_FQ_ASM_HEADER  // fq_mul_asm / fq_sqr_asm: the multipliers as single inline-assembly blocks (tools/gen_fq29_asm.py)
 #endif
 namespace MSM_FIELD_NS {
 
 FQ_HD fq fq_zero() {
   fq r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.v[i] = 0;
+  for (int i = 0; i < FQ_L; i++) r.v[i] = 0;
   return r;
 }
 FQ_HD fq fq_one() {  // Montgomery form of 1
   fq r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.v[i] = FQ_ONE29[i];
+  for (int i = 0; i < FQ_L; i++) r.v[i] = FQ_ONE29[i];
   return r;
 }
 
@@ -78,8 +86,8 @@ FQ_HD fq fq_norm(const fq& x) {
   fq r;
   r.v[0] = x.v[0] & FQ_MASK;
 #pragma unroll
-  for (int i = 1; i < 8; i++) r.v[i] = (x.v[i] & FQ_MASK) + (x.v[i - 1] >> 29);
-  r.v[8] = x.v[8] + (x.v[7] >> 29);
+  for (int i = 1; i < FQ_L - 1; i++) r.v[i] = (x.v[i] & FQ_MASK) + (x.v[i - 1] >> FQ_W);
+  r.v[FQ_L - 1] = x.v[FQ_L - 1] + (x.v[FQ_L - 2] >> FQ_W);
   return r;
 }
 
@@ -87,7 +95,7 @@ FQ_HD fq fq_norm(const fq& x) {
 FQ_HD fq fq_add(const fq& a, const fq& b) {
   fq r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+  for (int i = 0; i < FQ_L; i++) r.v[i] = a.v[i] + b.v[i];
   return r;
 }
 FQ_HD fq fq_dbl(const fq& a) { return fq_add(a, a); }
@@ -98,9 +106,9 @@ FQ_HD fq fq_sub(const fq& a, const fq& b) {
   static_assert(K >= 2 && K <= 16, "K*p constant not tabulated");
   fq t;
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
-    FQ_ASSERT(FQ_KP29[K][i] >= b.v[i] || i == 8, "fq_sub: limb borrow");
-    FQ_ASSERT(i != 8 || FQ_KP29[K][8] + a.v[8] >= b.v[8], "fq_sub: top limb borrow");
+  for (int i = 0; i < FQ_L; i++) {
+    FQ_ASSERT(FQ_KP29[K][i] >= b.v[i] || i == FQ_L - 1, "fq_sub: limb borrow");
+    FQ_ASSERT(i != FQ_L - 1 || FQ_KP29[K][FQ_L - 1] + a.v[FQ_L - 1] >= b.v[FQ_L - 1], "fq_sub: top limb borrow");
     t.v[i] = a.v[i] + FQ_KP29[K][i] - b.v[i];
   }
   return fq_norm(t);
@@ -110,14 +118,14 @@ FQ_HD fq fq_sub(const fq& a, const fq& b) {
 // host-only (tests/test_fq29_host.py): r has exact limbs; is its value below 2p?  A Montgomery product's result is < 2p exactly when
 // its operands respected value(a) * value(b) <= (2^261 / p) p^2 -- the contract every bound comment in g1.h relies on.
 inline bool fq_check_below_2p(const fq& r) {
-  uint32_t two_p[9];
+  uint32_t two_p[FQ_L];
   uint64_t carry = 0;
-  for (int i = 0; i < 9; i++) {
+  for (int i = 0; i < FQ_L; i++) {
     const uint64_t t = 2ull * FQ_P29[i] + carry;
-    two_p[i] = (uint32_t)(i < 8 ? t & FQ_MASK : t);
-    carry = i < 8 ? t >> 29 : 0;
+    two_p[i] = (uint32_t)(i < FQ_L - 1 ? t & FQ_MASK : t);
+    carry = i < FQ_L - 1 ? t >> FQ_W : 0;
   }
-  for (int i = 8; i >= 0; i--) {
+  for (int i = FQ_L - 1; i >= 0; i--) {
     if (r.v[i] != two_p[i]) return r.v[i] < two_p[i];
   }
   return false;
@@ -130,27 +138,27 @@ FQ_HD fq fq_mul(const fq& a, const fq& b) {
 #if defined(FQ29_ASM) && defined(FQ29_ASM_EVERYWHERE)  // diagnostic build: the assembly multipliers in every kernel
   return fq_mul_asm(a, b);
 #endif
-  uint64_t c[18];
+  uint64_t c[2 * FQ_L];
 #pragma unroll
-  for (int k = 0; k < 18; k++) c[k] = 0;
+  for (int k = 0; k < 2 * FQ_L; k++) c[k] = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
-    FQ_ASSERT(a.v[i] <= (1u << 30) + 64 && b.v[i] <= (1u << 30) + 64, "fq_mul: operand limb too large");
+  for (int i = 0; i < FQ_L; i++) {
+    FQ_ASSERT(a.v[i] <= (1u << (FQ_W + 1)) + 64 && b.v[i] <= (1u << (FQ_W + 1)) + 64, "fq_mul: operand limb too large");
 #pragma unroll
-    for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a.v[j] * b.v[i];
+    for (int j = 0; j < FQ_L; j++) c[i + j] += (uint64_t)a.v[j] * b.v[i];
     const uint32_t m = ((uint32_t)c[i] * FQ_N0_29) & FQ_MASK;
 #pragma unroll
-    for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)m * FQ_P29[j];
-    c[i + 1] += c[i] >> 29;
+    for (int j = 0; j < FQ_L; j++) c[i + j] += (uint64_t)m * FQ_P29[j];
+    c[i + 1] += c[i] >> FQ_W;
   }
   fq r;
 #pragma unroll
-  for (int k = 9; k < 17; k++) {
-    r.v[k - 9] = (uint32_t)c[k] & FQ_MASK;
-    c[k + 1] += c[k] >> 29;
+  for (int k = FQ_L; k < 2 * FQ_L - 1; k++) {
+    r.v[k - FQ_L] = (uint32_t)c[k] & FQ_MASK;
+    c[k + 1] += c[k] >> FQ_W;
   }
-  r.v[8] = (uint32_t)c[17];
-  FQ_ASSERT((c[17] >> 26) == 0, "fq_mul: result >= 2^258");
+  r.v[FQ_L - 1] = (uint32_t)c[2 * FQ_L - 1];
+  FQ_ASSERT((c[2 * FQ_L - 1] >> (FQ_W - 3)) == 0, "fq_mul: result >= 2^258");
   FQ_ASSERT(fq_check_below_2p(r), "fq_mul: result >= 2p (operand value bound violated)");
   return r;
 }
@@ -163,30 +171,30 @@ FQ_HD fq fq_mul2(const fq& a, const fq& b, const fq& c_, const fq& d) {
 #if defined(FQ29_ASM) && defined(FQ29_ASM_EVERYWHERE)
   return fq_mul2_asm(a, b, c_, d);
 #endif
-  uint64_t c[18];
+  uint64_t c[2 * FQ_L];
 #pragma unroll
-  for (int k = 0; k < 18; k++) c[k] = 0;
+  for (int k = 0; k < 2 * FQ_L; k++) c[k] = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
-    FQ_ASSERT(a.v[i] <= (1u << 30) + 64 && b.v[i] <= (1u << 29) + 64 && c_.v[i] <= (1u << 29) + 64 && d.v[i] <= (1u << 29) + 64,
+  for (int i = 0; i < FQ_L; i++) {
+    FQ_ASSERT(a.v[i] <= (1u << (FQ_W + 1)) + 64 && b.v[i] <= (1u << FQ_W) + 64 && c_.v[i] <= (1u << FQ_W) + 64 && d.v[i] <= (1u << FQ_W) + 64,
               "fq_mul2: operand limb too large");
 #pragma unroll
-    for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a.v[j] * b.v[i];
+    for (int j = 0; j < FQ_L; j++) c[i + j] += (uint64_t)a.v[j] * b.v[i];
 #pragma unroll
-    for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)c_.v[j] * d.v[i];
+    for (int j = 0; j < FQ_L; j++) c[i + j] += (uint64_t)c_.v[j] * d.v[i];
     const uint32_t m = ((uint32_t)c[i] * FQ_N0_29) & FQ_MASK;
 #pragma unroll
-    for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)m * FQ_P29[j];
-    c[i + 1] += c[i] >> 29;
+    for (int j = 0; j < FQ_L; j++) c[i + j] += (uint64_t)m * FQ_P29[j];
+    c[i + 1] += c[i] >> FQ_W;
   }
   fq r;
 #pragma unroll
-  for (int k = 9; k < 17; k++) {
-    r.v[k - 9] = (uint32_t)c[k] & FQ_MASK;
-    c[k + 1] += c[k] >> 29;
+  for (int k = FQ_L; k < 2 * FQ_L - 1; k++) {
+    r.v[k - FQ_L] = (uint32_t)c[k] & FQ_MASK;
+    c[k + 1] += c[k] >> FQ_W;
   }
-  r.v[8] = (uint32_t)c[17];
-  FQ_ASSERT((c[17] >> 26) == 0, "fq_mul2: result >= 2^258");
+  r.v[FQ_L - 1] = (uint32_t)c[2 * FQ_L - 1];
+  FQ_ASSERT((c[2 * FQ_L - 1] >> (FQ_W - 3)) == 0, "fq_mul2: result >= 2^258");
   FQ_ASSERT(fq_check_below_2p(r), "fq_mul2: result >= 2p (operand value bound violated)");
   return r;
 }
@@ -196,35 +204,35 @@ FQ_HD fq fq_sqr(const fq& a) {
 #if defined(FQ29_ASM) && defined(FQ29_ASM_EVERYWHERE)
   return fq_sqr_asm(a);
 #endif
-  uint64_t c[18];
-  uint32_t a2[9];
+  uint64_t c[2 * FQ_L];
+  uint32_t a2[FQ_L];
 #pragma unroll
-  for (int k = 0; k < 18; k++) c[k] = 0;
+  for (int k = 0; k < 2 * FQ_L; k++) c[k] = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
-    FQ_ASSERT(a.v[i] <= (1u << 30) + 64, "fq_sqr: operand limb too large");
+  for (int i = 0; i < FQ_L; i++) {
+    FQ_ASSERT(a.v[i] <= (1u << (FQ_W + 1)) + 64, "fq_sqr: operand limb too large");
     a2[i] = a.v[i] << 1;
   }
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
+  for (int i = 0; i < FQ_L; i++) {
     c[2 * i] += (uint64_t)a.v[i] * a.v[i];
 #pragma unroll
-    for (int j = i + 1; j < 9; j++) c[i + j] += (uint64_t)a.v[i] * a2[j];
+    for (int j = i + 1; j < FQ_L; j++) c[i + j] += (uint64_t)a.v[i] * a2[j];
   }
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
+  for (int i = 0; i < FQ_L; i++) {
     const uint32_t m = ((uint32_t)c[i] * FQ_N0_29) & FQ_MASK;
 #pragma unroll
-    for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)m * FQ_P29[j];
-    c[i + 1] += c[i] >> 29;
+    for (int j = 0; j < FQ_L; j++) c[i + j] += (uint64_t)m * FQ_P29[j];
+    c[i + 1] += c[i] >> FQ_W;
   }
   fq r;
 #pragma unroll
-  for (int k = 9; k < 17; k++) {
-    r.v[k - 9] = (uint32_t)c[k] & FQ_MASK;
-    c[k + 1] += c[k] >> 29;
+  for (int k = FQ_L; k < 2 * FQ_L - 1; k++) {
+    r.v[k - FQ_L] = (uint32_t)c[k] & FQ_MASK;
+    c[k + 1] += c[k] >> FQ_W;
   }
-  r.v[8] = (uint32_t)c[17];
+  r.v[FQ_L - 1] = (uint32_t)c[2 * FQ_L - 1];
   FQ_ASSERT(fq_check_below_2p(r), "fq_sqr: result >= 2p (operand value bound violated)");
   return r;
 }
@@ -274,7 +282,7 @@ FQ_HD void fq_mul2_fast_ip(const fq& a, const fq& b, fq& c_, const fq& d) {
 FQ_HD bool fq_is_zero_exact(const fq& x) {
   uint32_t z = 0, e = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
+  for (int i = 0; i < FQ_L; i++) {
     z |= x.v[i];
     e |= x.v[i] ^ FQ_P29[i];
   }
@@ -286,14 +294,14 @@ FQ_HD fq fq_canonical(const fq& x) {
   fq d;
   uint32_t borrow = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
+  for (int i = 0; i < FQ_L; i++) {
     const uint32_t t = x.v[i] - FQ_P29[i] - borrow;
     borrow = t >> 31;
-    d.v[i] = (i < 8) ? (t & FQ_MASK) : t;
+    d.v[i] = (i < FQ_L - 1) ? (t & FQ_MASK) : t;
   }
   fq r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.v[i] = borrow ? x.v[i] : d.v[i];
+  for (int i = 0; i < FQ_L; i++) r.v[i] = borrow ? x.v[i] : d.v[i];
   return r;
 }
 
@@ -301,30 +309,30 @@ FQ_HD fq fq_canonical(const fq& x) {
 FQ_HD fq fq_tidy(const fq& x) { return fq_mul(x, fq_one()); }
 
 // 8 x 32-bit packed words (value < 2^256)  <->  9 x 29-bit limbs (exact)
-FQ_HD fq fq_unpack(const uint32_t w[8]) {
+FQ_HD fq fq_unpack(const uint32_t w[FQ_WORDS]) {
   fq r;
   uint64_t acc = 0;
   int bits = 0, k = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
-    if (bits < 29 && k < 8) {
+  for (int i = 0; i < FQ_L; i++) {
+    if (bits < FQ_W && k < FQ_WORDS) {
       acc |= (uint64_t)w[k++] << bits;
       bits += 32;
     }
     r.v[i] = (uint32_t)acc & FQ_MASK;
-    acc >>= 29;
-    bits -= 29;
+    acc >>= FQ_W;
+    bits -= FQ_W;
   }
   return r;
 }
-FQ_HD void fq_pack(uint32_t w[8], const fq& x) {  // x exact, value < 2^256
+FQ_HD void fq_pack(uint32_t w[FQ_WORDS], const fq& x) {  // x exact, value < 2^(32 FQ_WORDS)
   uint64_t acc = 0;
   int bits = 0, k = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
+  for (int i = 0; i < FQ_L; i++) {
     acc |= (uint64_t)x.v[i] << bits;
-    bits += 29;
-    if (bits >= 32 && k < 8) {
+    bits += FQ_W;
+    if (bits >= 32 && k < FQ_WORDS) {
       w[k++] = (uint32_t)acc;
       acc >>= 32;
       bits -= 32;
@@ -336,14 +344,14 @@ FQ_HD void fq_pack(uint32_t w[8], const fq& x) {  // x exact, value < 2^256
 FQ_HD fq fq_to_mont(const fq& x_plain) {
   fq r2;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r2.v[i] = FQ_R2_29[i];
+  for (int i = 0; i < FQ_L; i++) r2.v[i] = FQ_R2_29[i];
   return fq_canonical(fq_mul(x_plain, r2));
 }
 // x * 2^256 mod p (the in-memory form of a 4 x 64-bit Montgomery library with R = 2^256, canonical) -> device Montgomery form
 FQ_HD fq fq_from_mont256(const fq& x_r256) {
   fq c;
 #pragma unroll
-  for (int i = 0; i < 9; i++) c.v[i] = FQ_2P266_29[i];
+  for (int i = 0; i < FQ_L; i++) c.v[i] = FQ_2P266_29[i];
   return fq_canonical(fq_mul(x_r256, c));  // x 2^256 * 2^266 / 2^261 = x 2^261
 }
 FQ_HD fq fq_from_mont(const fq& x) {  // x normal, value <= 84p
@@ -356,7 +364,7 @@ FQ_HD fq fq_from_mont(const fq& x) {  // x normal, value <= 84p
 FQ_HD fq fq_neg_lazy(const fq& y) {
   fq r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
+  for (int i = 0; i < FQ_L; i++) {
     FQ_ASSERT(FQ_2P_LAZY29[i] >= y.v[i], "fq_neg_lazy: limb borrow");
     r.v[i] = FQ_2P_LAZY29[i] - y.v[i];
   }
@@ -366,14 +374,14 @@ FQ_HD fq fq_neg_lazy(const fq& y) {
 FQ_HD fq fq_neg_canonical(const fq& y) {  // y canonical in [0,p) -> p - y (or 0)
   uint32_t z = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) z |= y.v[i];
+  for (int i = 0; i < FQ_L; i++) z |= y.v[i];
   fq t;
   uint32_t borrow = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
+  for (int i = 0; i < FQ_L; i++) {
     const uint32_t d = FQ_P29[i] - y.v[i] - borrow;
     borrow = d >> 31;
-    t.v[i] = (i < 8) ? (d & FQ_MASK) : d;
+    t.v[i] = (i < FQ_L - 1) ? (d & FQ_MASK) : d;
   }
   return z ? t : y;
 }

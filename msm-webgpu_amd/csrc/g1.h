@@ -147,7 +147,7 @@ FQ_HD void g1_madd_w(g1_xyzz& a, bool& wneg, const fq& px, const fq& py, bool sn
   {
     const fq n = fq_neg_lazy(py);
 #pragma unroll
-    for (int i = 0; i < 9; i++) pye.v[i] = negp ? n.v[i] : py.v[i];
+    for (int i = 0; i < FQ_L; i++) pye.v[i] = negp ? n.v[i] : py.v[i];
   }
   const fq U2 = fq_mul_fast(px, a.zz);                  // < 2p
   const fq S2 = fq_mul_fast(pye, a.zzz);                // 2p * 2p           -> < 2p, exact
@@ -183,7 +183,7 @@ FQ_HD int g1_madd_w_hot(g1_xyzz& a, bool& wneg, const fq& px, const fq& py, bool
   {
     const fq n = fq_neg_lazy(py);
 #pragma unroll
-    for (int i = 0; i < 9; i++) pye.v[i] = negp ? n.v[i] : py.v[i];
+    for (int i = 0; i < FQ_L; i++) pye.v[i] = negp ? n.v[i] : py.v[i];
   }
   const fq U2 = fq_mul_fast(px, a.zz);                  // < 2p
   const fq S2 = fq_mul_fast(pye, a.zzz);                // 2p * 2p           -> < 2p, exact
@@ -269,7 +269,7 @@ FQ_HD void g1_to_jacobian(const g1_xyzz& a, fq& X, fq& Y, fq& Z) {
 FQ_HD g1_xyzz g1_from_jacobian(const fq& X, const fq& Y, const fq& Z) {
   uint32_t z = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) z |= Z.v[i];
+  for (int i = 0; i < FQ_L; i++) z |= Z.v[i];
   if (z == 0) return g1_identity();
   g1_xyzz r;
   r.x = X;

@@ -1,4 +1,5 @@
-// Host finalisation arithmetic: BN254 Fq as 4 x 64-bit Montgomery limbs (R = 2^256) and Jacobian G1.
+// Host finalisation arithmetic: the unit's base field as HL x 64-bit Montgomery limbs (4, R = 2^256, for BN254 and the other 254 / 255-bit
+// fields; 6 for BLS12-381) and Jacobian G1.
 //
 // The only host-side group arithmetic in the product: the window combine result = sum_w 2^(16w) S_w
 // (≙ src/cuzk/msm.rs:391-416, which the reference also runs on the host).  It is 240 dependent doublings --
@@ -17,19 +18,25 @@ namespace host {
 
 typedef unsigned __int128 u128;
 
+// HL 64-bit limbs per element (4 for the 254 / 255-bit fields, 6 for BLS12-381), CB bytes per coordinate on the wire (32 / 48);
+// a Jacobian record is 3 CB bytes, an affine one 2 CB
+constexpr int HL = FQ_WORDS / 2;
+constexpr int CB = 4 * FQ_WORDS;
+constexpr int JB = 3 * CB;
+
 struct hfq {
-  uint64_t l[4];
+  uint64_t l[HL];
 };
 
 inline bool hfq_geq_p(const hfq& a) {
-  for (int i = 3; i >= 0; i--) {
+  for (int i = HL - 1; i >= 0; i--) {
     if (a.l[i] != FQ_P64[i]) return a.l[i] > FQ_P64[i];
   }
   return true;
 }
 inline void hfq_sub_p(hfq& a) {
   uint64_t borrow = 0;
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < HL; i++) {
     u128 d = (u128)a.l[i] - FQ_P64[i] - borrow;
     a.l[i] = (uint64_t)d;
     borrow = (uint64_t)(d >> 64) & 1u;
@@ -38,7 +45,7 @@ inline void hfq_sub_p(hfq& a) {
 inline hfq hfq_add(const hfq& a, const hfq& b) {
   hfq r;
   u128 c = 0;
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < HL; i++) {
     c += (u128)a.l[i] + b.l[i];
     r.l[i] = (uint64_t)c;
     c >>= 64;
@@ -49,14 +56,14 @@ inline hfq hfq_add(const hfq& a, const hfq& b) {
 inline hfq hfq_sub(const hfq& a, const hfq& b) {
   hfq r;
   uint64_t borrow = 0;
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < HL; i++) {
     u128 d = (u128)a.l[i] - b.l[i] - borrow;
     r.l[i] = (uint64_t)d;
     borrow = (uint64_t)(d >> 64) & 1u;
   }
   if (borrow) {
     u128 c = 0;
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < HL; i++) {
       c += (u128)r.l[i] + FQ_P64[i];
       r.l[i] = (uint64_t)c;
       c >>= 64;
@@ -64,59 +71,72 @@ inline hfq hfq_sub(const hfq& a, const hfq& b) {
   }
   return r;
 }
-// Montgomery product, separated operand scanning: full 512-bit product first, then four reduction rounds
+// Montgomery product (R = 2^(64 HL)), separated operand scanning: the full double-width product first, then HL reduction rounds
 inline hfq hfq_mul(const hfq& a, const hfq& b) {
-  uint64_t t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < 4; i++) {
+  uint64_t t[2 * HL + 1];
+  for (int i = 0; i < 2 * HL + 1; i++) t[i] = 0;
+  for (int i = 0; i < HL; i++) {
     u128 carry = 0;
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < HL; j++) {
       carry += (u128)a.l[i] * b.l[j] + t[i + j];
       t[i + j] = (uint64_t)carry;
       carry >>= 64;
     }
-    t[i + 4] = (uint64_t)carry;
+    t[i + HL] = (uint64_t)carry;
   }
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < HL; i++) {
     const uint64_t m = t[i] * FQ_N0_64;
     u128 carry = 0;
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < HL; j++) {
       carry += (u128)m * FQ_P64[j] + t[i + j];
       t[i + j] = (uint64_t)carry;
       carry >>= 64;
     }
-    for (int k = i + 4; carry && k < 9; k++) {
+    for (int k = i + HL; carry && k < 2 * HL + 1; k++) {
       carry += t[k];
       t[k] = (uint64_t)carry;
       carry >>= 64;
     }
   }
-  hfq r = {{t[4], t[5], t[6], t[7]}};
-  if (t[8] || hfq_geq_p(r)) hfq_sub_p(r);
+  hfq r;
+  for (int i = 0; i < HL; i++) r.l[i] = t[HL + i];
+  if (t[2 * HL] || hfq_geq_p(r)) hfq_sub_p(r);
   return r;
 }
 inline hfq hfq_sqr(const hfq& a) { return hfq_mul(a, a); }
-inline bool hfq_is_zero(const hfq& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
-inline bool hfq_eq(const hfq& a, const hfq& b) { return memcmp(a.l, b.l, 32) == 0; }
+inline bool hfq_is_zero(const hfq& a) {
+  uint64_t z = 0;
+  for (int i = 0; i < HL; i++) z |= a.l[i];
+  return z == 0;
+}
+inline bool hfq_eq(const hfq& a, const hfq& b) { return memcmp(a.l, b.l, CB) == 0; }
+inline hfq hfq_const(const uint64_t* c) {
+  hfq r;
+  for (int i = 0; i < HL; i++) r.l[i] = c[i];
+  return r;
+}
 
 // canonical little-endian bytes <-> Montgomery; returns false when the encoding is >= p
-inline bool hfq_from_bytes(hfq& r, const uint8_t b[32]) {
+inline bool hfq_from_bytes(hfq& r, const uint8_t* b) {
   hfq t;
-  memcpy(t.l, b, 32);
+  memcpy(t.l, b, CB);
   const bool ok = !hfq_geq_p(t);
-  hfq r2 = {{FQ_R2_64[0], FQ_R2_64[1], FQ_R2_64[2], FQ_R2_64[3]}};
-  r = hfq_mul(t, r2);
+  r = hfq_mul(t, hfq_const(FQ_R2_64));
   return ok;
 }
-inline void hfq_to_bytes(uint8_t b[32], const hfq& a) {
-  hfq one = {{1, 0, 0, 0}};
+inline void hfq_to_bytes(uint8_t* b, const hfq& a) {
+  hfq one;
+  for (int i = 0; i < HL; i++) one.l[i] = i == 0 ? 1 : 0;
   hfq t = hfq_mul(a, one);
-  memcpy(b, t.l, 32);
+  memcpy(b, t.l, CB);
 }
 
 inline hfq hfq_inv(const hfq& a) {  // a^(p-2), square-and-multiply from the top bit
-  uint64_t e[4] = {FQ_P64[0] - 2, FQ_P64[1], FQ_P64[2], FQ_P64[3]};
-  hfq acc = {{FQ_ONE64[0], FQ_ONE64[1], FQ_ONE64[2], FQ_ONE64[3]}};
-  for (int i = 255; i >= 0; i--) {
+  uint64_t e[HL];
+  for (int i = 0; i < HL; i++) e[i] = FQ_P64[i];
+  e[0] -= 2;  // (p is odd and > 2: no borrow)
+  hfq acc = hfq_const(FQ_ONE64);
+  for (int i = 64 * HL - 1; i >= 0; i--) {
     acc = hfq_sqr(acc);
     if ((e[i >> 6] >> (i & 63)) & 1) acc = hfq_mul(acc, a);
   }
@@ -173,45 +193,46 @@ inline hg1 hg1_add(const hg1& p, const hg1& q) {  // add-2007-bl with the usual 
   r.z = hfq_mul(hfq_sub(hfq_sub(hfq_sqr(zz), z1z1), z2z2), h);
   return r;
 }
-inline bool hg1_from_bytes96(hg1& r, const uint8_t b[96]) {
+// (the "96" of these names is the record size of the 254 / 255-bit curves; a record is JB = 3 CB bytes)
+inline bool hg1_from_bytes96(hg1& r, const uint8_t* b) {
   bool ok = hfq_from_bytes(r.x, b);
-  ok &= hfq_from_bytes(r.y, b + 32);
-  ok &= hfq_from_bytes(r.z, b + 64);
+  ok &= hfq_from_bytes(r.y, b + CB);
+  ok &= hfq_from_bytes(r.z, b + 2 * CB);
   return ok;
 }
-inline void hg1_to_bytes96(uint8_t b[96], const hg1& p) {
+inline void hg1_to_bytes96(uint8_t* b, const hg1& p) {
   if (hg1_is_identity(p)) {
-    memset(b, 0, 96);
+    memset(b, 0, JB);
     return;
   }
   hfq_to_bytes(b, p.x);
-  hfq_to_bytes(b + 32, p.y);
-  hfq_to_bytes(b + 64, p.z);
+  hfq_to_bytes(b + CB, p.y);
+  hfq_to_bytes(b + 2 * CB, p.z);
 }
 
 // Jacobian bytes -> canonical affine x || y (≙ Curve::to_affine); returns 1 for the identity (out zeroed), -1 on a
 // non-canonical coordinate, 0 otherwise
-inline int to_affine64(const uint8_t xyz[96], uint8_t out[64]) {
+inline int to_affine64(const uint8_t* xyz, uint8_t* out) {
   hg1 p;
   if (!hg1_from_bytes96(p, xyz)) return -1;
   if (hg1_is_identity(p)) {
-    memset(out, 0, 64);
+    memset(out, 0, 2 * CB);
     return 1;
   }
   const hfq zi = hfq_inv(p.z), zi2 = hfq_sqr(zi);
   hfq_to_bytes(out, hfq_mul(p.x, zi2));
-  hfq_to_bytes(out + 32, hfq_mul(p.y, hfq_mul(zi2, zi)));
+  hfq_to_bytes(out + CB, hfq_mul(p.y, hfq_mul(zi2, zi)));
   return 0;
 }
 
 // result = sum_w 2^(window_bits * w) * S_w, from the top window down  (src/cuzk/msm.rs:411-416)
-inline bool combine_windows(const uint8_t* sums96, int num_windows, int window_bits, uint8_t out[96]) {
+inline bool combine_windows(const uint8_t* sums96, int num_windows, int window_bits, uint8_t* out) {
   hg1 acc = hg1_identity();
   bool ok = true;
   for (int w = num_windows - 1; w >= 0; w--) {
     for (int k = 0; k < window_bits; k++) acc = hg1_double(acc);
     hg1 s;
-    ok &= hg1_from_bytes96(s, sums96 + 96 * (size_t)w);
+    ok &= hg1_from_bytes96(s, sums96 + JB * (size_t)w);
     acc = hg1_add(acc, s);
   }
   hg1_to_bytes96(out, acc);
@@ -228,16 +249,16 @@ inline bool window_sum_from_planes(const uint8_t* planes, hg1& sum) {
   for (int pos = 14; pos >= 0; pos--) {
     acc = hg1_double(acc);
     hg1 term;
-    ok &= hg1_from_bytes96(term, planes + 96 * (size_t)(pos >= 7 ? pos - 7 : 8 + pos));
+    ok &= hg1_from_bytes96(term, planes + JB * (size_t)(pos >= 7 ? pos - 7 : 8 + pos));
     acc = hg1_add(acc, term);
   }
   hg1 tc;
-  ok &= hg1_from_bytes96(tc, planes + 96 * (size_t)(PLANES_PER_WINDOW - 1));
+  ok &= hg1_from_bytes96(tc, planes + JB * (size_t)(PLANES_PER_WINDOW - 1));
   sum = hg1_add(acc, tc);
   return ok;
 }
 // ... as a 96-byte Jacobian record (one window: the caller spreads the windows of a launch over host threads)
-inline bool window_from_planes(const uint8_t* planes, uint8_t sum96[96]) {
+inline bool window_from_planes(const uint8_t* planes, uint8_t* sum96) {
   hg1 s;
   const bool ok = window_sum_from_planes(planes, s);
   hg1_to_bytes96(sum96, s);

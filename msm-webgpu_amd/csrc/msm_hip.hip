@@ -44,6 +44,7 @@ inline const CurveOps* curve_ops(int curve) {
     case MSM_HIP_CURVE_GRUMPKIN: return msm_hip_curve_ops_grumpkin();
     case MSM_HIP_CURVE_PALLAS: return msm_hip_curve_ops_pallas();
     case MSM_HIP_CURVE_VESTA: return msm_hip_curve_ops_vesta();
+    case MSM_HIP_CURVE_BLS12_381: return msm_hip_curve_ops_bls12_381();
     default: return &BN254_OPS;
   }
 }
@@ -57,9 +58,9 @@ enum LaunchMode {
 
 constexpr int N_MAIN_EVENTS = 7;  // boundaries of the 6 timed stages on the main stream
 constexpr uint32_t MAX_TILES = 1024;
-constexpr size_t PLANE_BYTES = (size_t)PLANES_PER_WINDOW * 96;  // a window's bit-plane sums (k_bpr_planes)
-constexpr size_t WSUM_BYTES = (size_t)24 * PLANE_BYTES;  // MAXLW window sums (96 B each) or, for one host-combined MSM, the plane sums of its <= 22 windows
-static_assert(WSUM_BYTES >= (size_t)MAXLW * 96, "window-sum buffer");
+constexpr size_t MAX_JB = 144;  // the largest Jacobian record of any curve (BLS12-381: 3 x 48 B; the 254 / 255-bit curves: 96 B)
+constexpr size_t WSUM_BYTES = (size_t)24 * PLANES_PER_WINDOW * MAX_JB;  // MAXLW window sums or, for one host-combined MSM, the bit-plane sums (k_bpr_planes) of its <= 22 windows
+static_assert(WSUM_BYTES >= (size_t)MAXLW * MAX_JB, "window-sum buffer");
 constexpr int NSLOT = MSM_HIP_NUM_SLOTS;  // result slots
 constexpr int NREDUCE = 2;  // reduce streams (slot k uses stream k % NREDUCE): two bucket reduces may be in flight when the
                             // main-stream work of one MSM is shorter than its bucket reduce (few windows per GPU).  The context
@@ -101,6 +102,7 @@ struct msm_hip_ctx {
   int device = 0;
   int curve = MSM_HIP_CURVE_BN254_G1;
   const CurveOps* ops = nullptr;
+  size_t cb = 32, pb = 64, jb = 96;     // bytes of a coordinate, an affine point and a Jacobian record on this curve's wire (48 / 96 / 144: BLS12-381)
   hipStream_t stream = nullptr;         // main
   hipStream_t reduce_stream[NREDUCE] = {};  // bucket reduce + result copies
   int last_hip_error = 0;
@@ -240,9 +242,9 @@ int setup_slot(msm_hip_ctx* ctx, Slot& s) {
     memset(s.h_wsums, 0, WSUM_BYTES + 4);
   }
   if ((rc = dev_alloc(ctx, s.d_wsums, WSUM_BYTES + 4))) return rc;
-  if ((rc = dev_alloc(ctx, s.d_partials, (size_t)MAXLW * (256 + 256 + 3) * XYZZ_WORDS))) return rc;
+  if ((rc = dev_alloc(ctx, s.d_partials, (size_t)MAXLW * (256 + 256 + PLANES_PER_WINDOW) * ctx->ops->xyzz_words))) return rc;
   if ((rc = dev_alloc(ctx, s.d_col_ptr, (size_t)MAXLW * (HALF + 1)))) return rc;
-  if ((rc = dev_alloc(ctx, s.d_big_queue, BIGQ_WORDS))) return rc;
+  if ((rc = dev_alloc(ctx, s.d_big_queue, BIGQ_SCRATCH + (size_t)STITCH_BLOCKS * ctx->ops->rec_words))) return rc;
   // zeroed on the stream that first reads them (the slot's reduce stream; the error word is first written on the main
   // stream, which waits for `done` below) -- not on the null stream, which the non-blocking streams do not order with
   hipStream_t rs = ctx->reduce_stream[(&s - ctx->slot) % NREDUCE];
@@ -302,8 +304,8 @@ int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, int full_win
     size_t recs = piece_records_for(n);
     if (recs < need_recs) recs = need_recs;
     s.cap_recs = 0;
-    if ((rc = dev_alloc(ctx, s.d_heads, recs * REC_WORDS))) return rc;
-    if ((rc = dev_alloc(ctx, s.d_tails, recs * REC_WORDS))) return rc;
+    if ((rc = dev_alloc(ctx, s.d_heads, recs * ctx->ops->rec_words))) return rc;
+    if ((rc = dev_alloc(ctx, s.d_tails, recs * ctx->ops->rec_words))) return rc;
     s.cap_recs = recs;
   }
   const size_t need_buckets = (size_t)w_count << (wbits - 1);
@@ -311,7 +313,7 @@ int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, int full_win
     size_t recs = (size_t)NWIN * HALF;
     if (recs < need_buckets) recs = need_buckets;
     s.cap_buckets = 0;
-    if ((rc = dev_alloc(ctx, s.d_buckets, recs * REC_WORDS))) return rc;
+    if ((rc = dev_alloc(ctx, s.d_buckets, recs * ctx->ops->rec_words))) return rc;
     s.cap_buckets = recs;
   }
   if (n >= ctx->fine_hist_min_n && !ctx->d_part_hist) {
@@ -501,8 +503,8 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     HIP_TRY(ctx, hipEventRecord(s.red0, rs));
   }
   uint32_t* d_rows = s.d_partials;
-  uint32_t* d_cols = d_rows + (size_t)MAXLW * 256 * XYZZ_WORDS;
-  uint32_t* d_parts = d_cols + (size_t)MAXLW * 256 * XYZZ_WORDS;
+  uint32_t* d_cols = d_rows + (size_t)MAXLW * 256 * ctx->ops->xyzz_words;
+  uint32_t* d_parts = d_cols + (size_t)MAXLW * 256 * ctx->ops->xyzz_words;
   static const int force_logr = [] { const char* e = getenv("MSM_HIP_BPR_LOGR"); return e ? atoi(e) : 0; }();  // tuning aid
   // serial run per thread before the LDS tree: 16 buckets when many windows are reduced at once (fewest wave-additions),
   // 4 for a few windows (shallowest); measured optimum for 16 and for 2 windows respectively
@@ -532,14 +534,20 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     hipLaunchKernelGGL(ctx->ops->bpr_planes, dim3(PLANES_PER_WINDOW, w_count), dim3(256), 0, rs, d_rows, d_cols, wsums_out, (int)(half / BPR_COLS),
                        s.d_big_queue);
     AFTER_KERNEL(ctx, "k_bpr_planes", rs);
-  } else {
+  } else if (ctx->ops->use_w256) {
     hipLaunchKernelGGL(ctx->ops->bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts, (int)(half / BPR_COLS));
     AFTER_KERNEL(ctx, "k_bpr_w256", rs);
     hipLaunchKernelGGL(ctx->ops->bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue);
     AFTER_KERNEL(ctx, "k_bpr_final", rs);
+  } else {  // a field too wide for k_bpr_w256's LDS footprint (BLS12-381): the same bit-plane sums, finished on the device
+    hipLaunchKernelGGL(ctx->ops->bpr_planes_xyzz, dim3(PLANES_PER_WINDOW, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts, (int)(half / BPR_COLS),
+                       s.d_big_queue);
+    AFTER_KERNEL(ctx, "k_bpr_planes<xyzz>", rs);
+    hipLaunchKernelGGL(ctx->ops->bpr_final_planes, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue);
+    AFTER_KERNEL(ctx, "k_bpr_final_planes", rs);
   }
   if (tl >= 2) HIP_TRY(ctx, hipEventRecord(s.red1, rs));
-  if (to_host) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * (parts_mode ? PLANE_BYTES : 96), hipMemcpyDeviceToHost, rs));
+  if (to_host) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * (parts_mode ? PLANES_PER_WINDOW : 1) * ctx->jb, hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums + WSUM_BYTES, d_err, 4, hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipMemsetAsync(d_err, 0, 4, rs));  // ready for the slot's next occupant
   HIP_TRY(ctx, hipEventRecord(s.done, rs));
@@ -607,13 +615,14 @@ int reserve_bases(msm_hip_ctx* ctx, size_t n, uint32_t flags) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   const bool tables = (flags & MSM_HIP_BASES_PRECOMPUTE) != 0, endo = (flags & MSM_HIP_BASES_ENDOMORPHISM) != 0;
   if (n > MAX_POINTS || (tables && n > MAX_PRECOMPUTE_POINTS) || (endo && n > MAX_POINTS / 2) || (tables && endo)) return MSM_HIP_ERR_INVALID_ARG;
+  if (endo && !ctx->ops->glv) return MSM_HIP_ERR_INVALID_ARG;
   ctx->n_bases = 0;
   ctx->precomputed = false;
   ctx->endo = false;
   const size_t records = tables ? n * NWIN : endo ? 2 * n : n;
   if (records > ctx->cap_bases) {
     ctx->cap_bases = 0;
-    int rc = dev_alloc(ctx, ctx->d_bases, records * 16);
+    int rc = dev_alloc(ctx, ctx->d_bases, records * 2 * (size_t)ctx->ops->coord_words);
     if (rc) return rc;
     ctx->cap_bases = records;
   }
@@ -673,7 +682,7 @@ int run_batch_groups(msm_hip_ctx* ctx, size_t n, size_t batch, uint8_t* out_xyz,
   for (size_t j = 0; j < groups + DEPTH; j++) {
     if (j >= DEPTH) {
       const size_t k = j - DEPTH;
-      if ((rc = msm_hip_finish_batch_bn254(ctx, (int)(k % NSLOT), out_xyz + 96 * k * g))) break;
+      if ((rc = msm_hip_finish_batch_bn254(ctx, (int)(k % NSLOT), out_xyz + ctx->jb * k * g))) break;
     }
     if (j < groups) {
       const size_t first = j * g, count = first + g <= batch ? g : batch - first;
@@ -727,6 +736,9 @@ int msm_hip_ctx_create_curve(msm_hip_ctx** out, int device_id, int curve) {
   ctx->device = device_id;
   ctx->curve = curve;
   ctx->ops = curve_ops(curve);
+  ctx->cb = 4 * (size_t)ctx->ops->coord_words;
+  ctx->pb = 2 * ctx->cb;
+  ctx->jb = 3 * ctx->cb;
   if (const char* e = getenv("MSM_HIP_FINE_HIST_MIN_LOGN")) {  // tuning aid
     const int l = atoi(e);
     if (l >= 0 && l < 40) ctx->fine_hist_min_n = (size_t)1 << l;
@@ -802,7 +814,7 @@ int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, 
   int rc = reserve_bases(ctx, n, flags);
   if (rc) return rc;
   // the wire bytes land in the bases array itself and are converted in place (same 64 B per point): no staging buffer
-  if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bases, xy_host, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bases, xy_host, n * ctx->pb, hipMemcpyHostToDevice, ctx->stream));
   return set_bases_from_device(ctx, ctx->d_bases, n, flags);
 }
 
@@ -837,7 +849,7 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
     s.timed = false;
     memset(s.h_wsums, 0, WSUM_BYTES + 4);
     if (window_sums_dev) {
-      HIP_TRY(ctx, hipMemsetAsync(window_sums_dev, 0, (size_t)w_local * 96, ctx->reduce_stream[slot % NREDUCE]));
+      HIP_TRY(ctx, hipMemsetAsync(window_sums_dev, 0, (size_t)w_local * ctx->jb, ctx->reduce_stream[slot % NREDUCE]));
       HIP_TRY(ctx, hipEventRecord(s.done, ctx->reduce_stream[slot % NREDUCE]));
     }
     return MSM_HIP_OK;
@@ -923,14 +935,15 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   auto t0 = std::chrono::steady_clock::now();
   std::atomic<bool> all_ok{true};
   if (s.parts) {  // one MSM, its windows as bit-plane sums: the windows' positional sums side by side, then the Horner chain over them
-    uint8_t sums[24 * 96];
+    uint8_t sums[24 * MAX_JB];
+    const size_t jb = ctx->jb;
     combine_pool().run(nwin, [&](int w) {
-      if (!ctx->ops->window_from_planes(s.h_wsums + (size_t)w * PLANE_BYTES, sums + 96 * (size_t)w)) all_ok = false;
+      if (!ctx->ops->window_from_planes(s.h_wsums + (size_t)w * PLANES_PER_WINDOW * jb, sums + jb * (size_t)w)) all_ok = false;
     });
     if (!ctx->ops->combine_windows(sums, nwin, s.wbits, out_xyz)) all_ok = false;
   } else {
     combine_pool().run(s.nvec, [&](int v) {  // one independent Horner chain per MSM of the launch: side by side when there are several
-      if (!ctx->ops->combine_windows(s.h_wsums + (size_t)v * nwin * 96, nwin, s.wbits, out_xyz + 96 * (size_t)v)) all_ok = false;
+      if (!ctx->ops->combine_windows(s.h_wsums + (size_t)v * nwin * ctx->jb, nwin, s.wbits, out_xyz + ctx->jb * (size_t)v)) all_ok = false;
     });
   }
   if (!all_ok) return MSM_HIP_ERR_HIP;
@@ -1012,7 +1025,7 @@ int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_
   int rc = check_run_args(ctx, scalars_host, n);
   if (rc) return rc;
   if (n == 0) {
-    if (batch) memset(out_xyz, 0, 96 * batch);
+    if (batch) memset(out_xyz, 0, ctx->jb * batch);
     return MSM_HIP_OK;
   }
   ON_DEVICE(ctx);
@@ -1052,10 +1065,11 @@ int msm_hip_combine_windows_batch_curve(int curve, const uint8_t* window_sums_ho
   if (curve < 0 || curve >= MSM_HIP_NUM_CURVES) return MSM_HIP_ERR_INVALID_ARG;
   if (!window_sums_host || !out_xyz || num_windows < 1 || num_windows > NWIN || nvec < 0) return MSM_HIP_ERR_INVALID_ARG;
   const CurveOps* ops = curve_ops(curve);
+  const size_t jb = 12 * (size_t)ops->coord_words;
   std::atomic<bool> ok{true};
   // independent Horner chains (47 us each on one core): side by side on the combine pool when there are several
   combine_pool().run(nvec, [&](int v) {
-    if (!ops->combine_windows(window_sums_host + (size_t)v * num_windows * 96, num_windows, WBITS, out_xyz + (size_t)v * 96)) ok = false;
+    if (!ops->combine_windows(window_sums_host + (size_t)v * num_windows * jb, num_windows, WBITS, out_xyz + (size_t)v * jb)) ok = false;
   });
   return ok ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
 }
@@ -1237,30 +1251,31 @@ int msm_hip_read_val_idxs(msm_hip_ctx* ctx, uint32_t* out, size_t cap_elems) {
 int msm_hip_read_buckets(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
   if (!ctx || !out) return MSM_HIP_ERR_INVALID_ARG;
   const size_t count = (size_t)ctx->last_w_count << (ctx->last_wbits - 1);  // [w][2^(bits-1)]
-  if (count * 96 > cap_bytes) return MSM_HIP_ERR_INVALID_ARG;
+  if (count * ctx->jb > cap_bytes) return MSM_HIP_ERR_INVALID_ARG;
   if (count == 0) return MSM_HIP_OK;
   ON_DEVICE(ctx);
   for (hipStream_t r : ctx->reduce_stream) HIP_TRY(ctx, hipStreamSynchronize(r));
-  int rc = ensure_stage(ctx, count * 96);
+  int rc = ensure_stage(ctx, count * ctx->jb);
   if (rc) return rc;
   hipLaunchKernelGGL(ctx->ops->export_buckets, dim3(blocks_for(count, 256)), dim3(256), 0, ctx->stream, ctx->slot[ctx->last_slot].d_buckets,
                      reinterpret_cast<uint32_t*>(ctx->d_stage), count);
   HIP_TRY(ctx, hipGetLastError());
-  return read_back(ctx, out, ctx->d_stage, count * 96, cap_bytes);
+  return read_back(ctx, out, ctx->d_stage, count * ctx->jb, cap_bytes);
 }
 
 int msm_hip_read_window_sums(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
   const Slot& s = ctx->slot[ctx->last_slot];
-  if (!s.parts) return read_back(ctx, out, s.d_wsums, (size_t)ctx->last_w_count * 96, cap_bytes);
+  if (!s.parts) return read_back(ctx, out, s.d_wsums, (size_t)ctx->last_w_count * ctx->jb, cap_bytes);
   // the last launch handed its window sums to the host as bit-plane sums (k_bpr_planes): finish them here
   const size_t w = (size_t)ctx->last_w_count;
-  if (!out || w * 96 > cap_bytes || w > 24) return MSM_HIP_ERR_INVALID_ARG;
+  if (!out || w * ctx->jb > cap_bytes || w > 24) return MSM_HIP_ERR_INVALID_ARG;
   uint8_t planes[WSUM_BYTES];
-  int rc = read_back(ctx, planes, s.d_wsums, w * PLANE_BYTES, sizeof planes);
+  const size_t plane_bytes = PLANES_PER_WINDOW * ctx->jb;
+  int rc = read_back(ctx, planes, s.d_wsums, w * plane_bytes, sizeof planes);
   if (rc) return rc;
   bool ok = true;
-  for (size_t k = 0; k < w; k++) ok &= ctx->ops->window_from_planes(planes + k * PLANE_BYTES, out + k * 96);
+  for (size_t k = 0; k < w; k++) ok &= ctx->ops->window_from_planes(planes + k * plane_bytes, out + k * ctx->jb);
   return ok ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
 }
 
@@ -1286,37 +1301,43 @@ int msm_hip_test_fq_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t
   if (n == 0) return MSM_HIP_OK;
   if (op < 0 || op > 9) return MSM_HIP_ERR_INVALID_ARG;
   uint8_t *da, *db, *dout;
-  int rc = run_hook(ctx, a, n * 32, b, b ? n * 32 : 0, out, n * 32, da, db, dout);
+  if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  const size_t cb = ctx->cb;
+  int rc = run_hook(ctx, a, n * cb, b, b ? n * cb : 0, out, n * cb, da, db, dout);
   if (rc) return rc;
   hipLaunchKernelGGL(ctx->ops->test_fq, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, op, (const uint32_t*)da, (const uint32_t*)db,
                      (uint32_t*)dout, n);
   HIP_TRY(ctx, hipGetLastError());
-  return read_back(ctx, out, dout, n * 32, n * 32);
+  return read_back(ctx, out, dout, n * cb, n * cb);
 }
 
 int msm_hip_test_g1_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
   if (n == 0) return MSM_HIP_OK;
   if (op < 0 || op > 4 || (op != 1 && !b)) return MSM_HIP_ERR_INVALID_ARG;
-  const size_t b_bytes = op == 0 ? n * 96 : (op >= 2 ? n * 64 : 0);
+  if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  const size_t jb = ctx->jb;
+  const size_t b_bytes = op == 0 ? n * jb : (op >= 2 ? n * ctx->pb : 0);
   uint8_t *da, *db, *dout;
-  int rc = run_hook(ctx, a, n * 96, op == 1 ? nullptr : b, b_bytes, out, n * 96, da, db, dout);
+  int rc = run_hook(ctx, a, n * jb, op == 1 ? nullptr : b, b_bytes, out, n * jb, da, db, dout);
   if (rc) return rc;
   hipLaunchKernelGGL(ctx->ops->test_g1, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, op, (const uint32_t*)da, (const uint32_t*)db,
                      (uint32_t*)dout, n);
   HIP_TRY(ctx, hipGetLastError());
-  return read_back(ctx, out, dout, n * 96, n * 96);
+  return read_back(ctx, out, dout, n * jb, n * jb);
 }
 
 int msm_hip_test_g1_mul_u32(msm_hip_ctx* ctx, const uint8_t* a, const uint32_t* k, uint8_t* out, size_t n) {
   if (n == 0) return MSM_HIP_OK;
   if (!k) return MSM_HIP_ERR_INVALID_ARG;
   uint8_t *da, *db, *dout;
-  int rc = run_hook(ctx, a, n * 96, reinterpret_cast<const uint8_t*>(k), n * 4, out, n * 96, da, db, dout);
+  if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  const size_t jb = ctx->jb;
+  int rc = run_hook(ctx, a, n * jb, reinterpret_cast<const uint8_t*>(k), n * 4, out, n * jb, da, db, dout);
   if (rc) return rc;
   hipLaunchKernelGGL(ctx->ops->test_g1_mul_u32, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)da,
                      (const uint32_t*)db, (uint32_t*)dout, n);
   HIP_TRY(ctx, hipGetLastError());
-  return read_back(ctx, out, dout, n * 96, n * 96);
+  return read_back(ctx, out, dout, n * jb, n * jb);
 }
 
 }  // extern "C"

@@ -32,6 +32,10 @@ constexpr int WBITS = 16;   // the reference's window (chunk_size, src/cuzk/msm.
 constexpr int NWIN = 16;
 constexpr int MAXLW = 64;  // local windows one launch may carry: (scalar vectors of the launch) x (windows of each)
 constexpr int HALF = 1 << (WBITS - 1);  // 32768 bucket slots per window at 16 bits (the largest window supported)
+// Sizes that follow the unit's field (FQ_WORDS packed 32-bit words per coordinate: 8 for the 254 / 255-bit fields, 12 for BLS12-381)
+constexpr int CW = FQ_WORDS;        // words of a coordinate on the wire and in the resident bases
+constexpr int PT_WORDS = 2 * CW;    // an affine point x || y: 64 B (96 B)
+constexpr int JAC_WORDS = 3 * CW;   // a Jacobian record x || y || z: 96 B (144 B)
 
 // Window size as a parameter (the reference hard-codes c, src/cuzk/msm.rs:79-82): C-bit signed digits,
 // 2^(C-1) bucket slots per window, NWIN = ceil(255 / C) windows (254-bit scalars + one bit for the recode's carry).
@@ -52,8 +56,18 @@ struct WinCfg {
 };
 __host__ __device__ constexpr int nwin_of(int bits, bool halves = false) { return ((halves ? 127 : 254) + bits) / bits; }
 
-__device__ __constant__ uint32_t c_pp1d4[8] = {FQ_PP1D4_32[0], FQ_PP1D4_32[1], FQ_PP1D4_32[2], FQ_PP1D4_32[3],
-                                               FQ_PP1D4_32[4], FQ_PP1D4_32[5], FQ_PP1D4_32[6], FQ_PP1D4_32[7]};
+// (exponent tables live in constant memory; filled from the generated constexpr arrays)
+template <int N>
+struct cwords {
+  uint32_t w[N];
+};
+template <int N>
+constexpr cwords<N> make_cwords(const uint32_t (&src)[N]) {
+  cwords<N> r{};
+  for (int i = 0; i < N; i++) r.w[i] = src[i];
+  return r;
+}
+__device__ __constant__ cwords<CW> c_pp1d4 = make_cwords(FQ_PP1D4_32);
 
 // ------------------------------------------------------------------------------------------------ small helpers
 __device__ __forceinline__ void ld8(const uint32_t* p, uint32_t w[8]) {
@@ -66,22 +80,34 @@ __device__ __forceinline__ void st8(uint32_t* p, const uint32_t w[8]) {
   reinterpret_cast<uint4*>(p)[0] = make_uint4(w[0], w[1], w[2], w[3]);
   reinterpret_cast<uint4*>(p)[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
+// a coordinate's CW packed words (16-byte aligned: CW is a multiple of 4)
+__device__ __forceinline__ void ld_coord(const uint32_t* p, uint32_t w[CW]) {
+#pragma unroll
+  for (int k = 0; k < CW / 4; k++) {
+    const uint4 a = reinterpret_cast<const uint4*>(p)[k];
+    w[4 * k] = a.x; w[4 * k + 1] = a.y; w[4 * k + 2] = a.z; w[4 * k + 3] = a.w;
+  }
+}
+__device__ __forceinline__ void st_coord(uint32_t* p, const uint32_t w[CW]) {
+#pragma unroll
+  for (int k = 0; k < CW / 4; k++) reinterpret_cast<uint4*>(p)[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
 __device__ __forceinline__ fq ld_fq(const uint32_t* p) {  // packed -> limbs (no domain change)
-  uint32_t w[8];
-  ld8(p, w);
+  uint32_t w[CW];
+  ld_coord(p, w);
   return fq_unpack(w);
 }
-__device__ __forceinline__ void st_fq(uint32_t* p, const fq& x) {  // x exact, < 2^256
-  uint32_t w[8];
+__device__ __forceinline__ void st_fq(uint32_t* p, const fq& x) {  // x exact, < 2^(32 CW)
+  uint32_t w[CW];
   fq_pack(w, x);
-  st8(p, w);
+  st_coord(p, w);
 }
-// w >= modulus ?   MOD = 0: Fq modulus p, MOD = 1: Fr modulus r  (constants fold to immediates)
+// w >= modulus ?   MOD = 0: Fq modulus p (CW words), MOD = 1: Fr modulus r (8 words)  (constants fold to immediates)
 template <int MOD>
-__device__ __forceinline__ bool geq_modulus(const uint32_t w[8]) {
+__device__ __forceinline__ bool geq_modulus(const uint32_t* w) {
   bool gt = false, lt = false;
 #pragma unroll
-  for (int i = 7; i >= 0; i--) {
+  for (int i = (MOD == 0 ? CW : 8) - 1; i >= 0; i--) {
     const uint32_t m = MOD == 0 ? FQ_P32[i] : FR_R32[i];
     gt = gt || (!lt && w[i] > m);
     lt = lt || (!gt && w[i] < m);
@@ -91,13 +117,13 @@ __device__ __forceinline__ bool geq_modulus(const uint32_t w[8]) {
 __device__ __forceinline__ bool fq_equal_exact(const fq& a, const fq& b) {
   uint32_t d = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) d |= a.v[i] ^ b.v[i];
+  for (int i = 0; i < FQ_L; i++) d |= a.v[i] ^ b.v[i];
   return d == 0;
 }
 __device__ __forceinline__ fq fq_curve_b() {  // the curve constant b (y^2 = x^3 + b), Montgomery form
   fq r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.v[i] = FQ_B29[i];
+  for (int i = 0; i < FQ_L; i++) r.v[i] = FQ_B29[i];
   return r;
 }
 
@@ -106,38 +132,38 @@ __device__ __forceinline__ void st_jacobian_plain(uint32_t* p, const g1_xyzz& a)
   fq X, Y, Z;
   g1_to_jacobian(a, X, Y, Z);
   st_fq(p, fq_from_mont(X));
-  st_fq(p + 8, fq_from_mont(Y));
-  st_fq(p + 16, fq_from_mont(Z));
+  st_fq(p + CW, fq_from_mont(Y));
+  st_fq(p + 2 * CW, fq_from_mont(Z));
 }
 __device__ __forceinline__ g1_xyzz ld_jacobian_plain(const uint32_t* p) {
-  const fq X = fq_to_mont(ld_fq(p)), Y = fq_to_mont(ld_fq(p + 8)), Z = fq_to_mont(ld_fq(p + 16));
+  const fq X = fq_to_mont(ld_fq(p)), Y = fq_to_mont(ld_fq(p + CW)), Z = fq_to_mont(ld_fq(p + 2 * CW));
   return g1_from_jacobian(X, Y, Z);
 }
 
-// XYZZ record in scratch memory / LDS: 36 limbs + identity flag
-constexpr int XYZZ_WORDS = 37;
+// XYZZ record in scratch memory / LDS: 4 FQ_L limbs + identity flag (37 words with 9 limbs: an odd stride, no LDS bank conflicts)
+constexpr int XYZZ_WORDS = 4 * FQ_L + 1;
 template <typename PTR>
 __device__ __forceinline__ void st_xyzz(PTR p, const g1_xyzz& a) {
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
+  for (int i = 0; i < FQ_L; i++) {
     p[i] = a.x.v[i];
-    p[9 + i] = a.y.v[i];
-    p[18 + i] = a.zz.v[i];
-    p[27 + i] = a.zzz.v[i];
+    p[FQ_L + i] = a.y.v[i];
+    p[2 * FQ_L + i] = a.zz.v[i];
+    p[3 * FQ_L + i] = a.zzz.v[i];
   }
-  p[36] = a.inf ? 1u : 0u;
+  p[4 * FQ_L] = a.inf ? 1u : 0u;
 }
 template <typename PTR>
 __device__ __forceinline__ g1_xyzz ld_xyzz(PTR p) {
   g1_xyzz a;
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
+  for (int i = 0; i < FQ_L; i++) {
     a.x.v[i] = p[i];
-    a.y.v[i] = p[9 + i];
-    a.zz.v[i] = p[18 + i];
-    a.zzz.v[i] = p[27 + i];
+    a.y.v[i] = p[FQ_L + i];
+    a.zz.v[i] = p[2 * FQ_L + i];
+    a.zzz.v[i] = p[3 * FQ_L + i];
   }
-  a.inf = p[36] != 0;
+  a.inf = p[4 * FQ_L] != 0;
   return a;
 }
 
@@ -152,9 +178,9 @@ __global__ void __launch_bounds__(256) k_convert_points(const uint32_t* in, uint
                                                         uint32_t flags, uint32_t* __restrict__ err) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint32_t wx[8], wy[8];
-  ld8(in + i * 16, wx);
-  ld8(in + i * 16 + 8, wy);
+  uint32_t wx[CW], wy[CW];
+  ld_coord(in + i * PT_WORDS, wx);
+  ld_coord(in + i * PT_WORDS + CW, wy);
   if (geq_modulus<0>(wx) || geq_modulus<0>(wy)) atomicOr(err, ERRBIT_NONCANONICAL);
   // flags bit 1 (MSM_HIP_BASES_MONT256): the words are x * 2^256 mod p, not x
   const bool m256 = (flags & 2u) != 0;
@@ -165,8 +191,8 @@ __global__ void __launch_bounds__(256) k_convert_points(const uint32_t* in, uint
     const fq rhs = fq_canonical(fq_tidy(fq_add(fq_mul(fq_sqr(x), x), fq_curve_b())));
     if (!fq_equal_exact(lhs, rhs)) atomicOr(err, ERRBIT_NOT_ON_CURVE);
   }
-  st_fq(out + i * 16, x);
-  st_fq(out + i * 16 + 8, y);
+  st_fq(out + i * PT_WORDS, x);
+  st_fq(out + i * PT_WORDS + CW, y);
 }
 
 // The endomorphism's point half (csrc/glv.h): record n + i = phi(P_i) = (beta x_i, y_i) behind the n plain bases
@@ -175,12 +201,12 @@ __global__ void __launch_bounds__(256) k_endo_points(uint32_t* __restrict__ base
   if (i >= n) return;
   fq beta;
 #pragma unroll
-  for (int k = 0; k < 9; k++) beta.v[k] = FQ_BETA29[k];
-  st_fq(bases + (n + i) * 16, fq_mul(ld_fq(bases + i * 16), beta));
-  const uint4* y = reinterpret_cast<const uint4*>(bases + i * 16 + 8);
-  uint4* o = reinterpret_cast<uint4*>(bases + (n + i) * 16 + 8);
-  o[0] = y[0];
-  o[1] = y[1];
+  for (int k = 0; k < FQ_L; k++) beta.v[k] = FQ_BETA29[k];
+  st_fq(bases + (n + i) * PT_WORDS, fq_mul(ld_fq(bases + i * PT_WORDS), beta));
+  const uint4* y = reinterpret_cast<const uint4*>(bases + i * PT_WORDS + CW);
+  uint4* o = reinterpret_cast<uint4*>(bases + (n + i) * PT_WORDS + CW);
+#pragma unroll
+  for (int k = 0; k < CW / 4; k++) o[k] = y[k];
 }
 
 // ... and its scalar half: vector v's n scalars -> 2n halves of 16 B, |k1| of scalar i at [v][i], |k2| at [v][n + i] (signs in
@@ -210,19 +236,19 @@ __global__ void __launch_bounds__(256) k_glv_split(const uint32_t* __restrict__ 
 // bases[(w * nb + i)][16]: table w behind table w - 1; table 0 is the plain converted base set (so every entry point that does
 // not use the tables keeps working on the same buffer).  One thread per point: 16 doublings per table in XYZZ, then back to
 // affine (one inversion by Fermat, a^(p-2)).
-__device__ __constant__ uint32_t c_pm2[8] = {FQ_PM2_32[0], FQ_PM2_32[1], FQ_PM2_32[2], FQ_PM2_32[3], FQ_PM2_32[4], FQ_PM2_32[5], FQ_PM2_32[6], FQ_PM2_32[7]};
+__device__ __constant__ cwords<CW> c_pm2 = make_cwords(FQ_PM2_32);
 __device__ __forceinline__ fq fq_inv(const fq& a) {  // a exact, nonzero; result exact, < 2p
   fq acc = fq_one();
-  for (int bit = 255; bit >= 0; bit--) {  // (leading zero bits of p - 2 only square the initial one)
+  for (int bit = 32 * CW - 1; bit >= 0; bit--) {  // (leading zero bits of p - 2 only square the initial one)
     acc = fq_sqr(acc);
-    if ((c_pm2[bit >> 5] >> (bit & 31)) & 1u) acc = fq_mul(acc, a);
+    if ((c_pm2.w[bit >> 5] >> (bit & 31)) & 1u) acc = fq_mul(acc, a);
   }
   return acc;
 }
 __global__ void __launch_bounds__(256) k_precompute_tables(uint32_t* __restrict__ bases, size_t n, size_t nb, int num_tables) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const fq px = ld_fq(bases + i * 16), py = ld_fq(bases + i * 16 + 8);
+  const fq px = ld_fq(bases + i * PT_WORDS), py = ld_fq(bases + i * PT_WORDS + CW);
   g1_xyzz acc = g1_from_affine(px, py);
   for (int w = 1; w < num_tables; w++) {
 #pragma unroll 1
@@ -231,8 +257,8 @@ __global__ void __launch_bounds__(256) k_precompute_tables(uint32_t* __restrict_
     const fq t = fq_inv(fq_mul(acc.zz, acc.zzz));
     const fq x = fq_canonical(fq_mul(acc.x, fq_mul(t, acc.zzz)));
     const fq y = fq_canonical(fq_mul(acc.y, fq_mul(t, acc.zz)));
-    st_fq(bases + ((size_t)w * nb + i) * 16, x);
-    st_fq(bases + ((size_t)w * nb + i) * 16 + 8, y);
+    st_fq(bases + ((size_t)w * nb + i) * PT_WORDS, x);
+    st_fq(bases + ((size_t)w * nb + i) * PT_WORDS + CW, y);
     acc = g1_from_affine(x, y);
   }
 }
@@ -309,36 +335,45 @@ __device__ __forceinline__ uint32_t code_of_window(const uint32_t* t, int w) {  
 // Scalars handed over as s * 2^256 mod r (the in-memory limbs of a 4 x 64-bit Montgomery library with R = 2^256) are turned
 // into the canonical wire format by one pre-pass: a 9-limb Montgomery reduction of (s_mont << 5), i.e. s_mont * 2^5 / 2^261.
 __device__ __forceinline__ void fr_from_mont256(const uint32_t w[8], uint32_t out[8]) {
-  const fq x = fq_unpack(w);
-  uint64_t c[18];
+  // (the scalar field's 256-bit values in the unit's limb layout: FQ_L limbs of FQ_W bits hold them with room to spare)
+  constexpr int SH = FQ_W * FQ_L - 256, SH_LIMBS = SH / FQ_W, SH_BITS = SH % FQ_W;  // s_mont * 2^SH / 2^(FQ_W FQ_L) = s_mont / 2^256
+  uint32_t wide[CW];
 #pragma unroll
-  for (int k = 0; k < 18; k++) c[k] = k < 9 ? (uint64_t)x.v[k] << 5 : 0;
+  for (int k = 0; k < CW; k++) wide[k] = k < 8 ? w[k] : 0u;
+  const fq x = fq_unpack(wide);
+  uint64_t c[2 * FQ_L + 1];
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
+  for (int k = 0; k < 2 * FQ_L + 1; k++) c[k] = 0;
+#pragma unroll
+  for (int k = 0; k < FQ_L; k++) c[k + SH_LIMBS] = (uint64_t)x.v[k] << SH_BITS;
+#pragma unroll
+  for (int i = 0; i < FQ_L; i++) {
     const uint32_t m = ((uint32_t)c[i] * FR_N0_29) & FQ_MASK;
 #pragma unroll
-    for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)m * FR_R29[j];
-    c[i + 1] += c[i] >> 29;
+    for (int j = 0; j < FQ_L; j++) c[i + j] += (uint64_t)m * FR_R29[j];
+    c[i + 1] += c[i] >> FQ_W;
   }
   fq t;
 #pragma unroll
-  for (int k = 9; k < 17; k++) {
-    t.v[k - 9] = (uint32_t)c[k] & FQ_MASK;
-    c[k + 1] += c[k] >> 29;
+  for (int k = FQ_L; k < 2 * FQ_L - 1; k++) {
+    t.v[k - FQ_L] = (uint32_t)c[k] & FQ_MASK;
+    c[k + 1] += c[k] >> FQ_W;
   }
-  t.v[8] = (uint32_t)c[17];
+  t.v[FQ_L - 1] = (uint32_t)c[2 * FQ_L - 1];
   // t <= r: one conditional subtraction makes it canonical
   fq d;
   uint32_t borrow = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
+  for (int i = 0; i < FQ_L; i++) {
     const uint32_t u = t.v[i] - FR_R29[i] - borrow;
     borrow = u >> 31;
-    d.v[i] = (i < 8) ? (u & FQ_MASK) : u;
+    d.v[i] = (i < FQ_L - 1) ? (u & FQ_MASK) : u;
   }
 #pragma unroll
-  for (int i = 0; i < 9; i++) t.v[i] = borrow ? t.v[i] : d.v[i];
-  fq_pack(out, t);
+  for (int i = 0; i < FQ_L; i++) t.v[i] = borrow ? t.v[i] : d.v[i];
+  fq_pack(wide, t);
+#pragma unroll
+  for (int k = 0; k < 8; k++) out[k] = wide[k];
 }
 
 __global__ void __launch_bounds__(256) k_scalars_from_mont256(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t count,
@@ -933,36 +968,44 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
 constexpr int SMVP_CHUNK_MIN = SMVP_CHUNK_MIN_ENTRIES;
 constexpr int SMVP_CHUNK_MAX = 1024;
 constexpr int SMVP_TARGET_LANES = 3 << 17;  // 1.5 x (256 CUs x 4 SIMDs x 4 waves x 64 lanes): measured optimum of SMVP + stitch
-constexpr int REC_WORDS = 40;  // 160 B record: 36 limbs, valid flag, 3 pad words; 16-byte aligned
+constexpr int REC_WORDS = (XYZZ_WORDS + 3) / 4 * 4;  // 160 B record with 9 limbs: 36 limbs, valid flag, 3 pad words; 16-byte aligned (240 B with 14)
+constexpr int REC_FLAG = 4 * FQ_L;                   // word index of the valid flag
 
 __device__ __forceinline__ void st_rec(uint32_t* p, const g1_xyzz& a) {
+  uint32_t f[REC_WORDS];
+#pragma unroll
+  for (int i = 0; i < FQ_L; i++) {
+    f[i] = a.x.v[i];
+    f[FQ_L + i] = a.y.v[i];
+    f[2 * FQ_L + i] = a.zz.v[i];
+    f[3 * FQ_L + i] = a.zzz.v[i];
+  }
+  f[REC_FLAG] = a.inf ? 0u : 1u;
+#pragma unroll
+  for (int i = REC_FLAG + 1; i < REC_WORDS; i++) f[i] = 0u;
   uint4* q = reinterpret_cast<uint4*>(p);
-  q[0] = make_uint4(a.x.v[0], a.x.v[1], a.x.v[2], a.x.v[3]);
-  q[1] = make_uint4(a.x.v[4], a.x.v[5], a.x.v[6], a.x.v[7]);
-  q[2] = make_uint4(a.x.v[8], a.y.v[0], a.y.v[1], a.y.v[2]);
-  q[3] = make_uint4(a.y.v[3], a.y.v[4], a.y.v[5], a.y.v[6]);
-  q[4] = make_uint4(a.y.v[7], a.y.v[8], a.zz.v[0], a.zz.v[1]);
-  q[5] = make_uint4(a.zz.v[2], a.zz.v[3], a.zz.v[4], a.zz.v[5]);
-  q[6] = make_uint4(a.zz.v[6], a.zz.v[7], a.zz.v[8], a.zzz.v[0]);
-  q[7] = make_uint4(a.zzz.v[1], a.zzz.v[2], a.zzz.v[3], a.zzz.v[4]);
-  q[8] = make_uint4(a.zzz.v[5], a.zzz.v[6], a.zzz.v[7], a.zzz.v[8]);
-  q[9] = make_uint4(a.inf ? 0u : 1u, 0u, 0u, 0u);
+#pragma unroll
+  for (int k = 0; k < REC_WORDS / 4; k++) q[k] = make_uint4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
 }
 __device__ __forceinline__ g1_xyzz ld_rec(const uint32_t* p) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
-  const uint4 f = q[9];
-  if (f.x == 0) return g1_identity();
-  const uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5], a6 = q[6], a7 = q[7], a8 = q[8];
+  const uint4 fl = q[REC_FLAG / 4];
+  const uint32_t flag = REC_FLAG % 4 == 0 ? fl.x : (REC_FLAG % 4 == 1 ? fl.y : (REC_FLAG % 4 == 2 ? fl.z : fl.w));
+  if (flag == 0) return g1_identity();
+  uint32_t f[REC_WORDS];
+#pragma unroll
+  for (int k = 0; k < REC_WORDS / 4; k++) {
+    const uint4 a = k == REC_FLAG / 4 ? fl : q[k];
+    f[4 * k] = a.x; f[4 * k + 1] = a.y; f[4 * k + 2] = a.z; f[4 * k + 3] = a.w;
+  }
   g1_xyzz a;
-  a.x.v[0] = a0.x; a.x.v[1] = a0.y; a.x.v[2] = a0.z; a.x.v[3] = a0.w;
-  a.x.v[4] = a1.x; a.x.v[5] = a1.y; a.x.v[6] = a1.z; a.x.v[7] = a1.w;
-  a.x.v[8] = a2.x; a.y.v[0] = a2.y; a.y.v[1] = a2.z; a.y.v[2] = a2.w;
-  a.y.v[3] = a3.x; a.y.v[4] = a3.y; a.y.v[5] = a3.z; a.y.v[6] = a3.w;
-  a.y.v[7] = a4.x; a.y.v[8] = a4.y; a.zz.v[0] = a4.z; a.zz.v[1] = a4.w;
-  a.zz.v[2] = a5.x; a.zz.v[3] = a5.y; a.zz.v[4] = a5.z; a.zz.v[5] = a5.w;
-  a.zz.v[6] = a6.x; a.zz.v[7] = a6.y; a.zz.v[8] = a6.z; a.zzz.v[0] = a6.w;
-  a.zzz.v[1] = a7.x; a.zzz.v[2] = a7.y; a.zzz.v[3] = a7.z; a.zzz.v[4] = a7.w;
-  a.zzz.v[5] = a8.x; a.zzz.v[6] = a8.y; a.zzz.v[7] = a8.z; a.zzz.v[8] = a8.w;
+#pragma unroll
+  for (int i = 0; i < FQ_L; i++) {
+    a.x.v[i] = f[i];
+    a.y.v[i] = f[FQ_L + i];
+    a.zz.v[i] = f[2 * FQ_L + i];
+    a.zzz.v[i] = f[3 * FQ_L + i];
+  }
   a.inf = false;
   return a;
 }
@@ -973,11 +1016,11 @@ __device__ __forceinline__ g1_xyzz ld_rec(const uint32_t* p) {
 // path, which updates the coordinates in place, pays a copy per limb and iteration to get there and back (measured: 36 + 18 v_mov).
 __device__ __forceinline__ void smvp_set(fq& dst, const fq& src) {
 #pragma unroll
-  for (int i = 0; i < 9; i++) asm("v_mov_b32 %0, %1" : "+v"(dst.v[i]) : "v"(src.v[i]));
+  for (int i = 0; i < FQ_L; i++) asm("v_mov_b32 %0, %1" : "+v"(dst.v[i]) : "v"(src.v[i]));
 }
 __device__ __forceinline__ void smvp_set_one(fq& dst) {
 #pragma unroll
-  for (int i = 0; i < 9; i++) asm("v_mov_b32 %0, %1" : "+v"(dst.v[i]) : "s"(FQ_ONE29[i]));
+  for (int i = 0; i < FQ_L; i++) asm("v_mov_b32 %0, %1" : "+v"(dst.v[i]) : "s"(FQ_ONE29[i]));
 }
 __device__ __forceinline__ void smvp_restart(g1_xyzz& acc, const fq& px, const fq& py) {
   smvp_set(acc.x, px);
@@ -994,7 +1037,8 @@ __device__ __forceinline__ void smvp_assign(g1_xyzz& acc, const g1_xyzz& src) {
   acc.inf = src.inf;
 }
 
-__global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ col_ptr,
+constexpr int SMVP_WAVES_PER_SIMD = FQ_L <= 9 ? 3 : 2;  // 168 VGPRs hold the 9-limb loop; 14 limbs take up to 256
+__global__ void __launch_bounds__(256, SMVP_WAVES_PER_SIMD) k_smvp_chunks(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ col_ptr,
                                                      const uint32_t* __restrict__ val_idxs, size_t stride, uint32_t chunks,
                                                      const uint32_t* __restrict__ chunk_len_dev, const uint32_t* __restrict__ chunk_slot,
                                                      uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
@@ -1021,26 +1065,24 @@ __global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restri
   const uint32_t last = end - 1;
   uint32_t vnext = vi[begin];
   uint32_t vnn = vi[begin + 1 < end ? begin + 1 : last];
-  uint32_t wx[8], wy[8];
-  ld8(bases + (size_t)(vnext & 0x7fffffffu) * 16, wx);
-  ld8(bases + (size_t)(vnext & 0x7fffffffu) * 16 + 8, wy);
+  uint32_t wx[CW], wy[CW];
+  ld_coord(bases + (size_t)(vnext & 0x7fffffffu) * PT_WORDS, wx);
+  ld_coord(bases + (size_t)(vnext & 0x7fffffffu) * PT_WORDS + CW, wy);
   for (uint32_t t = begin; t < end; t++) {
     const uint32_t v = vnext;
     fq px = fq_unpack(wx), py = fq_unpack(wy);
 #if defined(__HIP_DEVICE_COMPILE__)
     // the loads below stay behind the unpacking (the limbs are pinned in front of this point): they can then reuse the registers of
     // wx / wy; hoisted above it they need a second set and 16 copies per iteration
-    asm volatile("" : "+v"(px.v[0]), "+v"(px.v[1]), "+v"(px.v[2]), "+v"(px.v[3]), "+v"(px.v[4]), "+v"(px.v[5]), "+v"(px.v[6]), "+v"(px.v[7]), "+v"(px.v[8]),
-                      "+v"(py.v[0]), "+v"(py.v[1]), "+v"(py.v[2]), "+v"(py.v[3]), "+v"(py.v[4]), "+v"(py.v[5]), "+v"(py.v[6]), "+v"(py.v[7]), "+v"(py.v[8])
-                 :
-                 : "memory");
+#pragma unroll
+    for (int i = 0; i < FQ_L; i++) asm volatile("" : "+v"(px.v[i]), "+v"(py.v[i]) : : "memory");
 #endif
     vnext = vnn;
     vnn = vi[t + 2 < end ? t + 2 : last];
     {
-      const uint32_t* pt = bases + (size_t)(vnext & 0x7fffffffu) * 16;
-      ld8(pt, wx);
-      ld8(pt + 8, wy);
+      const uint32_t* pt = bases + (size_t)(vnext & 0x7fffffffu) * PT_WORDS;
+      ld_coord(pt, wx);
+      ld_coord(pt + CW, wy);
     }
     const bool sneg = (v >> 31) != 0u;  // bit 31: the digit is negative
     if (t == run_end) {  // the run of slot s ended inside this chunk
@@ -1072,8 +1114,8 @@ __global__ void __launch_bounds__(256, 3) k_smvp_chunks(const uint32_t* __restri
       if (status) {  // the point met itself or its negative in the accumulator (duplicate bases): repair, from the point read again
         wneg = false;
         if (status == 1) {
-          const uint32_t* pt = bases + (size_t)(v & 0x7fffffffu) * 16;
-          const fq qy = ld_fq(pt + 8);
+          const uint32_t* pt = bases + (size_t)(v & 0x7fffffffu) * PT_WORDS;
+          const fq qy = ld_fq(pt + CW);
           smvp_assign(acc, g1_double_affine(ld_fq(pt), sneg ? fq_neg_canonical(qy) : qy));
         } else {
           acc.inf = true;
@@ -1330,17 +1372,17 @@ constexpr int bpr_rowcol_blocks() {
 // barriers.  An addition then costs 4 multiplication latencies + 5 barriers, a doubling 3 + 4.
 // Every thread of the block must call these functions (they contain __syncthreads); octet o = threadIdx.x >> 3 works on
 // its own operands `pa`, `pb` -> `pout` (LDS pointers to XYZZ_WORDS records; pout may alias pa or pb) when `active`.
-constexpr int COOP_WORDS = 16 * 9;  // scratch words per octet
+constexpr int COOP_WORDS = 16 * FQ_L;  // scratch words per octet
 
 __device__ __forceinline__ fq ldf(const uint32_t* p) {
   fq r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.v[i] = p[i];
+  for (int i = 0; i < FQ_L; i++) r.v[i] = p[i];
   return r;
 }
 __device__ __forceinline__ void stf(uint32_t* p, const fq& a) {
 #pragma unroll
-  for (int i = 0; i < 9; i++) p[i] = a.v[i];
+  for (int i = 0; i < FQ_L; i++) p[i] = a.v[i];
 }
 __device__ __forceinline__ void coop_copy(uint32_t* dst, const uint32_t* src, int r) {  // 8 lanes copy one record
   if (dst != src)
@@ -1352,7 +1394,7 @@ __device__ __noinline__ void coop_add(uint32_t* sc_all, const uint32_t* pa, cons
   uint32_t* sc = sc_all + (threadIdx.x >> 3) * COOP_WORDS;
   // mode 0: full addition; 1: result = a (b is the identity); 2: result = b; 3: inactive
   int mode = 3;
-  if (active) mode = pa[36] != 0 ? 2 : (pb[36] != 0 ? 1 : 0);
+  if (active) mode = pa[4 * FQ_L] != 0 ? 2 : (pb[4 * FQ_L] != 0 ? 1 : 0);
   fq keep = fq_zero();  // r0 keeps P, r1 keeps R across stages
   // stage 1: U1 = ax*bzz, U2 = bx*azz, S1 = ay*bzzz, S2 = by*azzz, ZZ12 = azz*bzz, ZZZ12 = azzz*bzzz  -> sc[0..5]
   if (mode == 0 && r < 6) {
@@ -1360,43 +1402,43 @@ __device__ __noinline__ void coop_add(uint32_t* sc_all, const uint32_t* pa, cons
     if (r < 4) {
       const uint32_t* first = (r & 1) ? pb : pa;
       const uint32_t* second = (r & 1) ? pa : pb;
-      fa = first + ((r & 2) ? 9 : 0);
-      fb = second + ((r & 2) ? 27 : 18);
+      fa = first + ((r & 2) ? FQ_L : 0);
+      fb = second + ((r & 2) ? 3 * FQ_L : 2 * FQ_L);
     } else {
-      fa = pa + (r == 4 ? 18 : 27);
-      fb = pb + (r == 4 ? 18 : 27);
+      fa = pa + (r == 4 ? 2 * FQ_L : 3 * FQ_L);
+      fb = pb + (r == 4 ? 2 * FQ_L : 3 * FQ_L);
     }
-    stf(sc + r * 9, fq_mul(ldf(fa), ldf(fb)));
+    stf(sc + r * FQ_L, fq_mul(ldf(fa), ldf(fb)));
   }
   __syncthreads();
   // stage 2: r0: P = U2 - U1, PP = P^2 -> sc[6] ; r1: R = S2 - S1 -> sc[9], RR = R^2 -> sc[7]
   if (mode == 0 && r < 2) {
-    keep = fq_sub<3>(ldf(sc + (r == 0 ? 1 : 3) * 9), ldf(sc + (r == 0 ? 0 : 2) * 9));
-    stf(sc + (6 + r) * 9, fq_sqr(keep));
-    if (r == 1) stf(sc + 9 * 9, keep);
+    keep = fq_sub<3>(ldf(sc + (r == 0 ? 1 : 3) * FQ_L), ldf(sc + (r == 0 ? 0 : 2) * FQ_L));
+    stf(sc + (6 + r) * FQ_L, fq_sqr(keep));
+    if (r == 1) stf(sc + 9 * FQ_L, keep);
   }
   __syncthreads();
   bool special = false;  // equal x coordinates: doubling or cancellation, done serially by lane 0 at the end
-  if (mode == 0) special = fq_is_zero_exact(ldf(sc + 6 * 9));
+  if (mode == 0) special = fq_is_zero_exact(ldf(sc + 6 * FQ_L));
   // stage 3: PPP = P*PP -> sc[10], Q = U1*PP -> sc[11], ZZ3 = ZZ12*PP -> sc[12]
   if (mode == 0 && !special && r < 3) {
-    const fq PP = ldf(sc + 6 * 9);
-    const fq other = r == 0 ? keep : ldf(sc + (r == 1 ? 0 : 4) * 9);
-    stf(sc + (10 + r) * 9, fq_mul(other, PP));
+    const fq PP = ldf(sc + 6 * FQ_L);
+    const fq other = r == 0 ? keep : ldf(sc + (r == 1 ? 0 : 4) * FQ_L);
+    stf(sc + (10 + r) * FQ_L, fq_mul(other, PP));
   }
   __syncthreads();
   // stage 4: r0: X3 = RR - PPP - 2Q -> sc[13], Y3 = R*(Q - X3) - S1*PPP -> sc[14] ; r1: ZZZ3 = ZZZ12*PPP -> sc[15]
   if (mode == 0 && !special && r < 2) {
-    const fq PPP = ldf(sc + 10 * 9);
+    const fq PPP = ldf(sc + 10 * FQ_L);
     if (r == 0) {
-      const fq Q = ldf(sc + 11 * 9);
-      const fq X3 = fq_sub<7>(ldf(sc + 7 * 9), fq_add(PPP, fq_dbl(Q)));
+      const fq Q = ldf(sc + 11 * FQ_L);
+      const fq X3 = fq_sub<7>(ldf(sc + 7 * FQ_L), fq_add(PPP, fq_dbl(Q)));
       const fq T = fq_sub<10>(Q, X3);
-      const fq nS1 = fq_sub<3>(fq_zero(), ldf(sc + 2 * 9));
-      stf(sc + 13 * 9, X3);
-      stf(sc + 14 * 9, fq_mul2(ldf(sc + 9 * 9), T, nS1, PPP));
+      const fq nS1 = fq_sub<3>(fq_zero(), ldf(sc + 2 * FQ_L));
+      stf(sc + 13 * FQ_L, X3);
+      stf(sc + 14 * FQ_L, fq_mul2(ldf(sc + 9 * FQ_L), T, nS1, PPP));
     } else {
-      stf(sc + 15 * 9, fq_mul(ldf(sc + 5 * 9), PPP));
+      stf(sc + 15 * FQ_L, fq_mul(ldf(sc + 5 * FQ_L), PPP));
     }
   }
   __syncthreads();
@@ -1405,9 +1447,9 @@ __device__ __noinline__ void coop_add(uint32_t* sc_all, const uint32_t* pa, cons
       if (r == 0) st_xyzz(pout, g1_add(ld_xyzz(pa), ld_xyzz(pb)));
     } else if (r < 4) {
       const int src = r == 0 ? 13 : (r == 1 ? 14 : (r == 2 ? 12 : 15));
-      stf(pout + r * 9, ldf(sc + src * 9));
+      stf(pout + r * FQ_L, ldf(sc + src * FQ_L));
     } else if (r == 4) {
-      pout[36] = 0;
+      pout[4 * FQ_L] = 0;
     }
   } else if (mode == 1) {
     coop_copy(pout, pa, r);
@@ -1420,53 +1462,53 @@ __device__ __noinline__ void coop_add(uint32_t* sc_all, const uint32_t* pa, cons
 __device__ __noinline__ void coop_double(uint32_t* sc_all, const uint32_t* pa, uint32_t* pout, bool active) {
   const int r = threadIdx.x & 7;
   uint32_t* sc = sc_all + (threadIdx.x >> 3) * COOP_WORDS;
-  const bool work = active && pa[36] == 0;  // doubling the identity leaves it unchanged
+  const bool work = active && pa[4 * FQ_L] == 0;  // doubling the identity leaves it unchanged
   fq keep = fq_zero();                      // r0 keeps U = 2Y
   // stage 1: r0: V = U^2 -> sc[0] ; r1: XX = X^2 -> sc[1]
   if (work && r < 2) {
     if (r == 0) {
-      keep = fq_dbl(ldf(pa + 9));
-      stf(sc + 0 * 9, fq_sqr(keep));
+      keep = fq_dbl(ldf(pa + FQ_L));
+      stf(sc + 0 * FQ_L, fq_sqr(keep));
     } else {
-      stf(sc + 1 * 9, fq_sqr(ldf(pa)));
+      stf(sc + 1 * FQ_L, fq_sqr(ldf(pa)));
     }
   }
   __syncthreads();
   // stage 2: r0: W = U*V -> sc[2] ; r1: S = X*V -> sc[3] ; r2: M = 3*XX -> sc[5], MM = M^2 -> sc[4] ; r3: ZZ3 = V*ZZ -> sc[6]
   if (work && r < 4) {
     if (r == 2) {
-      const fq XX = ldf(sc + 1 * 9);
+      const fq XX = ldf(sc + 1 * FQ_L);
       const fq M = fq_norm(fq_add(fq_dbl(XX), XX));
-      stf(sc + 5 * 9, M);
-      stf(sc + 4 * 9, fq_sqr(M));
+      stf(sc + 5 * FQ_L, M);
+      stf(sc + 4 * FQ_L, fq_sqr(M));
     } else {
-      const fq V = ldf(sc + 0 * 9);
-      const fq other = r == 0 ? keep : ldf(pa + (r == 1 ? 0 : 18));
-      stf(sc + (r == 0 ? 2 : (r == 1 ? 3 : 6)) * 9, fq_mul(other, V));
+      const fq V = ldf(sc + 0 * FQ_L);
+      const fq other = r == 0 ? keep : ldf(pa + (r == 1 ? 0 : 2 * FQ_L));
+      stf(sc + (r == 0 ? 2 : (r == 1 ? 3 : 6)) * FQ_L, fq_mul(other, V));
     }
   }
   __syncthreads();
   // stage 3: r0: X3 = MM - 2S -> sc[7], Y3 = M*(S - X3) - W*Y -> sc[8] ; r1: ZZZ3 = W*ZZZ -> sc[9]
   if (work && r < 2) {
-    const fq W = ldf(sc + 2 * 9);
+    const fq W = ldf(sc + 2 * FQ_L);
     if (r == 0) {
-      const fq S = ldf(sc + 3 * 9);
-      const fq X3 = fq_sub<5>(ldf(sc + 4 * 9), fq_dbl(S));
+      const fq S = ldf(sc + 3 * FQ_L);
+      const fq X3 = fq_sub<5>(ldf(sc + 4 * FQ_L), fq_dbl(S));
       const fq T = fq_sub<8>(S, X3);
-      const fq nY = fq_sub<6>(fq_zero(), ldf(pa + 9));
-      stf(sc + 7 * 9, X3);
-      stf(sc + 8 * 9, fq_mul2(ldf(sc + 5 * 9), T, nY, W));
+      const fq nY = fq_sub<6>(fq_zero(), ldf(pa + FQ_L));
+      stf(sc + 7 * FQ_L, X3);
+      stf(sc + 8 * FQ_L, fq_mul2(ldf(sc + 5 * FQ_L), T, nY, W));
     } else {
-      stf(sc + 9 * 9, fq_mul(W, ldf(pa + 27)));
+      stf(sc + 9 * FQ_L, fq_mul(W, ldf(pa + 3 * FQ_L)));
     }
   }
   __syncthreads();
   if (work) {
     if (r < 4) {
       const int src = r == 0 ? 7 : (r == 1 ? 8 : (r == 2 ? 6 : 9));
-      stf(pout + r * 9, ldf(sc + src * 9));
+      stf(pout + r * FQ_L, ldf(sc + src * FQ_L));
     } else if (r == 4) {
-      pout[36] = 0;
+      pout[4 * FQ_L] = 0;
     }
   } else if (active) {
     coop_copy(pout, pa, r);
@@ -1479,10 +1521,14 @@ __device__ __noinline__ void coop_double(uint32_t* sc_all, const uint32_t* pa, u
 // 16 x 16 split (RR_a = row sums, CC_b = column sums of the 16 x 16 arrangement of X): W = 16 * W16(RR) + W16(CC);
 // W16(V) by a 4 x 4 split: W16 = 4 * W4(r) + W4(c); W4(u) = u1 + 2 u2 + 3 u3 = (u1 + u3) + 2 (u2 + u3).
 // Levels with at most 32 independent operations use the cooperative octet operations above.
+// (needs 256 records + 32 octets of scratch in LDS: 50 KB with 9 limbs; with 14 limbs it would pass the 64 KB a workgroup may declare, so
+//  a unit of that size finishes its window sums from the bit-plane sums instead: k_bpr_planes<true> + k_bpr_final_planes below)
+constexpr bool BPR_USE_W256 = (256 * XYZZ_WORDS + 32 * COOP_WORDS) * 4 <= 65536;
 __global__ void __launch_bounds__(256) k_bpr_w256(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ cols,
                                                   uint32_t* __restrict__ out, int nrows) {
-  __shared__ uint32_t x[256 * XYZZ_WORDS];
-  __shared__ uint32_t sc[32 * COOP_WORDS];
+  __shared__ uint32_t x[BPR_USE_W256 ? 256 * XYZZ_WORDS : 1];
+  __shared__ uint32_t sc[BPR_USE_W256 ? 32 * COOP_WORDS : 1];
+  if constexpr (!BPR_USE_W256) return;
   const int w = blockIdx.y, which_in = blockIdx.x, t = threadIdx.x;
   const int a = t >> 4, b = t & 15, o = t >> 3;  // o: octet index, 0..31
   auto X = [&](int i) { return x + i * XYZZ_WORDS; };
@@ -1624,7 +1670,7 @@ __global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ p
   g1_xyzz acc = ld_xyzz(parts + ((size_t)w * 3 + 0) * XYZZ_WORDS);
   for (int i = 0; i < 7; i++) acc = g1_double(acc);
   acc = g1_add(acc, g1_add(ld_xyzz(parts + ((size_t)w * 3 + 1) * XYZZ_WORDS), ld_xyzz(parts + ((size_t)w * 3 + 2) * XYZZ_WORDS)));
-  st_jacobian_plain(wsums + (size_t)w * 24, acc);
+  st_jacobian_plain(wsums + (size_t)w * JAC_WORDS, acc);
 }
 
 // ... or, for a launch whose sums go to the host anyway (one MSM per launch: its LATENCY is what counts): the narrow end of the reduction
@@ -1634,12 +1680,14 @@ __global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ p
 // combination S_w = sum_b 2^(b+7) PR_b + sum_b 2^b PC_b + TC is 29 group operations per window on the host (host_g1.h:
 // window_sum_from_planes, ~8 us; the windows side by side on the host pool).
 // Grid (PLANES_PER_WINDOW, windows); plane 0 .. 7: row bit b, 8 .. 14: column bit b - 8, 15: column total.  out[w][plane] x 96 B Jacobian.
+// XYZZ_OUT: the plane sums stay on the device as XYZZ records (k_bpr_final_planes finishes the window sums there).
 constexpr int PLANES_PER_WINDOW = 16;
+template <bool XYZZ_OUT>
 __global__ void __launch_bounds__(256) k_bpr_planes(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ cols, uint32_t* __restrict__ out,
                                                     int nrows, uint32_t* __restrict__ big_queue) {
   __shared__ uint32_t x[256 * XYZZ_WORDS];
   const int w = blockIdx.y, plane = blockIdx.x, t = threadIdx.x;
-  if (w == 0 && plane == 0 && t == 0) big_queue[0] = 0;  // as k_bpr_final: the stitch's queue is empty for the slot's next launch
+  if (!XYZZ_OUT && w == 0 && plane == 0 && t == 0) big_queue[0] = 0;  // as k_bpr_final: the stitch's queue is empty for the slot's next launch
   const bool is_row = plane < 8;
   const int bit = is_row ? plane : plane - 8;  // 7 for the column total: bit 7 of a column index is never set -> handled by `all`
   const bool all = plane == PLANES_PER_WINDOW - 1;
@@ -1659,14 +1707,35 @@ __global__ void __launch_bounds__(256) k_bpr_planes(const uint32_t* __restrict__
     if (t < sft) lds_add_pair(x, t, t + sft);
     __syncthreads();
   }
-  if (t == 0) st_jacobian_plain(out + ((size_t)w * PLANES_PER_WINDOW + plane) * 24, ld_xyzz(x));
+  if constexpr (XYZZ_OUT) {
+    if (t < XYZZ_WORDS) out[((size_t)w * PLANES_PER_WINDOW + plane) * XYZZ_WORDS + t] = x[t];
+  } else {
+    if (t == 0) st_jacobian_plain(out + ((size_t)w * PLANES_PER_WINDOW + plane) * JAC_WORDS, ld_xyzz(x));
+  }
+}
+// one lane per window: S_w = sum_b 2^(b+7) PR_b + sum_b 2^b PC_b + TC from the plane sums (XYZZ records), as canonical Jacobian bytes --
+// the device-side counterpart of host_g1.h: window_sum_from_planes, for sums that stay on the device
+__global__ void __launch_bounds__(64) k_bpr_final_planes(const uint32_t* __restrict__ planes, int w_count, uint32_t* __restrict__ wsums,
+                                                         uint32_t* __restrict__ big_queue) {
+  const int w = threadIdx.x;
+  if (w == 0) big_queue[0] = 0;
+  if (w >= w_count) return;
+  const uint32_t* pw = planes + (size_t)w * PLANES_PER_WINDOW * XYZZ_WORDS;
+  g1_xyzz acc = g1_identity();
+#pragma unroll 1
+  for (int pos = 14; pos >= 0; pos--) {
+    acc = g1_double(acc);
+    acc = g1_add(acc, ld_xyzz(pw + (size_t)(pos >= 7 ? pos - 7 : 8 + pos) * XYZZ_WORDS));
+  }
+  acc = g1_add(acc, ld_xyzz(pw + (size_t)(PLANES_PER_WINDOW - 1) * XYZZ_WORDS));
+  st_jacobian_plain(wsums + (size_t)w * JAC_WORDS, acc);
 }
 
 // bucket records -> Jacobian wire records (stage read-back for the parity tests)
 __global__ void __launch_bounds__(256) k_export_buckets(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out, size_t count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  st_jacobian_plain(out + i * 24, ld_rec(buckets + i * REC_WORDS));
+  st_jacobian_plain(out + i * JAC_WORDS, ld_rec(buckets + i * REC_WORDS));
 }
 
 // ------------------------------------------------------------------------------------------------ samplers
@@ -1678,17 +1747,23 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-__device__ __forceinline__ void draw256(uint64_t seed, uint64_t index, uint64_t attempt, uint64_t domain, uint32_t w[8]) {
+// NW 32-bit words (8: a scalar or a coordinate of the 254 / 255-bit fields, masked to 254 bits; 12: a BLS12-381 coordinate, 381 bits)
+template <int NW>
+__device__ __forceinline__ void draw_words(uint64_t seed, uint64_t index, uint64_t attempt, uint64_t domain, uint32_t w[NW]) {
   uint64_t base = splitmix64(seed ^ ((domain & 0xFF) << 56)) ^ (index * 0xD1342543DE82EF95ull);
   base = splitmix64(base ^ (attempt * 0xA0761D6478BD642Full));
   uint64_t s = base;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < NW / 2; i++) {
     s = splitmix64(s);
     w[2 * i] = (uint32_t)s;
     w[2 * i + 1] = (uint32_t)(s >> 32);
   }
-  w[7] &= 0x3FFFFFFFu;  // 254 bits
+  if constexpr (NW == 8) w[7] &= 0x3FFFFFFFu;        // 254 bits
+  else w[NW - 1] &= (1u << (FQ_BITS - 32 * (NW - 1))) - 1u;  // as many bits as p has
+}
+__device__ __forceinline__ void draw256(uint64_t seed, uint64_t index, uint64_t attempt, uint64_t domain, uint32_t w[8]) {
+  draw_words<8>(seed, index, attempt, domain, w);
 }
 
 __global__ void __launch_bounds__(256) k_sample_scalars(uint64_t seed, size_t n, uint32_t* __restrict__ out) {
@@ -1702,13 +1777,11 @@ __global__ void __launch_bounds__(256) k_sample_scalars(uint64_t seed, size_t n,
   st8(out + i * 8, w);
 }
 
-__device__ __constant__ uint32_t c_sqrt_t[8] = {FQ_SQRT_T_32[0], FQ_SQRT_T_32[1], FQ_SQRT_T_32[2], FQ_SQRT_T_32[3],
-                                                FQ_SQRT_T_32[4], FQ_SQRT_T_32[5], FQ_SQRT_T_32[6], FQ_SQRT_T_32[7]};
-__device__ __constant__ uint32_t c_sqrt_tp1h[8] = {FQ_SQRT_TP1H_32[0], FQ_SQRT_TP1H_32[1], FQ_SQRT_TP1H_32[2], FQ_SQRT_TP1H_32[3],
-                                                   FQ_SQRT_TP1H_32[4], FQ_SQRT_TP1H_32[5], FQ_SQRT_TP1H_32[6], FQ_SQRT_TP1H_32[7]};
-__device__ __forceinline__ fq fq_pow254(const fq& a, const uint32_t* e) {  // a^e, e < 2^254 (constant memory), a exact
+__device__ __constant__ cwords<CW> c_sqrt_t = make_cwords(FQ_SQRT_T_32);
+__device__ __constant__ cwords<CW> c_sqrt_tp1h = make_cwords(FQ_SQRT_TP1H_32);
+__device__ __forceinline__ fq fq_pow254(const fq& a, const uint32_t* e) {  // a^e, e < 2^(32 CW - 2) (constant memory), a exact
   fq acc = fq_one();
-  for (int bit = 253; bit >= 0; bit--) {
+  for (int bit = 32 * CW - 3; bit >= 0; bit--) {
     acc = fq_sqr(acc);
     if ((e[bit >> 5] >> (bit & 31)) & 1u) acc = fq_mul(acc, a);
   }
@@ -1718,11 +1791,11 @@ __device__ __forceinline__ fq fq_pow254(const fq& a, const uint32_t* e) {  // a^
 // field, p - 1 = 2^28 t): Tonelli-Shanks with every loop bounded by the 2-adicity, so a non-residue just yields a wrong candidate.
 __device__ __forceinline__ fq fq_sqrt_candidate(const fq& a) {  // a exact
   if constexpr (FQ_SQRT_S == 0) {
-    return fq_pow254(a, c_pp1d4);
+    return fq_pow254(a, c_pp1d4.w);
   } else {
-    fq x = fq_pow254(a, c_sqrt_tp1h), b = fq_pow254(a, c_sqrt_t), c;
+    fq x = fq_pow254(a, c_sqrt_tp1h.w), b = fq_pow254(a, c_sqrt_t.w), c;
 #pragma unroll
-    for (int i = 0; i < 9; i++) c.v[i] = FQ_SQRT_C0_29[i];
+    for (int i = 0; i < FQ_L; i++) c.v[i] = FQ_SQRT_C0_29[i];
     const fq one = fq_canonical(fq_one());
     int m = FQ_SQRT_S;
     for (int round = 0; round < FQ_SQRT_S; round++) {
@@ -1748,9 +1821,9 @@ __device__ __forceinline__ fq fq_sqrt_candidate(const fq& a) {  // a exact
 __global__ void __launch_bounds__(256) k_sample_points(uint64_t seed, size_t n, uint32_t* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint32_t wx[8];
+  uint32_t wx[CW];
   for (uint64_t attempt = 0;; attempt++) {
-    draw256(seed, i, attempt, 2, wx);
+    draw_words<CW>(seed, i, attempt, 2, wx);
     if (geq_modulus<0>(wx)) continue;
     const fq x = fq_to_mont(fq_unpack(wx));
     const fq rhs = fq_canonical(fq_tidy(fq_add(fq_mul(fq_sqr(x), x), fq_curve_b())));
@@ -1758,8 +1831,8 @@ __global__ void __launch_bounds__(256) k_sample_points(uint64_t seed, size_t n, 
     if (!fq_equal_exact(fq_canonical(fq_sqr(y)), rhs)) continue;
     fq yp = fq_from_mont(y);  // canonical integer
     if ((yp.v[0] & 1u) != ((wx[0] >> 1) & 1u)) yp = fq_neg_canonical(yp);
-    st8(out + i * 16, wx);
-    st_fq(out + i * 16 + 8, yp);
+    st_coord(out + i * PT_WORDS, wx);
+    st_fq(out + i * PT_WORDS + CW, yp);
     break;
   }
 }
@@ -1770,8 +1843,8 @@ __global__ void __launch_bounds__(256) k_test_fq(int op, const uint32_t* __restr
                                                  uint32_t* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const fq x = fq_to_mont(ld_fq(a + i * 8));
-  const fq y = b ? fq_to_mont(ld_fq(b + i * 8)) : fq_zero();
+  const fq x = fq_to_mont(ld_fq(a + i * CW));
+  const fq y = b ? fq_to_mont(ld_fq(b + i * CW)) : fq_zero();
   fq z;
   switch (op) {
     case 0: z = fq_add(x, y); break;
@@ -1786,25 +1859,25 @@ __global__ void __launch_bounds__(256) k_test_fq(int op, const uint32_t* __restr
     case 8: z = fq_mul_fast(fq_add(x, y), fq_dbl(x)); break;        // (x + y) * 2x, limbs up to 2^30
     default: z = fq_sqr_fast(fq_add(x, y)); break;                  // (x + y)^2
   }
-  st_fq(out + i * 8, fq_from_mont(z));
+  st_fq(out + i * CW, fq_from_mont(z));
 }
 
 __global__ void __launch_bounds__(256) k_test_g1(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                  uint32_t* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  g1_xyzz p = ld_jacobian_plain(a + i * 24);
+  g1_xyzz p = ld_jacobian_plain(a + i * JAC_WORDS);
   g1_xyzz r;
   if (op == 0) {
-    r = g1_add(p, ld_jacobian_plain(b + i * 24));
+    r = g1_add(p, ld_jacobian_plain(b + i * JAC_WORDS));
   } else if (op == 1) {
     r = g1_double(p);
   } else if (op == 2) {
-    const fq qx = fq_to_mont(ld_fq(b + i * 16)), qy = fq_to_mont(ld_fq(b + i * 16 + 8));
+    const fq qx = fq_to_mont(ld_fq(b + i * PT_WORDS)), qy = fq_to_mont(ld_fq(b + i * PT_WORDS + CW));
     g1_madd(p, qx, qy);
     r = p;
   } else {  // the SMVP's signed-state form (g1_madd_w): 3: p + q - q + q ; 4: p - q - q  (every sign state, both digit signs)
-    const fq qx = fq_to_mont(ld_fq(b + i * 16)), qy = fq_to_mont(ld_fq(b + i * 16 + 8));
+    const fq qx = fq_to_mont(ld_fq(b + i * PT_WORDS)), qy = fq_to_mont(ld_fq(b + i * PT_WORDS + CW));
     bool wneg = false;
     if (op == 3) {
       g1_madd_w(p, wneg, qx, qy, false);
@@ -1816,14 +1889,14 @@ __global__ void __launch_bounds__(256) k_test_g1(int op, const uint32_t* __restr
     }
     r = g1_unsigned(p, wneg);
   }
-  st_jacobian_plain(out + i * 24, r);
+  st_jacobian_plain(out + i * JAC_WORDS, r);
 }
 
 __global__ void __launch_bounds__(256) k_test_g1_mul_u32(const uint32_t* __restrict__ a, const uint32_t* __restrict__ k,
                                                          uint32_t* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  st_jacobian_plain(out + i * 24, g1_mul_u32(ld_jacobian_plain(a + i * 24), k[i]));
+  st_jacobian_plain(out + i * JAC_WORDS, g1_mul_u32(ld_jacobian_plain(a + i * JAC_WORDS), k[i]));
 }
 
 }  // namespace MSM_KERNEL_NS

@@ -184,9 +184,9 @@ int mgpu_launch_on_device(msm_hip_mgpu* m, int d, int k, const void* scalars, bo
     ON_DEVICE(ctx);
     hipStream_t gs = m->gather_stream[d];
     if (e > b) HIP_TRY(ctx, hipStreamWaitEvent(gs, ctx->slot[k].done, 0));
-    if (m->api.AllGather(ms.d_send[d], ms.d_gather[d], (size_t)rows * 96, NCCL_UINT8, m->comm[d], gs) != 0) return MSM_HIP_ERR_HIP;
+    if (m->api.AllGather(ms.d_send[d], ms.d_gather[d], (size_t)rows * ctx->jb, NCCL_UINT8, m->comm[d], gs) != 0) return MSM_HIP_ERR_HIP;
     if (d == 0) {
-      HIP_TRY(ctx, hipMemcpyAsync(ms.h_gather, ms.d_gather[0], (size_t)m->n * rows * 96, hipMemcpyDeviceToHost, gs));
+      HIP_TRY(ctx, hipMemcpyAsync(ms.h_gather, ms.d_gather[0], (size_t)m->n * rows * ctx->jb, hipMemcpyDeviceToHost, gs));
       HIP_TRY(ctx, hipEventRecord(ms.gathered, gs));
     }
   }
@@ -299,15 +299,15 @@ int msm_hip_mgpu_create_curve(msm_hip_mgpu** out, const int* device_ids, int n_d
       ok = guard.ok && hipStreamCreateWithFlags(&m->gather_stream[d], hipStreamNonBlocking) == hipSuccess;
       for (int k = 0; ok && k < NSLOT; k++) {
         MgpuSlot& ms = m->slot[k];
-        ok = hipMalloc((void**)&ms.d_send[d], (size_t)MAXLW * 96) == hipSuccess &&
-             hipMalloc((void**)&ms.d_gather[d], (size_t)n_devices * MAXLW * 96) == hipSuccess &&
-             hipMemset(ms.d_send[d], 0, (size_t)MAXLW * 96) == hipSuccess;
+        ok = hipMalloc((void**)&ms.d_send[d], (size_t)MAXLW * MAX_JB) == hipSuccess &&
+             hipMalloc((void**)&ms.d_gather[d], (size_t)n_devices * MAXLW * MAX_JB) == hipSuccess &&
+             hipMemset(ms.d_send[d], 0, (size_t)MAXLW * MAX_JB) == hipSuccess;
         if (ok && d == 0) ok = hipEventCreateWithFlags(&ms.gathered, hipEventDisableTiming) == hipSuccess;
       }
       ok = ok && hipDeviceSynchronize() == hipSuccess;
     }
     for (int k = 0; ok && k < NSLOT; k++)
-      ok = hipHostMalloc((void**)&m->slot[k].h_gather, (size_t)n_devices * MAXLW * 96, hipHostMallocDefault) == hipSuccess;
+      ok = hipHostMalloc((void**)&m->slot[k].h_gather, (size_t)n_devices * MAXLW * MAX_JB, hipHostMallocDefault) == hipSuccess;
     if (!ok && flags == MSM_HIP_MGPU_GATHER_RCCL) {
       msm_hip_mgpu_destroy(m);
       return MSM_HIP_ERR_HIP;
@@ -383,29 +383,30 @@ int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz)
   if (rc) return rc;
   if (!hip_ok) return MSM_HIP_ERR_HIP;
   if (ms.n == 0) {  // nothing was launched anywhere
-    memset(out_xyz, 0, (size_t)nvec * 96);
+    memset(out_xyz, 0, (size_t)nvec * m->ctx[0]->jb);
     return MSM_HIP_OK;
   }
   // 4. one host window combine per MSM, side by side on the host pool
-  const size_t rec = parts ? PLANE_BYTES : 96;  // (one vector per launch through the pinned buffers: the windows arrive as bit-plane sums)
+  const size_t jb = m->ctx[0]->jb;
+  const size_t rec = parts ? PLANES_PER_WINDOW * jb : jb;  // (one vector per launch through the pinned buffers: the windows arrive as bit-plane sums)
   const CurveOps* ops = curve_ops(m->curve);
   std::atomic<bool> ok{true};
   combine_pool().run(nvec, [&](int v) {
-    uint8_t all[NWIN * PLANE_BYTES], sums[NWIN * 96];
+    uint8_t all[NWIN * PLANES_PER_WINDOW * MAX_JB], sums[NWIN * MAX_JB];
     for (int d = 0; d < G; d++) {
       int b, e;
       (void)msm_hip_window_range(d, G, W, &b, &e);
       if (e == b) continue;
-      const uint8_t* block = m->rccl ? ms.h_gather + (size_t)d * rows * 96 : m->ctx[d]->slot[slot].h_wsums;
+      const uint8_t* block = m->rccl ? ms.h_gather + (size_t)d * rows * jb : m->ctx[d]->slot[slot].h_wsums;
       memcpy(all + (size_t)b * rec, block + (size_t)v * (e - b) * rec, (size_t)(e - b) * rec);
     }
     const uint8_t* records = all;
     if (parts) {
       for (int w = 0; w < W; w++)
-        if (!ops->window_from_planes(all + (size_t)w * PLANE_BYTES, sums + 96 * (size_t)w)) ok = false;
+        if (!ops->window_from_planes(all + (size_t)w * rec, sums + jb * (size_t)w)) ok = false;
       records = sums;
     }
-    if (!ops->combine_windows(records, W, WBITS, out_xyz + (size_t)v * 96)) ok = false;
+    if (!ops->combine_windows(records, W, WBITS, out_xyz + (size_t)v * jb)) ok = false;
   });
   return ok ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
 }
@@ -413,7 +414,7 @@ int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz)
 int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
   if (!m || !out_xyz || (!scalars_host && n)) return MSM_HIP_ERR_INVALID_ARG;
   if (n == 0) {
-    memset(out_xyz, 0, 96);
+    memset(out_xyz, 0, m->ctx[0]->jb);
     return MSM_HIP_OK;
   }
   int rc = msm_hip_mgpu_launch_batch_bn254(m, scalars_host, n, 1, 0);
@@ -430,7 +431,7 @@ int msm_hip_mgpu_run_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, s
     int b, e;
     (void)msm_hip_window_range(d, m->n, (int)batch, &b, &e);
     if (e == b) return (int)MSM_HIP_OK;
-    return msm_hip_run_batch_bn254(m->ctx[d], scalars_host + (size_t)b * n * 32, n, (size_t)(e - b), out_xyz + (size_t)b * 96);
+    return msm_hip_run_batch_bn254(m->ctx[d], scalars_host + (size_t)b * n * 32, n, (size_t)(e - b), out_xyz + (size_t)b * m->ctx[d]->jb);
   });
 }
 

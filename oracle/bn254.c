@@ -11,7 +11,22 @@ typedef unsigned __int128 u128;
 /* ------------------------------------------------------------------------------------------------
  * Fq : 4 x 64-bit Montgomery, R = 2^256  (the in-memory form halo2curves uses)
  * ---------------------------------------------------------------------------------------------- */
-#if !defined(ORACLE_GRUMPKIN) && !defined(ORACLE_PALLAS) && !defined(ORACLE_VESTA)
+/* NL 64-bit limbs per base-field element (4; 6 for BLS12-381: bn254.h), CB bytes per coordinate on the wire, PB per affine point, JB per
+ * Jacobian record; scalars are 32 bytes on every curve */
+#define NL ONL
+#define CB (8 * NL)
+#define PB (2 * CB)
+#define JB (3 * CB)
+#define FBITS (64 * NL)
+#if defined(ORACLE_BLS12_381)
+/* -DORACLE_BLS12_381: BLS12-381 G1 (reference README.md "Implement cuzk on other curves"): y^2 = x^3 + 4 over the 381-bit p
+ * (6 x 64-bit limbs, R = 2^384, 48-byte coordinates), scalars modulo the 255-bit r; p = 3 mod 4. */
+static const uint64_t FQ_P[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull, 0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
+static const uint64_t FR_R[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+static const uint64_t FQ_N0 = 0x89f3fffcfffcfffdull; /* -p^-1 mod 2^64 */
+#define CURVE_B_IS_MINUS 0
+#define CURVE_B_ABS 4
+#elif !defined(ORACLE_GRUMPKIN) && !defined(ORACLE_PALLAS) && !defined(ORACLE_VESTA)
 static const uint64_t FQ_P[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
 static const uint64_t FR_R[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
 static const uint64_t FQ_N0 = 0x87d20782e4866389ull; /* -p^-1 mod 2^64 */
@@ -46,16 +61,16 @@ static const uint64_t FQ_N0 = 0x8c46eb20ffffffffull;
 static ofq FQ_R1, FQ_R2, FQ_ZERO, FQ_B3; /* R mod p, R^2 mod p, 0, 3*R mod p ; filled by init */
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
 
-static int ge_p(const uint64_t a[4]) {
-  for (int i = 3; i >= 0; i--) {
+static int ge_p(const uint64_t a[NL]) {
+  for (int i = NL - 1; i >= 0; i--) {
     if (a[i] > FQ_P[i]) return 1;
     if (a[i] < FQ_P[i]) return 0;
   }
   return 1;
 }
-static void sub_p(uint64_t a[4]) {
+static void sub_p(uint64_t a[NL]) {
   u128 br = 0;
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < NL; i++) {
     u128 t = (u128)a[i] - FQ_P[i] - br;
     a[i] = (uint64_t)t;
     br = (t >> 64) & 1;
@@ -63,103 +78,114 @@ static void sub_p(uint64_t a[4]) {
 }
 static void fq_add(ofq* o, const ofq* a, const ofq* b) {
   u128 c = 0;
-  uint64_t t[4];
-  for (int i = 0; i < 4; i++) {
+  uint64_t t[NL];
+  for (int i = 0; i < NL; i++) {
     c += (u128)a->l[i] + b->l[i];
     t[i] = (uint64_t)c;
     c >>= 64;
   }
   /* p < 2^254 so a + b < 2^255: no carry out */
   if (ge_p(t)) sub_p(t);
-  memcpy(o->l, t, 32);
+  memcpy(o->l, t, CB);
 }
 static void fq_sub(ofq* o, const ofq* a, const ofq* b) {
   u128 br = 0;
-  uint64_t t[4];
-  for (int i = 0; i < 4; i++) {
+  uint64_t t[NL];
+  for (int i = 0; i < NL; i++) {
     u128 d = (u128)a->l[i] - b->l[i] - br;
     t[i] = (uint64_t)d;
     br = (d >> 64) & 1;
   }
   if (br) {
     u128 c = 0;
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NL; i++) {
       c += (u128)t[i] + FQ_P[i];
       t[i] = (uint64_t)c;
       c >>= 64;
     }
   }
-  memcpy(o->l, t, 32);
+  memcpy(o->l, t, CB);
 }
 static void fq_neg(ofq* o, const ofq* a) { fq_sub(o, &FQ_ZERO, a); }
 static void fq_dbl(ofq* o, const ofq* a) { fq_add(o, a, a); }
-static int fq_is_zero(const ofq* a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
-static int fq_eq(const ofq* a, const ofq* b) { return memcmp(a->l, b->l, 32) == 0; }
+static int fq_is_zero(const ofq* a) {
+  uint64_t z = 0;
+  for (int i = 0; i < NL; i++) z |= a->l[i];
+  return z == 0;
+}
+static int fq_eq(const ofq* a, const ofq* b) { return memcmp(a->l, b->l, CB) == 0; }
 
 /* CIOS Montgomery product */
 static void fq_mul(ofq* o, const ofq* a, const ofq* b) {
-  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < 4; i++) {
+  uint64_t t[NL + 2];
+  memset(t, 0, sizeof t);
+  for (int i = 0; i < NL; i++) {
     u128 c = 0;
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NL; j++) {
       c += (u128)a->l[j] * b->l[i] + t[j];
       t[j] = (uint64_t)c;
       c >>= 64;
     }
-    c += t[4];
-    t[4] = (uint64_t)c;
-    t[5] = (uint64_t)(c >> 64);
+    c += t[NL];
+    t[NL] = (uint64_t)c;
+    t[NL + 1] = (uint64_t)(c >> 64);
     uint64_t m = t[0] * FQ_N0;
     c = (u128)m * FQ_P[0] + t[0];
     c >>= 64;
-    for (int j = 1; j < 4; j++) {
+    for (int j = 1; j < NL; j++) {
       c += (u128)m * FQ_P[j] + t[j];
       t[j - 1] = (uint64_t)c;
       c >>= 64;
     }
-    c += t[4];
-    t[3] = (uint64_t)c;
-    t[4] = t[5] + (uint64_t)(c >> 64);
+    c += t[NL];
+    t[NL - 1] = (uint64_t)c;
+    t[NL] = t[NL + 1] + (uint64_t)(c >> 64);
   }
-  if (t[4] || ge_p(t)) sub_p(t);
-  memcpy(o->l, t, 32);
+  if (t[NL] || ge_p(t)) sub_p(t);
+  memcpy(o->l, t, CB);
 }
 static void fq_sqr(ofq* o, const ofq* a) { fq_mul(o, a, a); }
 
-static void fq_pow(ofq* o, const ofq* a, const uint64_t e[4]) {
+static void fq_pow(ofq* o, const ofq* a, const uint64_t e[NL]) {
   ofq acc = FQ_R1, base = *a;
-  for (int i = 0; i < 256; i++) {
+  for (int i = 0; i < FBITS; i++) {
     if ((e[i >> 6] >> (i & 63)) & 1) fq_mul(&acc, &acc, &base);
     fq_sqr(&base, &base);
   }
   *o = acc;
 }
 static void fq_inv(ofq* o, const ofq* a) {
-  uint64_t e[4] = {FQ_P[0] - 2, FQ_P[1], FQ_P[2], FQ_P[3]};
+  uint64_t e[NL];
+  memcpy(e, FQ_P, CB);
+  e[0] -= 2;
   fq_pow(o, a, e);
 }
 /* canonical LE bytes <-> Montgomery */
-static int fq_from_bytes(ofq* o, const uint8_t b[32]) {
+static int fq_from_bytes(ofq* o, const uint8_t* b) {
   ofq t;
-  memcpy(t.l, b, 32); /* little-endian host */
+  memcpy(t.l, b, CB); /* little-endian host */
   int canonical = !ge_p(t.l);
   fq_mul(o, &t, &FQ_R2);
   return canonical;
 }
-static void fq_to_bytes(uint8_t b[32], const ofq* a) {
-  ofq one = {{1, 0, 0, 0}}, t;
+static void fq_to_bytes(uint8_t* b, const ofq* a) {
+  ofq one, t;
+  memset(&one, 0, sizeof one);
+  one.l[0] = 1;
   fq_mul(&t, a, &one);
-  memcpy(b, t.l, 32);
+  memcpy(b, t.l, CB);
 }
 
 static void oracle_init(void) {
   memset(&FQ_ZERO, 0, sizeof FQ_ZERO);
-  /* R mod p by 256 modular doublings of 1; R^2 by 256 more */
-  ofq one = {{1, 0, 0, 0}};
+  /* R mod p by FBITS modular doublings of 1; R^2 by FBITS more */
+  ofq one;
+  memset(&one, 0, sizeof one);
+  one.l[0] = 1;
   ofq t = one;
-  for (int i = 0; i < 256; i++) fq_dbl(&t, &t);
+  for (int i = 0; i < FBITS; i++) fq_dbl(&t, &t);
   FQ_R1 = t;
-  for (int i = 0; i < 256; i++) fq_dbl(&t, &t);
+  for (int i = 0; i < FBITS; i++) fq_dbl(&t, &t);
   FQ_R2 = t;
   ofq b = FQ_ZERO; /* the curve constant in Montgomery form (the name FQ_B3 is BN254's: b = 3) */
   for (int i = 0; i < CURVE_B_ABS; i++) fq_add(&b, &b, &FQ_R1);
@@ -294,15 +320,15 @@ static void g1_mul_u64(og1* o, const og1* p, uint64_t k) {
   memcpy(b, &k, 8);
   g1_mul_bytes(o, p, b);
 }
-static void g1_from_bytes96(og1* o, const uint8_t b[96]) {
+static void g1_from_bytes96(og1* o, const uint8_t* b) { /* (96: the record size of the 4-limb curves; JB in general) */
   fq_from_bytes(&o->x, b);
-  fq_from_bytes(&o->y, b + 32);
-  fq_from_bytes(&o->z, b + 64);
+  fq_from_bytes(&o->y, b + CB);
+  fq_from_bytes(&o->z, b + 2 * CB);
 }
-static void g1_to_bytes96(uint8_t b[96], const og1* p) {
+static void g1_to_bytes96(uint8_t* b, const og1* p) {
   fq_to_bytes(b, &p->x);
-  fq_to_bytes(b + 32, &p->y);
-  fq_to_bytes(b + 64, &p->z);
+  fq_to_bytes(b + CB, &p->y);
+  fq_to_bytes(b + 2 * CB, &p->z);
 }
 
 /* ------------------------------------------------------------------------------------------------ hooks */
@@ -310,9 +336,9 @@ void oracle_fq_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size
   ensure_init();
   for (size_t i = 0; i < n; i++) {
     ofq x, y, z;
-    fq_from_bytes(&x, a + 32 * i);
+    fq_from_bytes(&x, a + CB * i);
     if (b)
-      fq_from_bytes(&y, b + 32 * i);
+      fq_from_bytes(&y, b + CB * i);
     else
       y = FQ_ZERO;
     switch (op) {
@@ -323,7 +349,7 @@ void oracle_fq_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size
       case 4: fq_neg(&z, &x); break;
       default: fq_inv(&z, &x); break;
     }
-    fq_to_bytes(out + 32 * i, &z);
+    fq_to_bytes(out + CB * i, &z);
   }
 }
 
@@ -331,16 +357,16 @@ void oracle_g1_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size
   ensure_init();
   for (size_t i = 0; i < n; i++) {
     og1 p, q, r;
-    g1_from_bytes96(&p, a + 96 * i);
+    g1_from_bytes96(&p, a + JB * i);
     if (op == 0) {
-      g1_from_bytes96(&q, b + 96 * i);
+      g1_from_bytes96(&q, b + JB * i);
       g1_add(&r, &p, &q);
     } else if (op == 1) {
       g1_double(&r, &p);
     } else {
       g1_neg(&r, &p);
     }
-    g1_to_bytes96(out + 96 * i, &r);
+    g1_to_bytes96(out + JB * i, &r);
   }
 }
 
@@ -348,20 +374,20 @@ void oracle_g1_scalar_mul(const uint8_t* p_xy, const uint8_t* k, uint8_t* out, s
   ensure_init();
   for (size_t i = 0; i < n; i++) {
     og1 p, r;
-    fq_from_bytes(&p.x, p_xy + 64 * i);
-    fq_from_bytes(&p.y, p_xy + 64 * i + 32);
+    fq_from_bytes(&p.x, p_xy + PB * i);
+    fq_from_bytes(&p.y, p_xy + PB * i + CB);
     p.z = FQ_R1;
     g1_mul_bytes(&r, &p, k + 32 * i);
-    g1_to_bytes96(out + 96 * i, &r);
+    g1_to_bytes96(out + JB * i, &r);
   }
 }
 
-int oracle_g1_to_affine64(const uint8_t xyz[96], uint8_t out[64]) {
+int oracle_g1_to_affine64(const uint8_t* xyz, uint8_t* out) {
   ensure_init();
   og1 p;
   g1_from_bytes96(&p, xyz);
   if (g1_is_identity(&p)) {
-    memset(out, 0, 64);
+    memset(out, 0, PB);
     return 1;
   }
   ofq zi, zi2, zi3, x, y;
@@ -371,7 +397,7 @@ int oracle_g1_to_affine64(const uint8_t xyz[96], uint8_t out[64]) {
   fq_mul(&x, &p.x, &zi2);
   fq_mul(&y, &p.y, &zi3);
   fq_to_bytes(out, &x);
-  fq_to_bytes(out + 32, &y);
+  fq_to_bytes(out + CB, &y);
   return 0;
 }
 
@@ -379,8 +405,8 @@ int oracle_points_on_curve(const uint8_t* xy, size_t n) {
   ensure_init();
   for (size_t i = 0; i < n; i++) {
     ofq x, y, l, r;
-    if (!fq_from_bytes(&x, xy + 64 * i)) return 0;
-    if (!fq_from_bytes(&y, xy + 64 * i + 32)) return 0;
+    if (!fq_from_bytes(&x, xy + PB * i)) return 0;
+    if (!fq_from_bytes(&y, xy + PB * i + CB)) return 0;
     fq_sqr(&l, &y);
     fq_sqr(&r, &x);
     fq_mul(&r, &r, &x);
@@ -390,12 +416,14 @@ int oracle_points_on_curve(const uint8_t* xy, size_t n) {
   return 1;
 }
 
-void oracle_constants(uint8_t p[32], uint8_t r[32], uint8_t r2_mod_p[32], uint8_t one_mont[32], uint64_t* n0inv64) {
+int oracle_coord_bytes(void) { return CB; }
+
+void oracle_constants(uint8_t* p, uint8_t r[32], uint8_t* r2_mod_p, uint8_t* one_mont, uint64_t* n0inv64) {
   ensure_init();
-  memcpy(p, FQ_P, 32);
+  memcpy(p, FQ_P, CB);
   memcpy(r, FR_R, 32);
-  memcpy(r2_mod_p, FQ_R2.l, 32);
-  memcpy(one_mont, FQ_R1.l, 32);
+  memcpy(r2_mod_p, FQ_R2.l, CB);
+  memcpy(one_mont, FQ_R1.l, CB);
   *n0inv64 = FQ_N0;
 }
 
@@ -464,7 +492,7 @@ static void* msm_job_run(void* arg) {
   return NULL;
 }
 
-int oracle_msm_bn254_g1_mt(const uint8_t* xy, const uint8_t* scalars, size_t n, int n_threads, uint8_t out_xyz[96]) {
+int oracle_msm_bn254_g1_mt(const uint8_t* xy, const uint8_t* scalars, size_t n, int n_threads, uint8_t* out_xyz) {
   ensure_init();
   og1 acc;
   g1_identity(&acc);
@@ -475,8 +503,8 @@ int oracle_msm_bn254_g1_mt(const uint8_t* xy, const uint8_t* scalars, size_t n, 
   ofq* bx = (ofq*)malloc(n * sizeof(ofq));
   ofq* by = (ofq*)malloc(n * sizeof(ofq));
   for (size_t i = 0; i < n; i++) {
-    fq_from_bytes(&bx[i], xy + 64 * i);
-    fq_from_bytes(&by[i], xy + 64 * i + 32);
+    fq_from_bytes(&bx[i], xy + PB * i);
+    fq_from_bytes(&by[i], xy + PB * i + CB);
   }
   if (n_threads < 1) n_threads = 1;
   if ((size_t)n_threads > n) n_threads = (int)n;
@@ -511,7 +539,7 @@ int oracle_msm_bn254_g1_mt(const uint8_t* xy, const uint8_t* scalars, size_t n, 
   return 0;
 }
 
-int oracle_msm_bn254_g1(const uint8_t* xy, const uint8_t* scalars, size_t n, uint8_t out_xyz[96]) {
+int oracle_msm_bn254_g1(const uint8_t* xy, const uint8_t* scalars, size_t n, uint8_t* out_xyz) {
   return oracle_msm_bn254_g1_mt(xy, scalars, n, 1, out_xyz);
 }
 
@@ -568,9 +596,9 @@ void oracle_smvp_signed(const int32_t* col_ptr, const int32_t* val_idxs, const u
       g1_identity(&sum);
       for (int32_t t = col_ptr[row]; t < col_ptr[row + 1]; t++) {
         ofq x, y;
-        const uint8_t* pt = xy + 64 * (size_t)val_idxs[t];
+        const uint8_t* pt = xy + PB * (size_t)val_idxs[t];
         fq_from_bytes(&x, pt);
-        fq_from_bytes(&y, pt + 32);
+        fq_from_bytes(&y, pt + CB);
         g1_add_affine(&sum, &sum, &x, &y, 0);
       }
       int bi;
@@ -582,13 +610,13 @@ void oracle_smvp_signed(const int32_t* col_ptr, const int32_t* val_idxs, const u
       }
       if (bi > 0) g1_add(&bucket, &bucket, &sum);
     }
-    g1_to_bytes96(buckets_xyz + 96 * (size_t)k, &bucket);
+    g1_to_bytes96(buckets_xyz + JB * (size_t)k, &bucket);
   }
 }
 
 static og1* load_points96(const uint8_t* b, int n) {
   og1* p = (og1*)malloc(sizeof(og1) * (size_t)n);
-  for (int i = 0; i < n; i++) g1_from_bytes96(&p[i], b + 96 * (size_t)i);
+  for (int i = 0; i < n; i++) g1_from_bytes96(&p[i], b + JB * (size_t)i);
   return p;
 }
 
@@ -619,7 +647,7 @@ static void par_reduce_2(const og1* g_in, const og1* m_in, int nb, int nt, og1* 
   }
 }
 
-void oracle_bucket_reduction(int kind, const uint8_t* buckets_xyz, int num_buckets, int num_threads, uint8_t out_xyz[96]) {
+void oracle_bucket_reduction(int kind, const uint8_t* buckets_xyz, int num_buckets, int num_threads, uint8_t* out_xyz) {
   ensure_init();
   og1* b = load_points96(buckets_xyz, num_buckets);
   og1 acc;
@@ -661,8 +689,8 @@ void oracle_parallel_bucket_reduction_1(const uint8_t* buckets_xyz, int num_buck
   og1* m = (og1*)malloc(sizeof(og1) * (size_t)num_threads);
   par_reduce_1(b, num_buckets, num_threads, g, m);
   for (int t = 0; t < num_threads; t++) {
-    g1_to_bytes96(g_out + 96 * (size_t)t, &g[t]);
-    g1_to_bytes96(m_out + 96 * (size_t)t, &m[t]);
+    g1_to_bytes96(g_out + JB * (size_t)t, &g[t]);
+    g1_to_bytes96(m_out + JB * (size_t)t, &m[t]);
   }
   free(b);
   free(g);
@@ -676,13 +704,13 @@ void oracle_parallel_bucket_reduction_2(const uint8_t* g_in, const uint8_t* m_in
   og1* m = load_points96(m_in, num_threads);
   og1* r = (og1*)malloc(sizeof(og1) * (size_t)num_threads);
   par_reduce_2(g, m, num_buckets, num_threads, r);
-  for (int t = 0; t < num_threads; t++) g1_to_bytes96(out + 96 * (size_t)t, &r[t]);
+  for (int t = 0; t < num_threads; t++) g1_to_bytes96(out + JB * (size_t)t, &r[t]);
   free(g);
   free(m);
   free(r);
 }
 
-void oracle_horner(const uint8_t* window_sums_xyz, int num_words, int word_size, uint8_t out_xyz[96]) {
+void oracle_horner(const uint8_t* window_sums_xyz, int num_words, int word_size, uint8_t* out_xyz) {
   ensure_init();
   og1* s = load_points96(window_sums_xyz, num_words);
   og1 acc = s[num_words - 1];
@@ -694,7 +722,7 @@ void oracle_horner(const uint8_t* window_sums_xyz, int num_words, int word_size,
   free(s);
 }
 
-int oracle_msm_cuzk_model(const uint8_t* xy, const uint8_t* scalars, size_t n, int word_size, uint8_t out_xyz[96]) {
+int oracle_msm_cuzk_model(const uint8_t* xy, const uint8_t* scalars, size_t n, int word_size, uint8_t* out_xyz) {
   ensure_init();
   int num_words = (256 + word_size - 1) / word_size;
   int num_columns = 1 << word_size;
@@ -706,12 +734,12 @@ int oracle_msm_cuzk_model(const uint8_t* xy, const uint8_t* scalars, size_t n, i
   }
   int32_t* col_ptr = (int32_t*)malloc(sizeof(int32_t) * ((size_t)num_columns + 1));
   int32_t* val = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
-  uint8_t* buckets = (uint8_t*)malloc(96 * (size_t)h);
-  uint8_t* sums = (uint8_t*)malloc(96 * (size_t)num_words);
+  uint8_t* buckets = (uint8_t*)malloc(JB * (size_t)h);
+  uint8_t* sums = (uint8_t*)malloc(JB * (size_t)num_words);
   for (int w = 0; w < num_words; w++) {
     oracle_transpose(digits + (size_t)w * n, n, num_columns, col_ptr, val);
     oracle_smvp_signed(col_ptr, val, xy, n, num_columns, buckets);
-    oracle_bucket_reduction(1, buckets, h, 1, sums + 96 * (size_t)w);
+    oracle_bucket_reduction(1, buckets, h, 1, sums + JB * (size_t)w);
   }
   oracle_horner(sums, num_words, word_size, out_xyz);
   free(digits);
@@ -732,15 +760,25 @@ static uint64_t splitmix64(uint64_t x) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-static void draw256(uint64_t seed, uint64_t index, uint64_t attempt, uint64_t domain, uint64_t out[4]) {
+/* nl 64-bit words: 4 = a scalar or a coordinate of the 4-limb fields, masked to 254 bits; 6 = a BLS12-381 coordinate, masked to p's 381 bits */
+static void draw_words(uint64_t seed, uint64_t index, uint64_t attempt, uint64_t domain, uint64_t* out, int nl) {
   uint64_t base = splitmix64(seed ^ ((domain & 0xFF) << 56)) ^ (index * 0xD1342543DE82EF95ull);
   base = splitmix64(base ^ (attempt * 0xA0761D6478BD642Full));
   uint64_t s = base;
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < nl; i++) {
     s = splitmix64(s);
     out[i] = s;
   }
-  out[3] &= 0x3FFFFFFFFFFFFFFFull; /* 254 bits */
+  if (nl == 4) out[3] &= 0x3FFFFFFFFFFFFFFFull; /* 254 bits */
+  else out[nl - 1] &= (1ull << (381 - 64 * (nl - 1))) - 1; /* 381 bits */
+}
+static void draw256(uint64_t seed, uint64_t index, uint64_t attempt, uint64_t domain, uint64_t out[4]) { draw_words(seed, index, attempt, domain, out, 4); }
+static int ltn(const uint64_t* a, const uint64_t* m, int nl) {
+  for (int i = nl - 1; i >= 0; i--) {
+    if (a[i] < m[i]) return 1;
+    if (a[i] > m[i]) return 0;
+  }
+  return 0;
 }
 static int lt4(const uint64_t a[4], const uint64_t m[4]) {
   for (int i = 3; i >= 0; i--) {
@@ -763,22 +801,26 @@ void oracle_sample_scalars(uint64_t seed, size_t first, size_t n, uint8_t* out32
 
 /* square root in Fq for the samplers: y with y^2 = a, or 0 (return value) if a is not a square.
  * p = 3 mod 4 (BN254 Fq): a^((p+1)/4).  Otherwise (Grumpkin's base field, p - 1 = 2^28 t): Tonelli-Shanks. */
-static int fq_sqrt(ofq* y, const ofq* a, const uint64_t e_p3[4]) {
+static int fq_sqrt(ofq* y, const ofq* a, const uint64_t* e_p3) {
   ofq y2;
   if ((FQ_P[0] & 3) == 3) {
     fq_pow(y, a, e_p3);
   } else {
     /* p - 1 = 2^s t */
-    uint64_t t[4] = {FQ_P[0] - 1, FQ_P[1], FQ_P[2], FQ_P[3]};
+    uint64_t t[NL];
+    memcpy(t, FQ_P, CB);
+    t[0] -= 1;
     int s = 0;
     while (!(t[0] & 1)) {
-      for (int i = 0; i < 4; i++) t[i] = (t[i] >> 1) | (i < 3 ? t[i + 1] << 63 : 0);
+      for (int i = 0; i < NL; i++) t[i] = (t[i] >> 1) | (i < NL - 1 ? t[i + 1] << 63 : 0);
       s++;
     }
-    uint64_t half[4]; /* (p - 1) / 2 */
+    uint64_t half[NL]; /* (p - 1) / 2 */
     {
-      uint64_t pm1[4] = {FQ_P[0] - 1, FQ_P[1], FQ_P[2], FQ_P[3]};
-      for (int i = 0; i < 4; i++) half[i] = (pm1[i] >> 1) | (i < 3 ? pm1[i + 1] << 63 : 0);
+      uint64_t pm1[NL];
+      memcpy(pm1, FQ_P, CB);
+      pm1[0] -= 1;
+      for (int i = 0; i < NL; i++) half[i] = (pm1[i] >> 1) | (i < NL - 1 ? pm1[i + 1] << 63 : 0);
     }
     static ofq c0; /* z^t for the smallest non-residue z: a generator of the 2-Sylow subgroup */
     static int have_c0 = 0;
@@ -795,18 +837,18 @@ static int fq_sqrt(ofq* y, const ofq* a, const uint64_t e_p3[4]) {
     ofq chk;
     fq_pow(&chk, a, half);
     if (!fq_eq(&chk, &FQ_R1) && !fq_is_zero(a)) return 0;
-    uint64_t tp1h[4]; /* (t + 1) / 2 */
+    uint64_t tp1h[NL]; /* (t + 1) / 2 */
     {
       u128 c = (u128)t[0] + 1;
-      uint64_t u[4];
+      uint64_t u[NL];
       u[0] = (uint64_t)c;
       c >>= 64;
-      for (int i = 1; i < 4; i++) {
+      for (int i = 1; i < NL; i++) {
         c += t[i];
         u[i] = (uint64_t)c;
         c >>= 64;
       }
-      for (int i = 0; i < 4; i++) tp1h[i] = (u[i] >> 1) | (i < 3 ? u[i + 1] << 63 : 0);
+      for (int i = 0; i < NL; i++) tp1h[i] = (u[i] >> 1) | (i < NL - 1 ? u[i + 1] << 63 : 0);
     }
     ofq x, b, c = c0;
     fq_pow(&x, a, tp1h);
@@ -835,41 +877,41 @@ static int fq_sqrt(ofq* y, const ofq* a, const uint64_t e_p3[4]) {
 void oracle_sample_points(uint64_t seed, size_t first, size_t n, uint8_t* out64) {
   ensure_init();
   /* (p + 1) / 4 */
-  uint64_t e[4];
+  uint64_t e[NL];
   {
     u128 c = (u128)FQ_P[0] + 1;
-    uint64_t t[4];
+    uint64_t t[NL];
     t[0] = (uint64_t)c;
     c >>= 64;
-    for (int i = 1; i < 4; i++) {
+    for (int i = 1; i < NL; i++) {
       c += FQ_P[i];
       t[i] = (uint64_t)c;
       c >>= 64;
     }
-    for (int i = 0; i < 4; i++) e[i] = (t[i] >> 2) | (i < 3 ? t[i + 1] << 62 : 0);
+    for (int i = 0; i < NL; i++) e[i] = (t[i] >> 2) | (i < NL - 1 ? t[i + 1] << 62 : 0);
   }
   for (size_t i = 0; i < n; i++) {
     for (uint64_t attempt = 0;; attempt++) {
-      uint64_t v[4];
-      draw256(seed, first + i, attempt, 2, v);
-      if (!lt4(v, FQ_P)) continue;
+      uint64_t v[NL];
+      draw_words(seed, first + i, attempt, 2, v, NL);
+      if (!ltn(v, FQ_P, NL)) continue;
       ofq x, rhs, y, y2;
-      uint8_t xb[32];
-      memcpy(xb, v, 32);
+      uint8_t xb[CB];
+      memcpy(xb, v, CB);
       fq_from_bytes(&x, xb);
       fq_sqr(&rhs, &x);
       fq_mul(&rhs, &rhs, &x);
       fq_add(&rhs, &rhs, &FQ_B3);
       (void)y2;
       if (!fq_sqrt(&y, &rhs, e)) continue;
-      uint8_t yb[32];
+      uint8_t yb[CB];
       fq_to_bytes(yb, &y);
       if ((unsigned)(yb[0] & 1) != (unsigned)((xb[0] >> 1) & 1)) {
         fq_neg(&y, &y);
         fq_to_bytes(yb, &y);
       }
-      memcpy(out64 + 64 * i, xb, 32);
-      memcpy(out64 + 64 * i + 32, yb, 32);
+      memcpy(out64 + PB * i, xb, CB);
+      memcpy(out64 + PB * i + CB, yb, CB);
       break;
     }
   }

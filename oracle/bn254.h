@@ -31,7 +31,13 @@
 extern "C" {
 #endif
 
-typedef struct { uint64_t l[4]; } ofq;          /* Fq element, Montgomery form, R = 2^256 */
+#if defined(ORACLE_BLS12_381)
+#define ONL 6 /* 64-bit limbs of a base-field element: BLS12-381's p has 381 bits (48-byte coordinates, 96-byte points, 144-byte Jacobian records:
+                 every "32 B" / "64 B" / "96 B" below reads 48 / 96 / 144 for this build; scalars stay 32 B) */
+#else
+#define ONL 4
+#endif
+typedef struct { uint64_t l[ONL]; } ofq;        /* Fq element, Montgomery form, R = 2^(64 ONL) */
 typedef struct { ofq x, y, z; } og1;            /* Jacobian; z == 0 <=> identity (ec.template.wgsl:4) */
 
 /* ---- field / point op hooks (≙ tests/field.rs, tests/point.rs) : all I/O canonical little-endian ---- */
@@ -42,15 +48,15 @@ void oracle_g1_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size
 /* out[i] = k[i] * P[i];  P: n x 64 B affine, k: n x 32 B scalars, out: n x 96 B Jacobian */
 void oracle_g1_scalar_mul(const uint8_t* p_xy, const uint8_t* k, uint8_t* out, size_t n);
 /* 96 B Jacobian -> 64 B canonical affine (64 zero bytes for the identity); returns 1 if identity */
-int oracle_g1_to_affine64(const uint8_t xyz[96], uint8_t out[64]);
+int oracle_g1_to_affine64(const uint8_t* xyz, uint8_t* out);
 /* 1 if every point satisfies y^2 = x^3 + 3 with canonical coordinates */
 int oracle_points_on_curve(const uint8_t* xy, size_t n);
 
 /* ---- MSM (≙ cpu_msm, src/lib.rs:45-47).  out: 96 B Jacobian canonical LE.  returns 0 ---- */
-int oracle_msm_bn254_g1(const uint8_t* xy, const uint8_t* scalars, size_t n, uint8_t out_xyz[96]);
+int oracle_msm_bn254_g1(const uint8_t* xy, const uint8_t* scalars, size_t n, uint8_t* out_xyz);
 /* same, split over n_threads pthreads by point ranges (plonky2_maybe_rayon with rayon would do this; the
  * reference lockfile is serial, Cargo.lock:961-964) */
-int oracle_msm_bn254_g1_mt(const uint8_t* xy, const uint8_t* scalars, size_t n, int n_threads, uint8_t out_xyz[96]);
+int oracle_msm_bn254_g1_mt(const uint8_t* xy, const uint8_t* scalars, size_t n, int n_threads, uint8_t* out_xyz);
 
 /* ---- cuZK stage models ---- */
 /* digits[w*n + i] = biased signed digit in [0, 2^c); returns -1 if a final carry occurs */
@@ -61,23 +67,25 @@ void oracle_transpose(const int32_t* digits_w, size_t n, int num_columns, int32_
 void oracle_smvp_signed(const int32_t* col_ptr, const int32_t* val_idxs, const uint8_t* xy, size_t n, int num_columns,
                         uint8_t* buckets_xyz);
 /* kind: 0 serial (k * B[k]), 1 running-sum, 2 parallel (num_threads simulated, results summed) ; out 96 B */
-void oracle_bucket_reduction(int kind, const uint8_t* buckets_xyz, int num_buckets, int num_threads, uint8_t out_xyz[96]);
+void oracle_bucket_reduction(int kind, const uint8_t* buckets_xyz, int num_buckets, int num_threads, uint8_t* out_xyz);
 /* parallel_bucket_reduction_1 + _2 kept separate: g_out/m_out num_threads x 96 B each */
 void oracle_parallel_bucket_reduction_1(const uint8_t* buckets_xyz, int num_buckets, int num_threads, uint8_t* g_out,
                                         uint8_t* m_out);
 void oracle_parallel_bucket_reduction_2(const uint8_t* g_in, const uint8_t* m_in, int num_buckets, int num_threads,
                                         uint8_t* out);
 /* result = sum_w 2^(word_size*w) * S_w ; window_sums: num_words x 96 B */
-void oracle_horner(const uint8_t* window_sums_xyz, int num_words, int word_size, uint8_t out_xyz[96]);
+void oracle_horner(const uint8_t* window_sums_xyz, int num_words, int word_size, uint8_t* out_xyz);
 /* the whole cuZK pipeline on the CPU stage models (cf. tests/cuzk.rs:11-95) */
-int oracle_msm_cuzk_model(const uint8_t* xy, const uint8_t* scalars, size_t n, int word_size, uint8_t out_xyz[96]);
+int oracle_msm_cuzk_model(const uint8_t* xy, const uint8_t* scalars, size_t n, int word_size, uint8_t* out_xyz);
 
 /* ---- deterministic synthetic inputs (same definition as oracle/bn254_ref.py and the HIP samplers) ---- */
 void oracle_sample_scalars(uint64_t seed, size_t first, size_t n, uint8_t* out32);
 void oracle_sample_points(uint64_t seed, size_t first, size_t n, uint8_t* out64);
 
-/* constants for KAT tests: writes 32-byte LE values */
-void oracle_constants(uint8_t p[32], uint8_t r[32], uint8_t r2_mod_p[32], uint8_t one_mont[32], uint64_t* n0inv64);
+/* bytes of a coordinate on this build's wire: 32, or 48 for -DORACLE_BLS12_381 */
+int oracle_coord_bytes(void);
+/* constants for KAT tests: writes LE values (p, R^2 mod p, R mod p: oracle_coord_bytes() bytes each; r: 32 bytes) */
+void oracle_constants(uint8_t* p, uint8_t r[32], uint8_t* r2_mod_p, uint8_t* one_mont, uint64_t* n0inv64);
 
 #ifdef __cplusplus
 }

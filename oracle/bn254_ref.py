@@ -30,6 +30,7 @@ G = (1, 2)                # generator, SURVEY.md Appendix A.8
 INF = None                # affine point at infinity
 
 MASK64 = (1 << 64) - 1
+CB = 32  # bytes of a coordinate on the wire (48 in the BLS12-381 instance of this model, oracle/bls12_381_ref.py); scalars: 32 everywhere
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -95,7 +96,7 @@ def points_to_bytes(points):
     for pt in points:
         if pt is INF:
             raise ValueError("point at infinity is not representable (src/lib.rs:58 panics)")
-        out += pt[0].to_bytes(32, "little") + pt[1].to_bytes(32, "little")
+        out += pt[0].to_bytes(CB, "little") + pt[1].to_bytes(CB, "little")
     return bytes(out)
 
 
@@ -104,9 +105,9 @@ def scalars_to_bytes(scalars):
 
 
 def bytes_to_points(b):
-    assert len(b) % 64 == 0
-    return [(int.from_bytes(b[i:i + 32], "little"), int.from_bytes(b[i + 32:i + 64], "little"))
-            for i in range(0, len(b), 64)]
+    assert len(b) % (2 * CB) == 0
+    return [(int.from_bytes(b[i:i + CB], "little"), int.from_bytes(b[i + CB:i + 2 * CB], "little"))
+            for i in range(0, len(b), 2 * CB)]
 
 
 def bytes_to_scalars(b):
@@ -116,9 +117,9 @@ def bytes_to_scalars(b):
 
 def jacobian_bytes_to_affine(xyz):
     """96 B x||y||z canonical LE (z = 0 => infinity) -> affine tuple or INF."""
-    x = int.from_bytes(xyz[0:32], "little")
-    y = int.from_bytes(xyz[32:64], "little")
-    z = int.from_bytes(xyz[64:96], "little")
+    x = int.from_bytes(xyz[0:CB], "little")
+    y = int.from_bytes(xyz[CB:2 * CB], "little")
+    z = int.from_bytes(xyz[2 * CB:3 * CB], "little")
     if z == 0:
         return INF
     zi = pow(z, -1, P)
@@ -128,8 +129,8 @@ def jacobian_bytes_to_affine(xyz):
 def affine_to_bytes64(pt):
     """Canonical 64-byte affine encoding used for bit-exact comparison; infinity = 64 zero bytes."""
     if pt is INF:
-        return bytes(64)
-    return pt[0].to_bytes(32, "little") + pt[1].to_bytes(32, "little")
+        return bytes(2 * CB)
+    return pt[0].to_bytes(CB, "little") + pt[1].to_bytes(CB, "little")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -153,17 +154,16 @@ def splitmix64(x):
     return z ^ (z >> 31)
 
 
-def _draw256(seed, index, attempt, domain):
-    """Four 64-bit words -> 254-bit candidate (top two bits cleared)."""
+def _draw256(seed, index, attempt, domain, words64=4):
+    """Four 64-bit words -> 254-bit candidate (top two bits cleared); six words (a BLS12-381 coordinate) -> as many bits as P has."""
     base = splitmix64(seed ^ ((domain & 0xFF) << 56)) ^ ((index * 0xD1342543DE82EF95) & MASK64)
     base = splitmix64(base ^ ((attempt * 0xA0761D6478BD642F) & MASK64))
-    words = []
+    v = 0
     s = base
-    for _ in range(4):
+    for k in range(words64):
         s = splitmix64(s)
-        words.append(s)
-    v = words[0] | (words[1] << 64) | (words[2] << 128) | (words[3] << 192)
-    return v & ((1 << 254) - 1)
+        v |= s << (64 * k)
+    return v & ((1 << (254 if words64 == 4 else P.bit_length())) - 1)
 
 
 def sample_scalar(seed, index):
@@ -208,7 +208,7 @@ def sqrt_mod(a):
 def sample_point(seed, index):
     attempt = 0
     while True:
-        x = _draw256(seed, index, attempt, 2)
+        x = _draw256(seed, index, attempt, 2, CB // 8)
         if x < P:
             rhs = (x * x * x + B) % P
             y = sqrt_mod(rhs)

@@ -42,6 +42,7 @@ def lib():
         L.oracle_sample_scalars.argtypes = [C.c_uint64, sz, sz, u8p]
         L.oracle_sample_points.argtypes = [C.c_uint64, sz, sz, u8p]
         L.oracle_constants.argtypes = [u8p, u8p, u8p, u8p, C.POINTER(C.c_uint64)]
+        L.oracle_coord_bytes.restype = C.c_int
         _lib = L
     return _lib
 
@@ -50,46 +51,55 @@ def _buf(n):
     return C.create_string_buffer(n)
 
 
+def coord_bytes():
+    """Bytes of a coordinate on this build's wire: 32, or 48 for the BLS12-381 build (points 2 x, Jacobian records 3 x that)."""
+    return lib().oracle_coord_bytes()
+
+
+def _cb():
+    return coord_bytes()
+
+
 def fq_op(op, a, b=None):
     """op in {add, sub, mul, sqr, neg, inv}; a, b: bytes of n x 32 B canonical LE."""
     code = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "neg": 4, "inv": 5}[op]
-    n = len(a) // 32
-    out = _buf(32 * n)
+    n = len(a) // _cb()
+    out = _buf(_cb() * n)
     lib().oracle_fq_op(code, a, b, out, n)
     return out.raw
 
 
 def g1_op(op, a, b=None):
     code = {"add": 0, "double": 1, "negate": 2}[op]
-    n = len(a) // 96
-    out = _buf(96 * n)
+    n = len(a) // (3 * _cb())
+    out = _buf(3 * _cb() * n)
     lib().oracle_g1_op(code, a, b, out, n)
     return out.raw
 
 
 def g1_scalar_mul(points_xy, scalars):
-    n = len(points_xy) // 64
-    out = _buf(96 * n)
+    n = len(points_xy) // (2 * _cb())
+    out = _buf(3 * _cb() * n)
     lib().oracle_g1_scalar_mul(points_xy, scalars, out, n)
     return out.raw
 
 
 def to_affine64(xyz):
     """96 B Jacobian -> 64 B canonical affine (64 zero bytes for the identity)."""
-    out = _buf(64)
+    out = _buf(2 * _cb())
     lib().oracle_g1_to_affine64(bytes(xyz), out)
     return out.raw
 
 
 def points_on_curve(xy):
-    return bool(lib().oracle_points_on_curve(xy, len(xy) // 64))
+    return bool(lib().oracle_points_on_curve(xy, len(xy) // (2 * _cb())))
 
 
 def cpu_msm(points_xy, scalars, n_threads=1):
     """≙ cpu_msm (src/lib.rs:45-47).  Returns the 96 B Jacobian result."""
     n = len(scalars) // 32
-    assert len(points_xy) == 64 * n
-    out = _buf(96)
+    assert len(points_xy) == 2 * _cb() * n
+    out = _buf(3 * _cb())
     lib().oracle_msm_bn254_g1_mt(points_xy, scalars, n, n_threads, out)
     return out.raw
 
@@ -115,38 +125,38 @@ def transpose(digits_w, num_columns):
 def smvp_signed(col_ptr, val_idxs, points_xy, num_columns):
     col_ptr = np.ascontiguousarray(col_ptr, dtype=np.int32)
     val_idxs = np.ascontiguousarray(val_idxs, dtype=np.int32)
-    out = _buf(96 * (num_columns // 2))
-    lib().oracle_smvp_signed(col_ptr.ctypes.data, val_idxs.ctypes.data, points_xy, len(points_xy) // 64, num_columns, out)
+    out = _buf(3 * _cb() * (num_columns // 2))
+    lib().oracle_smvp_signed(col_ptr.ctypes.data, val_idxs.ctypes.data, points_xy, len(points_xy) // (2 * _cb()), num_columns, out)
     return out.raw
 
 
 def bucket_reduction(kind, buckets_xyz, num_threads=1):
     code = {"serial": 0, "running_sum": 1, "parallel": 2}[kind]
-    out = _buf(96)
-    lib().oracle_bucket_reduction(code, buckets_xyz, len(buckets_xyz) // 96, num_threads, out)
+    out = _buf(3 * _cb())
+    lib().oracle_bucket_reduction(code, buckets_xyz, len(buckets_xyz) // (3 * _cb()), num_threads, out)
     return out.raw
 
 
 def parallel_bucket_reduction_1(buckets_xyz, num_threads):
-    g, m = _buf(96 * num_threads), _buf(96 * num_threads)
-    lib().oracle_parallel_bucket_reduction_1(buckets_xyz, len(buckets_xyz) // 96, num_threads, g, m)
+    g, m = _buf(3 * _cb() * num_threads), _buf(3 * _cb() * num_threads)
+    lib().oracle_parallel_bucket_reduction_1(buckets_xyz, len(buckets_xyz) // (3 * _cb()), num_threads, g, m)
     return g.raw, m.raw
 
 
 def parallel_bucket_reduction_2(g, m, num_buckets, num_threads):
-    out = _buf(96 * num_threads)
+    out = _buf(3 * _cb() * num_threads)
     lib().oracle_parallel_bucket_reduction_2(g, m, num_buckets, num_threads, out)
     return out.raw
 
 
 def horner(window_sums_xyz, word_size=16):
-    out = _buf(96)
-    lib().oracle_horner(window_sums_xyz, len(window_sums_xyz) // 96, word_size, out)
+    out = _buf(3 * _cb())
+    lib().oracle_horner(window_sums_xyz, len(window_sums_xyz) // (3 * _cb()), word_size, out)
     return out.raw
 
 
 def msm_cuzk_model(points_xy, scalars, word_size=16):
-    out = _buf(96)
+    out = _buf(3 * _cb())
     rc = lib().oracle_msm_cuzk_model(points_xy, scalars, len(scalars) // 32, word_size, out)
     if rc != 0:
         raise ValueError("final carry is 1")
@@ -160,13 +170,13 @@ def sample_scalars(seed, n, first=0):
 
 
 def sample_points(seed, n, first=0):
-    out = _buf(64 * n)
+    out = _buf(2 * _cb() * n)
     lib().oracle_sample_points(seed, first, n, out)
     return out.raw
 
 
 def constants():
-    p, r, r2, one = _buf(32), _buf(32), _buf(32), _buf(32)
+    p, r, r2, one = _buf(_cb()), _buf(32), _buf(_cb()), _buf(_cb())
     n0 = C.c_uint64()
     lib().oracle_constants(p, r, r2, one, C.byref(n0))
     le = lambda b: int.from_bytes(b.raw, "little")

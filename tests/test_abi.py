@@ -126,8 +126,16 @@ def test_host_only_helpers_of_window_sizes_and_curves(built):
         cx = __import__("importlib").import_module("oracle.cpu_" + name)
         sums_x = cx.g1_scalar_mul(cx.sample_points(5, 16), cx.sample_scalars(6, 16))
         assert m.MsmContext.combine_windows(sums_x, curve=name).to_affine_bytes() == cx.to_affine64(cx.horner(sums_x)), name
-    out = C.create_string_buffer(96)
-    assert L.msm_hip_combine_windows_curve(4, sums, 16, out) == -2  # unknown curve
+    # ... and for BLS12-381 (6 x 64-bit limbs on the host, 144-byte Jacobian records)
+    from oracle import cpu_bls12_381 as cb
+
+    sums_b = cb.g1_scalar_mul(cb.sample_points(7, 16), cb.sample_scalars(8, 16))
+    assert len(sums_b) == 16 * 144
+    got_b = m.MsmContext.combine_windows(sums_b, curve="bls12_381")
+    assert got_b.to_affine_bytes() == cb.to_affine64(cb.horner(sums_b)) and len(got_b.to_affine_bytes()) == 96
+    assert [g.to_affine_bytes() for g in m.MsmContext.combine_windows_batch(sums_b[: 8 * 144] + sums_b[: 8 * 144], 8, curve="bls12_381")] == [cb.to_affine64(cb.horner(sums_b[: 8 * 144]))] * 2
+    out = C.create_string_buffer(144)
+    assert L.msm_hip_combine_windows_curve(5, sums, 16, out) == -2  # unknown curve
     h = C.c_void_p()
     assert L.msm_hip_ctx_create_curve(C.byref(h), 0, 7) == -2
 
