@@ -1,6 +1,6 @@
 """Randomised differential test of the HIP engine against the CPU oracle: random sizes (tile / chunk / alignment edges),
 random scalar distributions (uniform, few distinct values, small values, zeros, equal), random window ranges.
-Usage: python tools/fuzz_gpu.py [cases] [seed] [bn254|grumpkin|pallas|vesta]   (test infrastructure: uses the oracle)"""
+Usage: python tools/fuzz_gpu.py [cases] [seed] [bn254|grumpkin|pallas|vesta|bls12_381]   (test infrastructure: uses the oracle)"""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,6 +16,13 @@ else:
     from oracle import cpu, bn254_ref as ref
 rnd = random.Random(seed)
 ctx = m.MsmContext(0, curve=curve)
+CBY = ctx.cb  # bytes per coordinate (48 on BLS12-381)
+# BLS12-381's cofactor is not 1: the samplers' points are outside the order-r subgroup, where the endomorphism modes are not exact (and the
+# R = 2^256 input format is the 4-limb curves')
+MODES = ["host", "device", "windows", "batch", "group", "hostbatch", "mont", "bits", "tables", "tables_batch", "hostpipe", "mgpu", "endo", "endo_batch",
+         "group_halves", "mgpu_batch", "mgpu_batch_endo"]
+if curve == "bls12_381":
+    MODES = [x for x in MODES if x not in ("mont", "endo", "endo_batch", "group_halves", "mgpu_batch_endo")]
 combine = lambda sums: m.MsmContext.combine_windows(sums, curve=curve)
 mg = {}  # lazily created msm_hip_mgpu handles by rank count (several contexts on this one GPU, pinned-buffer gather)
 R = ref.R
@@ -50,8 +57,8 @@ for case in range(cases):
         sc = [base[i % max(1, n // 5)] for i in range(n)]
     sb = ref.scalars_to_bytes(sc)
     want = cpu.to_affine64(cpu.cpu_msm(points, sb))
-    mode = rnd.choice(["host", "device", "windows", "batch", "group", "hostbatch", "mont", "bits", "tables", "tables_batch", "hostpipe", "mgpu", "endo", "endo_batch"])
-    ctx.set_bases(points, precompute=mode.startswith("tables"), endomorphism=mode.startswith("endo"))
+    mode = rnd.choice(MODES)
+    ctx.set_bases(points, precompute=mode.startswith("tables"), endomorphism=mode.startswith("endo") or mode == "group_halves")
     if mode == "mont":
         # both inputs as R = 2^256 Montgomery words (MSM_HIP_BASES_MONT256, MSM_HIP_SCALARS_MONT256)
         PM, RM = ref.P, ref.R
@@ -101,6 +108,47 @@ for case in range(cases):
             mg[world] = m.MultiGpuMsm([0] * world, "host", curve=curve)
         mg[world].set_bases(points)
         got = mg[world].msm(sb) if rnd.random() < 0.6 else mg[world].msm_batch(sb + sb, n)[1]
+    elif mode in ("mgpu_batch", "mgpu_batch_endo"):
+        # the asynchronous grouped form (msm_hip_mgpu_launch_batch_* / finish_batch): this case's vector at a random position of a group,
+        # two slots in flight, host or device-resident scalars; with endomorphism bases the devices share the 8 half-length windows
+        world = rnd.choice([1, 2, 3, 5, 8, 16])
+        key = (world, "b")
+        if key not in mg:
+            mg[key] = m.MultiGpuMsm([0] * world, "host", curve=curve)
+        mg[key].set_bases(points, endomorphism=mode == "mgpu_batch_endo")
+        g = rnd.randrange(1, mg[key].group_size + 1)
+        pos = rnd.randrange(g)
+        vecs = [bytes(len(sb)) if rnd.random() < 0.5 else sb for _ in range(g)]
+        vecs[pos] = sb
+        blob = b"".join(vecs)
+        if rnd.random() < 0.5:
+            t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+            torch.cuda.synchronize()
+            mg[key].launch_batch([t] * world, n, 1)
+            mg[key].launch_batch([t] * world, n, 2)
+        else:
+            mg[key].launch_batch(blob, n, 1)
+            mg[key].launch_batch(blob, n, 2)
+        a, b2 = mg[key].finish_batch(1, g), mg[key].finish_batch(2, g)
+        assert a[pos] == b2[pos]
+        got = a[pos]
+    elif mode == "group_halves":
+        # grouped half-length window shares (endomorphism bases): every rank's share of a group, gathered and combined (8 sums per MSM)
+        world = rnd.choice([2, 3, 4, 8])
+        per = -(-8 // world)
+        g = max(1, 8 // per)
+        pos = rnd.randrange(g)
+        vecs = [bytes(len(sb)) if rnd.random() < 0.5 else sb for _ in range(g)]
+        vecs[pos] = sb
+        t = torch.frombuffer(bytearray(b"".join(vecs)), dtype=torch.uint8).cuda()
+        parts = []
+        for r in range(world):
+            b, e = window_range(r, world, 8)
+            out = torch.empty((g * (e - b), 3 * CBY), dtype=torch.uint8, device="cuda")
+            ctx.launch_half_windows_batch(t, n, b, e, r % 4, out)
+            ctx.slot_sync(r % 4)
+            parts.append(out[pos * (e - b):(pos + 1) * (e - b)])
+        got = combine(torch.cat(parts, dim=0))
     elif mode == "device":
         t = torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda()
         got = ctx.msm(t)
@@ -121,7 +169,7 @@ for case in range(cases):
         parts = []
         for r in range(world):
             b, e = window_range(r, world)
-            out = torch.empty((g * (e - b), 96), dtype=torch.uint8, device="cuda")
+            out = torch.empty((g * (e - b), 3 * CBY), dtype=torch.uint8, device="cuda")
             ctx.launch_windows_batch(t, n, b, e, r % 4, out)
             ctx.slot_sync(r % 4)
             parts.append(out[pos * (e - b):(pos + 1) * (e - b)])
