@@ -138,6 +138,68 @@ class MsmContext {
   msm_hip_ctx* ctx_ = nullptr;
 };
 
+/// Several GPUs of one node from one process (msm_hip_mgpu_*): every MSM's windows are sharded over the devices, the window sums gathered
+/// (RCCL, or pinned buffers when device ids repeat) and combined on the host.  `msm_stream` is the throughput form: groups of `group_size()`
+/// scalar vectors per launch, up to three launches in flight, one result per vector -- what a prover with a queue of jobs over one set of
+/// bases drives (the caller of src/lib.rs:76-82 many times over; the reference creates its device per call, src/cuzk/msm.rs:88-94).
+class MultiGpuMsm {
+ public:
+  explicit MultiGpuMsm(const std::vector<int>& devices, uint32_t gather = MSM_HIP_MGPU_GATHER_AUTO) {
+    check(msm_hip_mgpu_create(&m_, devices.data(), (int)devices.size(), gather), "msm_hip_mgpu_create");
+  }
+  ~MultiGpuMsm() { msm_hip_mgpu_destroy(m_); }
+  MultiGpuMsm(const MultiGpuMsm&) = delete;
+  MultiGpuMsm& operator=(const MultiGpuMsm&) = delete;
+
+  void set_bases(const std::vector<G1Affine>& g, uint32_t flags = 0) {  // replicated on every device
+    const std::vector<uint8_t> b = points_to_bytes(g);
+    check(msm_hip_mgpu_set_bases_bn254(m_, b.data(), g.size(), flags), "msm_hip_mgpu_set_bases_bn254");
+  }
+  int group_size() const { return msm_hip_mgpu_group_size(m_); }
+  bool uses_rccl() const { return msm_hip_mgpu_uses_rccl(m_) == 1; }
+  G1 msm(const std::vector<Fr>& v) {
+    const std::vector<uint8_t> b = scalars_to_bytes(v);
+    G1 r;
+    check(msm_hip_mgpu_run_bn254(m_, b.data(), v.size(), r.xyz.data()), "msm_hip_mgpu_run_bn254");
+    return r;
+  }
+  std::vector<G1> msm_stream(const std::vector<std::vector<Fr>>& jobs) {
+    if (jobs.empty()) return {};
+    constexpr size_t IN_FLIGHT = 3;
+    const size_t n = jobs[0].size(), g = (size_t)group_size();
+    std::vector<std::vector<uint8_t>> groups;  // the library reads a group's bytes until its finish
+    for (size_t first = 0; first < jobs.size(); first += g) {
+      std::vector<uint8_t> blob;
+      for (size_t k = first; k < jobs.size() && k < first + g; k++) {
+        if (jobs[k].size() != n) throw std::invalid_argument("msm_stream: scalar vectors differ in length");
+        const std::vector<uint8_t> b = scalars_to_bytes(jobs[k]);
+        blob.insert(blob.end(), b.begin(), b.end());
+      }
+      groups.push_back(std::move(blob));
+    }
+    std::vector<G1> out;
+    std::vector<uint8_t> xyz(96 * g);
+    for (size_t i = 0; i < groups.size() + IN_FLIGHT; i++) {
+      if (i >= IN_FLIGHT) {
+        const size_t k = i - IN_FLIGHT, nvec = groups[k].size() / (32 * n);
+        check(msm_hip_mgpu_finish_batch_bn254(m_, (int)(k % MSM_HIP_NUM_SLOTS), xyz.data()), "msm_hip_mgpu_finish_batch_bn254");
+        for (size_t v = 0; v < nvec; v++) {
+          G1 r;
+          std::memcpy(r.xyz.data(), xyz.data() + 96 * v, 96);
+          out.push_back(r);
+        }
+      }
+      if (i < groups.size())
+        check(msm_hip_mgpu_launch_batch_bn254(m_, groups[i].data(), n, (int)(groups[i].size() / (32 * n)), (int)(i % MSM_HIP_NUM_SLOTS)),
+              "msm_hip_mgpu_launch_batch_bn254");
+    }
+    return out;
+  }
+
+ private:
+  msm_hip_mgpu* m_ = nullptr;
+};
+
 /// ≙ compute_msm (src/cuzk/msm.rs:75): one-shot MSM including device set-up and base upload
 inline G1 compute_msm(const std::vector<G1Affine>& points, const std::vector<Fr>& scalars) {
   if (points.size() != scalars.size()) throw std::invalid_argument("compute_msm: points and scalars differ in length");

@@ -206,13 +206,20 @@ class ShardedMsmPipeline:
         """Result of the oldest launch in flight: a G1, or the list of its G1 results when msms_per_issue > 1."""
         assert self.completed < self.issued
         slot = self.completed % self.SLOTS
+        synced = False
         try:  # a launch that failed (device-side input error) is retired too: the pipeline stays usable
             self.copied[slot].synchronize()
             if self.w_end > self.w_begin:
+                synced = True
                 self.ctx.slot_sync(slot)
             out = self._combine(slot, self.nvec[slot])
         finally:
             self.completed += 1
+            if not synced and self.w_end > self.w_begin:  # whatever failed above: the engine's slot is collected (never left busy)
+                try:
+                    self.ctx.slot_sync(slot)
+                except Exception:
+                    pass
         return out if self.g > 1 else out[0]
 
     def _combine(self, slot, nvec):

@@ -50,6 +50,22 @@ int main(int argc, char** argv) {
   if (ctx.msm(v) != fast) return 6;
   const std::vector<G1> many2 = ctx.msm_batch({v, v});
   if (many2.size() != 2 || many2[0] != fast || many2[1] != fast) return 7;
+  // several engine contexts from one process (here: three on the one GPU, pinned-buffer gather): the synchronous call and the
+  // grouped asynchronous stream of jobs, plain and endomorphism bases
+  {
+    MultiGpuMsm node({0, 0, 0}, MSM_HIP_MGPU_GATHER_HOST);
+    node.set_bases(g);
+    if (node.group_size() != 2 || node.uses_rccl()) return 8;
+    if (node.msm(v) != fast) return 9;
+    const std::vector<std::vector<Fr>> jobs = {v, std::vector<Fr>(n), v, v, v, std::vector<Fr>(n), v, v, v};  // 9 jobs: 5 launches, three in flight
+    const std::vector<G1> res = node.msm_stream(jobs);
+    if (res.size() != jobs.size()) return 10;
+    for (size_t k = 0; k < jobs.size(); k++)
+      if ((k == 1 || k == 5) ? !res[k].to_affine().infinity : res[k] != fast) return 11;
+    node.set_bases(g, MSM_HIP_BASES_ENDOMORPHISM);  // the devices then share the 8 half-length windows
+    const std::vector<G1> res2 = node.msm_stream({v, v, v});
+    if (res2.size() != 3 || res2[0] != fast || res2[2] != fast) return 12;
+  }
   const G1Affine a = fast.to_affine();
   std::vector<uint8_t> got(64, 0);
   if (!a.infinity) {
