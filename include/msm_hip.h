@@ -274,6 +274,7 @@ void* msm_hip_stream(msm_hip_ctx* ctx);
  *      buffer left by the last run to host memory.  Layouts:
  *      digits    : u16[num_windows_run][n]    code = sign << 15 | (|d| & 0x7fff); 0 = digit 0 (no entry);
  *                  0x8000 = digit -2^15 (bucket slot 0)        cf. decompose_scalars.template.wgsl:93-112
+ *                  (endomorphism launches: 2n inputs per window, input 2 j = first half of scalar j, 2 j + 1 = its second half)
  *      (shapes for 16-bit windows; with b-bit windows: 2^(b-1) buckets per window, col_ptr rows of 2^(b-1) + 1 entries)
  *      col_ptr   : u32[num_windows_run][32769] start of bucket slot k in val_idxs   cf. transpose.template.wgsl:58-61
  *      val_idxs  : u32[num_windows_run][n]    point index | sign << 31, grouped by slot (order within a slot is

@@ -11,7 +11,8 @@ struct CurveOps {
   void (*convert_points)(const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t*);
   void (*precompute_tables)(uint32_t*, size_t, size_t, int);
   void (*endo_points)(uint32_t*, size_t);
-  void (*glv_split)(const uint32_t*, uint32_t*, size_t, int, uint32_t*);
+  // k_count<C, 4, true> for C = 12 / 14 / 16: the first sort pass of endomorphism launches, which splits the scalars itself (csrc/glv.h)
+  void (*count_split[3])(const uint32_t*, size_t, uint32_t, uint32_t, int, int, int, size_t, uint32_t*, uint16_t*, int, uint64_t*, uint32_t*, uint32_t*, size_t);
   void (*scalars_from_mont256)(const uint32_t*, uint32_t*, size_t, uint32_t*);
   void (*smvp_chunks)(const uint32_t*, const uint32_t*, const uint32_t*, size_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*,
                       uint32_t*, uint32_t);
@@ -43,7 +44,7 @@ struct CurveOps {
   int (*to_affine64)(const uint8_t*, uint8_t*);
 };
 #define MSM_CURVE_OPS(K, F)                                                                                                              \
-  {K::k_convert_points, K::k_precompute_tables, K::k_endo_points, K::k_glv_split, K::k_scalars_from_mont256, K::k_smvp_chunks, K::k_smvp_stitch, K::k_smvp_stitch_big,       \
+  {K::k_convert_points, K::k_precompute_tables, K::k_endo_points, {K::k_count<12, 4, true>, K::k_count<14, 4, true>, K::k_count<16, 4, true>}, K::k_scalars_from_mont256, K::k_smvp_chunks, K::k_smvp_stitch, K::k_smvp_stitch_big,       \
    K::k_bpr_rowcol<4, 8>, K::k_bpr_rowcol<2, 8>, K::k_bpr_rowcol<3, 8>, K::k_bpr_rowcol<4, 6>, K::k_bpr_rowcol<2, 6>, K::k_bpr_rowcol<2, 4>, \
    K::k_bpr_w256, K::k_bpr_final, K::k_bpr_planes<false>, K::k_bpr_planes<true>, K::k_bpr_final_planes, K::BPR_USE_W256, K::CW, K::REC_WORDS, K::XYZZ_WORDS, F::GLV_SUPPORTED, K::k_sample_scalars, K::k_sample_points, K::k_export_buckets, K::k_test_fq, K::k_test_g1,                \
    K::k_test_g1_mul_u32, F::host::combine_windows, F::host::window_from_planes, F::host::to_affine64}

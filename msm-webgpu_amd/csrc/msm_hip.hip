@@ -123,7 +123,7 @@ struct msm_hip_ctx {
   size_t cap_batch_stage = 0;
   uint16_t* d_digits = nullptr;  // digit-code planes [local window][n]: debug read-back, or the input of the second sort pass (k_scatter_planes)
   uint64_t* d_negbits = nullptr; // with the planes of a launch: one sign bit per input of every vector
-  size_t cap_planes = 0;         // capacity (u16 entries) of d_digits; d_negbits holds cap_planes / 64 + MAXLW words
+  size_t cap_planes = 0;         // capacity (u16 entries) of d_digits; d_negbits holds cap_planes / 64 + 2 MAXLW words
   bool debug = false;
   int timing_level = 2;  // 0: no stage events, 1: only around the SMVP kernel, 2: every stage boundary
   uint32_t* d_counts = nullptr;      // [W][tiles][128]
@@ -277,7 +277,7 @@ int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, int full_win
     if (entries < ctx->cap_entries) entries = ctx->cap_entries;
     ctx->cap_planes = 0;
     if ((rc = dev_alloc(ctx, ctx->d_digits, entries))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->d_negbits, entries / 64 + MAXLW))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->d_negbits, entries / 64 + 2 * MAXLW))) return rc;
     ctx->cap_planes = entries;
   }
   if (need_entries > ctx->cap_entries || need_recs > ctx->cap_chunk_slot) {
@@ -395,7 +395,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   // fixed-base tables (`merge`): the w_count_vec windows of a vector feed one bucket set -- one local window of up to
   // n * w_count_vec entries per vector -- whose entries index the tables (window w of point i = record w * n_bases + i)
   const size_t merge_nb = merge ? ctx->n_bases : 0;
-  // endomorphism (`halves`): the recode reads 2n halves of 16 B (k_glv_split) against 2n points -- P_i and, n_bases records
+  // endomorphism (`halves`): the recode runs over 2n halves of 16 B (the first pass splits the scalars) against 2n points -- P_i and, n_bases records
   // further on, phi(P_i) -- in half as many windows
   const size_t n_sc = halves ? 2 * n : n;  // inputs of the recode
   const size_t n_entries = merge ? n * (size_t)w_count_vec : n_sc;
@@ -435,41 +435,42 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     AFTER_KERNEL(ctx, "k_scalars_from_mont256", st);
     d_scalars = ctx->d_scalar_conv;
   }
-  if (halves) {  // k = k1 + k2 lambda: the halves of every vector (part of stage 0)
-    const size_t count = (size_t)nvec * n;
-    hipLaunchKernelGGL(ctx->ops->glv_split, dim3(blocks_for(count, 256)), dim3(256), 0, st, d_scalars, ctx->d_halves, n, nvec, d_err);
-    AFTER_KERNEL(ctx, "k_glv_split", st);
-    d_scalars = ctx->d_halves;
-  }
 #define LAUNCH_BY_WBITS_SW(KERNEL, SW, ...)                                              \
   do {                                                                                   \
     if (wbits == 16) hipLaunchKernelGGL((KERNEL<16, SW>), dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
     else if (wbits == 14) hipLaunchKernelGGL((KERNEL<14, SW>), dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
     else hipLaunchKernelGGL((KERNEL<12, SW>), dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
   } while (0)
-#define LAUNCH_BY_WBITS(KERNEL, ...)                           \
-  do {                                                         \
-    if (halves) LAUNCH_BY_WBITS_SW(KERNEL, 4, __VA_ARGS__);    \
-    else LAUNCH_BY_WBITS_SW(KERNEL, 8, __VA_ARGS__);           \
-  } while (0)
-  // (a vector's 2n halves take the room of its n scalars: the vector stride is n * 8 words either way)
-  LAUNCH_BY_WBITS(k_count, d_scalars, n_sc, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, planes ? ctx->d_digits : digits,
-                  planes ? ctx->d_negbits : nullptr, d_err, merge_nb);
+  // first pass: recode + coarse histogram (+ digit planes: 1 = debug read-back, 2 = the second pass reads them).  Endomorphism launches:
+  // the same kernel splits every scalar k = k1 + k2 lambda itself and leaves the halves (interleaved: input 2 j = k1 of scalar j, 2 j + 1 =
+  // k2; a vector's 2n halves take the room of its n scalars, vector stride n * 8 words either way) for a scalar-reading second pass.
+  uint16_t* plane_out = planes ? ctx->d_digits : digits;
+  const int plane_mode = planes ? 2 : (digits ? 1 : 0);
+  if (halves) {
+    hipLaunchKernelGGL(ctx->ops->count_split[wbits == 16 ? 2 : wbits == 14 ? 1 : 0], dim3(tiles), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, w_begin,
+                       w_count_vec, nvec, n * 8, ctx->d_counts, plane_out, plane_mode, planes ? ctx->d_negbits : nullptr,
+                       planes ? nullptr : ctx->d_halves, d_err, merge_nb);
+    d_scalars = ctx->d_halves;
+  } else {
+    LAUNCH_BY_WBITS_SW(k_count, 8, d_scalars, n_sc, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, plane_out, plane_mode,
+                       (uint64_t*)nullptr, (uint32_t*)nullptr, d_err, merge_nb);
+  }
   AFTER_KERNEL(ctx, "k_count", st);
   HIP_TRY(ctx, mark(1, false));
   hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total);  // all 128 bins: the scatter scans them
   AFTER_KERNEL(ctx, "k_scan_tiles", st);
   HIP_TRY(ctx, mark(2, false));
   if (planes) {
-    hipLaunchKernelGGL(k_scatter_planes, dim3(tiles), dim3(256), 0, st, ctx->d_digits, ctx->d_negbits, n_sc, stride, tile_len, tiles, w_count, w_count_vec,
-                       ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, halves ? (uint32_t)n : 0xffffffffu,
-                       halves ? (uint32_t)(ctx->n_bases - n) : 0u, chunks, chunk_len, d_chunk_len);
+    hipLaunchKernelGGL(k_scatter_planes, dim3(tiles), dim3(256), 0, st, ctx->d_digits, halves ? ctx->d_negbits : (const uint64_t*)nullptr, n_sc, stride, tile_len,
+                       tiles, w_count, w_count_vec, ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine,
+                       (uint32_t)ctx->n_bases, chunks, chunk_len, d_chunk_len);
+  } else if (halves) {
+    LAUNCH_BY_WBITS_SW(k_scatter_coarse, 4, d_scalars, n_sc, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
+                       ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, (uint32_t)n, (uint32_t)ctx->n_bases, chunks, chunk_len, d_chunk_len);
   } else {
-    LAUNCH_BY_WBITS(k_scatter_coarse, d_scalars, n_sc, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
-                    ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, (uint32_t)n, (uint32_t)(ctx->n_bases - n), chunks, chunk_len,
-                    d_chunk_len);
+    LAUNCH_BY_WBITS_SW(k_scatter_coarse, 8, d_scalars, n_sc, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
+                       ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, (uint32_t)n, 0u, chunks, chunk_len, d_chunk_len);
   }
-#undef LAUNCH_BY_WBITS
 #undef LAUNCH_BY_WBITS_SW
   AFTER_KERNEL(ctx, "k_scatter_coarse", st);
   HIP_TRY(ctx, mark(3, false));
@@ -513,7 +514,11 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   if (wbits == 16) {
     // one small MSM alone in its launch (8 half-length windows, up to 2^18 points): 8 buckets per thread -- its latency is what counts
     // (-4 % at 2^16, -2.6 % at 2^18; the same setting costs grouped launches 3 - 16 % and a pipelined 2^20 MSM 0.5 %)
-    const bool small_single = nvec == 1 && w_count == 8 && n_entries <= ((size_t)1 << 19);
+    // ... and so is a larger one that has the GPU to itself: no other result slot of the context is in flight when it is launched
+    // (latency 1.81 -> 1.77 ms at 2^20; in a pipeline only the very first launch is alone: throughput unchanged)
+    bool alone = nvec == 1 && w_count == 8;
+    for (const Slot& o : ctx->slot) alone = alone && (&o == &s || !o.pending);
+    const bool small_single = nvec == 1 && w_count == 8 && (n_entries <= ((size_t)1 << 19) || alone);
     if (force_logr == 4 || (force_logr == 0 && w_count >= 8 && !small_single)) ROWCOL(4, 8);
     else if (force_logr == 3 || (force_logr == 0 && small_single)) ROWCOL(3, 8);
     else ROWCOL(2, 8);

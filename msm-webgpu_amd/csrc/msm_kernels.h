@@ -209,27 +209,6 @@ __global__ void __launch_bounds__(256) k_endo_points(uint32_t* __restrict__ base
   for (int k = 0; k < CW / 4; k++) o[k] = y[k];
 }
 
-// ... and its scalar half: vector v's n scalars -> 2n halves of 16 B, |k1| of scalar i at [v][i], |k2| at [v][n + i] (signs in
-// bit 127); the halves are then recoded like scalars of 4 words (k_count / k_scatter_coarse with SW = 4) against the 2n points
-__global__ void __launch_bounds__(256) k_glv_split(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ halves, size_t n, int nvec,
-                                                   uint32_t* __restrict__ err) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n * (size_t)nvec) return;
-  const size_t v = idx / n, i = idx - v * n;
-  uint32_t k[8], h1[4], h2[4];
-  ld8(scalars + idx * 8, k);
-  // the input contract of the plain path: scalars that overflow the reference's 16-bit recode are rejected (test/utils.rs:150-152)
-  uint64_t c = 0;
-#pragma unroll
-  for (int w = 0; w < 8; w++) c = (c + k[w] + 0x80008000u) >> 32;
-  const bool ok = glv_split(k, h1, h2);
-  if (c != 0 || !ok) atomicOr(err, ERRBIT_SCALAR_CARRY);
-  uint32_t* o = halves + v * n * 8;
-  *reinterpret_cast<uint4*>(o + i * 4) = make_uint4(h1[0], h1[1], h1[2], h1[3]);
-  *reinterpret_cast<uint4*>(o + (n + i) * 4) = make_uint4(h2[0], h2[1], h2[2], h2[3]);
-}
-
-
 // Fixed-base tables (reference README.md "Future work": the Elastic-MSM precomputation trade-off): with
 // T_w[i] = 2^(16 w) P_i stored for every window, sum_i s_i P_i = sum_i sum_w d_{i,w} T_w[i] needs ONE bucket set for all
 // windows -- one stitch / bucket reduce instead of 16 and no window combine -- for 16 x the base memory.
@@ -393,17 +372,25 @@ __global__ void __launch_bounds__(256) k_scalars_from_mont256(const uint32_t* __
 // lw = v * w_count + (w - w_begin), nvec * w_count <= MAXLW -- several MSMs over the same bases sorted, accumulated and reduced
 // by one kernel sequence (used by the window-sharded multi-GPU pipeline, where one MSM's share is too small to fill a GPU).
 //
-// Digit planes.  `planes` (may be null) receives every local window's digit code, u16 planes[lw][n]:
-//   negbits == null  (debug read-back, msm_hip_read_digits): the half's sign folded into bit 15;
-//   negbits != null  (the launch's second pass reads the planes instead of the scalars, k_scatter_planes): the raw code, and the
-//                    signs of a vector's inputs as one bit each, negbits[v][n / 64 rounded up] (all zero for 8-word scalars).
+// Digit planes.  `planes` receives every local window's digit code, u16 planes[lw][n] (PLANE_MODE below): for the debug read-back
+// (msm_hip_read_digits), or as the input of the launch's second pass (k_scatter_planes reads them instead of the scalars).
 // A rank of a window-sharded run needs 1 - 4 of a scalar's 16 digits: its second pass then reads 2 - 8 B per scalar instead of 32,
 // and keeps no scalar in registers (the scalar-reading scatter holds 8 biased scalars per thread: 282 VGPRs at 16 bits).
-template <int C, int SW>
+// PLANE_MODE of k_count's `planes` output: 0 none; 1 debug read-back (the half's sign folded into bit 15); 2 raw codes for k_scatter_planes
+// (with the signs of the halves, if any, in `negbits`).
+// SPLIT (endomorphism launches, SW = 4): `scalars` are the nvec x n / 2 full 8-word scalars; the kernel splits each into its two halves
+// (csrc/glv.h) itself -- the separate pass of round 2 (k_glv_split: 32 B read + 32 B written per scalar and a kernel of its own in front of
+// every launch) is gone -- and treats them as inputs 2 j (k1, multiplies P_j) and 2 j + 1 (k2, multiplies phi(P_j)) of the 2n-input problem:
+// INTERLEAVED positions, so that a tile of positions is a tile of scalars and one LDS histogram serves both halves.  The halves go to
+// `halves_out` (position p at word 4 p: the same 32 B the scalar took) for k_scatter_coarse<C, 4>; negbits[v][h][n / 128 rounded up]: bit j of
+// half h's array is the sign of half h of scalar j.
+template <int C, int SW, bool SPLIT = false>
 __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles,
                                                int w_begin, int w_count, int nvec, size_t vec_stride,
-                                               uint32_t* __restrict__ counts, uint16_t* __restrict__ planes, uint64_t* __restrict__ negbits,
+                                               uint32_t* __restrict__ counts, uint16_t* __restrict__ planes, int plane_mode,
+                                               uint64_t* __restrict__ negbits, uint32_t* __restrict__ halves_out,
                                                uint32_t* __restrict__ err, size_t merge_nb) {
+  static_assert(!SPLIT || SW == 4, "the split produces 4-word halves");
   // merge_nb != 0 (fixed-base tables, see k_precompute_tables): every window of vector v feeds ONE bucket set, local window v
   __shared__ uint32_t cnt[MAXLW * NCOARSE];
   const int tid = threadIdx.x;
@@ -412,36 +399,69 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * tile_len;
   const size_t end = base + tile_len < n ? base + tile_len : n;
-  const size_t neg_words = (n + 63) / 64;
   uint32_t bad = 0;
+  // one recoded input: histogram and plane entries of its local windows
+  auto emit = [&](int v, size_t pos, const uint32_t* tb, uint32_t neg) {
+#pragma unroll
+    for (int w = 0; w < WinCfg<C, SW>::NWIN; w++) {
+      const int lw = w - w_begin;
+      if (lw >= 0 && lw < w_count) {
+        const int le = merge_nb ? v : v * w_count + lw;
+        const uint32_t code = code_of_window<C>(tb, w);
+        if (code != 0) atomicAdd(&cnt[le * NCOARSE + ((code & 0x7fffu) >> 8)], 1u);
+        if (plane_mode) planes[((size_t)v * w_count + lw) * n + pos] = (uint16_t)(plane_mode == 2 ? code : (code ? code ^ (neg << 15) : 0u));
+      }
+    }
+  };
   for (int v = 0; v < nvec; v++) {
     const uint32_t* sv = scalars + (size_t)v * vec_stride;
-    for (size_t i0 = base; i0 < end; i0 += 256) {  // (tile_len is a multiple of 256: a wave's 64 inputs share one word of negbits)
-      const size_t i = i0 + tid;
-      const bool valid = i < end;
-      uint32_t s[SW], tb[WinCfg<C, SW>::WORDS], neg = 0;
+    if constexpr (SPLIT) {
+      const size_t nsc = n / 2, neg_words = (nsc + 63) / 64;
+      for (size_t j0 = base / 2; j0 < end / 2; j0 += 256) {  // (tile_len is a multiple of 256 positions: a wave's 64 scalars share a word of negbits)
+        const size_t j = j0 + tid;
+        const bool valid = j < end / 2;
+        uint32_t k[8], h[2][4];
 #pragma unroll
-      for (int k = 0; k < SW; k++) s[k] = 0;  // an all-zero scalar recodes to all-zero digits
-      if (valid) ld_scalar<SW>(sv + i * SW, s, neg);
-      bad |= bias_scalar<C, SW>(s, tb);
-      if constexpr (C != 16 && SW == 8) {  // the same input contract for every window size: scalars that overflow the reference's
-        uint32_t t16[8];                   // 16-bit recode ("final carry is 1", test/utils.rs:150-152) are rejected
-        bad |= bias_scalar<16>(s, t16);    // (halves: k_glv_split checks the scalar they come from)
-      }
-      if (negbits) {
-        const unsigned long long nb = __ballot(neg != 0u);
-        if ((tid & 63) == 0 && i < end) negbits[(size_t)v * neg_words + i / 64] = nb;
-      }
-      if (!valid) continue;
+        for (int q = 0; q < 8; q++) k[q] = 0;
+        if (valid) ld8(sv + j * 8, k);
+        // the input contract of the plain path: scalars that overflow the reference's 16-bit recode are rejected (test/utils.rs:150-152)
+        uint64_t c = 0;
 #pragma unroll
-      for (int w = 0; w < WinCfg<C, SW>::NWIN; w++) {
-        const int lw = w - w_begin;
-        if (lw >= 0 && lw < w_count) {
-          const int le = merge_nb ? v : v * w_count + lw;
-          const uint32_t code = code_of_window<C>(tb, w);
-          if (code != 0) atomicAdd(&cnt[le * NCOARSE + ((code & 0x7fffu) >> 8)], 1u);
-          if (planes) planes[((size_t)v * w_count + lw) * n + i] = (uint16_t)(negbits ? code : (code ? code ^ (neg << 15) : 0u));
+        for (int q = 0; q < 8; q++) c = (c + k[q] + 0x80008000u) >> 32;
+        const bool ok = glv_split(k, h[0], h[1]);
+        if (c != 0 || !ok) bad = 1;
+        if (negbits) {
+#pragma unroll
+          for (int hh = 0; hh < 2; hh++) {
+            const unsigned long long nb = __ballot((h[hh][3] >> 31) != 0u);
+            if ((tid & 63) == 0 && valid) negbits[((size_t)v * 2 + hh) * neg_words + j / 64] = nb;
+          }
         }
+        if (!valid) continue;
+        if (halves_out) {
+          uint4* o = reinterpret_cast<uint4*>(halves_out + ((size_t)v * nsc + j) * 8);
+          o[0] = make_uint4(h[0][0], h[0][1], h[0][2], h[0][3]);
+          o[1] = make_uint4(h[1][0], h[1][1], h[1][2], h[1][3]);
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+          uint32_t s[4] = {h[hh][0], h[hh][1], h[hh][2], h[hh][3] & 0x7fffffffu}, tb[WinCfg<C, 4>::WORDS];
+          bad |= bias_scalar<C, 4>(s, tb);
+          emit(v, 2 * j + hh, tb, h[hh][3] >> 31);
+        }
+      }
+    } else {
+      for (size_t i0 = base; i0 < end; i0 += 256) {
+        const size_t i = i0 + tid;
+        if (i >= end) continue;
+        uint32_t s[SW], tb[WinCfg<C, SW>::WORDS], neg = 0;
+        ld_scalar<SW>(sv + i * SW, s, neg);
+        bad |= bias_scalar<C, SW>(s, tb);
+        if constexpr (C != 16 && SW == 8) {  // the same input contract for every window size: scalars that overflow the reference's
+          uint32_t t16[8];                   // 16-bit recode ("final carry is 1", test/utils.rs:150-152) are rejected
+          bad |= bias_scalar<16>(s, t16);
+        }
+        emit(v, i, tb, neg);
       }
     }
   }
@@ -521,8 +541,8 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
                                                         uint32_t* __restrict__ tmp_val,
                                                         uint8_t* __restrict__ tmp_fine, size_t merge_nb, uint32_t half_n, uint32_t half_shift,
                                                         uint32_t chunks, uint32_t host_chunk_len, uint32_t* __restrict__ chunk_len_dev) {
-  // SW = 4 (endomorphism halves): input j < half_n is k1 of scalar j and multiplies base j; input half_n + j is k2 and multiplies
-  // phi(P_j), stored half_shift = n_bases - half_n records further on than its position
+  // SW = 4 (endomorphism halves, interleaved by k_count<C, 4, true>): input 2 j is k1 of scalar j and multiplies base j; input 2 j + 1 is
+  // k2 and multiplies phi(P_j), record half_shift = n_bases + j
   __shared__ uint32_t gpos[MAXLW * NCOARSE];  // global write cursor of every (window, coarse bin) run of this tile
   __shared__ uint32_t hist[NCOARSE];
   __shared__ uint32_t lstart[NCOARSE];
@@ -606,7 +626,7 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
           const uint32_t slot = code & 0x7fffu, bin = slot >> 8;
           const uint32_t e = lstart[bin] + rank[j];
           uint32_t pos = (uint32_t)(sub + (size_t)j * 256 + tid);
-          if constexpr (SW == 4) pos += pos >= half_n ? half_shift : 0u;
+          if constexpr (SW == 4) pos = (pos >> 1) + ((pos & 1u) ? half_shift : 0u);
           st_val[e] = (idx_base + pos) | (((code >> 15) ^ ((negs >> j) & 1u)) << 31);
           st_fine[e] = (uint8_t)(slot & 0xffu);
           st_dst[e] = gpos[lw * NCOARSE + bin] + rank[j];
@@ -628,13 +648,14 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
 
 // The second pass of a launch whose first pass left digit planes (k_count with negbits != null): the same LDS-ranked, LDS-staged
 // scatter as k_scatter_coarse, reading 2 B per (input, local window) from the planes.  No scalar arithmetic and no scalars in
-// registers.  `w_eff` local windows of `w_count_vec` windows per scalar vector; input `pos` of a vector is scalar / half `pos`,
-// its sign bit `pos` of the vector's negbits; inputs from half_n on multiply the record half_shift further on (endomorphism).
+// registers.  `w_eff` local windows of `w_count_vec` windows per scalar vector.  negbits == null: input `pos` is scalar `pos` and multiplies
+// base `pos`.  Endomorphism halves (k_count<C, 4, true>): input 2 j + h is half h of scalar j, its sign bit j of negbits[v][h], and it
+// multiplies record j + h * half_shift (half_shift = n_bases).
 __global__ void __launch_bounds__(256) k_scatter_planes(const uint16_t* __restrict__ planes, const uint64_t* __restrict__ negbits, size_t n,
                                                         size_t stride, uint32_t tile_len, uint32_t tiles, int w_eff, int w_count_vec,
                                                         const uint32_t* __restrict__ counts, const uint32_t* __restrict__ bin_total,
                                                         uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ tmp_val,
-                                                        uint8_t* __restrict__ tmp_fine, uint32_t half_n, uint32_t half_shift,
+                                                        uint8_t* __restrict__ tmp_fine, uint32_t half_shift,
                                                         uint32_t chunks, uint32_t host_chunk_len, uint32_t* __restrict__ chunk_len_dev) {
   __shared__ uint32_t gpos[MAXLW * NCOARSE];
   __shared__ uint32_t hist[NCOARSE];
@@ -673,10 +694,10 @@ __global__ void __launch_bounds__(256) k_scatter_planes(const uint16_t* __restri
   if (blockIdx.x == 0 && tid == 0) *chunk_len_dev = smvp_chunk_len(max_total, chunks, host_chunk_len);
   const size_t tile_base = (size_t)blockIdx.x * tile_len;
   const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
-  const size_t neg_words = (n + 63) / 64;
+  const size_t neg_words = (n / 2 + 63) / 64;
   for (int lw = 0; lw < w_eff; lw++) {
     const uint16_t* pl = planes + (size_t)lw * n;
-    const uint64_t* nb = negbits + (size_t)(lw / w_count_vec) * neg_words;
+    const uint64_t* nb = negbits ? negbits + (size_t)(lw / w_count_vec) * 2 * neg_words : nullptr;
     uint32_t* ov = tmp_val + (size_t)lw * stride;
     uint8_t* of = tmp_fine + (size_t)lw * stride;
     for (size_t sub = tile_base; sub < tile_end; sub += SCAT_SUB) {
@@ -686,7 +707,7 @@ __global__ void __launch_bounds__(256) k_scatter_planes(const uint16_t* __restri
       for (int j = 0; j < 8; j++) {
         const size_t i = sub + (size_t)j * 256 + tid;
         code[j] = i < tile_end ? pl[i] : 0u;
-        if (i < tile_end) negs |= (uint32_t)((nb[i / 64] >> (i & 63)) & 1ull) << j;  // (i - lane is a multiple of 64: one word per wave)
+        if (nb && i < tile_end) negs |= (uint32_t)((nb[(i & 1) * neg_words + (i >> 1) / 64] >> ((i >> 1) & 63)) & 1ull) << j;
       }
       if (tid < NCOARSE) hist[tid] = 0;
       __syncthreads();
@@ -705,7 +726,7 @@ __global__ void __launch_bounds__(256) k_scatter_planes(const uint16_t* __restri
           const uint32_t slot = code[j] & 0x7fffu, bin = slot >> 8;
           const uint32_t e = lstart[bin] + rank[j];
           uint32_t pos = (uint32_t)(sub + (size_t)j * 256 + tid);
-          pos += pos >= half_n ? half_shift : 0u;
+          if (nb) pos = (pos >> 1) + ((pos & 1u) ? half_shift : 0u);
           st_val[e] = pos | (((code[j] >> 15) ^ ((negs >> j) & 1u)) << 31);
           st_fine[e] = (uint8_t)(slot & 0xffu);
           st_dst[e] = gpos[lw * NCOARSE + bin] + rank[j];

@@ -33,6 +33,12 @@ def equivalent_problem(model, points, scalars):
     return model.points_to_bytes(out_p), b"".join(b32(v) for v in out_s), negs
 
 
+def _halves_first_then_second(planes):
+    """The device numbers its 2n inputs interleaved (input 2 j = first half of scalar j, 2 j + 1 = its second half: the first sort pass
+    splits a scalar and handles both halves); the equivalent problem lists all first halves, then all second halves."""
+    return np.concatenate([planes[:, 0::2], planes[:, 1::2]], axis=1)
+
+
 @pytest.fixture(scope="module", params=[16, 14, 12], ids=lambda b: "c%d" % b)
 def run(ctx, request):
     bits = request.param
@@ -57,7 +63,7 @@ def run(ctx, request):
         ctx.set_window_bits(0)
     eq_points, eq_scalars, negs = equivalent_problem(ref, points, scalars)
     return {"bits": bits, "W": W, "H": H, "points": points, "scalars": scalars, "result": result, "negs": np.array(negs, dtype=np.int64),
-            "eq_points": eq_points, "eq_scalars": eq_scalars, "digits": ctx.read_digits(2 * N, W), "col_ptr": ctx.read_col_ptr(W, H),
+            "eq_points": eq_points, "eq_scalars": eq_scalars, "digits": _halves_first_then_second(ctx.read_digits(2 * N, W)), "col_ptr": ctx.read_col_ptr(W, H),
             "val": ctx.read_val_idxs(2 * N, W), "buckets": ctx.read_buckets(W, H), "wsums": ctx.read_window_sums(W),
             "model_digits": cpu.decompose_scalars_signed(eq_scalars, W, bits)}
 
