@@ -1,0 +1,47 @@
+"""bench.py's output contract, on the GPU: ONE JSON line with the driver's keys, the roofline object of the SMVP kernel, the CPU baseline
+timed in the same run, and this round's additions (value_cold_protocol, pre_timed_msms, roofline.kernel_ms_rocprof).  A small size keeps it short;
+the numbers themselves are not judged here."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_keys(built):
+    d = _bench(["--steps", "6", "--warmup", "2", "--logn", "14", "--cpu-sample-logn", "12"], BENCH_STEADY_MSMS="8")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline", "value_cold_protocol", "pre_timed_msms"):
+        assert key in d, key
+    assert d["unit"] == "MSM/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"] and d["value_cold_protocol"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel"] == "k_smvp_chunks"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1 and "traffic" in rf and "kernel_ms_rocprof" in rf
+    # grouped small MSMs run 14-bit windows: the algorithmic bytes follow the engine's window size, not the 16-bit constants
+    assert d["config"]["window_bits"] == 14 and d["config"]["msms_per_launch"] > 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "MSM/s" and cb["value"] > 0 and "sample" in cb
+    assert d["pre_timed_msms"] >= 8 + 2
+
+
+def test_emulated_share_line_and_native_multi_gpu_mode(built):
+    d = _bench(["--steps", "8", "--warmup", "2", "--logn", "14", "--no-cpu-baseline"], BENCH_EMULATE_WORLD="8", BENCH_STEADY_MSMS="8")
+    assert d["emulated_world"] == 8 and d["config"]["msms_per_launch"] == 8 and d["config"]["windows_per_gpu"] == 2 and "cpu_baseline" not in d
+    n = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--logn", "14"], BENCH_MGPU_NATIVE="1", BENCH_MGPU_IDS="0,0", BENCH_STEADY_MSMS="4")
+    assert n["native_mgpu"] is True and n["n_gpus"] == 2 and n["sharded_result_equals_single_gpu"] is True
