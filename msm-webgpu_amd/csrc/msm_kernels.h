@@ -25,6 +25,8 @@
 #endif
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 namespace MSM_KERNEL_NS {
 using namespace MSM_FIELD_NS;
 
@@ -981,52 +983,62 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
 // The reference gives one thread one bucket, so a wave runs as long as its fullest bucket.  Here every lane owns a
 // fixed-length chunk of `chunk_len` consecutive entries of the slot-sorted list -- equal work per lane whatever the bucket
 // sizes -- and flushes its accumulator whenever the slot changes.  The host picks a chunk length (a multiple of 4 in
-// [SMVP_CHUNK_MIN, SMVP_CHUNK_MAX]) so that about SMVP_TARGET_LANES lanes exist for n entries per window (about two rounds of 3 waves
+// [SMVP_CHUNK_MIN, SMVP_CHUNK_MAX]) so that about SMVP_TARGET_LANES lanes exist for n entries per window (about three rounds of 3 waves
 // per SIMD at 168 VGPRs, no scratch) and sizes the chunk arrays and grids with it; the length actually used is settled on the device
 // from the entries the sort produced (smvp_chunk_len above: never longer than the host's).  Runs that cross a chunk boundary leave a "tail" piece
 // (in the chunk where the run starts) and "head" pieces (in the chunks it continues into); k_smvp_stitch adds them.
 // Buckets and pieces are stored as raw XYZZ records (no multiplication on the flush path).
 constexpr int SMVP_CHUNK_MIN = SMVP_CHUNK_MIN_ENTRIES;
 constexpr int SMVP_CHUNK_MAX = 1024;
-constexpr int SMVP_TARGET_LANES = 3 << 17;  // 1.5 x (256 CUs x 4 SIMDs x 4 waves x 64 lanes): measured optimum of SMVP + stitch
+constexpr int SMVP_TARGET_LANES = 9 << 16;  // three rounds of 3 waves per SIMD (1024 SIMDs x 64 lanes).  Round 3 sweep (profiles/r03_lanes_sweep.txt): against two
+                                             // rounds the kernel itself is 3 % faster (shorter chunks even out the SIMDs' finishing times), the stitch has 1.5 x the pieces to
+                                             // add, and the step is equal or up to 2 % shorter (2^18, plain bases, window shares); four rounds and more lose to the stitch
 constexpr int REC_WORDS = (XYZZ_WORDS + 3) / 4 * 4;  // 160 B record with 9 limbs: 36 limbs, valid flag, 3 pad words; 16-byte aligned (240 B with 14)
 constexpr int REC_FLAG = 4 * FQ_L;                   // word index of the valid flag
 
+// word I of a record: limbs of x, y, zz, zzz, then the valid flag, then padding (static indices only: an intermediate word array would
+// not be promoted to registers and cost the stitch / row-column kernels a 148-byte scratch object each)
+template <int I>
+__device__ __forceinline__ uint32_t rec_get(const g1_xyzz& a) {
+  if constexpr (I < FQ_L) return a.x.v[I];
+  else if constexpr (I < 2 * FQ_L) return a.y.v[I - FQ_L];
+  else if constexpr (I < 3 * FQ_L) return a.zz.v[I - 2 * FQ_L];
+  else if constexpr (I < 4 * FQ_L) return a.zzz.v[I - 3 * FQ_L];
+  else if constexpr (I == REC_FLAG) return a.inf ? 0u : 1u;
+  else return 0u;
+}
+template <int I>
+__device__ __forceinline__ void rec_set(g1_xyzz& a, uint32_t v) {
+  if constexpr (I < FQ_L) a.x.v[I] = v;
+  else if constexpr (I < 2 * FQ_L) a.y.v[I - FQ_L] = v;
+  else if constexpr (I < 3 * FQ_L) a.zz.v[I - 2 * FQ_L] = v;
+  else if constexpr (I < 4 * FQ_L) a.zzz.v[I - 3 * FQ_L] = v;
+}
+template <int... K>
+__device__ __forceinline__ void st_rec_quads(uint4* q, const g1_xyzz& a, std::integer_sequence<int, K...>) {
+  ((q[K] = make_uint4(rec_get<4 * K>(a), rec_get<4 * K + 1>(a), rec_get<4 * K + 2>(a), rec_get<4 * K + 3>(a))), ...);
+}
+template <int... K>
+__device__ __forceinline__ void ld_rec_quads(const uint4* q, g1_xyzz& a, std::integer_sequence<int, K...>) {
+  ((void)([&] {
+     const uint4 v = q[K];
+     rec_set<4 * K>(a, v.x);
+     rec_set<4 * K + 1>(a, v.y);
+     rec_set<4 * K + 2>(a, v.z);
+     rec_set<4 * K + 3>(a, v.w);
+   }()),
+   ...);
+}
 __device__ __forceinline__ void st_rec(uint32_t* p, const g1_xyzz& a) {
-  uint32_t f[REC_WORDS];
-#pragma unroll
-  for (int i = 0; i < FQ_L; i++) {
-    f[i] = a.x.v[i];
-    f[FQ_L + i] = a.y.v[i];
-    f[2 * FQ_L + i] = a.zz.v[i];
-    f[3 * FQ_L + i] = a.zzz.v[i];
-  }
-  f[REC_FLAG] = a.inf ? 0u : 1u;
-#pragma unroll
-  for (int i = REC_FLAG + 1; i < REC_WORDS; i++) f[i] = 0u;
-  uint4* q = reinterpret_cast<uint4*>(p);
-#pragma unroll
-  for (int k = 0; k < REC_WORDS / 4; k++) q[k] = make_uint4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
+  st_rec_quads(reinterpret_cast<uint4*>(p), a, std::make_integer_sequence<int, REC_WORDS / 4>{});
 }
 __device__ __forceinline__ g1_xyzz ld_rec(const uint32_t* p) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
   const uint4 fl = q[REC_FLAG / 4];
   const uint32_t flag = REC_FLAG % 4 == 0 ? fl.x : (REC_FLAG % 4 == 1 ? fl.y : (REC_FLAG % 4 == 2 ? fl.z : fl.w));
   if (flag == 0) return g1_identity();
-  uint32_t f[REC_WORDS];
-#pragma unroll
-  for (int k = 0; k < REC_WORDS / 4; k++) {
-    const uint4 a = k == REC_FLAG / 4 ? fl : q[k];
-    f[4 * k] = a.x; f[4 * k + 1] = a.y; f[4 * k + 2] = a.z; f[4 * k + 3] = a.w;
-  }
   g1_xyzz a;
-#pragma unroll
-  for (int i = 0; i < FQ_L; i++) {
-    a.x.v[i] = f[i];
-    a.y.v[i] = f[FQ_L + i];
-    a.zz.v[i] = f[2 * FQ_L + i];
-    a.zzz.v[i] = f[3 * FQ_L + i];
-  }
+  ld_rec_quads(q, a, std::make_integer_sequence<int, REC_WORDS / 4>{});
   a.inf = false;
   return a;
 }
