@@ -94,7 +94,13 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx);
                                      points n x 96 B (x || y), results and window sums 144 B Jacobian records (x || y || z), scalars 32 B as everywhere;
                                      every `[96]` / `[64]` / "x 96 B" of this header reads 144 / 96 for such a context.  Device arithmetic: 14 limbs of
                                      28 bits (csrc/curve_bls12_381.hip).  All modes (window sizes, fixed-base tables, endomorphism, shards, batches). */
-#define MSM_HIP_NUM_CURVES 5
+#define MSM_HIP_CURVE_BN254_G2 5 /* G2 of BN254: the twist y^2 = x^3 + 3 / (9 + u) over Fq2 = Fq[u] / (u^2 + 1), scalars modulo the same r as curve 0.
+                                    A coordinate is an Fq2 element c0 || c1, each 32 B canonical little-endian: 64 bytes; points n x 128 B (x || y), results
+                                    and window sums 192 B Jacobian records, scalars 32 B; every `[96]` / `[64]` / "x 96 B" of this header reads 192 / 128.
+                                    Device arithmetic: csrc/fq2.h on the 9 x 29-bit prime field (csrc/curve_bn254_g2.hip).  Window sizes, window shards,
+                                    batches, grouped launches, the multi-GPU calls: as for curve 0.  NOT available (MSM_HIP_ERR_INVALID_ARG):
+                                    MSM_HIP_BASES_ENDOMORPHISM, MSM_HIP_BASES_PRECOMPUTE, MSM_HIP_SCALARS_MONT256, the device point sampler. */
+#define MSM_HIP_NUM_CURVES 6
 int msm_hip_ctx_create_curve(msm_hip_ctx** out, int device_id, int curve);
 int msm_hip_ctx_curve(const msm_hip_ctx* ctx);
 /* the context-free host helpers for a given curve (msm_hip_combine_windows_bn254 / msm_hip_g1_to_affine_bn254 are curve 0) */

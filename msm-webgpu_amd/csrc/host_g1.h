@@ -18,23 +18,32 @@ namespace host {
 
 typedef unsigned __int128 u128;
 
-// HL 64-bit limbs per element (4 for the 254 / 255-bit fields, 6 for BLS12-381), CB bytes per coordinate on the wire (32 / 48);
-// a Jacobian record is 3 CB bytes, an affine one 2 CB
-constexpr int HL = FQ_WORDS / 2;
+// HL 64-bit limbs per prime-field element (4 for the 254 / 255-bit fields, 6 for BLS12-381), CB bytes per coordinate on the wire (32 / 48;
+// 64 in the G2 unit, whose coordinates are Fq2 elements c0 || c1); a Jacobian record is 3 CB bytes, an affine one 2 CB
+constexpr int HL = FQ_WORDS / 2 / FQ_EXT;
 constexpr int CB = 4 * FQ_WORDS;
 constexpr int JB = 3 * CB;
+constexpr int PCB = CB / FQ_EXT;  // bytes of a prime-field element
 
-struct hfq {
+// the prime field (in a G2 unit: `hfp`, with the coordinate field `hfq` = Fq2 defined on it below)
+#if defined(MSM_FQ2)
+#define HFQ_BASE(name) hfp##name
+#else
+#define HFQ_BASE(name) hfq##name
+#endif
+#define hfq_t HFQ_BASE()
+
+struct hfq_t {
   uint64_t l[HL];
 };
 
-inline bool hfq_geq_p(const hfq& a) {
+inline bool HFQ_BASE(_geq_p)(const hfq_t& a) {
   for (int i = HL - 1; i >= 0; i--) {
     if (a.l[i] != FQ_P64[i]) return a.l[i] > FQ_P64[i];
   }
   return true;
 }
-inline void hfq_sub_p(hfq& a) {
+inline void HFQ_BASE(_sub_p)(hfq_t& a) {
   uint64_t borrow = 0;
   for (int i = 0; i < HL; i++) {
     u128 d = (u128)a.l[i] - FQ_P64[i] - borrow;
@@ -42,19 +51,19 @@ inline void hfq_sub_p(hfq& a) {
     borrow = (uint64_t)(d >> 64) & 1u;
   }
 }
-inline hfq hfq_add(const hfq& a, const hfq& b) {
-  hfq r;
+inline hfq_t HFQ_BASE(_add)(const hfq_t& a, const hfq_t& b) {
+  hfq_t r;
   u128 c = 0;
   for (int i = 0; i < HL; i++) {
     c += (u128)a.l[i] + b.l[i];
     r.l[i] = (uint64_t)c;
     c >>= 64;
   }
-  if (hfq_geq_p(r)) hfq_sub_p(r);
+  if (HFQ_BASE(_geq_p)(r)) HFQ_BASE(_sub_p)(r);
   return r;
 }
-inline hfq hfq_sub(const hfq& a, const hfq& b) {
-  hfq r;
+inline hfq_t HFQ_BASE(_sub)(const hfq_t& a, const hfq_t& b) {
+  hfq_t r;
   uint64_t borrow = 0;
   for (int i = 0; i < HL; i++) {
     u128 d = (u128)a.l[i] - b.l[i] - borrow;
@@ -72,7 +81,7 @@ inline hfq hfq_sub(const hfq& a, const hfq& b) {
   return r;
 }
 // Montgomery product (R = 2^(64 HL)), separated operand scanning: the full double-width product first, then HL reduction rounds
-inline hfq hfq_mul(const hfq& a, const hfq& b) {
+inline hfq_t HFQ_BASE(_mul)(const hfq_t& a, const hfq_t& b) {
   uint64_t t[2 * HL + 1];
   for (int i = 0; i < 2 * HL + 1; i++) t[i] = 0;
   for (int i = 0; i < HL; i++) {
@@ -98,50 +107,87 @@ inline hfq hfq_mul(const hfq& a, const hfq& b) {
       carry >>= 64;
     }
   }
-  hfq r;
+  hfq_t r;
   for (int i = 0; i < HL; i++) r.l[i] = t[HL + i];
-  if (t[2 * HL] || hfq_geq_p(r)) hfq_sub_p(r);
+  if (t[2 * HL] || HFQ_BASE(_geq_p)(r)) HFQ_BASE(_sub_p)(r);
   return r;
 }
-inline hfq hfq_sqr(const hfq& a) { return hfq_mul(a, a); }
-inline bool hfq_is_zero(const hfq& a) {
+inline hfq_t HFQ_BASE(_sqr)(const hfq_t& a) { return HFQ_BASE(_mul)(a, a); }
+inline bool HFQ_BASE(_is_zero)(const hfq_t& a) {
   uint64_t z = 0;
   for (int i = 0; i < HL; i++) z |= a.l[i];
   return z == 0;
 }
-inline bool hfq_eq(const hfq& a, const hfq& b) { return memcmp(a.l, b.l, CB) == 0; }
-inline hfq hfq_const(const uint64_t* c) {
-  hfq r;
+inline bool HFQ_BASE(_eq)(const hfq_t& a, const hfq_t& b) { return memcmp(a.l, b.l, PCB) == 0; }
+inline hfq_t HFQ_BASE(_const)(const uint64_t* c) {
+  hfq_t r;
   for (int i = 0; i < HL; i++) r.l[i] = c[i];
   return r;
 }
 
 // canonical little-endian bytes <-> Montgomery; returns false when the encoding is >= p
-inline bool hfq_from_bytes(hfq& r, const uint8_t* b) {
-  hfq t;
-  memcpy(t.l, b, CB);
-  const bool ok = !hfq_geq_p(t);
-  r = hfq_mul(t, hfq_const(FQ_R2_64));
+inline bool HFQ_BASE(_from_bytes)(hfq_t& r, const uint8_t* b) {
+  hfq_t t;
+  memcpy(t.l, b, PCB);
+  const bool ok = !HFQ_BASE(_geq_p)(t);
+  r = HFQ_BASE(_mul)(t, HFQ_BASE(_const)(FQ_R2_64));
   return ok;
 }
-inline void hfq_to_bytes(uint8_t* b, const hfq& a) {
-  hfq one;
+inline void HFQ_BASE(_to_bytes)(uint8_t* b, const hfq_t& a) {
+  hfq_t one;
   for (int i = 0; i < HL; i++) one.l[i] = i == 0 ? 1 : 0;
-  hfq t = hfq_mul(a, one);
-  memcpy(b, t.l, CB);
+  hfq_t t = HFQ_BASE(_mul)(a, one);
+  memcpy(b, t.l, PCB);
 }
 
-inline hfq hfq_inv(const hfq& a) {  // a^(p-2), square-and-multiply from the top bit
+inline hfq_t HFQ_BASE(_inv)(const hfq_t& a) {  // a^(p-2), square-and-multiply from the top bit
   uint64_t e[HL];
   for (int i = 0; i < HL; i++) e[i] = FQ_P64[i];
   e[0] -= 2;  // (p is odd and > 2: no borrow)
-  hfq acc = hfq_const(FQ_ONE64);
+  hfq_t acc = HFQ_BASE(_const)(FQ_ONE64);
   for (int i = 64 * HL - 1; i >= 0; i--) {
-    acc = hfq_sqr(acc);
-    if ((e[i >> 6] >> (i & 63)) & 1) acc = hfq_mul(acc, a);
+    acc = HFQ_BASE(_sqr)(acc);
+    if ((e[i >> 6] >> (i & 63)) & 1) acc = HFQ_BASE(_mul)(acc, a);
   }
   return acc;
 }
+
+#undef hfq_t
+#if defined(MSM_FQ2)
+// The coordinate field of a G2 unit: Fq2 = Fq[u] / (u^2 + 1) on the prime field above, under the names the group code below uses.
+// Wire form of an element: c0 || c1, each PCB bytes canonical little-endian.
+struct hfq {
+  hfp c0, c1;
+};
+inline hfq hfq_add(const hfq& a, const hfq& b) { return {hfp_add(a.c0, b.c0), hfp_add(a.c1, b.c1)}; }
+inline hfq hfq_sub(const hfq& a, const hfq& b) { return {hfp_sub(a.c0, b.c0), hfp_sub(a.c1, b.c1)}; }
+inline hfq hfq_mul(const hfq& a, const hfq& b) {  // Karatsuba: 3 prime-field products
+  const hfp v0 = hfp_mul(a.c0, b.c0), v1 = hfp_mul(a.c1, b.c1);
+  const hfp s = hfp_mul(hfp_add(a.c0, a.c1), hfp_add(b.c0, b.c1));
+  return {hfp_sub(v0, v1), hfp_sub(hfp_sub(s, v0), v1)};
+}
+inline hfq hfq_sqr(const hfq& a) {
+  const hfp t = hfp_mul(a.c0, a.c1);
+  return {hfp_mul(hfp_add(a.c0, a.c1), hfp_sub(a.c0, a.c1)), hfp_add(t, t)};
+}
+inline bool hfq_is_zero(const hfq& a) { return hfp_is_zero(a.c0) && hfp_is_zero(a.c1); }
+inline bool hfq_eq(const hfq& a, const hfq& b) { return hfp_eq(a.c0, b.c0) && hfp_eq(a.c1, b.c1); }
+inline bool hfq_from_bytes(hfq& r, const uint8_t* b) {
+  const bool ok0 = hfp_from_bytes(r.c0, b), ok1 = hfp_from_bytes(r.c1, b + PCB);
+  return ok0 && ok1;
+}
+inline void hfq_to_bytes(uint8_t* b, const hfq& a) {
+  hfp_to_bytes(b, a.c0);
+  hfp_to_bytes(b + PCB, a.c1);
+}
+inline hfq hfq_inv(const hfq& a) {  // 1 / (c0 + c1 u) = (c0 - c1 u) / (c0^2 + c1^2)
+  const hfp n = hfp_inv(hfp_add(hfp_sqr(a.c0), hfp_sqr(a.c1)));
+  hfp zero;
+  for (int i = 0; i < HL; i++) zero.l[i] = 0;
+  return {hfp_mul(a.c0, n), hfp_mul(hfp_sub(zero, a.c1), n)};
+}
+#endif
+#undef HFQ_BASE
 
 struct hg1 {  // Jacobian, z == 0 <=> identity
   hfq x, y, z;

@@ -45,6 +45,7 @@ inline const CurveOps* curve_ops(int curve) {
     case MSM_HIP_CURVE_PALLAS: return msm_hip_curve_ops_pallas();
     case MSM_HIP_CURVE_VESTA: return msm_hip_curve_ops_vesta();
     case MSM_HIP_CURVE_BLS12_381: return msm_hip_curve_ops_bls12_381();
+    case MSM_HIP_CURVE_BN254_G2: return msm_hip_curve_ops_bn254_g2();
     default: return &BN254_OPS;
   }
 }
@@ -58,7 +59,7 @@ enum LaunchMode {
 
 constexpr int N_MAIN_EVENTS = 7;  // boundaries of the 6 timed stages on the main stream
 constexpr uint32_t MAX_TILES = 1024;
-constexpr size_t MAX_JB = 144;  // the largest Jacobian record of any curve (BLS12-381: 3 x 48 B; the 254 / 255-bit curves: 96 B)
+constexpr size_t MAX_JB = 192;  // the largest Jacobian record of any curve (BN254 G2: 3 x 64 B; BLS12-381: 3 x 48 B; the 254 / 255-bit G1 curves: 96 B)
 constexpr size_t WSUM_BYTES = (size_t)24 * PLANES_PER_WINDOW * MAX_JB;  // MAXLW window sums or, for one host-combined MSM, the bit-plane sums (k_bpr_planes) of its <= 22 windows
 static_assert(WSUM_BYTES >= (size_t)MAXLW * MAX_JB, "window-sum buffer");
 constexpr int NSLOT = MSM_HIP_NUM_SLOTS;  // result slots
@@ -620,7 +621,7 @@ int reserve_bases(msm_hip_ctx* ctx, size_t n, uint32_t flags) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   const bool tables = (flags & MSM_HIP_BASES_PRECOMPUTE) != 0, endo = (flags & MSM_HIP_BASES_ENDOMORPHISM) != 0;
   if (n > MAX_POINTS || (tables && n > MAX_PRECOMPUTE_POINTS) || (endo && n > MAX_POINTS / 2) || (tables && endo)) return MSM_HIP_ERR_INVALID_ARG;
-  if (endo && !ctx->ops->glv) return MSM_HIP_ERR_INVALID_ARG;
+  if ((endo && !ctx->ops->glv) || (tables && !ctx->ops->precompute_tables)) return MSM_HIP_ERR_INVALID_ARG;  // (a G2 context has neither)
   ctx->n_bases = 0;
   ctx->precomputed = false;
   ctx->endo = false;
@@ -1155,6 +1156,7 @@ int msm_hip_sample_scalars_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, voi
 int msm_hip_sample_points_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void* xy_dev) {
   if (!ctx || (!xy_dev && n)) return MSM_HIP_ERR_INVALID_ARG;
   if (n == 0) return MSM_HIP_OK;
+  if (!ctx->ops->sample_points) return MSM_HIP_ERR_INVALID_ARG;  // no device sampler for this curve (G2: needs a square root in Fq2)
   ON_DEVICE(ctx);
   hipLaunchKernelGGL(ctx->ops->sample_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, seed, n, static_cast<uint32_t*>(xy_dev));
   HIP_TRY(ctx, hipGetLastError());
@@ -1189,6 +1191,7 @@ int msm_hip_set_stage_timing(msm_hip_ctx* ctx, int level) {
 
 int msm_hip_set_scalar_format(msm_hip_ctx* ctx, uint32_t format) {
   if (!ctx || (format != MSM_HIP_SCALARS_CANONICAL && format != MSM_HIP_SCALARS_MONT256)) return MSM_HIP_ERR_INVALID_ARG;
+  if (format == MSM_HIP_SCALARS_MONT256 && !ctx->ops->scalars_from_mont256) return MSM_HIP_ERR_INVALID_ARG;
   ctx->scalar_format = format;
   return MSM_HIP_OK;
 }

@@ -69,7 +69,12 @@ constexpr cwords<N> make_cwords(const uint32_t (&src)[N]) {
   for (int i = 0; i < N; i++) r.w[i] = src[i];
   return r;
 }
+// MSM_FQ2 (a G2 unit, csrc/fq2.h: the coordinate field is a quadratic extension): the pieces that need a square root, an inversion or the
+// (beta x, y) endomorphism of the prime field -- device sampler, fixed-base tables, endomorphism bases, Montgomery-form scalars -- are
+// not built; the unit's table carries null entries for them and the host refuses the corresponding options.
+#ifndef MSM_FQ2
 __device__ __constant__ cwords<CW> c_pp1d4 = make_cwords(FQ_PP1D4_32);
+#endif
 
 // ------------------------------------------------------------------------------------------------ small helpers
 __device__ __forceinline__ void ld8(const uint32_t* p, uint32_t w[8]) {
@@ -104,17 +109,24 @@ __device__ __forceinline__ void st_fq(uint32_t* p, const fq& x) {  // x exact, <
   fq_pack(w, x);
   st_coord(p, w);
 }
-// w >= modulus ?   MOD = 0: Fq modulus p (CW words), MOD = 1: Fr modulus r (8 words)  (constants fold to immediates)
+// w >= modulus ?   MOD = 0: Fq modulus p (CW words; in an extension-field unit: ANY of the FQ_EXT components of CW / FQ_EXT words),
+// MOD = 1: Fr modulus r (8 words)  (constants fold to immediates)
 template <int MOD>
 __device__ __forceinline__ bool geq_modulus(const uint32_t* w) {
-  bool gt = false, lt = false;
+  constexpr int NW = MOD == 0 ? CW / FQ_EXT : 8;
+  bool any = false;
 #pragma unroll
-  for (int i = (MOD == 0 ? CW : 8) - 1; i >= 0; i--) {
-    const uint32_t m = MOD == 0 ? FQ_P32[i] : FR_R32[i];
-    gt = gt || (!lt && w[i] > m);
-    lt = lt || (!gt && w[i] < m);
+  for (int e = 0; e < (MOD == 0 ? FQ_EXT : 1); e++) {
+    bool gt = false, lt = false;
+#pragma unroll
+    for (int i = NW - 1; i >= 0; i--) {
+      const uint32_t m = MOD == 0 ? FQ_P32[i] : FR_R32[i];
+      gt = gt || (!lt && w[e * NW + i] > m);
+      lt = lt || (!gt && w[e * NW + i] < m);
+    }
+    any = any || !lt;
   }
-  return !lt;
+  return any;
 }
 __device__ __forceinline__ bool fq_equal_exact(const fq& a, const fq& b) {
   uint32_t d = 0;
@@ -197,6 +209,7 @@ __global__ void __launch_bounds__(256) k_convert_points(const uint32_t* in, uint
   st_fq(out + i * PT_WORDS + CW, y);
 }
 
+#ifndef MSM_FQ2
 // The endomorphism's point half (csrc/glv.h): record n + i = phi(P_i) = (beta x_i, y_i) behind the n plain bases
 __global__ void __launch_bounds__(256) k_endo_points(uint32_t* __restrict__ bases, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -243,6 +256,7 @@ __global__ void __launch_bounds__(256) k_precompute_tables(uint32_t* __restrict_
     acc = g1_from_affine(x, y);
   }
 }
+#endif  // MSM_FQ2
 
 // ------------------------------------------------------------------------------------------------ stage 1+2: recode + sort
 // Signed 16-bit digit recode (≙ decompose_scalars.template.wgsl:83-112, CPU model test/utils.rs:121-161):
@@ -313,6 +327,7 @@ __device__ __forceinline__ uint32_t code_of_window(const uint32_t* t, int w) {  
   return 0x8000u | ((H - b) & (H - 1u));          // d = -(2^(C-1) - b): magnitude 1 .. 2^(C-1) (2^(C-1) -> slot 0)
 }
 
+#ifndef MSM_FQ2
 // Scalars handed over as s * 2^256 mod r (the in-memory limbs of a 4 x 64-bit Montgomery library with R = 2^256) are turned
 // into the canonical wire format by one pre-pass: a 9-limb Montgomery reduction of (s_mont << 5), i.e. s_mont * 2^5 / 2^261.
 __device__ __forceinline__ void fr_from_mont256(const uint32_t w[8], uint32_t out[8]) {
@@ -369,6 +384,7 @@ __global__ void __launch_bounds__(256) k_scalars_from_mont256(const uint32_t* __
   q[0] = make_uint4(o[0], o[1], o[2], o[3]);
   q[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
+#endif  // MSM_FQ2
 
 // `nvec` scalar vectors (vec_stride words apart) may share one launch: vector v, window w is handled as local window
 // lw = v * w_count + (w - w_begin), nvec * w_count <= MAXLW -- several MSMs over the same bases sorted, accumulated and reduced
@@ -1070,7 +1086,7 @@ __device__ __forceinline__ void smvp_assign(g1_xyzz& acc, const g1_xyzz& src) {
   acc.inf = src.inf;
 }
 
-constexpr int SMVP_WAVES_PER_SIMD = FQ_L <= 9 ? 3 : 2;  // 168 VGPRs hold the 9-limb loop; 14 limbs take up to 256
+constexpr int SMVP_WAVES_PER_SIMD = FQ_L <= 9 ? 3 : FQ_L <= 14 ? 2 : 1;  // 168 VGPRs hold the 9-limb loop; 14 limbs take up to 256; Fq2's 18 limbs the whole file
 __global__ void __launch_bounds__(256, SMVP_WAVES_PER_SIMD) k_smvp_chunks(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ col_ptr,
                                                      const uint32_t* __restrict__ val_idxs, size_t stride, uint32_t chunks,
                                                      const uint32_t* __restrict__ chunk_len_dev, const uint32_t* __restrict__ chunk_slot,
@@ -1810,6 +1826,7 @@ __global__ void __launch_bounds__(256) k_sample_scalars(uint64_t seed, size_t n,
   st8(out + i * 8, w);
 }
 
+#ifndef MSM_FQ2
 __device__ __constant__ cwords<CW> c_sqrt_t = make_cwords(FQ_SQRT_T_32);
 __device__ __constant__ cwords<CW> c_sqrt_tp1h = make_cwords(FQ_SQRT_TP1H_32);
 __device__ __forceinline__ fq fq_pow254(const fq& a, const uint32_t* e) {  // a^e, e < 2^(32 CW - 2) (constant memory), a exact
@@ -1869,6 +1886,7 @@ __global__ void __launch_bounds__(256) k_sample_points(uint64_t seed, size_t n, 
     break;
   }
 }
+#endif  // MSM_FQ2
 
 // ------------------------------------------------------------------------------------------------ op hooks for tests
 // (≙ src/cuzk/wgsl/test/test_field.wgsl:13-62, test_point.wgsl:18-88)

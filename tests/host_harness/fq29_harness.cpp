@@ -2,8 +2,10 @@
 // the HIP kernels inline.  Test-only: not part of libmsm_hip.so.
 #include <cstring>
 
+#ifndef HARNESS_PRELUDE_DONE  // (fq2_harness.cpp instantiates the G2 unit's headers itself, then includes this file)
 #include "g1.h"
 #include "glv.h"
+#endif
 
 #ifndef HARNESS_FIELD_NS  // -DMSM_FIELD_NS=... -DMSM_CURVE_CONSTANTS=... -DHARNESS_FIELD_NS=...: the same harness for another curve
 #define HARNESS_FIELD_NS bn254
@@ -31,6 +33,7 @@ static void store_jac(uint8_t* b, const g1_xyzz& p) {
 }
 
 extern "C" {
+#ifndef MSM_FQ2
 // scalar split of the curve endomorphism (csrc/glv.h): n x 32 B scalars -> n x (16 B half 1 | 16 B half 2), sign in bit 127;
 // returns the number of scalars whose halves did not fit
 size_t h_glv_split(const uint8_t* scalars, uint8_t* out, size_t n) {
@@ -50,6 +53,7 @@ void h_fq_mul_beta(const uint8_t* a, uint8_t* out, size_t n) {
   for (int i = 0; i < FQ_LIMBS; i++) beta.v[i] = FQ_BETA29[i];
   for (size_t i = 0; i < n; i++) store_fq(out + HB * i, fq_mul(load_fq(a + HB * i), beta));
 }
+#endif
 // op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg
 void h_fq_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
   for (size_t i = 0; i < n; i++) {
@@ -86,6 +90,7 @@ void h_g1_madd_w_chain(const uint8_t* acc, const uint8_t* pts, const uint8_t* ne
   for (size_t i = 0; i < m; i++) g1_madd_w(a, wneg, load_fq(pts + 2 * HB * i), load_fq(pts + 2 * HB * i + HB), negs[i] != 0);
   store_jac(out, g1_unsigned(a, wneg));
 }
+#ifndef MSM_FQ2  // (csrc/fq2.h reduces after every addition: there are no lazy bounds to push)
 // The value bounds g1.h promises between operations (X < 9p, Y < 5p, ZZ < 2p, ZZZ < 2p), pushed to their limits: the accumulator's
 // coordinates are raised by kx / ky / kz multiples of p (same residues, larger representatives) before each operation; every Montgomery
 // result is asserted below 2p (-DFQ_CHECK), i.e. the operand bounds of every multiplication in the formulas hold at the edge.
@@ -124,6 +129,7 @@ void h_g1_at_the_bounds(int op, const uint8_t* acc, const uint8_t* other, int ne
     store_jac(out, g1_double(a));
   }
 }
+#endif
 // op: 0 add, 1 double(a)
 void h_g1_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
   for (size_t i = 0; i < n; i++) {

@@ -1,0 +1,232 @@
+"""BN254 G2 behind the same ABI and kernels (SURVEY.md 8f-4 "other curves / G2"; the reference lists other curves as future work,
+README.md, and is hard-wired to BN254 G1, src/cuzk/msm.rs:37-43): the twist y^2 = x^3 + 3 / (9 + u) over Fq2 = Fq[u] / (u^2 + 1), scalars
+modulo the same r.  The coordinates are Fq2 elements -- csrc/fq2.h on the 9 x 29-bit prime field, 18 limbs per coordinate -- 64 bytes on
+the wire (c0 || c1), points 128 B, Jacobian records 192 B (csrc/curve_bn254_g2.hip).
+
+Checked against the pure-Python model oracle/bn254_g2_ref.py (pinned in tests/test_oracle_g2.py): its Pippenger and double-and-add MSMs at
+the sizes Python finishes in seconds, and at full size through a closed form the synthetic points offer -- they are KNOWN multiples m_i G of
+the generator, so sum_i s_i P_i = (sum_i s_i m_i mod r) G whatever the size and whatever method the device used."""
+import pytest
+import torch
+
+import msm_webgpu_amd as m
+from oracle import bn254_g2_ref as g2
+from tests.util import rng
+
+pytestmark = pytest.mark.gpu
+CB, PB, JB = 64, 128, 192
+
+
+def b32(x):
+    return int(x).to_bytes(32, "little")
+
+
+@pytest.fixture(scope="module")
+def ctx(built):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    c = m.MsmContext(0, curve="bn254_g2")
+    yield c
+    c.close()
+
+
+def affs(raw):
+    return [g2.jacobian_bytes_to_affine(raw[i:i + JB]) for i in range(0, len(raw), JB)]
+
+
+def jac(pt, r):
+    """A Jacobian record of `pt` with a random z"""
+    if pt is None:
+        return bytes(JB)
+    z = (r.randrange(1, g2.P), r.randrange(g2.P))
+    z2 = g2.f2_sqr(z)
+    return g2.f2_to_bytes(g2.f2_mul(pt[0], z2)) + g2.f2_to_bytes(g2.f2_mul(pt[1], g2.f2_mul(z2, z))) + g2.f2_to_bytes(z)
+
+
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "sqr", "neg", "mul_asm", "sqr_asm", "mul2_asm", "mul_asm_lazy", "sqr_asm_lazy"])
+def test_field_ops(ctx, op):
+    # (≙ tests/field.rs) Fq2 on the device: the C++ form of the prime-field multipliers and the SMVP's inline-assembly form
+    P = g2.P
+    r = rng(61)
+    edge = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, 1 << 253, (1 << 29) - 1, 1 << 29]
+    vals = [(a, b) for a in edge for b in edge] + [(r.randrange(P), r.randrange(P)) for _ in range(3000)]
+    other = [vals[(7 * i + 3) % len(vals)] for i in range(len(vals))]
+    a, b = b"".join(g2.f2_to_bytes(v) for v in vals), b"".join(g2.f2_to_bytes(v) for v in other)
+    mul, add = g2.f2_mul, g2.f2_add
+    want = {"add": add, "sub": g2.f2_sub, "mul": mul, "sqr": lambda x, y: mul(x, x), "neg": lambda x, y: g2.f2_neg(x), "mul_asm": mul,
+            "sqr_asm": lambda x, y: mul(x, x), "mul2_asm": lambda x, y: add(mul(x, y), mul(y, x)), "mul_asm_lazy": lambda x, y: mul(add(x, y), add(x, x)),
+            "sqr_asm_lazy": lambda x, y: mul(add(x, y), add(x, y))}[op]
+    assert ctx.fq_op(op, a, b) == b"".join(g2.f2_to_bytes(want(x, y)) for x, y in zip(vals, other))
+
+
+def test_point_ops_and_special_cases(ctx):
+    # (≙ tests/point.rs) the group formulas over Fq2 with the reference's case split: identity operands, P + P, P - P
+    r = rng(62)
+    pts = g2.sample_points(33, 12)
+    a = pts[:6] + [None, pts[3], pts[4], pts[5], None]
+    b = pts[6:12] + [pts[2], None, pts[4], g2.neg(pts[5]), None]
+    A, B = b"".join(jac(x, r) for x in a), b"".join(jac(x, r) for x in b)
+    assert affs(ctx.g1_op("add", A, B)) == [g2.add(x, y) for x, y in zip(a, b)]
+    assert affs(ctx.g1_op("double", A)) == [g2.add(x, x) for x in a]
+    q = pts[1:7] + [pts[6], pts[3], g2.neg(pts[4]), pts[5], pts[7]]
+    Q = g2.points_to_bytes(q)
+    assert affs(ctx.g1_op("add_affine", A, Q)) == [g2.add(x, y) for x, y in zip(a, q)]
+    assert affs(ctx.g1_op("madd_w_pmp", A, Q)) == [g2.add(x, y) for x, y in zip(a, q)]
+    assert affs(ctx.g1_op("madd_w_mm", A, Q)) == [g2.add(g2.add(x, g2.neg(y)), g2.neg(y)) for x, y in zip(a, q)]
+    ks = [0, 1, 2, 3, 0xFFFF, 0x8000, 0xFFFFFFFF, 12345, 7, 1 << 31, 99]
+    assert affs(ctx.g1_mul_u32(A, ks)) == [g2.mul(k, x) for k, x in zip(ks, a)]
+
+
+@pytest.mark.parametrize("n", [1, 3, 257, 4097])
+def test_msm_matches_the_model_every_window_size_and_entry_point(ctx, n):
+    pts = g2.sample_points(n, 34)
+    sc = [g2.sample_scalar(35, i) for i in range(n)]
+    for i, v in enumerate([0, 1, g2.R - 1, g2.R - 2, 0x8000, (1 << 253) + 0x80008000][: min(n, 6)]):
+        sc[i] = v
+    if n > 40:  # a duplicate and a negated duplicate of a point with equal scalars: the mixed addition's doubling / cancellation paths
+        pts[20], sc[20] = pts[21], sc[21]
+        pts[23], sc[23] = g2.neg(pts[22]), sc[22]
+    want = g2.msm_pippenger(pts, sc, c=10)
+    if n <= 257:
+        assert want == g2.msm_naive(pts, sc)
+    points, scb = g2.points_to_bytes(pts), g2.scalars_to_bytes(sc)
+    dev = torch.frombuffer(bytearray(scb), dtype=torch.uint8).cuda()
+    ctx.set_bases(points, check_on_curve=True)
+    for bits in (0, 12, 14, 16):
+        ctx.set_window_bits(bits)
+        got = ctx.msm(scb)
+        assert len(got.xyz) == JB and got.to_affine() == want and got.to_affine_bytes() == g2.affine_to_bytes(want), (n, bits)
+    ctx.set_window_bits(0)
+    assert ctx.msm(dev).to_affine() == want
+    assert [g.to_affine() for g in ctx.msm_batch(scb * 3, n)] == [want] * 3
+    ctx.launch(dev, 0)
+    ctx.launch(dev, 1)
+    assert ctx.finish(1).to_affine() == want and ctx.finish(0).to_affine() == want
+    # window shards combine to the whole (the multi-GPU decomposition); grouped shards; the in-process multi-GPU ABI
+    parts = [ctx.msm_windows(dev, 0, 6), ctx.msm_windows(dev, 6, 16)]
+    assert parts[0].shape == (6, JB)
+    assert m.MsmContext.combine_windows(torch.cat(parts, dim=0), curve="bn254_g2").to_affine() == want
+    two = torch.cat([dev, dev])
+    out = torch.zeros((2 * 4, JB), dtype=torch.uint8, device=dev.device)
+    shards = []
+    for k in range(4):
+        ctx.launch_windows_batch(two, n, 4 * k, 4 * k + 4, k % 3, out)
+        ctx.slot_sync(k % 3)
+        shards.append(out.clone().view(2, 4, JB))
+    for v in range(2):
+        assert m.MsmContext.combine_windows(torch.cat([s[v] for s in shards], dim=0), curve="bn254_g2").to_affine() == want
+    mg = m.MultiGpuMsm([0, 0, 0], "host", curve="bn254_g2")
+    try:
+        mg.set_bases(points)
+        assert mg.msm(scb).to_affine() == want
+        mg.launch_batch(scb * 2, n, 1)
+        assert [g.to_affine() for g in mg.finish_batch(1, 2)] == [want] * 2
+    finally:
+        mg.close()
+
+
+def test_bucket_sums_and_window_sums_against_the_model(ctx):
+    # (≙ tests/smvp_shader.rs:292-334, tests/cuzk.rs) stage read-back: every bucket of two windows is the signed sum of the points whose
+    # digit selects it (digits: the reference's recode, decompose_scalars.template.wgsl:83-112); the window sums are sum_k k B_k
+    n = 3000
+    pts = g2.sample_points(n, 44)
+    sc = [g2.sample_scalar(45, i) for i in range(n)]
+    ctx.set_bases(g2.points_to_bytes(pts))
+    ctx.set_debug(True)
+    ctx.set_window_bits(16)
+    try:
+        result = ctx.msm(g2.scalars_to_bytes(sc))
+    finally:
+        ctx.set_debug(False)
+        ctx.set_window_bits(0)
+    buckets, wsums = ctx.read_buckets(16, 1 << 15), ctx.read_window_sums(16)
+    digs = [g2.signed_digits(s) for s in sc]
+    for w in (0, 15):
+        want = {}
+        for i in range(n):
+            d = digs[i][w]
+            if d:
+                k = abs(d) & 0x7FFF  # slot 0 holds the digit -2^15
+                want[k] = g2.add(want.get(k), pts[i] if d > 0 else g2.neg(pts[i]))
+        raw = buckets[w].tobytes()
+        occupied = {k: g2.jacobian_bytes_to_affine(raw[JB * k:JB * k + JB]) for k in range(1 << 15) if raw[JB * k + 2 * CB:JB * k + JB] != bytes(CB)}
+        assert occupied == {k: v for k, v in want.items() if v is not None}
+        total = None
+        for k, v in want.items():
+            total = g2.add(total, g2.mul(k if k else 1 << 15, v))
+        assert g2.jacobian_bytes_to_affine(wsums[w].tobytes()) == total
+    acc = None
+    for w in range(15, -1, -1):
+        for _ in range(16):
+            acc = g2.add(acc, acc)
+        acc = g2.add(acc, g2.jacobian_bytes_to_affine(wsums[w].tobytes()))
+    assert acc == result.to_affine() == g2.msm_by_multipliers(g2.sample_multipliers(n, 44), sc)
+    # without debug the single-MSM launch leaves bit-plane sums: the read-back finishes them
+    ctx.set_window_bits(16)
+    try:
+        ctx.msm(g2.scalars_to_bytes(sc))
+        assert m.MsmContext.combine_windows(ctx.read_window_sums(16).tobytes(), curve="bn254_g2").to_affine() == acc
+    finally:
+        ctx.set_window_bits(0)
+
+
+@pytest.mark.parametrize("logn", [16, 18, 20])
+def test_large_msm_by_the_closed_form(ctx, logn):
+    # BASELINE config sizes (2^16: config 1; 2^20: config 2) on G2.  The bases are 2^14 known multiples of the generator repeated (equal
+    # points with independent scalars are ordinary inputs), so the expected result is (sum_i s_i m_i mod r) G without an MSM on the CPU.
+    n, base = 1 << logn, 1 << 14
+    pts, ms = g2.sample_points(base, 70), g2.sample_multipliers(base, 70)
+    points = torch.frombuffer(bytearray(g2.points_to_bytes(pts)), dtype=torch.uint8).cuda().view(base, PB).repeat(n // base, 1).contiguous()
+    ctx.set_bases(points)
+    sc = ctx.sample_scalars(n, 71 + logn)
+    sb = sc.cpu().numpy().tobytes()
+    scalars = g2.bytes_to_scalars(sb)
+    want = g2.msm_by_multipliers(ms * (n // base), scalars)
+    assert ctx.msm(sc).to_affine() == want
+    ctx.launch(sc, 0)
+    ctx.launch(sc, 1)
+    assert ctx.finish(0).to_affine() == want and ctx.finish(1).to_affine() == want
+    if logn == 16:
+        # skew: every scalar equal; a witness-like vector (70 % zeros and ones); one rank's shares of an 8-rank run, gathered in rank order
+        s = (0x1234_5678_9ABC_DEF0_1357_9BDF_2468_ACE0_FEDC_BA98_7654_3210 * 0x10001) % g2.R
+        assert ctx.msm(b32(s) * n).to_affine() == g2.mul(s * sum(ms) * (n // base), g2.G)
+        gen = torch.Generator(device=sc.device)
+        gen.manual_seed(3)
+        sel = torch.rand(n, device=sc.device, generator=gen)
+        wit = sc.clone()
+        wit[sel < 0.7] = 0
+        wit[(sel >= 0.4) & (sel < 0.7), 0] = 1
+        assert ctx.msm(wit).to_affine() == g2.msm_by_multipliers(ms * (n // base), g2.bytes_to_scalars(wit.cpu().numpy().tobytes()))
+        out = torch.zeros((16, JB), dtype=torch.uint8, device=sc.device)
+        for rank in range(8):
+            ctx.launch_windows_batch(sc, n, 2 * rank, 2 * rank + 2, rank % 3, out[2 * rank:2 * rank + 2])
+            ctx.slot_sync(rank % 3)
+        assert m.MsmContext.combine_windows(out, curve="bn254_g2").to_affine() == want
+    ctx.set_bases(points[:4].contiguous())
+
+
+def test_options_the_g2_unit_does_not_have_and_input_errors(ctx):
+    pts = g2.points_to_bytes(g2.sample_points(4, 38))
+    for kw in ({"endomorphism": True}, {"precompute": True}):
+        with pytest.raises(m.MsmHipError) as e:
+            ctx.set_bases(pts, **kw)
+        assert e.value.code == -2
+    with pytest.raises(m.MsmHipError):
+        ctx.set_scalar_format(True)
+    with pytest.raises(m.MsmHipError):
+        ctx.sample_points(4, 1)
+    with pytest.raises(m.MsmHipError):  # a component >= p (c1 of x)
+        ctx.set_bases(pts[:32] + b32(g2.P) + pts[64:])
+    with pytest.raises(m.MsmHipError):  # not on the twist
+        ctx.set_bases(b32(5) + b32(6) + b32(7) + b32(8) + pts[PB:], check_on_curve=True)
+    ctx.set_bases(pts, check_on_curve=True)
+    with pytest.raises(m.MsmHipError):  # a scalar that overflows the 16-bit recode
+        ctx.msm(b"\xff" * 32 + bytes(96))
+    assert ctx.msm(bytes(128)).is_identity()
+    assert m.lib().msm_hip_ctx_curve(ctx._h) == 5
+    # Montgomery-form coordinates (x * 2^256 mod p per component) are accepted: the same bases, the same result
+    mont = b"".join(b32(int.from_bytes(pts[i:i + 32], "little") * (1 << 256) % g2.P) for i in range(0, len(pts), 32))
+    sc = g2.scalars_to_bytes([5, 6, 7, 8])
+    want = ctx.msm(sc).to_affine()
+    ctx.set_bases(mont, mont256=True)
+    assert ctx.msm(sc).to_affine() == want == g2.msm_naive(g2.bytes_to_points(pts), [5, 6, 7, 8])

@@ -1,0 +1,44 @@
+"""The BN254 G2 model (oracle/bn254_g2_ref.py) pinned: public parameters, field identities, and its two MSM algorithms against each other."""
+import pytest
+
+from oracle import bn254_g2_ref as g2
+from oracle import bn254_ref as g1
+
+
+def test_parameters_and_generator():
+    assert g2.P == g1.P and g2.R == g1.R  # the same base and scalar fields as G1 (src/cuzk/msm.rs:39, src/naive/utils/bigint.rs:85)
+    assert g2.f2_mul((0, 1), (0, 1)) == (g2.P - 1, 0)  # u^2 = -1
+    assert g2.f2_mul(g2.B, (9, 1)) == (3, 0)  # the twist's constant is 3 / (9 + u)
+    assert g2.is_on_curve(g2.G)
+    assert g2.mul(g2.R, g2.G) is g2.INF and g2.add(g2.mul(g2.R - 1, g2.G), g2.G) is g2.INF  # the generator has order r
+    assert g2.mul(2, g2.G) == g2.add(g2.G, g2.G) and g2.is_on_curve(g2.mul(2, g2.G))
+    a = (123456789, 987654321)
+    assert g2.f2_mul(a, g2.f2_inv(a)) == (1, 0)
+
+
+def test_jacobian_and_affine_formulas_agree():
+    p, q = g2.mul(5, g2.G), g2.mul(7, g2.G)
+    jp, jq = g2.j_from_affine(p), g2.j_from_affine(q)
+    assert g2.j_to_affine(g2.j_add(jp, jq)) == g2.mul(12, g2.G)
+    assert g2.j_to_affine(g2.j_add(jp, jp)) == g2.mul(10, g2.G)  # equal inputs take the doubling branch
+    assert g2.j_to_affine(g2.j_add(jp, g2.j_from_affine(g2.neg(p)))) is g2.INF
+    assert g2.j_to_affine(g2.j_double(g2.JINF)) is g2.INF and g2.j_to_affine(g2.j_add(g2.JINF, jq)) == q
+
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (3, 2), (33, 3)])
+def test_the_two_msm_algorithms_agree(n, seed):
+    pts = g2.sample_points(n, seed)
+    assert all(g2.is_on_curve(p) for p in pts) and len(set(pts)) == n
+    sc = [g2.sample_scalar(seed + 100, i) for i in range(n)]
+    assert g2.msm_naive(pts, sc) == g2.msm_pippenger(pts, sc)
+    edge = [0, 1, g2.R - 1, 0x8000, 0x7fff, (1 << 253) + 0x80008000][:n]
+    assert g2.msm_naive(pts[: len(edge)], edge) == g2.msm_pippenger(pts[: len(edge)], edge)
+
+
+def test_wire_format_round_trip():
+    pts = g2.sample_points(4, 9)
+    b = g2.points_to_bytes(pts)
+    assert len(b) == 4 * 128 and g2.bytes_to_points(b) == pts
+    assert b[:32] == pts[0][0][0].to_bytes(32, "little") and b[32:64] == pts[0][0][1].to_bytes(32, "little")  # c0 || c1
+    j = g2.f2_to_bytes(pts[1][0]) + g2.f2_to_bytes(pts[1][1]) + g2.f2_to_bytes((1, 0))
+    assert g2.jacobian_bytes_to_affine(j) == pts[1] and g2.jacobian_bytes_to_affine(bytes(192)) is g2.INF
