@@ -100,7 +100,11 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx);
                                     Device arithmetic: csrc/fq2.h on the 9 x 29-bit prime field (csrc/curve_bn254_g2.hip).  Window sizes, window shards,
                                     batches, grouped launches, the multi-GPU calls: as for curve 0.  NOT available (MSM_HIP_ERR_INVALID_ARG):
                                     MSM_HIP_BASES_ENDOMORPHISM, MSM_HIP_BASES_PRECOMPUTE, MSM_HIP_SCALARS_MONT256, the device point sampler. */
-#define MSM_HIP_NUM_CURVES 6
+#define MSM_HIP_CURVE_BLS12_381_G2 6 /* G2 of BLS12-381: the twist y^2 = x^3 + 4 (1 + u) over Fq2, scalars modulo the same r as curve 4.  As curve 5 with 48-byte
+                                        components: coordinates 96 B (c0 || c1), points 192 B, results and window sums 288 B Jacobian records.  The same
+                                        options are unavailable.  Inputs are expected in the order-r subgroup (as every valid G2 point is); points outside
+                                        it are summed as the integers their scalars are, like on curve 4. */
+#define MSM_HIP_NUM_CURVES 7
 int msm_hip_ctx_create_curve(msm_hip_ctx** out, int device_id, int curve);
 int msm_hip_ctx_curve(const msm_hip_ctx* ctx);
 /* the context-free host helpers for a given curve (msm_hip_combine_windows_bn254 / msm_hip_g1_to_affine_bn254 are curve 0) */

@@ -23,12 +23,13 @@ PALLAS_P = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001  #
 VESTA_P = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001   # Vesta's base field = Pallas' scalar field
 BLS12_381_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 CURVES = {"bn254": (0, P), "grumpkin": (1, R_BN254), "pallas": (2, PALLAS_P), "vesta": (3, VESTA_P), "bls12_381": (4, BLS12_381_P),
-          "bn254_g2": (5, P)}  # G2: coordinates in Fq2 = Fq[u] / (u^2 + 1), an element on the wire is c0 || c1
+          "bn254_g2": (5, P), "bls12_381_g2": (6, BLS12_381_P)}  # G2: coordinates in Fq2 = Fq[u] / (u^2 + 1), an element on the wire is c0 || c1
 
 
 def coord_bytes(curve):
-    """Bytes of a coordinate on a curve's wire: 32; 48 for BLS12-381; 64 for BN254 G2 (an Fq2 element) -- points 2 x, Jacobian records 3 x that."""
-    return {"bls12_381": 48, "bn254_g2": 64}.get(curve, 32)
+    """Bytes of a coordinate on a curve's wire: 32; 48 for BLS12-381; 64 / 96 for BN254 / BLS12-381 G2 (an Fq2 element) -- points 2 x, Jacobian
+    records 3 x that."""
+    return {"bls12_381": 48, "bn254_g2": 64, "bls12_381_g2": 96}.get(curve, 32)
 NUM_WINDOWS = 16
 WINDOW_BITS = 16
 BUCKETS_PER_WINDOW = 1 << 15
@@ -159,17 +160,18 @@ class G1:
     def __init__(self, xyz, p=P):
         self.xyz = bytes(xyz)
         self.p = p  # base-field modulus of the point's curve
-        assert len(self.xyz) in (96, 144, 192)  # 3 coordinates of 32 bytes (48: BLS12-381; 64: BN254 G2, coordinates in Fq2)
+        assert len(self.xyz) in (96, 144, 192, 288)  # 3 coordinates of 32 bytes (48: BLS12-381; 64 / 96: BN254 / BLS12-381 G2, coordinates in Fq2)
 
     @property
     def quadratic(self):
-        """The coordinates are Fq2 elements (c0, c1) (a G2 point: 192-byte record)."""
-        return len(self.xyz) == 192
+        """The coordinates are Fq2 elements (c0, c1) (a G2 point: 192-byte record; 288 bytes on BLS12-381)."""
+        return len(self.xyz) in (192, 288)
 
     def coords(self):
         b, cb = self.xyz, len(self.xyz) // 3
         if self.quadratic:
-            return tuple((int.from_bytes(b[k:k + 32], "little"), int.from_bytes(b[k + 32:k + 64], "little")) for k in (0, cb, 2 * cb))
+            h = cb // 2
+            return tuple((int.from_bytes(b[k:k + h], "little"), int.from_bytes(b[k + h:k + cb], "little")) for k in (0, cb, 2 * cb))
         return tuple(int.from_bytes(b[k:k + cb], "little") for k in (0, cb, 2 * cb))
 
     def is_identity(self):
@@ -198,7 +200,7 @@ class G1:
         if a is None:
             return bytes(2 * cb)
         if self.quadratic:
-            return b"".join(c.to_bytes(32, "little") for c in (a[0][0], a[0][1], a[1][0], a[1][1]))
+            return b"".join(c.to_bytes(cb // 2, "little") for c in (a[0][0], a[0][1], a[1][0], a[1][1]))
         return a[0].to_bytes(cb, "little") + a[1].to_bytes(cb, "little")
 
     def __eq__(self, other):  # projective equality, as G1's PartialEq (src/lib.rs:166)

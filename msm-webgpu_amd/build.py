@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # MSM_HIP_SO: load (and build into) another file, e.g. a diagnostic variant next to the product library
 SO = os.environ.get("MSM_HIP_SO") or os.path.join(HERE, "libmsm_hip.so")
-SOURCES = ["msm_hip.hip", "curve_grumpkin.hip", "curve_pallas.hip", "curve_vesta.hip", "curve_bls12_381.hip", "curve_bn254_g2.hip", "fq2.h", "bn254_g2_constants.h", "fq28x14_asm.h", "bls12_381_constants.h", "curve_ops.h", "msm_kernels.h", "g1.h", "fq29.h", "fq29_asm.h", "host_g1.h", "host_pool.h", "glv.h", "msm_mgpu.h", "curve_select.h", "curve_unit.h", "grumpkin_constants.h", "bn254_constants.h", "pallas_constants.h", "vesta_constants.h"]
+SOURCES = ["msm_hip.hip", "curve_grumpkin.hip", "curve_pallas.hip", "curve_vesta.hip", "curve_bls12_381.hip", "curve_bn254_g2.hip", "curve_bls12_381_g2.hip", "fq2.h", "bn254_g2_constants.h", "bls12_381_g2_constants.h", "fq28x14_asm.h", "bls12_381_constants.h", "curve_ops.h", "msm_kernels.h", "g1.h", "fq29.h", "fq29_asm.h", "host_g1.h", "host_pool.h", "glv.h", "msm_mgpu.h", "curve_select.h", "curve_unit.h", "grumpkin_constants.h", "bn254_constants.h", "pallas_constants.h", "vesta_constants.h"]
 HEADER = os.path.join(HERE, "..", "include", "msm_hip.h")
 TEMPS = os.path.join(HERE, "..", "build", "temps" if not os.environ.get("MSM_HIP_SO") else "temps_" + os.path.basename(SO))
 
@@ -32,7 +32,7 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-TRANSLATION_UNITS = ["msm_hip.hip", "curve_bn254_g2.hip", "curve_bls12_381.hip", "curve_grumpkin.hip", "curve_pallas.hip", "curve_vesta.hip"]  # host + BN254's unit; one per further curve
+TRANSLATION_UNITS = ["msm_hip.hip", "curve_bls12_381_g2.hip", "curve_bn254_g2.hip", "curve_bls12_381.hip", "curve_grumpkin.hip", "curve_pallas.hip", "curve_vesta.hip"]  # host + BN254's unit; one per further curve
 
 
 def build(force=False, verbose=False):

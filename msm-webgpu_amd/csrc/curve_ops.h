@@ -64,4 +64,5 @@ __attribute__((visibility("hidden"))) const CurveOps* msm_hip_curve_ops_pallas(v
 __attribute__((visibility("hidden"))) const CurveOps* msm_hip_curve_ops_vesta(void);
 __attribute__((visibility("hidden"))) const CurveOps* msm_hip_curve_ops_bls12_381(void);
 __attribute__((visibility("hidden"))) const CurveOps* msm_hip_curve_ops_bn254_g2(void);
+__attribute__((visibility("hidden"))) const CurveOps* msm_hip_curve_ops_bls12_381_g2(void);
 }

@@ -23,6 +23,15 @@
 #include "fq29.h"
 #endif
 
+// The full addition and the doubling are inlined into every caller (G1_HD = FQ_HD) except in a unit that asks for calls instead
+// (MSM_G1_OUTLINE: BLS12-381 G2, where one inlined addition is ~16 000 instructions and the reduce kernels hold several: the unit's compile
+// time, not its speed, is what the calls are for; the SMVP's mixed addition stays inline everywhere).
+#if defined(MSM_G1_OUTLINE) && defined(__HIPCC__)
+#define G1_HD __host__ __device__ __noinline__
+#else
+#define G1_HD FQ_HD
+#endif
+
 namespace MSM_FIELD_NS {
 
 struct g1_affine {  // Montgomery form, canonical
@@ -74,7 +83,7 @@ FQ_HD g1_xyzz g1_double_affine(const fq& px, const fq& py) {
 }
 
 // 2 * a  (EFD dbl-2008-s-1, a = 0)
-FQ_HD g1_xyzz g1_double(const g1_xyzz& a) {
+G1_HD g1_xyzz g1_double(const g1_xyzz& a) {
   if (a.inf) return a;
   g1_xyzz r;
   const fq U = fq_dbl(a.y);                             // < 10p, lazy
@@ -213,7 +222,7 @@ FQ_HD g1_xyzz g1_unsigned(const g1_xyzz& a, bool wneg) {
 }
 
 // a + b   (EFD add-2008-s: 12M + 2S)
-FQ_HD g1_xyzz g1_add(const g1_xyzz& a, const g1_xyzz& b) {
+G1_HD g1_xyzz g1_add(const g1_xyzz& a, const g1_xyzz& b) {
   if (a.inf) return b;
   if (b.inf) return a;
   const fq U1 = fq_mul(a.x, b.zz);                      // 18 p^2
@@ -281,3 +290,4 @@ FQ_HD g1_xyzz g1_from_jacobian(const fq& X, const fq& Y, const fq& Z) {
 }
 
 }  // namespace MSM_FIELD_NS
+#undef G1_HD

@@ -46,6 +46,7 @@ inline const CurveOps* curve_ops(int curve) {
     case MSM_HIP_CURVE_VESTA: return msm_hip_curve_ops_vesta();
     case MSM_HIP_CURVE_BLS12_381: return msm_hip_curve_ops_bls12_381();
     case MSM_HIP_CURVE_BN254_G2: return msm_hip_curve_ops_bn254_g2();
+    case MSM_HIP_CURVE_BLS12_381_G2: return msm_hip_curve_ops_bls12_381_g2();
     default: return &BN254_OPS;
   }
 }
@@ -59,7 +60,7 @@ enum LaunchMode {
 
 constexpr int N_MAIN_EVENTS = 7;  // boundaries of the 6 timed stages on the main stream
 constexpr uint32_t MAX_TILES = 1024;
-constexpr size_t MAX_JB = 192;  // the largest Jacobian record of any curve (BN254 G2: 3 x 64 B; BLS12-381: 3 x 48 B; the 254 / 255-bit G1 curves: 96 B)
+constexpr size_t MAX_JB = 288;  // the largest Jacobian record of any curve (BLS12-381 G2: 3 x 96 B; BN254 G2: 3 x 64 B; BLS12-381 G1: 3 x 48 B; the 254 / 255-bit G1 curves: 96 B)
 constexpr size_t WSUM_BYTES = (size_t)24 * PLANES_PER_WINDOW * MAX_JB;  // MAXLW window sums or, for one host-combined MSM, the bit-plane sums (k_bpr_planes) of its <= 22 windows
 static_assert(WSUM_BYTES >= (size_t)MAXLW * MAX_JB, "window-sum buffer");
 constexpr int NSLOT = MSM_HIP_NUM_SLOTS;  // result slots

@@ -10,13 +10,15 @@ EIP-197 lies on the curve and has order r; u^2 = -1; the twist constant times (9
 
 Wire format (mirrors src/lib.rs:50-65 one level up the tower): an Fq2 element is c0 || c1, each 32 bytes canonical little-endian (64 B);
 an affine point x || y (128 B); a Jacobian record x || y || z (192 B, z = 0 <=> infinity); scalars 32 B as for G1.
+(oracle/bls12_381_g2_ref.py is this module with P, R, B, G, FB, CB and the G1 model it takes its scalars from rebound.)
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this package."""
 from . import bn254_ref as _g1
 
 P = _g1.P  # base field modulus, src/cuzk/msm.rs:39
 R = _g1.R  # group order (the scalar field), src/naive/utils/bigint.rs:85
-CB = 64    # bytes of a coordinate (an Fq2 element) on the wire
+FB = 32    # bytes of an Fq element on the wire (48 in the BLS12-381 instance of this model, oracle/bls12_381_g2_ref.py)
+CB = 64    # bytes of a coordinate (an Fq2 element c0 || c1) on the wire
 INF = None
 
 
@@ -225,11 +227,11 @@ def j_to_jac_mul(p, k):
 
 # --------------------------------------------------------------------------------------------------- wire format
 def f2_to_bytes(a):
-    return a[0].to_bytes(32, "little") + a[1].to_bytes(32, "little")
+    return a[0].to_bytes(FB, "little") + a[1].to_bytes(FB, "little")
 
 
 def f2_from_bytes(b):
-    return (int.from_bytes(b[0:32], "little"), int.from_bytes(b[32:64], "little"))
+    return (int.from_bytes(b[0:FB], "little"), int.from_bytes(b[FB:2 * FB], "little"))
 
 
 def points_to_bytes(points):
@@ -246,9 +248,16 @@ def bytes_to_points(b):
     return [(f2_from_bytes(b[i:i + CB]), f2_from_bytes(b[i + CB:i + 2 * CB])) for i in range(0, len(b), 2 * CB)]
 
 
-scalars_to_bytes = _g1.scalars_to_bytes
-bytes_to_scalars = _g1.bytes_to_scalars
-sample_scalar = _g1.sample_scalar
+def scalars_to_bytes(scalars):
+    return _g1.scalars_to_bytes(scalars)
+
+
+def bytes_to_scalars(b):
+    return _g1.bytes_to_scalars(b)
+
+
+def sample_scalar(seed, index):
+    return _g1.sample_scalar(seed, index)
 
 
 def jacobian_bytes_to_affine(xyz):

@@ -134,28 +134,30 @@ def test_host_only_helpers_of_window_sizes_and_curves(built):
     got_b = m.MsmContext.combine_windows(sums_b, curve="bls12_381")
     assert got_b.to_affine_bytes() == cb.to_affine64(cb.horner(sums_b)) and len(got_b.to_affine_bytes()) == 96
     assert [g.to_affine_bytes() for g in m.MsmContext.combine_windows_batch(sums_b[: 8 * 144] + sums_b[: 8 * 144], 8, curve="bls12_381")] == [cb.to_affine64(cb.horner(sums_b[: 8 * 144]))] * 2
-    # ... and for BN254 G2 (Fq2 on the host's 4 x 64-bit prime field, 192-byte Jacobian records) against the Python model
-    from oracle import bn254_g2_ref as g2
+    # ... and for G2 of BN254 / BLS12-381 (Fq2 on the host's prime field, 192- / 288-byte Jacobian records) against the Python models
+    import importlib
 
-    jac = []
-    for k in range(16):  # 16 Jacobian points with z != 1 (and one identity)
-        z = (g2.sample_scalar(11, k) % g2.P, g2.sample_scalar(12, k) % g2.P)
-        pt = g2.mul(g2.sample_scalar(13, k), g2.G)
-        z2 = g2.f2_sqr(z)
-        jac.append((g2.f2_mul(pt[0], z2), g2.f2_mul(pt[1], g2.f2_mul(z2, z)), z) if k != 5 else ((0, 0), (0, 0), (0, 0)))
-    sums_g = b"".join(g2.f2_to_bytes(x) + g2.f2_to_bytes(y) + g2.f2_to_bytes(z) for x, y, z in jac)
-    want = None
-    for x, y, z in reversed(jac):
-        for _ in range(16):
-            want = g2.add(want, want)
-        want = g2.add(want, g2.j_to_affine((x, y, z)))
-    got_g = m.MsmContext.combine_windows(sums_g, curve="bn254_g2")
-    assert len(got_g.xyz) == 192 and got_g.to_affine_bytes() == g2.affine_to_bytes(want)
-    assert g2.jacobian_bytes_to_affine(got_g.xyz) == want
-    out = C.create_string_buffer(192)
-    assert L.msm_hip_combine_windows_curve(6, sums, 16, out) == -2  # unknown curve
+    for name in ("bn254_g2", "bls12_381_g2"):
+        g2 = importlib.import_module("oracle." + name + "_ref")
+        jac = []
+        for k in range(16):  # 16 Jacobian points with z != 1 (and one identity)
+            z = (g2.sample_scalar(11, k) % g2.P, g2.sample_scalar(12, k) % g2.P)
+            pt = g2.mul(g2.sample_scalar(13, k), g2.G)
+            z2 = g2.f2_sqr(z)
+            jac.append((g2.f2_mul(pt[0], z2), g2.f2_mul(pt[1], g2.f2_mul(z2, z)), z) if k != 5 else ((0, 0), (0, 0), (0, 0)))
+        sums_g = b"".join(g2.f2_to_bytes(x) + g2.f2_to_bytes(y) + g2.f2_to_bytes(z) for x, y, z in jac)
+        want = None
+        for x, y, z in reversed(jac):
+            for _ in range(16):
+                want = g2.add(want, want)
+            want = g2.add(want, g2.j_to_affine((x, y, z)))
+        got_g = m.MsmContext.combine_windows(sums_g, curve=name)
+        assert len(got_g.xyz) == 3 * g2.CB and got_g.to_affine_bytes() == g2.affine_to_bytes(want), name
+        assert g2.jacobian_bytes_to_affine(got_g.xyz) == want
+    out = C.create_string_buffer(288)
+    assert L.msm_hip_combine_windows_curve(7, sums, 16, out) == -2  # unknown curve
     h = C.c_void_p()
-    assert L.msm_hip_ctx_create_curve(C.byref(h), 0, 7) == -2
+    assert L.msm_hip_ctx_create_curve(C.byref(h), 0, 9) == -2
 
 
 def test_header_is_plain_c_and_links_from_c(built, tmp_path):

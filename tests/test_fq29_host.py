@@ -332,18 +332,22 @@ def test_host_arithmetic_instantiated_for_bls12_381(tmp_path_factory):
     _check_bounds(Hc, rf, 32)
 
 
-def test_host_arithmetic_instantiated_for_bn254_g2(tmp_path_factory):
-    # the G2 unit: csrc/fq2.h (Fq2 on the 9 x 29-bit prime field, every sum reduced) under the same group formulas (g1.h), built as
-    # csrc/curve_bn254_g2.hip builds it, every limb bound and every Montgomery result asserted (-DFQ_CHECK), against the G2 model
-    from oracle import bn254_g2_ref as g2
+@pytest.mark.parametrize("curve", ["bn254_g2", "bls12_381_g2"])
+def test_host_arithmetic_instantiated_for_g2(tmp_path_factory, curve):
+    # a G2 unit: csrc/fq2.h (Fq2 on the curve's prime field -- 9 x 29 or 14 x 28-bit limbs --, every sum reduced) under the same group formulas
+    # (g1.h), built as csrc/curve_<curve>.hip builds it, every limb bound and every Montgomery result asserted (-DFQ_CHECK), against the G2 model
+    import importlib
 
-    so = str(tmp_path_factory.mktemp("fq2g2") / "fq2_harness.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFQ_CHECK", "-fPIC", "-shared", "-I", os.path.join(ROOT, "msm-webgpu_amd", "csrc"),
-                           "-I", os.path.join(ROOT, "tests", "host_harness"), os.path.join(ROOT, "tests", "host_harness", "fq2_harness.cpp"), "-o", so])
+    g2 = importlib.import_module("oracle." + curve + "_ref")
+    JREC = 3 * g2.CB
+    so = str(tmp_path_factory.mktemp("fq2" + curve) / "fq2_harness.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFQ_CHECK", "-fPIC", "-shared"] + (["-DHARNESS_G2_BLS12_381"] if curve == "bls12_381_g2" else []) +
+                          ["-I", os.path.join(ROOT, "msm-webgpu_amd", "csrc"), "-I", os.path.join(ROOT, "tests", "host_harness"),
+                           os.path.join(ROOT, "tests", "host_harness", "fq2_harness.cpp"), "-o", so])
     Hc = C.CDLL(so)
     r = rng(40)
     P = g2.P
-    edge = [0, 1, P - 1, P - 2, (P - 1) // 2, (1 << 253), (1 << 29) - 1, 1 << 29]
+    edge = [0, 1, P - 1, P - 2, (P - 1) // 2, 1 << (P.bit_length() - 1), (1 << 29) - 1, 1 << 28]
     vals = [(a, b) for a in edge for b in edge] + [(r.randrange(P), r.randrange(P)) for _ in range(1500)]
     n = len(vals)
     A = b"".join(g2.f2_to_bytes(v) for v in vals)
@@ -351,10 +355,10 @@ def test_host_arithmetic_instantiated_for_bn254_g2(tmp_path_factory):
     B = b"".join(g2.f2_to_bytes(v) for v in other)
     model = {"add": g2.f2_add, "sub": g2.f2_sub, "mul": g2.f2_mul, "sqr": lambda a, b: g2.f2_sqr(a), "neg": lambda a, b: g2.f2_neg(a)}
     for op, name in enumerate(["add", "sub", "mul", "sqr", "neg"]):
-        out = C.create_string_buffer(64 * n)
+        out = C.create_string_buffer(g2.CB * n)
         Hc.h_fq_op(op, A, B, out, n)
         assert out.raw == b"".join(g2.f2_to_bytes(model[name](a, b)) for a, b in zip(vals, other)), name
-    raw = b"".join(r.randrange(1 << 256).to_bytes(32, "little") for _ in range(2 * 300))
+    raw = b"".join(r.randrange(1 << (8 * g2.FB)).to_bytes(g2.FB, "little") for _ in range(2 * 300))
     out = C.create_string_buffer(len(raw))
     Hc.h_fq_roundtrip(raw, out, 300)
     assert out.raw == raw
@@ -362,8 +366,8 @@ def test_host_arithmetic_instantiated_for_bn254_g2(tmp_path_factory):
     pts = g2.sample_points(300, 5)
     chain = pts[:100] + [pts[7]] + pts[100:200] + [g2.neg(pts[150])] + pts[200:]
     negs = bytes(r.randrange(2) for _ in range(len(chain)))
-    out = C.create_string_buffer(192)
-    Hc.h_g1_madd_w_chain(bytes(192), g2.points_to_bytes(chain), negs, len(chain), out)
+    out = C.create_string_buffer(JREC)
+    Hc.h_g1_madd_w_chain(bytes(JREC), g2.points_to_bytes(chain), negs, len(chain), out)
     acc = None
     for pt, ng in zip(chain, negs):
         acc = g2.add(acc, g2.neg(pt) if ng else pt)
@@ -371,9 +375,9 @@ def test_host_arithmetic_instantiated_for_bn254_g2(tmp_path_factory):
     # P + P, P - P and -P + P through the signed form from an empty accumulator; the plain mixed addition likewise
     for seq, sg, want in (([pts[0], pts[0]], b"\0\0", g2.add(pts[0], pts[0])), ([pts[0], pts[0]], b"\0\1", None), ([pts[0], pts[0]], b"\1\0", None),
                           ([pts[0], pts[0], pts[1]], b"\1\1\0", g2.add(g2.neg(g2.add(pts[0], pts[0])), pts[1]))):
-        Hc.h_g1_madd_w_chain(bytes(192), g2.points_to_bytes(seq), sg, len(seq), out)
+        Hc.h_g1_madd_w_chain(bytes(JREC), g2.points_to_bytes(seq), sg, len(seq), out)
         assert g2.jacobian_bytes_to_affine(out.raw) == want
-    Hc.h_g1_madd_chain(bytes(192), g2.points_to_bytes(pts[:50] + [pts[3]]), 51, out)
+    Hc.h_g1_madd_chain(bytes(JREC), g2.points_to_bytes(pts[:50] + [pts[3]]), 51, out)
     want = None
     for pt in pts[:50] + [pts[3]]:
         want = g2.add(want, pt)
@@ -382,19 +386,19 @@ def test_host_arithmetic_instantiated_for_bn254_g2(tmp_path_factory):
     def jac(pt, k):
         z = (r.randrange(1, P), r.randrange(P)) if k else (1, 0)
         if pt is None:
-            return bytes(192)
+            return bytes(JREC)
         z2 = g2.f2_sqr(z)
         return g2.f2_to_bytes(g2.f2_mul(pt[0], z2)) + g2.f2_to_bytes(g2.f2_mul(pt[1], g2.f2_mul(z2, z))) + g2.f2_to_bytes(z)
 
     pa = [pts[i] for i in range(40)] + [None, pts[0], pts[1]]
     pb = [pts[i + 40] for i in range(40)] + [pts[2], pts[0], g2.neg(pts[1])]
     JA, JB = b"".join(jac(p_, 1) for p_ in pa), b"".join(jac(p_, i % 2) for i, p_ in enumerate(pb))
-    out = C.create_string_buffer(192 * len(pa))
+    out = C.create_string_buffer(JREC * len(pa))
     Hc.h_g1_op(0, JA, JB, out, len(pa))
-    assert [g2.jacobian_bytes_to_affine(out.raw[192 * i:192 * i + 192]) for i in range(len(pa))] == [g2.add(a, b) for a, b in zip(pa, pb)]
+    assert [g2.jacobian_bytes_to_affine(out.raw[JREC * i:JREC * i + JREC]) for i in range(len(pa))] == [g2.add(a, b) for a, b in zip(pa, pb)]
     Hc.h_g1_op(1, JA, None, out, len(pa))
-    assert [g2.jacobian_bytes_to_affine(out.raw[192 * i:192 * i + 192]) for i in range(len(pa))] == [g2.add(a, a) for a in pa]
-    o1 = C.create_string_buffer(192)
+    assert [g2.jacobian_bytes_to_affine(out.raw[JREC * i:JREC * i + JREC]) for i in range(len(pa))] == [g2.add(a, a) for a in pa]
+    o1 = C.create_string_buffer(JREC)
     for k in (0, 1, 2, 0x7fff, 0x8000, 0xffffffff):
         Hc.h_g1_mul_u32(jac(pts[9], 1), k, o1)
         assert g2.jacobian_bytes_to_affine(o1.raw) == g2.mul(k, pts[9]), k

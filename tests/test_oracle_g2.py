@@ -1,14 +1,27 @@
-"""The BN254 G2 model (oracle/bn254_g2_ref.py) pinned: public parameters, field identities, and its two MSM algorithms against each other."""
+"""The G2 models (oracle/bn254_g2_ref.py and its BLS12-381 instance) pinned: public parameters, field identities, and their two MSM
+algorithms against each other and against the closed form over known multiples of the generator."""
+import importlib
+
 import pytest
 
-from oracle import bn254_g2_ref as g2
-from oracle import bn254_ref as g1
+from oracle import bls12_381_ref, bn254_ref
+
+
+@pytest.fixture(params=["bn254_g2", "bls12_381_g2"], autouse=True)
+def model(request):
+    global g2
+    g2 = importlib.import_module("oracle." + request.param + "_ref")
+    return g2
 
 
 def test_parameters_and_generator():
-    assert g2.P == g1.P and g2.R == g1.R  # the same base and scalar fields as G1 (src/cuzk/msm.rs:39, src/naive/utils/bigint.rs:85)
+    g1 = bn254_ref if g2.FB == 32 else bls12_381_ref
+    assert g2.P == g1.P and g2.R == g1.R  # the same base and scalar fields as the curve's G1 (BN254: src/cuzk/msm.rs:39, src/naive/utils/bigint.rs:85)
     assert g2.f2_mul((0, 1), (0, 1)) == (g2.P - 1, 0)  # u^2 = -1
-    assert g2.f2_mul(g2.B, (9, 1)) == (3, 0)  # the twist's constant is 3 / (9 + u)
+    if g2.FB == 32:
+        assert g2.f2_mul(g2.B, (9, 1)) == (3, 0)  # BN254: the twist's constant is 3 / (9 + u)
+    else:
+        assert g2.B == g2.f2_scale((1, 1), 4)  # BLS12-381: 4 (1 + u)
     assert g2.is_on_curve(g2.G)
     assert g2.mul(g2.R, g2.G) is g2.INF and g2.add(g2.mul(g2.R - 1, g2.G), g2.G) is g2.INF  # the generator has order r
     assert g2.mul(2, g2.G) == g2.add(g2.G, g2.G) and g2.is_on_curve(g2.mul(2, g2.G))
@@ -30,7 +43,7 @@ def test_the_two_msm_algorithms_agree(n, seed):
     pts = g2.sample_points(n, seed)
     assert all(g2.is_on_curve(p) for p in pts) and len(set(pts)) == n
     sc = [g2.sample_scalar(seed + 100, i) for i in range(n)]
-    assert g2.msm_naive(pts, sc) == g2.msm_pippenger(pts, sc)
+    assert g2.msm_naive(pts, sc) == g2.msm_pippenger(pts, sc) == g2.msm_by_multipliers(g2.sample_multipliers(n, seed), sc)
     edge = [0, 1, g2.R - 1, 0x8000, 0x7fff, (1 << 253) + 0x80008000][:n]
     assert g2.msm_naive(pts[: len(edge)], edge) == g2.msm_pippenger(pts[: len(edge)], edge)
 
@@ -38,7 +51,8 @@ def test_the_two_msm_algorithms_agree(n, seed):
 def test_wire_format_round_trip():
     pts = g2.sample_points(4, 9)
     b = g2.points_to_bytes(pts)
-    assert len(b) == 4 * 128 and g2.bytes_to_points(b) == pts
-    assert b[:32] == pts[0][0][0].to_bytes(32, "little") and b[32:64] == pts[0][0][1].to_bytes(32, "little")  # c0 || c1
+    fb = g2.FB
+    assert len(b) == 4 * 4 * fb and g2.bytes_to_points(b) == pts
+    assert b[:fb] == pts[0][0][0].to_bytes(fb, "little") and b[fb:2 * fb] == pts[0][0][1].to_bytes(fb, "little")  # c0 || c1
     j = g2.f2_to_bytes(pts[1][0]) + g2.f2_to_bytes(pts[1][1]) + g2.f2_to_bytes((1, 0))
-    assert g2.jacobian_bytes_to_affine(j) == pts[1] and g2.jacobian_bytes_to_affine(bytes(192)) is g2.INF
+    assert g2.jacobian_bytes_to_affine(j) == pts[1] and g2.jacobian_bytes_to_affine(bytes(6 * fb)) is g2.INF

@@ -1,6 +1,6 @@
 """The same engine on every curve it is built for: pipelined MSM time at 2^logn (endomorphism bases, two launches in flight, as
 bench.py's single-GPU line), single-MSM latency, SMVP kernel time; one result per curve checked bit-exactly against that curve's oracle.
-usage: curve_throughput.py [logn]   (test infrastructure: uses the oracle)"""
+usage: curve_throughput.py [logn [curve ...]]   (test infrastructure: uses the oracle)"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,12 +8,21 @@ import msm_webgpu_amd as m
 
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 n = 1 << logn
-for curve in ("bn254", "grumpkin", "pallas", "vesta", "bls12_381"):
-    cpu = importlib.import_module("oracle.cpu" if curve == "bn254" else "oracle.cpu_" + curve)
+for curve in (sys.argv[2:] or ["bn254", "grumpkin", "pallas", "vesta", "bls12_381", "bn254_g2", "bls12_381_g2"]):
     ctx = m.MsmContext(0, curve=curve)
-    pts, sc = ctx.sample_points(n, 1), [ctx.sample_scalars(n, 2 + i) for i in range(2)]
-    # (BLS12-381's cofactor is not 1: the samplers' curve points are outside the order-r subgroup, where the endomorphism mode is not exact)
-    ctx.set_bases(pts, endomorphism=curve != "bls12_381")
+    sc = [ctx.sample_scalars(n, 2 + i) for i in range(2)]
+    if curve.endswith("_g2"):
+        # G2 (coordinates in Fq2: csrc/fq2.h): no device sampler and no second CPU model -- the bases are 2^14 known multiples of the generator,
+        # repeated, and the expected result is the closed form (sum_i s_i m_i mod r) G (oracle/bn254_g2_ref.py); plain bases (no endomorphism mode)
+        g2 = importlib.import_module("oracle." + curve + "_ref")
+        base = min(n, 1 << 14)
+        pts = torch.frombuffer(bytearray(g2.points_to_bytes(g2.sample_points(base, 1))), dtype=torch.uint8).cuda().view(base, 2 * g2.CB).repeat(n // base, 1).contiguous()
+        ctx.set_bases(pts)
+    else:
+        cpu = importlib.import_module("oracle.cpu" if curve == "bn254" else "oracle.cpu_" + curve)
+        pts = ctx.sample_points(n, 1)
+        # (BLS12-381's cofactor is not 1: the samplers' curve points are outside the order-r subgroup, where the endomorphism mode is not exact)
+        ctx.set_bases(pts, endomorphism=curve != "bls12_381")
     ctx.set_stage_timing(1)
     def run(k):
         fl, last = [], None
@@ -35,7 +44,10 @@ for curve in ("bn254", "grumpkin", "pallas", "vesta", "bls12_381"):
     lat = []
     for i in range(5):
         torch.cuda.synchronize(); t1 = time.perf_counter(); ctx.msm(sc[i & 1]); lat.append((time.perf_counter() - t1) * 1e3)
-    want = cpu.to_affine64(cpu.cpu_msm(pts.cpu().numpy().tobytes(), sc[1].cpu().numpy().tobytes(), min(os.cpu_count() or 1, 32)))
-    print("%-9s 2^%d: %.4f ms per MSM pipelined (%.0f MSM/s), SMVP kernel %.3f ms, latency %.3f ms, bit-exact vs its oracle: %s"
+    if curve.endswith("_g2"):
+        want = g2.affine_to_bytes(g2.msm_by_multipliers(g2.sample_multipliers(base, 1) * (n // base), g2.bytes_to_scalars(sc[1].cpu().numpy().tobytes())))
+    else:
+        want = cpu.to_affine64(cpu.cpu_msm(pts.cpu().numpy().tobytes(), sc[1].cpu().numpy().tobytes(), min(os.cpu_count() or 1, 32)))
+    print("%-12s 2^%d: %.4f ms per MSM pipelined (%.0f MSM/s), SMVP kernel %.3f ms, latency %.3f ms, bit-exact vs its oracle: %s"
           % (curve, logn, step, 1e3 / step, smvp, sorted(lat)[2], last.to_affine_bytes() == want), flush=True)
     ctx.close()
