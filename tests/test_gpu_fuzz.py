@@ -20,7 +20,7 @@ def test_fuzz_against_oracle(built, capsys):
     assert "fuzz ok: 60 cases" in capsys.readouterr().out
 
 
-@pytest.mark.parametrize("curve,cases", [("grumpkin", 30), ("pallas", 12), ("vesta", 12), ("bls12_381", 8)])
+@pytest.mark.parametrize("curve,cases", [("grumpkin", 30), ("pallas", 12), ("vesta", 12), ("bls12_381", 8), ("bn254_g2", 10), ("bls12_381_g2", 6)])
 def test_fuzz_against_oracle_other_curves(built, capsys, curve, cases):
     argv = sys.argv
     sys.argv = ["fuzz_gpu.py", str(cases), "20261005", curve]

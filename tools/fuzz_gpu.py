@@ -1,6 +1,6 @@
 """Randomised differential test of the HIP engine against the CPU oracle: random sizes (tile / chunk / alignment edges),
 random scalar distributions (uniform, few distinct values, small values, zeros, equal), random window ranges.
-Usage: python tools/fuzz_gpu.py [cases] [seed] [bn254|grumpkin|pallas|vesta|bls12_381]   (test infrastructure: uses the oracle)"""
+Usage: python tools/fuzz_gpu.py [cases] [seed] [bn254|grumpkin|pallas|vesta|bls12_381|bn254_g2|bls12_381_g2]   (test infrastructure: uses the oracle)"""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +9,39 @@ from msm_webgpu_amd.sharding import window_range
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 curve = sys.argv[3] if len(sys.argv) > 3 else "bn254"
-if curve != "bn254":  # another curve through the same entry points (its oracles: oracle/cpu_<curve>.py, <curve>_ref.py)
+if curve.endswith("_g2"):
+    # G2 (coordinates in Fq2): the checker is the Python model's CLOSED FORM -- the points are drawn from a pool of known multiples m G of the
+    # generator (and their negatives), so sum_i s_i P_i = (sum_i s_i m_i mod r) G for any size and scalar distribution
+    import importlib
+    ref = importlib.import_module("oracle." + curve + "_ref")
+
+    class ClosedFormG2:
+        POOL = 1 << 12
+
+        def __init__(self):
+            self.pts, self.mult = ref.sample_points(self.POOL, 99), ref.sample_multipliers(self.POOL, 99)
+            self.enc = [ref.points_to_bytes([p]) for p in self.pts]
+            self.m_of = {e: k for e, k in zip(self.enc, self.mult)}
+            self.m_of.update({ref.points_to_bytes([ref.neg(p)]): (-k) % ref.R for p, k in zip(self.pts, self.mult)})
+
+        def sample_points(self, seed, n):
+            r = random.Random(seed)
+            start, stride = r.randrange(self.POOL), r.choice([1, 3, 5, 7])
+            return b"".join(self.enc[(start + stride * i) % self.POOL] for i in range(n))
+
+        def sample_scalars(self, seed, n):
+            return ref.scalars_to_bytes([ref.sample_scalar(seed, i) for i in range(n)])
+
+        def cpu_msm(self, points, sb):
+            pb = 2 * ref.CB
+            k = sum(self.m_of[points[pb * i:pb * i + pb]] * s for i, s in enumerate(ref.bytes_to_scalars(sb))) % ref.R
+            return ref.affine_to_bytes(ref.mul(k, ref.G))  # (already affine: to_affine64 below is the identity on it)
+
+        def to_affine64(self, b):
+            return b if len(b) == 2 * ref.CB else ref.affine_to_bytes(ref.jacobian_bytes_to_affine(b))
+
+    cpu = ClosedFormG2()
+elif curve != "bn254":  # another curve through the same entry points (its oracles: oracle/cpu_<curve>.py, <curve>_ref.py)
     import importlib
     cpu, ref = importlib.import_module("oracle.cpu_" + curve), importlib.import_module("oracle." + curve + "_ref")
 else:
@@ -23,6 +55,8 @@ MODES = ["host", "device", "windows", "batch", "group", "hostbatch", "mont", "bi
          "group_halves", "mgpu_batch", "mgpu_batch_endo"]
 if curve == "bls12_381":
     MODES = [x for x in MODES if x not in ("mont", "endo", "endo_batch", "group_halves", "mgpu_batch_endo")]
+if curve.endswith("_g2"):  # (a G2 context has no endomorphism, fixed-base-table or Montgomery-scalar mode)
+    MODES = [x for x in MODES if x not in ("mont", "tables", "tables_batch", "endo", "endo_batch", "group_halves", "mgpu_batch_endo")]
 combine = lambda sums: m.MsmContext.combine_windows(sums, curve=curve)
 mg = {}  # lazily created msm_hip_mgpu handles by rank count (several contexts on this one GPU, pinned-buffer gather)
 R = ref.R
