@@ -1086,7 +1086,15 @@ __device__ __forceinline__ void smvp_assign(g1_xyzz& acc, const g1_xyzz& src) {
   acc.inf = src.inf;
 }
 
-constexpr int SMVP_WAVES_PER_SIMD = FQ_L <= 9 ? 3 : FQ_L <= 14 ? 2 : 1;  // 168 VGPRs hold the 9-limb loop; 14 limbs take up to 256; Fq2's 18 limbs the whole file
+// 168 VGPRs hold the 9-limb loop (3 waves per SIMD); 14 limbs take up to 256 (2 waves).  Fq2 on 9 limbs (BN254 G2) wants 278: capped at 256 -- 12 words
+// of scratch -- because the second wave is worth 23 % of the kernel (4.29 -> 3.31 ms at 2^20, profiles/r03_g2_throughput.txt); Fq2 on 14 limbs: one wave
+constexpr int SMVP_WAVES_PER_SIMD = FQ_L <= 9 ? 3 : FQ_L <= 18 ? 2 : 1;
+// the stitch and the row / column sums (full additions: the widest kernels after the SMVP) in a unit with 18 limbs per coordinate: two waves per
+// SIMD as well (256 VGPRs + 0.26 KB of scratch instead of 309 - 317 + AGPRs: -1.5 % per MSM)
+#ifndef MSM_REDUCE_WAVES_FQ2
+#define MSM_REDUCE_WAVES_FQ2 2
+#endif
+constexpr int REDUCE_WAVES_PER_SIMD = FQ_L == 18 ? MSM_REDUCE_WAVES_FQ2 : 1;  // (1: no constraint beyond the workgroup size)
 __global__ void __launch_bounds__(256, SMVP_WAVES_PER_SIMD) k_smvp_chunks(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ col_ptr,
                                                      const uint32_t* __restrict__ val_idxs, size_t stride, uint32_t chunks,
                                                      const uint32_t* __restrict__ chunk_len_dev, const uint32_t* __restrict__ chunk_slot,
@@ -1195,7 +1203,7 @@ __device__ __forceinline__ void lds_add_pair(uint32_t* x, int dst, int src) {
 constexpr uint32_t STITCH_BIG = 32;
 constexpr uint32_t STITCH_BIG_CAP = 1 << 15;  // queue capacity; more big buckets than this fall back to the serial walk
 
-__global__ void __launch_bounds__(256) k_smvp_stitch(const uint32_t* __restrict__ col_ptr, uint32_t chunks, const uint32_t* __restrict__ chunk_len_dev,
+__global__ void __launch_bounds__(256, REDUCE_WAVES_PER_SIMD) k_smvp_stitch(const uint32_t* __restrict__ col_ptr, uint32_t chunks, const uint32_t* __restrict__ chunk_len_dev,
                                                      const uint32_t* __restrict__ heads, const uint32_t* __restrict__ tails,
                                                      uint32_t* __restrict__ buckets, uint32_t* __restrict__ big_queue) {
   const int lw = blockIdx.y;
@@ -1357,7 +1365,7 @@ constexpr int BPR_ROWS = 256, BPR_COLS = 128;
 // LOG_ROWS = log2 of the rows of the window's bucket grid: 2^(C-1) buckets = 2^LOG_ROWS rows x 128 columns (8 / 6 / 4 for
 // C = 16 / 14 / 12).  The row sums of window w land in rows[w][0 .. ROWS) (stride BPR_ROWS), the column sums in cols[w][0 .. 128).
 template <int LOG_R, int LOG_ROWS>
-__global__ void __launch_bounds__(256) k_bpr_rowcol(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ rows,
+__global__ void __launch_bounds__(256, REDUCE_WAVES_PER_SIMD) k_bpr_rowcol(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ rows,
                                                     uint32_t* __restrict__ cols) {
   constexpr int R = 1 << LOG_R, ROWS = 1 << LOG_ROWS, NB = ROWS * BPR_COLS;
   static_assert(ROWS <= BPR_ROWS && R <= ROWS && R <= BPR_COLS, "bucket grid");
