@@ -14,7 +14,20 @@ typedef unsigned __int128 u128;
 /* NL 64-bit limbs per base-field element (4; 6 for BLS12-381: bn254.h), CB bytes per coordinate on the wire, PB per affine point, JB per
  * Jacobian record; scalars are 32 bytes on every curve */
 #define NL ONL
-#define CB (8 * NL)
+#define FB (8 * NL) /* bytes of a prime-field element */
+#if defined(ORACLE_G2)
+/* -DORACLE_G2 (with or without -DORACLE_BLS12_381): the same restatement over G2, the order-r subgroup of the sextic twist over
+ * Fq2 = Fq[u] / (u^2 + 1) (SURVEY.md 8f-4 "other curves / G2"; halo2curves' msm_best is generic over CurveAffine, so the reference's CPU path
+ * applied to G2Affine is this algorithm): the prime field below becomes `fp_*` / `ofp`, and `ofq` / `fq_*` -- what the group code, the MSM and
+ * the stage models are written against -- are Fq2 on top of it.  A coordinate is c0 || c1 on the wire. */
+#define CB (2 * FB)
+#define BF(name) fp_##name
+typedef ofp bfe;
+#else
+#define CB FB
+#define BF(name) fq_##name
+typedef ofq bfe;
+#endif
 #define PB (2 * CB)
 #define JB (3 * CB)
 #define FBITS (64 * NL)
@@ -58,7 +71,7 @@ static const uint64_t FQ_N0 = 0x8c46eb20ffffffffull;
 #define CURVE_B_ABS 5
 #endif
 
-static ofq FQ_R1, FQ_R2, FQ_ZERO, FQ_B3; /* R mod p, R^2 mod p, 0, 3*R mod p ; filled by init */
+static bfe BF_R1, BF_R2, BF_ZERO; /* prime field: R mod p, R^2 mod p, 0; filled by init */
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
 
 static int ge_p(const uint64_t a[NL]) {
@@ -76,7 +89,7 @@ static void sub_p(uint64_t a[NL]) {
     br = (t >> 64) & 1;
   }
 }
-static void fq_add(ofq* o, const ofq* a, const ofq* b) {
+static void BF(add)(bfe* o, const bfe* a, const bfe* b) {
   u128 c = 0;
   uint64_t t[NL];
   for (int i = 0; i < NL; i++) {
@@ -86,9 +99,9 @@ static void fq_add(ofq* o, const ofq* a, const ofq* b) {
   }
   /* p < 2^254 so a + b < 2^255: no carry out */
   if (ge_p(t)) sub_p(t);
-  memcpy(o->l, t, CB);
+  memcpy(o->l, t, FB);
 }
-static void fq_sub(ofq* o, const ofq* a, const ofq* b) {
+static void BF(sub)(bfe* o, const bfe* a, const bfe* b) {
   u128 br = 0;
   uint64_t t[NL];
   for (int i = 0; i < NL; i++) {
@@ -104,19 +117,19 @@ static void fq_sub(ofq* o, const ofq* a, const ofq* b) {
       c >>= 64;
     }
   }
-  memcpy(o->l, t, CB);
+  memcpy(o->l, t, FB);
 }
-static void fq_neg(ofq* o, const ofq* a) { fq_sub(o, &FQ_ZERO, a); }
-static void fq_dbl(ofq* o, const ofq* a) { fq_add(o, a, a); }
-static int fq_is_zero(const ofq* a) {
+static void BF(neg)(bfe* o, const bfe* a) { BF(sub)(o, &BF_ZERO, a); }
+static void BF(dbl)(bfe* o, const bfe* a) { BF(add)(o, a, a); }
+static int BF(is_zero)(const bfe* a) {
   uint64_t z = 0;
   for (int i = 0; i < NL; i++) z |= a->l[i];
   return z == 0;
 }
-static int fq_eq(const ofq* a, const ofq* b) { return memcmp(a->l, b->l, CB) == 0; }
+static int BF(eq)(const bfe* a, const bfe* b) { return memcmp(a->l, b->l, FB) == 0; }
 
 /* CIOS Montgomery product */
-static void fq_mul(ofq* o, const ofq* a, const ofq* b) {
+static void BF(mul)(bfe* o, const bfe* a, const bfe* b) {
   uint64_t t[NL + 2];
   memset(t, 0, sizeof t);
   for (int i = 0; i < NL; i++) {
@@ -142,55 +155,120 @@ static void fq_mul(ofq* o, const ofq* a, const ofq* b) {
     t[NL] = t[NL + 1] + (uint64_t)(c >> 64);
   }
   if (t[NL] || ge_p(t)) sub_p(t);
-  memcpy(o->l, t, CB);
+  memcpy(o->l, t, FB);
 }
-static void fq_sqr(ofq* o, const ofq* a) { fq_mul(o, a, a); }
+static void BF(sqr)(bfe* o, const bfe* a) { BF(mul)(o, a, a); }
 
-static void fq_pow(ofq* o, const ofq* a, const uint64_t e[NL]) {
-  ofq acc = FQ_R1, base = *a;
+static void BF(pow)(bfe* o, const bfe* a, const uint64_t e[NL]) {
+  bfe acc = BF_R1, base = *a;
   for (int i = 0; i < FBITS; i++) {
-    if ((e[i >> 6] >> (i & 63)) & 1) fq_mul(&acc, &acc, &base);
-    fq_sqr(&base, &base);
+    if ((e[i >> 6] >> (i & 63)) & 1) BF(mul)(&acc, &acc, &base);
+    BF(sqr)(&base, &base);
   }
   *o = acc;
 }
-static void fq_inv(ofq* o, const ofq* a) {
+static void BF(inv)(bfe* o, const bfe* a) {
   uint64_t e[NL];
-  memcpy(e, FQ_P, CB);
+  memcpy(e, FQ_P, FB);
   e[0] -= 2;
-  fq_pow(o, a, e);
+  BF(pow)(o, a, e);
 }
 /* canonical LE bytes <-> Montgomery */
-static int fq_from_bytes(ofq* o, const uint8_t* b) {
-  ofq t;
-  memcpy(t.l, b, CB); /* little-endian host */
+static int BF(from_bytes)(bfe* o, const uint8_t* b) {
+  bfe t;
+  memcpy(t.l, b, FB); /* little-endian host */
   int canonical = !ge_p(t.l);
-  fq_mul(o, &t, &FQ_R2);
+  BF(mul)(o, &t, &BF_R2);
   return canonical;
 }
-static void fq_to_bytes(uint8_t* b, const ofq* a) {
-  ofq one, t;
+static void BF(to_bytes)(uint8_t* b, const bfe* a) {
+  bfe one, t;
   memset(&one, 0, sizeof one);
   one.l[0] = 1;
-  fq_mul(&t, a, &one);
-  memcpy(b, t.l, CB);
+  BF(mul)(&t, a, &one);
+  memcpy(b, t.l, FB);
 }
 
+#if defined(ORACLE_G2)
+/* Fq2 = Fq[u] / (u^2 + 1): schoolbook / Karatsuba on the prime field above, under the names the rest of the file uses */
+static ofq FQ_R1, FQ_ZERO; /* 1 and 0 of Fq2 */
+static void fq_add(ofq* o, const ofq* a, const ofq* b) { fp_add(&o->c0, &a->c0, &b->c0); fp_add(&o->c1, &a->c1, &b->c1); }
+static void fq_sub(ofq* o, const ofq* a, const ofq* b) { fp_sub(&o->c0, &a->c0, &b->c0); fp_sub(&o->c1, &a->c1, &b->c1); }
+static void fq_neg(ofq* o, const ofq* a) { fp_neg(&o->c0, &a->c0); fp_neg(&o->c1, &a->c1); }
+static void fq_dbl(ofq* o, const ofq* a) { fq_add(o, a, a); }
+static int fq_is_zero(const ofq* a) { return fp_is_zero(&a->c0) && fp_is_zero(&a->c1); }
+static int fq_eq(const ofq* a, const ofq* b) { return fp_eq(&a->c0, &b->c0) && fp_eq(&a->c1, &b->c1); }
+static void fq_mul(ofq* o, const ofq* a, const ofq* b) {
+  ofp v0, v1, s, t;
+  fp_mul(&v0, &a->c0, &b->c0);
+  fp_mul(&v1, &a->c1, &b->c1);
+  fp_add(&s, &a->c0, &a->c1);
+  fp_add(&t, &b->c0, &b->c1);
+  fp_mul(&s, &s, &t);
+  fp_sub(&s, &s, &v0);
+  fp_sub(&o->c1, &s, &v1); /* a0 b1 + a1 b0 */
+  fp_sub(&o->c0, &v0, &v1); /* a0 b0 - a1 b1 */
+}
+static void fq_sqr(ofq* o, const ofq* a) { fq_mul(o, a, a); }
+static void fq_inv(ofq* o, const ofq* a) { /* (a0 - a1 u) / (a0^2 + a1^2) */
+  ofp n, t;
+  fp_sqr(&n, &a->c0);
+  fp_sqr(&t, &a->c1);
+  fp_add(&n, &n, &t);
+  fp_inv(&n, &n);
+  fp_mul(&o->c0, &a->c0, &n);
+  fp_neg(&t, &a->c1);
+  fp_mul(&o->c1, &t, &n);
+}
+static int fq_from_bytes(ofq* o, const uint8_t* b) {
+  const int ok0 = fp_from_bytes(&o->c0, b), ok1 = fp_from_bytes(&o->c1, b + FB);
+  return ok0 && ok1;
+}
+static void fq_to_bytes(uint8_t* b, const ofq* a) {
+  fp_to_bytes(b, &a->c0);
+  fp_to_bytes(b + FB, &a->c1);
+}
+#else
+#define FQ_R1 BF_R1
+#define FQ_R2 BF_R2
+#define FQ_ZERO BF_ZERO
+#endif
+static ofq FQ_B3; /* the curve constant b (G2: the twist's), Montgomery form (the name is BN254 G1's: b = 3) */
+
 static void oracle_init(void) {
-  memset(&FQ_ZERO, 0, sizeof FQ_ZERO);
+  memset(&BF_ZERO, 0, sizeof BF_ZERO);
   /* R mod p by FBITS modular doublings of 1; R^2 by FBITS more */
-  ofq one;
+  bfe one;
   memset(&one, 0, sizeof one);
   one.l[0] = 1;
-  ofq t = one;
-  for (int i = 0; i < FBITS; i++) fq_dbl(&t, &t);
-  FQ_R1 = t;
-  for (int i = 0; i < FBITS; i++) fq_dbl(&t, &t);
-  FQ_R2 = t;
-  ofq b = FQ_ZERO; /* the curve constant in Montgomery form (the name FQ_B3 is BN254's: b = 3) */
-  for (int i = 0; i < CURVE_B_ABS; i++) fq_add(&b, &b, &FQ_R1);
-  if (CURVE_B_IS_MINUS) fq_neg(&b, &b);
+  bfe t = one;
+  for (int i = 0; i < FBITS; i++) BF(dbl)(&t, &t);
+  BF_R1 = t;
+  for (int i = 0; i < FBITS; i++) BF(dbl)(&t, &t);
+  BF_R2 = t;
+  bfe b = BF_ZERO; /* the G1 curve constant in Montgomery form (the name FQ_B3 is BN254's: b = 3) */
+  for (int i = 0; i < CURVE_B_ABS; i++) BF(add)(&b, &b, &BF_R1);
+  if (CURVE_B_IS_MINUS) BF(neg)(&b, &b);
+#if defined(ORACLE_G2)
+  memset(&FQ_ZERO, 0, sizeof FQ_ZERO);
+  FQ_R1 = FQ_ZERO;
+  FQ_R1.c0 = BF_R1;
+  /* the twist's constant: b / xi with xi = 9 + u (BN254, a D-type twist: b' = 3 / (9 + u)), b * (1 + u) for BLS12-381 (M-type: 4 (1 + u)) */
+  ofq bq = FQ_ZERO, xi = FQ_ZERO;
+  bq.c0 = b;
+#if defined(ORACLE_BLS12_381)
+  xi.c0 = BF_R1;
+  xi.c1 = BF_R1;
+  fq_mul(&FQ_B3, &bq, &xi);
+#else
+  for (int i = 0; i < 9; i++) fp_add(&xi.c0, &xi.c0, &BF_R1);
+  xi.c1 = BF_R1;
+  fq_inv(&xi, &xi);
+  fq_mul(&FQ_B3, &bq, &xi);
+#endif
+#else
   FQ_B3 = b;
+#endif
 }
 static void ensure_init(void) { pthread_once(&g_once, oracle_init); }
 
@@ -420,10 +498,10 @@ int oracle_coord_bytes(void) { return CB; }
 
 void oracle_constants(uint8_t* p, uint8_t r[32], uint8_t* r2_mod_p, uint8_t* one_mont, uint64_t* n0inv64) {
   ensure_init();
-  memcpy(p, FQ_P, CB);
+  memcpy(p, FQ_P, FB); /* (prime-field constants in every build: FB bytes each) */
   memcpy(r, FR_R, 32);
-  memcpy(r2_mod_p, FQ_R2.l, CB);
-  memcpy(one_mont, FQ_R1.l, CB);
+  memcpy(r2_mod_p, BF_R2.l, FB);
+  memcpy(one_mont, BF_R1.l, FB);
   *n0inv64 = FQ_N0;
 }
 
@@ -773,7 +851,7 @@ static void draw_words(uint64_t seed, uint64_t index, uint64_t attempt, uint64_t
   else out[nl - 1] &= (1ull << (381 - 64 * (nl - 1))) - 1; /* 381 bits */
 }
 static void draw256(uint64_t seed, uint64_t index, uint64_t attempt, uint64_t domain, uint64_t out[4]) { draw_words(seed, index, attempt, domain, out, 4); }
-static int ltn(const uint64_t* a, const uint64_t* m, int nl) {
+static __attribute__((unused)) int ltn(const uint64_t* a, const uint64_t* m, int nl) {
   for (int i = nl - 1; i >= 0; i--) {
     if (a[i] < m[i]) return 1;
     if (a[i] > m[i]) return 0;
@@ -799,6 +877,7 @@ void oracle_sample_scalars(uint64_t seed, size_t first, size_t n, uint8_t* out32
   }
 }
 
+#if !defined(ORACLE_G2)
 /* square root in Fq for the samplers: y with y^2 = a, or 0 (return value) if a is not a square.
  * p = 3 mod 4 (BN254 Fq): a^((p+1)/4).  Otherwise (Grumpkin's base field, p - 1 = 2^28 t): Tonelli-Shanks. */
 static int fq_sqrt(ofq* y, const ofq* a, const uint64_t* e_p3) {
@@ -916,3 +995,62 @@ void oracle_sample_points(uint64_t seed, size_t first, size_t n, uint8_t* out64)
     }
   }
 }
+#else /* ORACLE_G2 */
+/* G2 has no try-and-increment sampler here (a square root in Fq2): the synthetic points are KNOWN multiples of the generator,
+ * P_i = (a + i b) G with a = sample_scalar(seed ^ 0x6732, 0) | 1, b = sample_scalar(seed ^ 0x6732, 1) | 1 -- the definition of
+ * oracle/bn254_g2_ref.py: sample_points, which this must reproduce byte for byte -- by repeated addition and one batched inversion. */
+static const uint64_t G2_GEN[4][NL] = {
+#if defined(ORACLE_BLS12_381) /* the standard generator of BLS12-381's G2 (x.c0, x.c1, y.c0, y.c1) */
+  {0xd48056c8c121bdb8ull, 0x0bac0326a805bbefull, 0xb4510b647ae3d177ull, 0xc6e47ad4fa403b02ull, 0x260805272dc51051ull, 0x024aa2b2f08f0a91ull},
+  {0xe5ac7d055d042b7eull, 0x334cf11213945d57ull, 0xb5da61bbdc7f5049ull, 0x596bd0d09920b61aull, 0x7dacd3a088274f65ull, 0x13e02b6052719f60ull},
+  {0xe193548608b82801ull, 0x923ac9cc3baca289ull, 0x6d429a695160d12cull, 0xadfd9baa8cbdd3a7ull, 0x8cc9cdc6da2e351aull, 0x0ce5d527727d6e11ull},
+  {0xaaa9075ff05f79beull, 0x3f370d275cec1da1ull, 0x267492ab572e99abull, 0xcb3e287e85a763afull, 0x32acd2b02bc28b99ull, 0x0606c4a02ea734ccull},
+#else /* BN254: the generator of EIP-197 */
+  {0x46debd5cd992f6edull, 0x674322d4f75edaddull, 0x426a00665e5c4479ull, 0x1800deef121f1e76ull},
+  {0x97e485b7aef312c2ull, 0xf1aa493335a9e712ull, 0x7260bfb731fb5d25ull, 0x198e9393920d483aull},
+  {0x4ce6cc0166fa7daaull, 0xe3d1e7690c43d37bull, 0x4aab71808dcb408full, 0x12c85ea5db8c6debull},
+  {0x55acdadcd122975bull, 0xbc4b313370b38ef3ull, 0xec9e99ad690c3395ull, 0x090689d0585ff075ull},
+#endif
+};
+void oracle_sample_points(uint64_t seed, size_t first, size_t n, uint8_t* out64) {
+  ensure_init();
+  if (n == 0) return;
+  uint8_t ab[64], gen[PB];
+  oracle_sample_scalars(seed ^ 0x6732ull, 0, 2, ab);
+  ab[0] |= 1;
+  ab[32] |= 1;
+  memcpy(gen, G2_GEN, PB);
+  og1 g, cur, step, t;
+  fq_from_bytes(&g.x, gen);
+  fq_from_bytes(&g.y, gen + CB);
+  g.z = FQ_R1;
+  g1_mul_bytes(&cur, &g, ab);        /* a G */
+  g1_mul_bytes(&step, &g, ab + 32);  /* b G */
+  g1_mul_u64(&t, &step, (uint64_t)first);
+  g1_add(&cur, &cur, &t);
+  og1* jac = (og1*)malloc(n * sizeof(og1));
+  ofq* pref = (ofq*)malloc(n * sizeof(ofq));
+  ofq run = FQ_R1;
+  for (size_t i = 0; i < n; i++) {  /* (no point of the sequence is the identity: a + i b = 0 mod r has probability ~2^-234) */
+    jac[i] = cur;
+    pref[i] = run;
+    fq_mul(&run, &run, &cur.z);
+    g1_add(&cur, &cur, &step);
+  }
+  ofq inv;
+  fq_inv(&inv, &run);
+  for (size_t i = n; i-- > 0;) {
+    ofq zi, zi2, zi3, x, y;
+    fq_mul(&zi, &inv, &pref[i]);
+    fq_mul(&inv, &inv, &jac[i].z);
+    fq_sqr(&zi2, &zi);
+    fq_mul(&zi3, &zi2, &zi);
+    fq_mul(&x, &jac[i].x, &zi2);
+    fq_mul(&y, &jac[i].y, &zi3);
+    fq_to_bytes(out64 + PB * i, &x);
+    fq_to_bytes(out64 + PB * i + CB, &y);
+  }
+  free(jac);
+  free(pref);
+}
+#endif

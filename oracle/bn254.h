@@ -21,6 +21,8 @@
  *   oracle_*_bucket_reduction  serial / running-sum / parallel (1,2)      src/cuzk/test/utils.rs:222-338
  *   oracle_horner           host finalisation                             src/cuzk/msm.rs:411-416
  *   oracle_points/scalars_* wire format                                   src/lib.rs:50-65, src/cuzk/utils.rs:10-21
+ * Builds: BN254 G1 (default), -DORACLE_GRUMPKIN / _PALLAS / _VESTA / _BLS12_381 (other G1 curves), and -DORACLE_G2 (with or without
+ * -DORACLE_BLS12_381): the same restatement over G2 of BN254 / BLS12-381, coordinates in Fq2 = Fq[u] / (u^2 + 1) (bn254.c).
  */
 #ifndef ORACLE_BN254_H
 #define ORACLE_BN254_H
@@ -37,7 +39,12 @@ extern "C" {
 #else
 #define ONL 4
 #endif
+#if defined(ORACLE_G2) /* the G2 builds: coordinates in Fq2 = Fq[u] / (u^2 + 1), c0 || c1 on the wire (64 B; 96 B with ORACLE_BLS12_381) */
+typedef struct { uint64_t l[ONL]; } ofp;        /* prime-field element, Montgomery form, R = 2^(64 ONL) */
+typedef struct { ofp c0, c1; } ofq;             /* c0 + c1 u */
+#else
 typedef struct { uint64_t l[ONL]; } ofq;        /* Fq element, Montgomery form, R = 2^(64 ONL) */
+#endif
 typedef struct { ofq x, y, z; } og1;            /* Jacobian; z == 0 <=> identity (ec.template.wgsl:4) */
 
 /* ---- field / point op hooks (≙ tests/field.rs, tests/point.rs) : all I/O canonical little-endian ---- */

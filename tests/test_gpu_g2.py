@@ -4,9 +4,12 @@ Fq2 = Fq[u] / (u^2 + 1), scalars modulo the curve's r.  The coordinates are Fq2 
 18 (BN254) or 28 (BLS12-381) limbs per coordinate -- c0 || c1 on the wire: coordinates 64 / 96 B, points 128 / 192 B, Jacobian records
 192 / 288 B (csrc/curve_bn254_g2.hip, csrc/curve_bls12_381_g2.hip).
 
-Checked against the pure-Python models oracle/bn254_g2_ref.py / bls12_381_g2_ref.py (pinned in tests/test_oracle_g2.py): their Pippenger and
-double-and-add MSMs at the sizes Python finishes in seconds, and at full size through a closed form the synthetic points offer -- they are
-KNOWN multiples m_i G of the generator, so sum_i s_i P_i = (sum_i s_i m_i mod r) G whatever the size and whatever method the device used."""
+Checked against BOTH models of each curve's G2 (pinned and cross-checked in tests/test_oracle_g2.py): the pure-Python one
+(oracle/bn254_g2_ref.py / bls12_381_g2_ref.py: Pippenger and double-and-add MSMs at the sizes Python finishes in seconds) and the G2 builds of
+the C restatement (oracle/bn254.c -DORACLE_G2: the reference's CPU MSM and its stage models over Fq2, at full size) -- and through a closed
+form the synthetic points offer: they are KNOWN multiples m_i G of the generator, so sum_i s_i P_i = (sum_i s_i m_i mod r) G whatever the
+size and whatever method anybody used."""
+import os
 import importlib
 
 import pytest
@@ -25,11 +28,12 @@ def b32(x):
 
 @pytest.fixture(scope="module", params=["bn254_g2", "bls12_381_g2"])
 def env(request, built):
-    """The context of the curve under test; the module's globals g2 (its model), FB, CB, PB, JB follow it"""
-    global g2, FB, CB, PB, JB
+    """The context of the curve under test; the module's globals g2 / cpu (its Python / C model), FB, CB, PB, JB follow it"""
+    global g2, cpu, FB, CB, PB, JB
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     g2 = importlib.import_module("oracle." + request.param + "_ref")
+    cpu = importlib.import_module("oracle.cpu_" + request.param)
     FB, CB, PB, JB = g2.FB, g2.CB, 2 * g2.CB, 3 * g2.CB
     c = m.MsmContext(0, curve=request.param)
     yield c
@@ -186,19 +190,22 @@ def test_bucket_sums_and_window_sums_against_the_model(ctx):
 
 
 @pytest.mark.parametrize("logn", [16, 18, 20])
-def test_large_msm_by_the_closed_form(ctx, logn):
+def test_large_msm_against_the_cpu_msm_and_the_closed_form(ctx, logn):
+    # BASELINE config sizes (2^16: config 1; 2^20: config 2) on G2: 2^logn DISTINCT points (the C model's sampler: the same known multiples of
+    # the generator as the Python model's), the result against the C restatement of the reference's CPU MSM on the same inputs AND against the
+    # closed form (sum_i s_i m_i mod r) G
     if logn == 20 and ctx.curve != "bn254_g2":
         pytest.skip("2^20 on the reference's curve only (2^18 covers the 28-limb unit)")
-    # BASELINE config sizes (2^16: config 1; 2^20: config 2) on G2.  The bases are 2^14 known multiples of the generator repeated (equal
-    # points with independent scalars are ordinary inputs), so the expected result is (sum_i s_i m_i mod r) G without an MSM on the CPU.
-    n, base = 1 << logn, 1 << 14
-    pts, ms = g2.sample_points(base, 70), g2.sample_multipliers(base, 70)
-    points = torch.frombuffer(bytearray(g2.points_to_bytes(pts)), dtype=torch.uint8).cuda().view(base, PB).repeat(n // base, 1).contiguous()
-    ctx.set_bases(points)
+    n = 1 << logn
+    pb = cpu.sample_points(70 + logn, n)
+    assert pb[: 8 * PB] == g2.points_to_bytes(g2.sample_points(8, 70 + logn))
+    ms = g2.sample_multipliers(n, 70 + logn)
+    ctx.set_bases(pb, check_on_curve=True)
     sc = ctx.sample_scalars(n, 71 + logn)
     sb = sc.cpu().numpy().tobytes()
-    scalars = g2.bytes_to_scalars(sb)
-    want = g2.msm_by_multipliers(ms * (n // base), scalars)
+    assert sb[: 32 * 100] == cpu.sample_scalars(71 + logn, 100)
+    want = g2.msm_by_multipliers(ms, g2.bytes_to_scalars(sb))
+    assert cpu.to_affine64(cpu.cpu_msm(pb, sb, max(1, min(16, os.cpu_count() or 1)))) == g2.affine_to_bytes(want)
     assert ctx.msm(sc).to_affine() == want
     ctx.launch(sc, 0)
     ctx.launch(sc, 1)
@@ -206,20 +213,46 @@ def test_large_msm_by_the_closed_form(ctx, logn):
     if logn == 16:
         # skew: every scalar equal; a witness-like vector (70 % zeros and ones); one rank's shares of an 8-rank run, gathered in rank order
         s = (0x1234_5678_9ABC_DEF0_1357_9BDF_2468_ACE0_FEDC_BA98_7654_3210 * 0x10001) % g2.R
-        assert ctx.msm(b32(s) * n).to_affine() == g2.mul(s * sum(ms) * (n // base), g2.G)
+        assert ctx.msm(b32(s) * n).to_affine() == g2.mul(s * sum(ms), g2.G)
         gen = torch.Generator(device=sc.device)
         gen.manual_seed(3)
         sel = torch.rand(n, device=sc.device, generator=gen)
         wit = sc.clone()
         wit[sel < 0.7] = 0
         wit[(sel >= 0.4) & (sel < 0.7), 0] = 1
-        assert ctx.msm(wit).to_affine() == g2.msm_by_multipliers(ms * (n // base), g2.bytes_to_scalars(wit.cpu().numpy().tobytes()))
+        wb = wit.cpu().numpy().tobytes()
+        assert ctx.msm(wit).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb, wb, 8)) == g2.affine_to_bytes(g2.msm_by_multipliers(ms, g2.bytes_to_scalars(wb)))
         out = torch.zeros((16, JB), dtype=torch.uint8, device=sc.device)
         for rank in range(8):
             ctx.launch_windows_batch(sc, n, 2 * rank, 2 * rank + 2, rank % 3, out[2 * rank:2 * rank + 2])
             ctx.slot_sync(rank % 3)
         assert m.MsmContext.combine_windows(out, curve=ctx.curve).to_affine() == want
-    ctx.set_bases(points[:4].contiguous())
+    ctx.set_bases(pb[: 4 * PB])
+
+
+def test_stages_against_the_cpu_stage_models(ctx):
+    # (≙ tests/smvp_shader.rs:292-334, tests/cuzk.rs) bucket sums and window sums of the device against the C restatement of the reference's CPU
+    # models (src/cuzk/test/utils.rs:61-338) over Fq2
+    n = 20000
+    points, scalars = cpu.sample_points(60, n), cpu.sample_scalars(61, n)
+    ctx.set_bases(points)
+    ctx.set_debug(True)
+    ctx.set_window_bits(16)
+    try:
+        result = ctx.msm(scalars)
+    finally:
+        ctx.set_debug(False)
+        ctx.set_window_bits(0)
+    buckets, wsums = ctx.read_buckets(16, 1 << 15), ctx.read_window_sums(16)
+    digits = cpu.decompose_scalars_signed(scalars, 16, 16)
+    for w in (3, 15):
+        cp, vi = cpu.transpose(digits[w], 1 << 16)
+        want = cpu.smvp_signed(cp, vi, points, 1 << 16)
+        got = buckets[w].tobytes()
+        assert [cpu.to_affine64(got[i:i + JB]) for i in range(0, len(got), JB)] == [cpu.to_affine64(want[i:i + JB]) for i in range(0, len(want), JB)]
+        assert cpu.to_affine64(wsums[w].tobytes()) == cpu.to_affine64(cpu.bucket_reduction("running_sum", got))
+    assert cpu.to_affine64(cpu.horner(wsums.tobytes(), 16)) == result.to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points, scalars))
+    assert result.to_affine_bytes() == cpu.to_affine64(cpu.msm_cuzk_model(points, scalars))
 
 
 def test_options_the_g2_unit_does_not_have_and_input_errors(ctx):

@@ -56,3 +56,34 @@ def test_wire_format_round_trip():
     assert b[:fb] == pts[0][0][0].to_bytes(fb, "little") and b[fb:2 * fb] == pts[0][0][1].to_bytes(fb, "little")  # c0 || c1
     j = g2.f2_to_bytes(pts[1][0]) + g2.f2_to_bytes(pts[1][1]) + g2.f2_to_bytes((1, 0))
     assert g2.jacobian_bytes_to_affine(j) == pts[1] and g2.jacobian_bytes_to_affine(bytes(6 * fb)) is g2.INF
+
+
+def test_the_c_restatement_agrees_with_the_python_model():
+    # oracle/bn254.c -DORACLE_G2 (the restatement of the reference's generic CPU MSM and of its stage models, over Fq2) against this model:
+    # field ops, group ops, the synthetic points byte for byte, the MSM (serial and threaded), the cuZK stage models end to end
+    cpu = importlib.import_module("oracle.cpu_" + g2.__name__.split(".")[-1].replace("_ref", ""))
+    import random
+
+    r = random.Random(5)
+    P, cb = g2.P, g2.CB
+    assert cpu.coord_bytes() == cb
+    vals = [(0, 0), (1, 0), (0, 1), (P - 1, P - 1), (P - 1, 0)] + [(r.randrange(P), r.randrange(P)) for _ in range(200)]
+    other = vals[3:] + vals[:3]
+    A, B = b"".join(g2.f2_to_bytes(v) for v in vals), b"".join(g2.f2_to_bytes(v) for v in other)
+    model = {"add": g2.f2_add, "sub": g2.f2_sub, "mul": g2.f2_mul, "sqr": lambda a, b: g2.f2_sqr(a), "neg": lambda a, b: g2.f2_neg(a)}
+    for name, f in model.items():
+        assert cpu.fq_op(name, A, B) == b"".join(g2.f2_to_bytes(f(a, b)) for a, b in zip(vals, other)), name
+    nz = [v for v in vals if v != (0, 0)]
+    assert cpu.fq_op("inv", b"".join(g2.f2_to_bytes(v) for v in nz), None) == b"".join(g2.f2_to_bytes(g2.f2_inv(v)) for v in nz)
+    n = 40
+    pts = g2.sample_points(n, 21)
+    pb = cpu.sample_points(21, n)
+    assert pb == g2.points_to_bytes(pts) and cpu.points_on_curve(pb) and not cpu.points_on_curve(pb[:cb] + pb[:cb] + pb[2 * cb:])
+    assert cpu.sample_points(21, 10, first=30) == pb[30 * 2 * cb:]  # the sequence can be entered anywhere
+    sb = cpu.sample_scalars(22, n)
+    sc = g2.bytes_to_scalars(sb)
+    want = g2.affine_to_bytes(g2.msm_pippenger(pts, sc))
+    assert cpu.to_affine64(cpu.cpu_msm(pb, sb)) == want == cpu.to_affine64(cpu.cpu_msm(pb, sb, 3)) == cpu.to_affine64(cpu.msm_cuzk_model(pb, sb))
+    jac = cpu.g1_scalar_mul(pb, sb)
+    assert [g2.jacobian_bytes_to_affine(jac[3 * cb * i:3 * cb * (i + 1)]) for i in range(n)] == [g2.mul(k, p_) for k, p_ in zip(sc, pts)]
+    assert cpu.to_affine64(cpu.horner(jac[: 16 * 3 * cb], 16)) == g2.affine_to_bytes(g2.msm_naive([g2.mul(k, p_) for k, p_ in zip(sc, pts)][:16], [1 << (16 * w) for w in range(16)]))

@@ -19,6 +19,7 @@ if curve.endswith("_g2"):
         POOL = 1 << 12
 
         def __init__(self):
+            self.c_model = importlib.import_module("oracle.cpu_" + curve)
             self.pts, self.mult = ref.sample_points(self.POOL, 99), ref.sample_multipliers(self.POOL, 99)
             self.enc = [ref.points_to_bytes([p]) for p in self.pts]
             self.m_of = {e: k for e, k in zip(self.enc, self.mult)}
@@ -35,7 +36,10 @@ if curve.endswith("_g2"):
         def cpu_msm(self, points, sb):
             pb = 2 * ref.CB
             k = sum(self.m_of[points[pb * i:pb * i + pb]] * s for i, s in enumerate(ref.bytes_to_scalars(sb))) % ref.R
-            return ref.affine_to_bytes(ref.mul(k, ref.G))  # (already affine: to_affine64 below is the identity on it)
+            want = ref.affine_to_bytes(ref.mul(k, ref.G))  # (already affine: to_affine64 below is the identity on it)
+            if len(sb) // 32 <= 20000:  # ... and the C restatement of the reference's CPU MSM over Fq2 agrees (oracle/bn254.c -DORACLE_G2)
+                assert self.c_model.to_affine64(self.c_model.cpu_msm(points, sb, 4)) == want, "the two G2 models disagree"
+            return want
 
         def to_affine64(self, b):
             return b if len(b) == 2 * ref.CB else ref.affine_to_bytes(ref.jacobian_bytes_to_affine(b))
