@@ -96,6 +96,19 @@ def test_point_ops_and_special_cases(ctx):
     assert affs(ctx.g1_mul_u32(A, ks)) == [g2.mul(k, x) for k, x in zip(ks, a)]
 
 
+def test_golden_vectors(ctx):
+    # the committed known answers (tests/golden/msm_vectors_g2.json): explicit edge cases (2 G, (r - 1) G, cancellations, the 0x8000 digit
+    # chain, duplicates and P / -P in one bucket, all-equal scalars) and seeded sizes up to 2^16 + 4
+    from tests.util import case_inputs_g2, golden_cases_g2
+
+    cases = [c for c in golden_cases_g2() if c["curve"] == ctx.curve]
+    assert len(cases) == 14
+    for case in cases:
+        pb, sb = case_inputs_g2(case)
+        ctx.set_bases(pb, check_on_curve=True)
+        assert ctx.msm(sb).to_affine_bytes() == bytes.fromhex(case["expected_affine"]), case["name"]
+
+
 @pytest.mark.parametrize("n", [1, 3, 257, 4097])
 def test_msm_matches_the_model_every_window_size_and_entry_point(ctx, n):
     pts = g2.sample_points(n, 34)

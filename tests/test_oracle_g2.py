@@ -87,3 +87,23 @@ def test_the_c_restatement_agrees_with_the_python_model():
     jac = cpu.g1_scalar_mul(pb, sb)
     assert [g2.jacobian_bytes_to_affine(jac[3 * cb * i:3 * cb * (i + 1)]) for i in range(n)] == [g2.mul(k, p_) for k, p_ in zip(sc, pts)]
     assert cpu.to_affine64(cpu.horner(jac[: 16 * 3 * cb], 16)) == g2.affine_to_bytes(g2.msm_naive([g2.mul(k, p_) for k, p_ in zip(sc, pts)][:16], [1 << (16 * w) for w in range(16)]))
+
+
+def test_both_models_reproduce_the_committed_golden_vectors():
+    # tests/golden/msm_vectors_g2.json (written by tests/golden/make_golden_g2.py): the C restatement on every case, the Python model on the
+    # small ones and, for the seeded cases, through the closed form
+    from tests.util import case_inputs_g2, golden_cases_g2
+
+    name = g2.__name__.split(".")[-1].replace("_ref", "")
+    cpu = importlib.import_module("oracle.cpu_" + name)
+    cases = [c for c in golden_cases_g2() if c["curve"] == name]
+    assert len(cases) == 14
+    for case in cases:
+        pb, sb = case_inputs_g2(case)
+        want = bytes.fromhex(case["expected_affine"])
+        assert cpu.to_affine64(cpu.cpu_msm(pb, sb, 4)) == want, case["name"]
+        sc = g2.bytes_to_scalars(sb)
+        if len(sc) <= 20:
+            assert g2.affine_to_bytes(g2.msm_naive(g2.bytes_to_points(pb), sc)) == want, case["name"]
+        if case["kind"] == "seeded":
+            assert g2.affine_to_bytes(g2.msm_by_multipliers(g2.sample_multipliers(case["n"], case["point_seed"]), sc)) == want, case["name"]

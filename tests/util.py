@@ -15,6 +15,24 @@ def golden_cases():
         return json.load(f)["cases"]
 
 
+GOLDEN_G2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "msm_vectors_g2.json")
+
+
+def golden_cases_g2():
+    """Known answers for G2 of BN254 / BLS12-381 (tests/golden/make_golden_g2.py); each case names its curve"""
+    with open(GOLDEN_G2) as f:
+        return json.load(f)["cases"]
+
+
+def case_inputs_g2(case):
+    import importlib
+
+    if case["kind"] == "explicit":
+        return bytes.fromhex(case["points"]), bytes.fromhex(case["scalars"])
+    c = importlib.import_module("oracle.cpu_" + case["curve"])
+    return c.sample_points(case["point_seed"], case["n"]), c.sample_scalars(case["scalar_seed"], case["n"])
+
+
 def case_inputs(case):
     if case["kind"] == "explicit":
         return bytes.fromhex(case["points"]), bytes.fromhex(case["scalars"])
