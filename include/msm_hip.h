@@ -98,8 +98,8 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx);
                                     A coordinate is an Fq2 element c0 || c1, each 32 B canonical little-endian: 64 bytes; points n x 128 B (x || y), results
                                     and window sums 192 B Jacobian records, scalars 32 B; every `[96]` / `[64]` / "x 96 B" of this header reads 192 / 128.
                                     Device arithmetic: csrc/fq2.h on the 9 x 29-bit prime field (csrc/curve_bn254_g2.hip).  Window sizes, window shards,
-                                    batches, grouped launches, the multi-GPU calls: as for curve 0.  NOT available (MSM_HIP_ERR_INVALID_ARG):
-                                    MSM_HIP_BASES_ENDOMORPHISM, MSM_HIP_BASES_PRECOMPUTE, MSM_HIP_SCALARS_MONT256, the device point sampler. */
+                                    batches, grouped launches, fixed-base tables, Montgomery-form inputs, the multi-GPU calls: as for curve 0.  NOT available
+                                    (MSM_HIP_ERR_INVALID_ARG): MSM_HIP_BASES_ENDOMORPHISM (G2's endomorphism is psi, not (beta x, y)) and the device point sampler. */
 #define MSM_HIP_CURVE_BLS12_381_G2 6 /* G2 of BLS12-381: the twist y^2 = x^3 + 4 (1 + u) over Fq2, scalars modulo the same r as curve 4.  As curve 5 with 48-byte
                                         components: coordinates 96 B (c0 || c1), points 192 B, results and window sums 288 B Jacobian records.  The same
                                         options are unavailable.  Inputs are expected in the order-r subgroup (as every valid G2 point is); points outside

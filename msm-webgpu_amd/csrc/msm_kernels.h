@@ -69,9 +69,9 @@ constexpr cwords<N> make_cwords(const uint32_t (&src)[N]) {
   for (int i = 0; i < N; i++) r.w[i] = src[i];
   return r;
 }
-// MSM_FQ2 (a G2 unit, csrc/fq2.h: the coordinate field is a quadratic extension): the pieces that need a square root, an inversion or the
-// (beta x, y) endomorphism of the prime field -- device sampler, fixed-base tables, endomorphism bases, Montgomery-form scalars -- are
-// not built; the unit's table carries null entries for them and the host refuses the corresponding options.
+// MSM_FQ2 (a G2 unit, csrc/fq2.h: the coordinate field is a quadratic extension): the pieces that need a square root in Fq2 or the
+// (beta x, y) endomorphism of the prime field -- the device point sampler, endomorphism bases -- are not built; the unit's table
+// carries null entries for them and the host refuses the corresponding options.
 #ifndef MSM_FQ2
 __device__ __constant__ cwords<CW> c_pp1d4 = make_cwords(FQ_PP1D4_32);
 #endif
@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(256) k_endo_points(uint32_t* __restrict__ base
 #pragma unroll
   for (int k = 0; k < CW / 4; k++) o[k] = y[k];
 }
+#endif  // MSM_FQ2
 
 // Fixed-base tables (reference README.md "Future work": the Elastic-MSM precomputation trade-off): with
 // T_w[i] = 2^(16 w) P_i stored for every window, sum_i s_i P_i = sum_i sum_w d_{i,w} T_w[i] needs ONE bucket set for all
@@ -230,7 +231,8 @@ __global__ void __launch_bounds__(256) k_endo_points(uint32_t* __restrict__ base
 // bases[(w * nb + i)][16]: table w behind table w - 1; table 0 is the plain converted base set (so every entry point that does
 // not use the tables keeps working on the same buffer).  One thread per point: 16 doublings per table in XYZZ, then back to
 // affine (one inversion by Fermat, a^(p-2)).
-__device__ __constant__ cwords<CW> c_pm2 = make_cwords(FQ_PM2_32);
+__device__ __constant__ cwords<CW / FQ_EXT> c_pm2 = make_cwords(FQ_PM2_32);  // p - 2 (the prime field's)
+#ifndef MSM_FQ2
 __device__ __forceinline__ fq fq_inv(const fq& a) {  // a exact, nonzero; result exact, < 2p
   fq acc = fq_one();
   for (int bit = 32 * CW - 1; bit >= 0; bit--) {  // (leading zero bits of p - 2 only square the initial one)
@@ -239,6 +241,18 @@ __device__ __forceinline__ fq fq_inv(const fq& a) {  // a exact, nonzero; result
   }
   return acc;
 }
+#else
+__device__ __forceinline__ fq fq_inv(const fq& a) {  // Fq2: 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2), one Fermat inversion in the prime field
+  const fp a0 = f2_c0(a), a1 = f2_c1(a);
+  const fp nrm = fpn::fq_mul2(a0, a0, a1, a1);  // the norm, exact, < 2p
+  fp acc = fpn::fq_one();
+  for (int bit = 32 * FP_WORDS - 1; bit >= 0; bit--) {
+    acc = fpn::fq_sqr(acc);
+    if ((c_pm2.w[bit >> 5] >> (bit & 31)) & 1u) acc = fpn::fq_mul(acc, nrm);
+  }
+  return f2_make(fpn::fq_mul(a0, acc), fpn::fq_mul(fpn::fq_sub<3>(fpn::fq_zero(), a1), acc));  // (3p - a1) / norm
+}
+#endif
 __global__ void __launch_bounds__(256) k_precompute_tables(uint32_t* __restrict__ bases, size_t n, size_t nb, int num_tables) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -256,7 +270,6 @@ __global__ void __launch_bounds__(256) k_precompute_tables(uint32_t* __restrict_
     acc = g1_from_affine(x, y);
   }
 }
-#endif  // MSM_FQ2
 
 // ------------------------------------------------------------------------------------------------ stage 1+2: recode + sort
 // Signed 16-bit digit recode (≙ decompose_scalars.template.wgsl:83-112, CPU model test/utils.rs:121-161):
@@ -327,47 +340,57 @@ __device__ __forceinline__ uint32_t code_of_window(const uint32_t* t, int w) {  
   return 0x8000u | ((H - b) & (H - 1u));          // d = -(2^(C-1) - b): magnitude 1 .. 2^(C-1) (2^(C-1) -> slot 0)
 }
 
-#ifndef MSM_FQ2
 // Scalars handed over as s * 2^256 mod r (the in-memory limbs of a 4 x 64-bit Montgomery library with R = 2^256) are turned
 // into the canonical wire format by one pre-pass: a 9-limb Montgomery reduction of (s_mont << 5), i.e. s_mont * 2^5 / 2^261.
+#ifdef MSM_FQ2  // (a G2 unit: the container of a 256-bit scalar is an element of the PRIME field)
+using sfe = fp;
+constexpr int SF_L = FP_L, SF_WORDS = FP_WORDS;
+__device__ __forceinline__ sfe sf_unpack(const uint32_t* w) { return fpn::fq_unpack(w); }
+__device__ __forceinline__ void sf_pack(uint32_t* w, const sfe& x) { fpn::fq_pack(w, x); }
+#else
+using sfe = fq;
+constexpr int SF_L = FQ_L, SF_WORDS = CW;
+__device__ __forceinline__ sfe sf_unpack(const uint32_t* w) { return fq_unpack(w); }
+__device__ __forceinline__ void sf_pack(uint32_t* w, const sfe& x) { fq_pack(w, x); }
+#endif
 __device__ __forceinline__ void fr_from_mont256(const uint32_t w[8], uint32_t out[8]) {
-  // (the scalar field's 256-bit values in the unit's limb layout: FQ_L limbs of FQ_W bits hold them with room to spare)
-  constexpr int SH = FQ_W * FQ_L - 256, SH_LIMBS = SH / FQ_W, SH_BITS = SH % FQ_W;  // s_mont * 2^SH / 2^(FQ_W FQ_L) = s_mont / 2^256
-  uint32_t wide[CW];
+  // (the scalar field's 256-bit values in the unit's limb layout: SF_L limbs of FQ_W bits hold them with room to spare)
+  constexpr int SH = FQ_W * SF_L - 256, SH_LIMBS = SH / FQ_W, SH_BITS = SH % FQ_W;  // s_mont * 2^SH / 2^(FQ_W SF_L) = s_mont / 2^256
+  uint32_t wide[SF_WORDS];
 #pragma unroll
-  for (int k = 0; k < CW; k++) wide[k] = k < 8 ? w[k] : 0u;
-  const fq x = fq_unpack(wide);
-  uint64_t c[2 * FQ_L + 1];
+  for (int k = 0; k < SF_WORDS; k++) wide[k] = k < 8 ? w[k] : 0u;
+  const sfe x = sf_unpack(wide);
+  uint64_t c[2 * SF_L + 1];
 #pragma unroll
-  for (int k = 0; k < 2 * FQ_L + 1; k++) c[k] = 0;
+  for (int k = 0; k < 2 * SF_L + 1; k++) c[k] = 0;
 #pragma unroll
-  for (int k = 0; k < FQ_L; k++) c[k + SH_LIMBS] = (uint64_t)x.v[k] << SH_BITS;
+  for (int k = 0; k < SF_L; k++) c[k + SH_LIMBS] = (uint64_t)x.v[k] << SH_BITS;
 #pragma unroll
-  for (int i = 0; i < FQ_L; i++) {
+  for (int i = 0; i < SF_L; i++) {
     const uint32_t m = ((uint32_t)c[i] * FR_N0_29) & FQ_MASK;
 #pragma unroll
-    for (int j = 0; j < FQ_L; j++) c[i + j] += (uint64_t)m * FR_R29[j];
+    for (int j = 0; j < SF_L; j++) c[i + j] += (uint64_t)m * FR_R29[j];
     c[i + 1] += c[i] >> FQ_W;
   }
-  fq t;
+  sfe t;
 #pragma unroll
-  for (int k = FQ_L; k < 2 * FQ_L - 1; k++) {
-    t.v[k - FQ_L] = (uint32_t)c[k] & FQ_MASK;
+  for (int k = SF_L; k < 2 * SF_L - 1; k++) {
+    t.v[k - SF_L] = (uint32_t)c[k] & FQ_MASK;
     c[k + 1] += c[k] >> FQ_W;
   }
-  t.v[FQ_L - 1] = (uint32_t)c[2 * FQ_L - 1];
+  t.v[SF_L - 1] = (uint32_t)c[2 * SF_L - 1];
   // t <= r: one conditional subtraction makes it canonical
-  fq d;
+  sfe d;
   uint32_t borrow = 0;
 #pragma unroll
-  for (int i = 0; i < FQ_L; i++) {
+  for (int i = 0; i < SF_L; i++) {
     const uint32_t u = t.v[i] - FR_R29[i] - borrow;
     borrow = u >> 31;
-    d.v[i] = (i < FQ_L - 1) ? (u & FQ_MASK) : u;
+    d.v[i] = (i < SF_L - 1) ? (u & FQ_MASK) : u;
   }
 #pragma unroll
-  for (int i = 0; i < FQ_L; i++) t.v[i] = borrow ? t.v[i] : d.v[i];
-  fq_pack(wide, t);
+  for (int i = 0; i < SF_L; i++) t.v[i] = borrow ? t.v[i] : d.v[i];
+  sf_pack(wide, t);
 #pragma unroll
   for (int k = 0; k < 8; k++) out[k] = wide[k];
 }
@@ -384,7 +407,6 @@ __global__ void __launch_bounds__(256) k_scalars_from_mont256(const uint32_t* __
   q[0] = make_uint4(o[0], o[1], o[2], o[3]);
   q[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
-#endif  // MSM_FQ2
 
 // `nvec` scalar vectors (vec_stride words apart) may share one launch: vector v, window w is handled as local window
 // lw = v * w_count + (w - w_begin), nvec * w_count <= MAXLW -- several MSMs over the same bases sorted, accumulated and reduced

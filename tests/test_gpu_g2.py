@@ -155,6 +155,17 @@ def test_msm_matches_the_model_every_window_size_and_entry_point(ctx, n):
         assert [g.to_affine() for g in mg.finish_batch(1, 2)] == [want] * 2
     finally:
         mg.close()
+    # fixed-base tables (one bucket set for all windows; an inversion in Fq2 per table entry), whole MSMs and batches
+    ctx.set_bases(points, precompute=True)
+    assert ctx.msm(scb).to_affine() == want and ctx.msm(dev).to_affine() == want
+    assert [g.to_affine() for g in ctx.msm_batch(scb * 2, n)] == [want] * 2
+    # scalars handed over as s * 2^256 mod r (the in-memory words of a 4 x 64-bit Montgomery library)
+    ctx.set_bases(points)
+    ctx.set_scalar_format(True)
+    try:
+        assert ctx.msm(b"".join(b32((v << 256) % g2.R) for v in sc)).to_affine() == want
+    finally:
+        ctx.set_scalar_format(False)
 
 
 def test_bucket_sums_and_window_sums_against_the_model(ctx):
@@ -270,13 +281,10 @@ def test_stages_against_the_cpu_stage_models(ctx):
 
 def test_options_the_g2_unit_does_not_have_and_input_errors(ctx):
     pts = g2.points_to_bytes(g2.sample_points(4, 38))
-    for kw in ({"endomorphism": True}, {"precompute": True}):
-        with pytest.raises(m.MsmHipError) as e:
-            ctx.set_bases(pts, **kw)
-        assert e.value.code == -2
-    with pytest.raises(m.MsmHipError):
-        ctx.set_scalar_format(True)
-    with pytest.raises(m.MsmHipError):
+    with pytest.raises(m.MsmHipError) as e:  # (the G2 endomorphism is psi, not (beta x, y): no such mode)
+        ctx.set_bases(pts, endomorphism=True)
+    assert e.value.code == -2
+    with pytest.raises(m.MsmHipError):  # (no device sampler: it would need a square root in Fq2)
         ctx.sample_points(4, 1)
     with pytest.raises(m.MsmHipError):  # a component >= p (c1 of x)
         ctx.set_bases(pts[:FB] + bf(g2.P) + pts[CB:])

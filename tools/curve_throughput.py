@@ -17,7 +17,7 @@ for curve in (sys.argv[2:] or ["bn254", "grumpkin", "pallas", "vesta", "bls12_38
         g2 = importlib.import_module("oracle." + curve + "_ref")
         base = min(n, 1 << 14)
         pts = torch.frombuffer(bytearray(g2.points_to_bytes(g2.sample_points(base, 1))), dtype=torch.uint8).cuda().view(base, 2 * g2.CB).repeat(n // base, 1).contiguous()
-        ctx.set_bases(pts)
+        ctx.set_bases(pts, precompute=os.environ.get("CURVE_BASES") == "tables")  # (G2 has no endomorphism mode; CURVE_BASES=tables: fixed-base tables)
     else:
         cpu = importlib.import_module("oracle.cpu" if curve == "bn254" else "oracle.cpu_" + curve)
         pts = ctx.sample_points(n, 1)
