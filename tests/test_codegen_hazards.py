@@ -48,6 +48,35 @@ def test_product_device_code_has_no_long_branch_over_a_pending_scalar_load():
     paths = chk.compile_to_asm([])  # one assembly file per translation unit (every curve)
     assert len(paths) >= 4
     for path in paths:
-        long_branches, found = chk.check_file(path)
+        long_branches, found, live = chk.check_file(path)
         assert found == [], (path, found)
+        assert live == [], (path, live)  # ... and no expanded branch whose scratch pair is read at its target before it is written
         assert long_branches >= 0
+
+
+LIVE = """
+k_demo2:                                ; @k_demo2
+	s_and_saveexec_b64 s[4:5], vcc
+	s_cbranch_execnz .LBB1_1
+	s_getpc_b64 s[%s]
+.Lpost_getpc7:
+	s_add_u32 s%d, s%d, (.LBB1_2-.Lpost_getpc7)&4294967295
+	s_addc_u32 s%d, s%d, (.LBB1_2-.Lpost_getpc7)>>32
+	s_setpc_b64 s[%s]
+.LBB1_1:
+	v_mov_b32_e32 v0, 1
+.LBB1_2:
+	s_or_b64 exec, exec, s[4:5]
+	s_endpgm
+.Lfunc_end1:
+"""
+
+
+def test_checker_sees_a_long_branch_through_a_live_register_pair():
+    def live(pair, lo, hi):
+        text = LIVE % (pair, lo, lo, hi, hi, pair)
+        return [h for name, lines in chk.functions(text) for h in chk.analyse_liveness(name, lines)]
+
+    bad = live("4:5", 4, 5)  # the saved exec mask is read at the target
+    assert len(bad) == 1 and bad[0][0] == "k_demo2" and bad[0][3] == [4, 5]
+    assert live("6:7", 6, 7) == []

@@ -34,6 +34,24 @@ for w in range(nwin):
     if diff:
         bad_b += 1
         print("window", w, "buckets differ at slots", diff[:8], "(digits of the duplicated pair:", digits[w][20], digits[w][21], ")")
+        if dup and n > 40 and len(diff) == 1:  # what the wrong bucket holds, if it is a small multiple of the duplicated point
+            pt = points[PB * 21:PB * 22]
+            k = diff[0]
+            got_aff = cpu.to_affine64(got[JB * k:JB * k + JB])
+            names = {}
+            for mult in (1, 2, 3, 4):
+                jac = cpu.g1_scalar_mul(pt, int(mult).to_bytes(32, "little"))
+                aff = cpu.to_affine64(jac)
+                names[aff] = "%d P" % mult
+                y = bytearray(aff)
+                fb = cb // (2 if curve.endswith("_g2") else 1)
+                neg = bytearray(aff[:cb])
+                for c0 in range(cb, 2 * cb, fb):
+                    v = int.from_bytes(aff[c0:c0 + fb], "little")
+                    neg += ((ctx.modulus - v) % ctx.modulus).to_bytes(fb, "little")
+                names[bytes(neg)] = "-%d P" % mult
+            names[bytes(2 * cb)] = "identity"
+            print("   wrong bucket holds:", names.get(got_aff, "none of +-1..4 P / identity"), "| expected:", names.get(cpu.to_affine64(want[JB * k:JB * k + JB]), "?"))
     if cpu.to_affine64(wsums[w].tobytes()) != cpu.to_affine64(cpu.bucket_reduction("running_sum", want)):
         bad_w += 1
         print("window", w, "window sum differs", "(its buckets were", "wrong)" if diff else "right)")
