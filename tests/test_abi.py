@@ -154,6 +154,11 @@ def test_host_only_helpers_of_window_sizes_and_curves(built):
         got_g = m.MsmContext.combine_windows(sums_g, curve=name)
         assert len(got_g.xyz) == 3 * g2.CB and got_g.to_affine_bytes() == g2.affine_to_bytes(want), name
         assert g2.jacobian_bytes_to_affine(got_g.xyz) == want
+        # ... and the library's own Jacobian -> affine conversion (an inversion in Fq2 on the host)
+        aff = C.create_string_buffer(2 * g2.CB)
+        assert L.msm_hip_g1_to_affine_curve({"bn254_g2": 5, "bls12_381_g2": 6}[name], got_g.xyz, aff) == 0
+        assert aff.raw == g2.affine_to_bytes(want)
+        assert L.msm_hip_g1_to_affine_curve({"bn254_g2": 5, "bls12_381_g2": 6}[name], bytes(3 * g2.CB), aff) == 1 and aff.raw == bytes(2 * g2.CB)  # identity
     out = C.create_string_buffer(288)
     assert L.msm_hip_combine_windows_curve(7, sums, 16, out) == -2  # unknown curve
     h = C.c_void_p()
