@@ -3,7 +3,7 @@
 Pippenger windows are independent: rank r computes the window sums S_w for its contiguous
 window range on its own GPU (all bases resident on every GPU, every rank recodes all scalars because the signed-digit
 carry chain runs across windows), then ONE collective -- an all-gather of world_size x W_local x 96 B over RCCL/xGMI --
-brings all 16 window sums to every rank, and the host window combine (src/cuzk/msm.rs:411-416) finishes.  Elliptic-curve
+brings all 16 window sums to every rank (a record is 96 B on BN254 G1; the context's curve decides: ctx.jb), and the host window combine (src/cuzk/msm.rs:411-416) finishes.  Elliptic-curve
 addition is not an RCCL reduction operator, hence gather + local combine rather than all-reduce.
 """
 import os
@@ -28,16 +28,16 @@ def max_windows_per_rank(world_size, num_windows=NUM_WINDOWS):
     return -(-num_windows // world_size)
 
 
-def gather_window_sums(local_sums, rank, world_size, group=None, num_windows=NUM_WINDOWS):
-    """local_sums: uint8 [W_local, 96] (device tensor under nccl, CPU tensor under gloo).
-    Returns uint8 [num_windows, 96] with every window sum in window order, on every rank."""
+def gather_window_sums(local_sums, rank, world_size, group=None, num_windows=NUM_WINDOWS, jb=96):
+    """local_sums: uint8 [W_local, jb] (device tensor under nccl, CPU tensor under gloo); jb = bytes of a Jacobian record of the curve
+    (96; 144 BLS12-381; 192 / 288 the G2 curves).  Returns uint8 [num_windows, jb] with every window sum in window order, on every rank."""
     per = max_windows_per_rank(world_size, num_windows)
-    padded = torch.zeros((per, 96), dtype=torch.uint8, device=local_sums.device)
+    padded = torch.zeros((per, jb), dtype=torch.uint8, device=local_sums.device)
     padded[: local_sums.shape[0]] = local_sums
     if world_size == 1:
         gathered = padded.unsqueeze(0)
     else:
-        gathered = torch.empty((world_size, per, 96), dtype=torch.uint8, device=local_sums.device)
+        gathered = torch.empty((world_size, per, jb), dtype=torch.uint8, device=local_sums.device)
         dist.all_gather_into_tensor(gathered.view(-1), padded.view(-1), group=group)
     rows = []
     for r in range(world_size):
@@ -52,9 +52,9 @@ def sharded_msm(ctx, scalars_dev, rank, world_size, group=None):
     if e > b:
         local = ctx.msm_windows(scalars_dev, b, e)
     else:
-        local = torch.empty((0, 96), dtype=torch.uint8, device=scalars_dev.device)
-    all_sums = gather_window_sums(local, rank, world_size, group)
-    return MsmContext.combine_windows(all_sums)
+        local = torch.empty((0, ctx.jb), dtype=torch.uint8, device=scalars_dev.device)
+    all_sums = gather_window_sums(local, rank, world_size, group, jb=ctx.jb)
+    return MsmContext.combine_windows(all_sums, curve=ctx.curve)
 
 
 def batch_range(rank, world_size, batch):
@@ -62,16 +62,16 @@ def batch_range(rank, world_size, batch):
     return window_range(rank, world_size, batch)
 
 
-def gather_batch_results(local_results, rank, world_size, batch, group=None):
-    """local_results: uint8 [B_local, 96] Jacobian records of this rank's share (device tensor under nccl, CPU tensor
-    under gloo).  Returns uint8 [batch, 96] in MSM order on every rank -- the only collective of the batch-sharded path."""
+def gather_batch_results(local_results, rank, world_size, batch, group=None, jb=96):
+    """local_results: uint8 [B_local, jb] Jacobian records of this rank's share (device tensor under nccl, CPU tensor
+    under gloo).  Returns uint8 [batch, jb] in MSM order on every rank -- the only collective of the batch-sharded path."""
     per = max_windows_per_rank(world_size, batch)
-    padded = torch.zeros((per, 96), dtype=torch.uint8, device=local_results.device)
+    padded = torch.zeros((per, jb), dtype=torch.uint8, device=local_results.device)
     padded[: local_results.shape[0]] = local_results
     if world_size == 1:
         gathered = padded.unsqueeze(0)
     else:
-        gathered = torch.empty((world_size, per, 96), dtype=torch.uint8, device=local_results.device)
+        gathered = torch.empty((world_size, per, jb), dtype=torch.uint8, device=local_results.device)
         dist.all_gather_into_tensor(gathered.view(-1), padded.view(-1), group=group)
     rows = []
     for r in range(world_size):
@@ -90,9 +90,10 @@ def sharded_batch_msm(ctx, scalars_dev, n, rank, world_size, group=None):
     b, e = batch_range(rank, world_size, batch)
     mine = ctx.msm_batch(scalars_dev[b * n:e * n], n) if e > b else []
     dev = scalars_dev.device
-    local = torch.tensor(list(b"".join(g.xyz for g in mine)), dtype=torch.uint8, device=dev).view(len(mine), 96)
-    allr = gather_batch_results(local, rank, world_size, batch, group).cpu().numpy().tobytes()
-    return [G1(allr[96 * k:96 * k + 96]) for k in range(batch)]
+    jb = ctx.jb
+    local = torch.tensor(list(b"".join(g.xyz for g in mine)), dtype=torch.uint8, device=dev).view(len(mine), jb)
+    allr = gather_batch_results(local, rank, world_size, batch, group, jb=jb).cpu().numpy().tobytes()
+    return [G1(allr[jb * k:jb * k + jb], ctx.modulus) for k in range(batch)]
 
 
 def msms_per_launch(world_size, num_windows=NUM_WINDOWS):
@@ -113,16 +114,17 @@ def group_window_rows(gathered, v, world_size, num_windows=NUM_WINDOWS, window_r
 
 
 def gathered_window_sums(host, nvec, world_size, num_windows=NUM_WINDOWS):
-    """host: numpy uint8 [world, rows, 96], the all-gathered blocks of one launch (rank r's block holds [nvec][its windows] records,
-    vector-major, then padding).  Returns a contiguous uint8 array [nvec, num_windows, 96]: every MSM's window sums in window order --
+    """host: numpy uint8 [world, rows, jb], the all-gathered blocks of one launch (rank r's block holds [nvec][its windows] records,
+    vector-major, then padding).  Returns a contiguous uint8 array [nvec, num_windows, jb]: every MSM's window sums in window order --
     the input of ONE msm_hip_combine_windows_batch_curve call for the whole launch."""
+    jb = host.shape[-1]
     if num_windows % world_size == 0:  # equal shares: one transpose
         per = num_windows // world_size
-        return np.ascontiguousarray(host[:, : nvec * per].reshape(world_size, nvec, per, 96).transpose(1, 0, 2, 3)).reshape(nvec, num_windows, 96)
-    out = np.empty((nvec, num_windows, 96), dtype=np.uint8)
+        return np.ascontiguousarray(host[:, : nvec * per].reshape(world_size, nvec, per, jb).transpose(1, 0, 2, 3)).reshape(nvec, num_windows, jb)
+    out = np.empty((nvec, num_windows, jb), dtype=np.uint8)
     for r in range(world_size):
         b, e = window_range(r, world_size, num_windows)
-        out[:, b:e] = host[r, : nvec * (e - b)].reshape(nvec, e - b, 96)
+        out[:, b:e] = host[r, : nvec * (e - b)].reshape(nvec, e - b, jb)
     return out
 
 
@@ -162,9 +164,10 @@ class ShardedMsmPipeline:
         assert self.g * self.per <= 64, "msms_per_issue x windows per rank must not exceed 64 local windows"
         dev = torch.device("cuda", ctx.device)
         rows = self.g * self.per
-        self.padded = [torch.zeros((rows, 96), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
-        self.gathered = [torch.empty((world_size, rows, 96), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
-        self.host = [torch.empty((world_size, rows, 96), dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
+        jb = ctx.jb  # bytes of a Jacobian record of the context's curve
+        self.padded = [torch.zeros((rows, jb), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
+        self.gathered = [torch.empty((world_size, rows, jb), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
+        self.host = [torch.empty((world_size, rows, jb), dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
         self.host_np = [h.numpy() for h in self.host]  # views of the pinned buffers
         self.copied = [torch.cuda.Event() for _ in range(self.SLOTS)]
         self.nvec = [1] * self.SLOTS

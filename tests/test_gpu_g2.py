@@ -279,6 +279,33 @@ def test_stages_against_the_cpu_stage_models(ctx):
     assert result.to_affine_bytes() == cpu.to_affine64(cpu.msm_cuzk_model(points, scalars))
 
 
+def test_window_sharded_pipeline_on_this_curve(ctx):
+    # msm-webgpu_amd/sharding.py (the one-process-per-GPU path of bench.py) with this curve's record size: the whole-MSM helper and the
+    # grouped asynchronous pipeline with one rank, and one rank's partial sums of an 8-rank run against the other seven's from msm_windows
+    from msm_webgpu_amd.sharding import ShardedMsmPipeline, sharded_msm, window_range
+
+    n = 3000
+    pb, sb = cpu.sample_points(81, n), cpu.sample_scalars(82, n)
+    want = cpu.to_affine64(cpu.cpu_msm(pb, sb))
+    ctx.set_bases(pb)
+    dev = torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda()
+    assert sharded_msm(ctx, dev, 0, 1).to_affine_bytes() == want
+    pipe = ShardedMsmPipeline(ctx, 0, 1, msms_per_issue=2)
+    two = torch.cat([dev, dev]).contiguous()
+    torch.cuda.synchronize()
+    pipe.issue(two, n=n, inputs_complete=True)
+    pipe.issue(two, n=n, inputs_complete=True)
+    assert [g.to_affine_bytes() for g in pipe.complete() + pipe.complete()] == [want] * 4
+    emu = ShardedMsmPipeline(ctx, 0, 1, msms_per_issue=1, emulate_world=8)  # rank 0's two windows of an 8-rank run (partial sums)
+    emu.issue(dev, inputs_complete=True)
+    part0 = emu.complete()
+    b, e = window_range(0, 8)
+    rest = ctx.msm_windows(dev, e, 16)
+    mine = ctx.msm_windows(dev, b, e)
+    assert part0.to_affine_bytes() == m.MsmContext.combine_windows(mine, curve=ctx.curve).to_affine_bytes()
+    assert m.MsmContext.combine_windows(torch.cat([mine, rest], dim=0), curve=ctx.curve).to_affine_bytes() == want
+
+
 def test_options_the_g2_unit_does_not_have_and_input_errors(ctx):
     pts = g2.points_to_bytes(g2.sample_points(4, 38))
     with pytest.raises(m.MsmHipError) as e:  # (the G2 endomorphism is psi, not (beta x, y): no such mode)

@@ -26,16 +26,22 @@ def test_window_range_partitions():
         window_range(2, 2)
 
 
-def _window_sums(points, scalars, b, e):
-    digits = cpu.decompose_scalars_signed(scalars)
+def _oracle(curve):
+    import importlib
+
+    return cpu if curve == "bn254" else importlib.import_module("oracle.cpu_" + curve)
+
+
+def _window_sums(c, points, scalars, b, e):
+    digits = c.decompose_scalars_signed(scalars)
     out = []
     for w in range(b, e):
-        cp, vi = cpu.transpose(digits[w], 1 << 16)
-        out.append(cpu.bucket_reduction("running_sum", cpu.smvp_signed(cp, vi, points, 1 << 16)))
+        cp, vi = c.transpose(digits[w], 1 << 16)
+        out.append(c.bucket_reduction("running_sum", c.smvp_signed(cp, vi, points, 1 << 16)))
     return b"".join(out)
 
 
-def _worker(rank, world, port, n, q):
+def _worker(rank, world, port, n, q, curve="bn254"):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -45,25 +51,29 @@ def _worker(rank, world, port, n, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    points, scalars = cpu.sample_points(91, n), cpu.sample_scalars(92, n)
+    c = _oracle(curve)
+    jb = 3 * c.coord_bytes()  # bytes of a Jacobian record on this curve
+    points, scalars = c.sample_points(91, n), c.sample_scalars(92, n)
     b, e = window_range(rank, world)
-    local = torch.from_numpy(np.frombuffer(_window_sums(points, scalars, b, e), dtype=np.uint8).copy()).view(e - b, 96)
-    all_sums = gather_window_sums(local, rank, world)
-    result = m.MsmContext.combine_windows(all_sums)
+    local = torch.from_numpy(np.frombuffer(_window_sums(c, points, scalars, b, e), dtype=np.uint8).copy()).view(e - b, jb)
+    all_sums = gather_window_sums(local, rank, world, jb=jb)
+    result = m.MsmContext.combine_windows(all_sums, curve=curve)
     q.put((rank, result.to_affine_bytes()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_gather_and_combine_gloo(built, world):
-    n = 600
+@pytest.mark.parametrize("world,curve", [(2, "bn254"), (3, "bn254"), (2, "bls12_381"), (2, "bn254_g2")])
+def test_sharded_gather_and_combine_gloo(built, world, curve):
+    # (the other curves: 144-byte records on BLS12-381, 192-byte ones on G2 -- coordinates in Fq2 -- through the same gather and combine)
+    n = 600 if curve == "bn254" else 150
+    cpu = _oracle(curve)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, curve)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(world)]
