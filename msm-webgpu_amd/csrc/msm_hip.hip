@@ -194,12 +194,48 @@ inline size_t target_lanes() {  // MSM_HIP_TARGET_LANES overrides the default fo
   }();
   return v;
 }
+// compute units of the current device (the devices of a node are alike: asked once)
+inline size_t num_cus() {
+  static const size_t v = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) return (size_t)cus;
+    return (size_t)256;
+  }();
+  return v;
+}
+// The SMVP is bound by the multiplier, so a SIMD needs time proportional to (waves it is given) x (chunk length) however many of them are
+// resident at once, and a workgroup puts one wave on each SIMD of its CU: the kernel takes  ceil(workgroups / CUs) x chunk length  (round 3
+// sweep of the length at 2^20, profiles/r03_chunk_len_sweep.txt: a sawtooth of 6.5 % that this expression reproduces within 1 - 2 %).  Around the
+// length that gives about SMVP_TARGET_LANES lanes (+- 25 %: the stitch's work follows the lane count) a length whose product is more than 1 % lower
+// than the plain quotient's replaces it (2^20 with 8 or 16 windows: 32, exact, instead of 29: 1.5 % per MSM).  (What the shares of an 8-rank run gained this round -- 3.5 % per MSM at 7 x 2 windows per launch -- came
+// from the quotient itself, 25, no longer being rounded up to a multiple of 4, 28.)  MSM_HIP_CHUNK_SEARCH=0: the plain quotient.
 inline uint32_t chunk_len_for(size_t n, int w_count) {
-  size_t len = (n * (size_t)w_count + target_lanes() - 1) / target_lanes();
-  len = (len + 3) & ~(size_t)3;
-  if (len < (size_t)SMVP_CHUNK_MIN) len = SMVP_CHUNK_MIN;
-  if (len > (size_t)SMVP_CHUNK_MAX) len = SMVP_CHUNK_MAX;
-  return (uint32_t)len;
+  static const bool search = [] { const char* e = getenv("MSM_HIP_CHUNK_SEARCH"); return !e || atoi(e) != 0; }();
+  size_t base = (n * (size_t)w_count + target_lanes() - 1) / target_lanes();
+  if (base < (size_t)SMVP_CHUNK_MIN) base = SMVP_CHUNK_MIN;
+  if (base > (size_t)SMVP_CHUNK_MAX) base = SMVP_CHUNK_MAX;
+  if (!search || base <= (size_t)SMVP_CHUNK_MIN) return (uint32_t)base;
+  const size_t cus = num_cus();
+  auto cost = [&](size_t c) {
+    const size_t groups = (size_t)w_count * (((n + c - 1) / c + 255) / 256);
+    return (groups + cus - 1) / cus * c;
+  };
+  size_t lo = base - base / 4, hi = base + base / 4 + 1;
+  if (lo < (size_t)SMVP_CHUNK_MIN) lo = SMVP_CHUNK_MIN;
+  if (hi > (size_t)SMVP_CHUNK_MAX) hi = SMVP_CHUNK_MAX;
+  // (only a length that is more than 1 % better than the plain quotient replaces it: the expression is a model, and a different lane count
+  //  moves work between the SMVP and the stitch -- at 2^24, 512 instead of 456 is 0.2 % better by the model and 1.5 % slower measured)
+  const size_t base_cost = cost(base);
+  size_t best = base, best_cost = base_cost - base_cost / 100;
+  for (size_t c = lo; c <= hi; c++) {
+    const size_t k = cost(c);
+    const size_t d = c > base ? c - base : base - c, bd = best > base ? best - base : base - best;
+    if (k < best_cost || (best != base && k == best_cost && d < bd)) {
+      best = c;
+      best_cost = k;
+    }
+  }
+  return (uint32_t)best;
 }
 inline uint32_t chunks_for(size_t n, uint32_t chunk_len) { return (uint32_t)((n + chunk_len - 1) / chunk_len); }
 // head/tail piece records needed for any run over at most n points: w_count * chunks is largest at w_count = NWIN

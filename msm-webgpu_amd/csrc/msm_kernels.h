@@ -562,9 +562,12 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* wa
 // the consumers load that one word (deriving it per workgroup from the 16 .. 64 window totals cost every SMVP workgroup a chain of
 // scalar loads at its start: +1 % on the whole MSM).
 constexpr int SMVP_CHUNK_MIN_ENTRIES = 8;
+// (rounds 1 - 2 kept chunk lengths multiples of 4 for the index loads of that time; any length works since the SMVP loads one index per entry,
+//  and the host now picks the length by the workgroups-per-CU count it produces: msm_hip.hip, chunk_len_for)
+constexpr uint32_t SMVP_CHUNK_ROUND = 1;
 __device__ __forceinline__ uint32_t smvp_chunk_len(uint32_t mx, uint32_t chunks, uint32_t host_len) {
   uint32_t len = (uint32_t)(((uint64_t)mx + chunks - 1) / chunks);
-  len = (len + 3u) & ~3u;
+  len = (len + (SMVP_CHUNK_ROUND - 1u)) / SMVP_CHUNK_ROUND * SMVP_CHUNK_ROUND;
   if (len < (uint32_t)SMVP_CHUNK_MIN_ENTRIES) len = SMVP_CHUNK_MIN_ENTRIES;
   return len < host_len ? len : host_len;
 }
