@@ -185,7 +185,7 @@ int ensure_stage(msm_hip_ctx* ctx, size_t bytes) {
   return MSM_HIP_OK;
 }
 
-// entries per SMVP lane: about SMVP_TARGET_LANES lanes over all windows of the run, a multiple of 4 within the kernel's limits
+// entries per SMVP lane: about SMVP_TARGET_LANES lanes over all windows of the run, within the kernel's limits
 inline size_t target_lanes() {  // MSM_HIP_TARGET_LANES overrides the default for tuning experiments
   static const size_t v = [] {
     const char* e = getenv("MSM_HIP_TARGET_LANES");

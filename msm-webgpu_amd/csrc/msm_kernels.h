@@ -1023,8 +1023,8 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
 //   B[w][k] = sum_{d=+k} P - sum_{d=-k} P  (k >= 1),   B[w][0] = -sum_{d=-2^15} P
 // The reference gives one thread one bucket, so a wave runs as long as its fullest bucket.  Here every lane owns a
 // fixed-length chunk of `chunk_len` consecutive entries of the slot-sorted list -- equal work per lane whatever the bucket
-// sizes -- and flushes its accumulator whenever the slot changes.  The host picks a chunk length (a multiple of 4 in
-// [SMVP_CHUNK_MIN, SMVP_CHUNK_MAX]) so that about SMVP_TARGET_LANES lanes exist for n entries per window (about three rounds of 3 waves
+// sizes -- and flushes its accumulator whenever the slot changes.  The host picks a chunk length (in
+// [SMVP_CHUNK_MIN, SMVP_CHUNK_MAX]; msm_hip.hip: chunk_len_for) so that about SMVP_TARGET_LANES lanes exist for n entries per window (about three rounds of 3 waves
 // per SIMD at 168 VGPRs, no scratch) and sizes the chunk arrays and grids with it; the length actually used is settled on the device
 // from the entries the sort produced (smvp_chunk_len above: never longer than the host's).  Runs that cross a chunk boundary leave a "tail" piece
 // (in the chunk where the run starts) and "head" pieces (in the chunks it continues into); k_smvp_stitch adds them.
