@@ -101,6 +101,31 @@ def self_launch(n_ranks):
     return worst
 
 
+def run_native_child(args, bases_mode, n_ranks):
+    """rank 0, after its own timed region (every rank idle in a host-side wait): ONE fresh child process times the same window-sharded
+    workload through the in-process C ABI a Rust caller gets (native_mgpu_main: msm_hip_mgpu_launch_batch_device_bn254 /
+    finish_batch over `n_ranks` devices, ncclAllGather per launch) -- reported beside the torch.distributed figure as value_native_mgpu.
+    A failing child is a non-zero exit of the child and null fields here; nothing of it runs inside this process."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                             "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    env.update(BENCH_MGPU_NATIVE="1", BENCH_BASES=bases_mode)
+    if os.environ.get("BENCH_ALL_ON_GPU0") == "1":  # one-GPU rehearsal: the contexts share GPU 0 (pinned-buffer gather)
+        env["BENCH_MGPU_IDS"] = ",".join(["0"] * n_ranks)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n_ranks), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--logn", str(args.logn), "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                           timeout=float(os.environ.get("BENCH_NATIVE_TIMEOUT_S", "600")))
+    except subprocess.TimeoutExpired:
+        return None, "native child timed out"
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        return None, "native child exit %d: %s" % (r.returncode, r.stderr.strip()[-300:])
+    return json.loads(lines[0]), None
+
+
 def native_mgpu_main(args):
     """BENCH_MGPU_NATIVE=1: the same window-sharded workload through the in-process multi-GPU C ABI (msm_hip_mgpu_launch_batch_device_bn254 /
     msm_hip_mgpu_finish_batch_bn254: one host process, one engine context and one persistent host thread per GPU, one ncclAllGather per
@@ -137,7 +162,7 @@ def native_mgpu_main(args):
         pending, last = [], None
         for i, gs in enumerate(sizes):
             slot = i % (depth + 1)
-            mg.launch_batch([t[: gs * n] for t in scal], n, slot)
+            mg.launch_batch([t[: gs * n] for t in scal], n, slot, inputs_complete=True)  # sampled and synchronised before the timed region
             pending.append((slot, gs))
             if len(pending) == depth:
                 s0, g0 = pending.pop(0)
@@ -165,7 +190,8 @@ def native_mgpu_main(args):
                                  "parallelism": "in-process msm_hip_mgpu_*: %s windows over %d contexts, %s gather" % (
                                      "8 half-length" if bases_mode == "endomorphism" else "16", len(ids), "RCCL" if mg.uses_rccl else "pinned-buffer"),
                                  "device_ids": ids, "msms_per_launch": group, "launches_in_flight": depth},
-                      "sharded_result_equals_single_gpu": ok, "native_mgpu": True}))
+                      "sharded_result_equals_single_gpu": ok, "native_mgpu": True, "rccl_ranks": len(ids) if mg.uses_rccl else 0,
+                      "pre_timed_msms": int(os.environ.get("BENCH_STEADY_MSMS", "40")) + max(args.warmup, 1)}))
     mg.close()
     ctx0.close()
 
@@ -233,6 +259,14 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    # a host-side (gloo) group beside RCCL's: where ranks must WAIT for one another without occupying their GPUs -- an RCCL barrier is a
+    # kernel that spins on every GPU until the last rank arrives (rank 0's native child, below, uses all of them meanwhile)
+    host_group = None
+    if use_dist and world > 1:
+        import datetime
+
+        host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=30)) if dist.get_backend() != "gloo" else dist.group.WORLD
+
     # ranks that really take part in the collectives: every rank contributes its id to one all-gather
     dist_ranks, dist_backend = None, None
     if use_dist:
@@ -292,8 +326,10 @@ def main():
     if sharded:
         full = msms_per_launch(emulate if emulate > 1 else world, shard_windows)
         group = int(os.environ.get("BENCH_MSMS_PER_LAUNCH", "0")) or full
+        # every MSM's host window combine runs ONCE across the ranks (vector v of a launch on rank v % world), not once per rank
+        combine_mode = os.environ.get("BENCH_COMBINE", "spread")
         pipe = ShardedMsmPipeline(ctx, rank, world, depth=int(os.environ.get("BENCH_PIPE_DEPTH", "3")), msms_per_issue=group,
-                                  emulate_world=emulate, halves=halves)
+                                  emulate_world=emulate, halves=halves, combine=combine_mode)
         w_local = pipe.w_end - pipe.w_begin
         # vector k of a group is scalar set k & 1
         group_scalars = torch.cat([scalar_sets[k & 1] for k in range(group)], dim=0).contiguous() if group > 1 else None
@@ -482,15 +518,23 @@ def main():
             isolated = ctx.stage_ms()
         latency_ms = sorted(lat)[len(lat) // 2]
 
-    # sharded runs: check the gathered + combined result against this rank's own whole 16-window MSM (outside the timed region)
+    # sharded runs: check the gathered + combined results of the last launch against this rank's own whole MSM (outside the timed region);
+    # a rank checks the vectors it combined ("spread": vector v on rank v % world), the verdict is the AND over the ranks
     sharded_ok = None
     if sharded and emulate <= 1:
-        if group > 1:  # `last` is the result list of the final group; its vector k used scalar set k & 1
-            whole = ctx.msm(scalar_sets[(len(last) - 1) & 1])
-            sharded_ok = bool(whole == last[-1])
-        else:
-            whole = ctx.msm(scalar_sets[(args.steps - 1) & 1])
-            sharded_ok = bool(whole == last)
+        res = last if isinstance(last, list) else [last]  # vector k of a group used scalar set k & 1
+        whole, sharded_ok = {}, True
+        for k, g1 in enumerate(res):
+            if g1 is None:
+                continue
+            idx = (k & 1) if group > 1 else ((args.steps - 1) & 1)
+            if idx not in whole:
+                whole[idx] = ctx.msm(scalar_sets[idx])
+            sharded_ok = sharded_ok and bool(whole[idx] == g1)
+        if use_dist:
+            t = torch.tensor([1 if sharded_ok else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            sharded_ok = bool(t.item())
 
     ms_per_step = elapsed * 1e3 / args.steps
     # roofline of the SMVP accumulate kernel: algorithmic bytes of all timed launches / their summed durations
@@ -510,7 +554,7 @@ def main():
             rp = json.load(f)
         key = "logn%d_%s_%s" % (args.logn, bases_mode, "w%d" % w_local if sharded else "single")
         if key in rp:
-            kernel_ms_rocprof, rocprof_source = rp[key]["k_smvp_chunks_avg_ms"], rp[key]["source"]
+            kernel_ms_rocprof, rocprof_source = rp[key]["k_smvp_chunks_avg_ms"], rp[key]["source"] + " (a committed profile of the same command, not measured in this run)"
     except (OSError, ValueError, KeyError):
         pass
 
@@ -571,6 +615,19 @@ def main():
                               "%d steady-state steps; the W warm-up steps" % steady,
     }
 
+    # N > 1: the same workload through the in-process multi-GPU C ABI (what a Rust caller of src/lib.rs:76-82 links against), timed by ONE
+    # fresh child of rank 0 while every rank of this job idles in a host-side wait -- value stays the torch.distributed figure
+    if use_dist and world > 1 and emulate <= 1 and os.environ.get("BENCH_NATIVE_CHILD", "1") != "0":
+        dist.barrier(group=host_group)
+        if rank == 0:
+            child, err = run_native_child(args, bases_mode, world)
+            out["value_native_mgpu"] = child["value"] if child else None
+            out["ms_per_step_native_mgpu"] = child["ms_per_step"] if child else None
+            out["native_rccl_ranks"] = child.get("rccl_ranks") if child else None
+            out["native_mgpu"] = ({"config": child["config"], "result_equals_single_gpu": child["sharded_result_equals_single_gpu"],
+                                   "pre_timed_msms": child.get("pre_timed_msms")} if child else {"error": err})
+        dist.barrier(group=host_group)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu as oracle_cpu  # the checker + the timed CPU baseline; never on the product path
 
@@ -588,7 +645,8 @@ def main():
                                          "scaled by 2^%d/2^%d)" % (logs, logs, args.logn),
                                "seconds": cpu_s}
         if ns == n:
-            out["verified_bit_exact_vs_cpu"] = bool(last.to_affine_bytes() == oracle_cpu.to_affine64(want))
+            last_g1 = last[-1] if isinstance(last, list) else last
+            out["verified_bit_exact_vs_cpu"] = bool(last_g1.to_affine_bytes() == oracle_cpu.to_affine64(want))
         threads = min(os.cpu_count() or 1, 64)
         t1 = time.perf_counter()
         want_mt = oracle_cpu.cpu_msm(pb, sb, threads)

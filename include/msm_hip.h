@@ -240,11 +240,18 @@ int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t 
  *   _bn254         : scalars in host memory (nvec x n x 32 B); every device uploads all of them (PCIe-bound: the latency form).  The buffer
  *                    must stay untouched until finish.
  *   _device_bn254  : scalars_dev[d] = the same nvec x n x 32 B already resident on device d (complete before the call; alive until finish).
- * A failing launch is reported by finish, which always leaves the slot free. */
+ * A failing launch is reported by finish, which always leaves the slot free.  RCCL gather: the devices' calls of a launch's all-gather
+ * are issued in lock-step -- a device whose own launch failed (slot busy, out of memory, a HIP error) still enters the collective, with a
+ * zeroed block -- so a failure on one device can neither hang the others' collectives nor shift the pairing of later launches; finish
+ * returns that device's error within the time of a normal launch and the next launch runs normally.  Only a collective that could not be
+ * ISSUED on some device leaves the object unusable (every later call returns MSM_HIP_ERR_HIP; destroy aborts the communicator). */
 int msm_hip_mgpu_launch_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, int nvec, int slot);
 int msm_hip_mgpu_launch_batch_device_bn254(msm_hip_mgpu* m, const void* const* scalars_dev, size_t n, int nvec, int slot);
 int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz);
 int msm_hip_mgpu_group_size(const msm_hip_mgpu* m);
+/* test hook: the next `launches` window-sharded launches fail on device index `device_index` (MSM_HIP_ERR_HIP, before anything is queued
+ * there) -- the rehearsal of one failing GPU; MSM_HIP_FAULT_DEVICE=<index> in the environment arms one such launch at creation. */
+int msm_hip_mgpu_inject_fault(msm_hip_mgpu* m, int device_index, int launches);
 int msm_hip_mgpu_run_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz);
 /* contiguous balanced partition of [0, num) over `world` ranks (the first num % world ranks take one more): the window ranges of
  * msm_hip_mgpu_run_bn254 and the MSM ranges of msm_hip_mgpu_run_batch_bn254; host-only */

@@ -179,19 +179,30 @@ class MultiGpuMsm {
     }
     std::vector<G1> out;
     std::vector<uint8_t> xyz(96 * g);
-    for (size_t i = 0; i < groups.size() + IN_FLIGHT; i++) {
-      if (i >= IN_FLIGHT) {
-        const size_t k = i - IN_FLIGHT, nvec = groups[k].size() / (32 * n);
-        check(msm_hip_mgpu_finish_batch_bn254(m_, (int)(k % MSM_HIP_NUM_SLOTS), xyz.data()), "msm_hip_mgpu_finish_batch_bn254");
-        for (size_t v = 0; v < nvec; v++) {
-          G1 r;
-          std::memcpy(r.xyz.data(), xyz.data() + 96 * v, 96);
-          out.push_back(r);
+    size_t launched = 0, finished = 0;  // groups launched / collected
+    try {
+      for (size_t i = 0; i < groups.size() + IN_FLIGHT; i++) {
+        if (i >= IN_FLIGHT) {
+          const size_t k = i - IN_FLIGHT, nvec = groups[k].size() / (32 * n);
+          finished = k + 1;  // (finish leaves the slot free whatever it returns)
+          check(msm_hip_mgpu_finish_batch_bn254(m_, (int)(k % MSM_HIP_NUM_SLOTS), xyz.data()), "msm_hip_mgpu_finish_batch_bn254");
+          for (size_t v = 0; v < nvec; v++) {
+            G1 r;
+            std::memcpy(r.xyz.data(), xyz.data() + 96 * v, 96);
+            out.push_back(r);
+          }
+        }
+        if (i < groups.size()) {
+          check(msm_hip_mgpu_launch_batch_bn254(m_, groups[i].data(), n, (int)(groups[i].size() / (32 * n)), (int)(i % MSM_HIP_NUM_SLOTS)),
+                "msm_hip_mgpu_launch_batch_bn254");
+          launched = i + 1;
         }
       }
-      if (i < groups.size())
-        check(msm_hip_mgpu_launch_batch_bn254(m_, groups[i].data(), n, (int)(groups[i].size() / (32 * n)), (int)(i % MSM_HIP_NUM_SLOTS)),
-              "msm_hip_mgpu_launch_batch_bn254");
+    } catch (...) {
+      // the launches still in flight read `groups` (pageable uploads on the devices' host threads): collect every one of them before the
+      // buffers go out of scope
+      for (size_t k = finished; k < launched; k++) (void)msm_hip_mgpu_finish_batch_bn254(m_, (int)(k % MSM_HIP_NUM_SLOTS), xyz.data());
+      throw;
     }
     return out;
   }

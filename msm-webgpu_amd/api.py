@@ -122,6 +122,7 @@ def lib():
         L.msm_hip_mgpu_launch_batch_device_bn254.argtypes = [vp, C.POINTER(vp), sz, i, i]
         L.msm_hip_mgpu_finish_batch_bn254.argtypes = [vp, i, u8p]
         L.msm_hip_mgpu_group_size.argtypes = [vp]
+        L.msm_hip_mgpu_inject_fault.argtypes = [vp, i, i]
         L.msm_hip_window_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
         _lib = L
     return _lib
@@ -610,15 +611,19 @@ class MultiGpuMsm:
         """MSMs per launch that fill a device (msm_hip_mgpu_group_size): 16 / windows per device (8 with endomorphism bases)."""
         return lib().msm_hip_mgpu_group_size(self._h)
 
-    def launch_batch(self, scalars, n, slot=0):
+    def launch_batch(self, scalars, n, slot=0, inputs_complete=False):
         """`scalars`: nvec x n x 32 B of host bytes (every device uploads them), or a list with one CUDA uint8 tensor per device
-        holding the same bytes.  Returns nvec; finish_batch(slot, nvec) collects."""
+        holding the same bytes (inputs_complete: they were synchronised before this call; otherwise every tensor's current torch stream is
+        waited for here).  Returns nvec; finish_batch(slot, nvec) collects."""
         if isinstance(scalars, (list, tuple)):
             ts = [_as_device_u8(t, 32, "scalars")[0] for t in scalars]
             rows = ts[0].numel() // 32
             if n <= 0 or rows % n or any(t.numel() != ts[0].numel() for t in ts):
                 raise ValueError("every device needs the same whole number of n-element vectors")
             ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+            if not inputs_complete:  # the header wants the device scalars complete before the call: wait for whatever torch still has queued on
+                for t in ts:          # each tensor's device (the engine's streams are not ordered with torch's)
+                    torch.cuda.current_stream(t.device).synchronize()
             _check(lib().msm_hip_mgpu_launch_batch_device_bn254(self._h, ptrs, n, rows // n, slot), "msm_hip_mgpu_launch_batch_device_bn254")
             self._keep = getattr(self, "_keep", {})
             self._keep[slot] = ts
@@ -630,6 +635,10 @@ class MultiGpuMsm:
         self._keep[slot] = b  # the library reads the buffer until finish
         _check(lib().msm_hip_mgpu_launch_batch_bn254(self._h, b, n, len(b) // (32 * n), slot), "msm_hip_mgpu_launch_batch_bn254")
         return len(b) // (32 * n)
+
+    def inject_fault(self, device_index, launches=1):
+        """test hook (msm_hip_mgpu_inject_fault): the next `launches` window-sharded launches fail on that device"""
+        _check(lib().msm_hip_mgpu_inject_fault(self._h, device_index, launches), "msm_hip_mgpu_inject_fault")
 
     def finish_batch(self, slot, nvec):
         out = C.create_string_buffer(self.jb * nvec)

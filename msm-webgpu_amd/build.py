@@ -35,6 +35,22 @@ def needs_build():
 TRANSLATION_UNITS = ["msm_hip.hip", "curve_bls12_381_g2.hip", "curve_bn254_g2.hip", "curve_bls12_381.hip", "curve_grumpkin.hip", "curve_pallas.hip", "curve_vesta.hip"]  # host + BN254's unit; one per further curve
 
 
+def compile_flags():
+    """hipcc flags of every translation unit (the environment switches of the diagnostic builds included)"""
+    # -fno-slp-vectorize: the SLP vectoriser packs the limb arrays into <2 x i32> values, which the backend keeps in 64 / 128-bit register
+    # tuples -- the shape on which this LLVM's register coalescer miscompiled the all-assembly diagnostic build (profiles/
+    # r04_asm_everywhere_rootcause.txt; gate: tools/check_machine_verifier.py).  Without it: same registers, 1 - 2 % shorter single-MSM
+    # latency, throughput unchanged (profiles/r04_ab_noslp.txt).  MSM_HIP_SLP=1 restores the compiler's default.
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
+    if os.environ.get("MSM_HIP_SLP") != "1":
+        flags.append("-fno-slp-vectorize")
+    if os.environ.get("MSM_HIP_NO_ASM") == "1":  # the C++ multipliers everywhere (the inline-assembly ones are only in g1_madd)
+        flags.append("-DFQ29_NO_ASM")
+    if os.environ.get("MSM_HIP_ASM_EVERYWHERE") == "1":  # diagnostic: the inline-assembly multipliers in every kernel
+        flags.append("-DFQ29_ASM_EVERYWHERE")
+    return flags + os.environ.get("MSM_HIP_EXTRA_FLAGS", "").split()
+
+
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950: every translation unit of csrc/ to an object (in parallel), then -shared -> msm-webgpu_amd/libmsm_hip.so"""
     if not force and not needs_build():
@@ -45,12 +61,7 @@ def build(force=False, verbose=False):
     # the compiler's intermediate files are kept (build/temps/, git-ignored): the device assembly among them is what the code-generation
     # gate reads (tools/check_long_branch_hazard.py, tests/test_codegen_hazards.py) instead of compiling everything a second time
     os.makedirs(TEMPS, exist_ok=True)
-    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
-    if os.environ.get("MSM_HIP_NO_ASM") == "1":  # the C++ multipliers everywhere (the inline-assembly ones are only in g1_madd)
-        flags.append("-DFQ29_NO_ASM")
-    if os.environ.get("MSM_HIP_ASM_EVERYWHERE") == "1":  # diagnostic: the inline-assembly multipliers in every kernel
-        flags.append("-DFQ29_ASM_EVERYWHERE")
-    flags += os.environ.get("MSM_HIP_EXTRA_FLAGS", "").split()
+    flags = compile_flags()
 
     def compile_unit(name):
         obj = os.path.join(TEMPS, os.path.splitext(name)[0] + ".o")

@@ -32,6 +32,7 @@ struct RcclApi {
   void* lib = nullptr;
   int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
   int (*CommDestroy)(void* comm) = nullptr;
+  int (*CommAbort)(void* comm) = nullptr;  // (optional: only used to tear down a communicator whose collective could not be issued)
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) = nullptr;
@@ -43,6 +44,7 @@ struct RcclApi {
     if (!lib) return false;
     CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
     GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
     GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
     AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
@@ -111,7 +113,7 @@ struct MgpuSlot {
   uint8_t* d_send[MGPU_MAX] = {};    // MAXLW x 96 B: this device's window sums [nvec][its windows], then padding
   uint8_t* d_gather[MGPU_MAX] = {};  // n x MAXLW x 96 B: every device's block after the all-gather
   uint8_t* h_gather = nullptr;       // pinned copy of device 0's gather buffer
-  hipEvent_t gathered = nullptr;     // device 0: h_gather is complete
+  hipEvent_t gathered[MGPU_MAX] = {};  // device d's call of this launch's all-gather has completed (device 0: and h_gather is complete)
 };
 
 }  // namespace
@@ -123,6 +125,9 @@ struct msm_hip_mgpu {
   msm_hip_ctx* ctx[MGPU_MAX] = {};
   DeviceWorker* worker[MGPU_MAX] = {};
   bool rccl = false;
+  std::atomic<bool> broken{false};  // a device could not issue its call of a collective: the communicator is out of step, every later call fails
+  std::atomic<int> fault_device{-1};  // test hook (msm_hip_mgpu_inject_fault / MSM_HIP_FAULT_DEVICE): the next `fault_left` launches fail on this device
+  std::atomic<int> fault_left{0};
   bool endo = false;  // the resident bases carry their endomorphism images: window-sharded launches use the 8 half-length windows
   RcclApi api;
   void* comm[MGPU_MAX] = {};
@@ -146,8 +151,46 @@ int mgpu_for_each(msm_hip_mgpu* m, F f) {
 inline int mgpu_windows(const msm_hip_mgpu* m, bool halves) { return halves ? nwin_of(WBITS, true) : NWIN; }
 inline int mgpu_per(const msm_hip_mgpu* m, bool halves) { return (mgpu_windows(m, halves) + m->n - 1) / m->n; }
 
-// device d's part of a window-sharded launch (on its worker thread): scalars up (host variant), its window range of every vector
-// into context slot `k`, then -- RCCL -- its call of the launch's all-gather, in stream order behind the slot
+// device d's own work of a window-sharded launch: scalars up (host variant), its window range of every vector into context slot `k`
+// (`launched`: the context slot now holds an unfinished launch)
+int mgpu_enqueue_on_device(msm_hip_mgpu* m, int d, int k, const void* scalars, bool host_scalars, size_t n, int nvec, int b, int e, bool& launched) {
+  MgpuSlot& ms = m->slot[k];
+  msm_hip_ctx* ctx = m->ctx[d];
+  const bool halves = ms.halves;
+  int rc = MSM_HIP_OK;
+  if (m->fault_device.load() == d && m->fault_left.load() > 0) {  // injected fault (tests): this device's launch fails before anything is queued
+    m->fault_left--;
+    return MSM_HIP_ERR_HIP;
+  }
+  const void* dev = scalars;
+  if (host_scalars) {  // all vectors of the launch into the slot's staging buffer, on the copy stream
+    ON_DEVICE(ctx);
+    Slot& s = ctx->slot[k];
+    if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;
+    if ((rc = setup_slot(ctx, s))) return rc;
+    if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    const size_t count = (size_t)nvec * n;
+    if (count > s.cap_host_scalars) {
+      s.cap_host_scalars = 0;
+      if ((rc = dev_alloc(ctx, s.d_host_scalars, count * 8))) return rc;
+      s.cap_host_scalars = count;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(s.d_host_scalars, scalars, count * 32, hipMemcpyHostToDevice, ctx->copy_stream));
+    HIP_TRY(ctx, hipEventRecord(s.staged, ctx->copy_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.staged, 0));
+    dev = s.d_host_scalars;
+  }
+  void* sums = m->rccl ? ms.d_send[d] : nullptr;  // host gather: the sums leave through the context slot's pinned buffer
+  rc = launch_impl(ctx, dev, n, nvec, b, e, WBITS, k, sums, halves ? MODE_HALVES : MODE_PLAIN);
+  launched = rc == MSM_HIP_OK;
+  return rc;
+}
+
+// device d's part of a window-sharded launch (on its worker thread): its own work (above), then -- RCCL -- its call of the launch's
+// all-gather, in stream order behind the slot.  The collective is issued WHATEVER happened before it: the devices' calls of one
+// all-gather must pair up, and a device that returned early (slot busy, out of memory, a HIP error) would leave its peers' calls
+// waiting for ever -- finish would hang -- and, with several slots in flight, pair its NEXT launch's call with their stale one (a
+// slot would then receive another launch's window sums).  A failed device sends a zeroed block; finish reports its status.
 int mgpu_launch_on_device(msm_hip_mgpu* m, int d, int k, const void* scalars, bool host_scalars, size_t n, int nvec) {
   MgpuSlot& ms = m->slot[k];
   msm_hip_ctx* ctx = m->ctx[d];
@@ -156,45 +199,33 @@ int mgpu_launch_on_device(msm_hip_mgpu* m, int d, int k, const void* scalars, bo
   int b, e;
   (void)msm_hip_window_range(d, m->n, W, &b, &e);
   int rc = MSM_HIP_OK;
-  if (e > b) {
-    const void* dev = scalars;
-    if (host_scalars) {  // all vectors of the launch into the slot's staging buffer, on the copy stream
-      ON_DEVICE(ctx);
-      Slot& s = ctx->slot[k];
-      if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;
-      if ((rc = setup_slot(ctx, s))) return rc;
-      if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-      const size_t count = (size_t)nvec * n;
-      if (count > s.cap_host_scalars) {
-        s.cap_host_scalars = 0;
-        if ((rc = dev_alloc(ctx, s.d_host_scalars, count * 8))) return rc;
-        s.cap_host_scalars = count;
-      }
-      HIP_TRY(ctx, hipMemcpyAsync(s.d_host_scalars, scalars, count * 32, hipMemcpyHostToDevice, ctx->copy_stream));
-      HIP_TRY(ctx, hipEventRecord(s.staged, ctx->copy_stream));
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.staged, 0));
-      dev = s.d_host_scalars;
-    }
-    void* sums = m->rccl ? ms.d_send[d] : nullptr;  // host gather: the sums leave through the context slot's pinned buffer
-    rc = launch_impl(ctx, dev, n, nvec, b, e, WBITS, k, sums, halves ? MODE_HALVES : MODE_PLAIN);
-    if (rc) return rc;
-    ms.launched[d] = true;
-  }
+  bool launched = false;
+  if (e > b) rc = mgpu_enqueue_on_device(m, d, k, scalars, host_scalars, n, nvec, b, e, launched);
+  ms.launched[d] = launched;
   if (m->rccl) {
-    ON_DEVICE(ctx);
-    hipStream_t gs = m->gather_stream[d];
-    if (e > b) HIP_TRY(ctx, hipStreamWaitEvent(gs, ctx->slot[k].done, 0));
-    if (m->api.AllGather(ms.d_send[d], ms.d_gather[d], (size_t)rows * ctx->jb, NCCL_UINT8, m->comm[d], gs) != 0) return MSM_HIP_ERR_HIP;
-    if (d == 0) {
-      HIP_TRY(ctx, hipMemcpyAsync(ms.h_gather, ms.d_gather[0], (size_t)m->n * rows * ctx->jb, hipMemcpyDeviceToHost, gs));
-      HIP_TRY(ctx, hipEventRecord(ms.gathered, gs));
+    auto collective = [&]() -> int {
+      ON_DEVICE(ctx);
+      hipStream_t gs = m->gather_stream[d];
+      const size_t bytes = (size_t)rows * ctx->jb;
+      if (launched) HIP_TRY(ctx, hipStreamWaitEvent(gs, ctx->slot[k].done, 0));
+      else if (e > b) HIP_TRY(ctx, hipMemsetAsync(ms.d_send[d], 0, bytes, gs));  // (a device without windows sends the zeros of its creation)
+      if (m->api.AllGather(ms.d_send[d], ms.d_gather[d], bytes, NCCL_UINT8, m->comm[d], gs) != 0) return MSM_HIP_ERR_HIP;
+      if (d == 0) HIP_TRY(ctx, hipMemcpyAsync(ms.h_gather, ms.d_gather[0], (size_t)m->n * bytes, hipMemcpyDeviceToHost, gs));
+      HIP_TRY(ctx, hipEventRecord(ms.gathered[d], gs));
+      return MSM_HIP_OK;
+    };
+    const int crc = collective();
+    if (crc) {  // this device's call could not be issued: the communicator is out of step for good
+      m->broken = true;
+      if (!rc) rc = crc;
     }
   }
-  return MSM_HIP_OK;
+  return rc;
 }
 
 int mgpu_launch(msm_hip_mgpu* m, const void* const* per_device, const void* host, bool is_host, size_t n, int nvec, int k) {
   if (!m || k < 0 || k >= NSLOT || nvec < 1 || n > MAX_POINTS) return MSM_HIP_ERR_INVALID_ARG;
+  if (m->broken) return MSM_HIP_ERR_HIP;  // (a collective could not be issued on some device earlier: destroy the object)
   MgpuSlot& ms = m->slot[k];
   if (ms.pending) return MSM_HIP_ERR_SLOT_BUSY;
   const bool halves = m->endo;
@@ -238,6 +269,14 @@ void msm_hip_mgpu_destroy(msm_hip_mgpu* m) {
     delete m->worker[d];  // (runs what is still queued, then joins)
     m->worker[d] = nullptr;
   }
+  if (m->broken && m->api.CommAbort) {  // collectives that can never pair up: abort them instead of waiting
+    for (int d = 0; d < m->n; d++)
+      if (m->comm[d]) {
+        DeviceGuard guard(m->device[d]);
+        (void)m->api.CommAbort(m->comm[d]);
+        m->comm[d] = nullptr;
+      }
+  }
   for (int d = 0; d < m->n; d++)  // every device's part of the collectives still in flight, before any communicator goes
     if (m->ctx[d] && m->gather_stream[d]) {
       DeviceGuard guard(m->device[d]);
@@ -250,7 +289,7 @@ void msm_hip_mgpu_destroy(msm_hip_mgpu* m) {
       for (MgpuSlot& ms : m->slot) {
         if (ms.d_send[d]) (void)hipFree(ms.d_send[d]);
         if (ms.d_gather[d]) (void)hipFree(ms.d_gather[d]);
-        if (d == 0 && ms.gathered) (void)hipEventDestroy(ms.gathered);
+        if (ms.gathered[d]) (void)hipEventDestroy(ms.gathered[d]);
       }
       if (m->gather_stream[d]) (void)hipStreamDestroy(m->gather_stream[d]);
     }
@@ -302,7 +341,7 @@ int msm_hip_mgpu_create_curve(msm_hip_mgpu** out, const int* device_ids, int n_d
         ok = hipMalloc((void**)&ms.d_send[d], (size_t)MAXLW * MAX_JB) == hipSuccess &&
              hipMalloc((void**)&ms.d_gather[d], (size_t)n_devices * MAXLW * MAX_JB) == hipSuccess &&
              hipMemset(ms.d_send[d], 0, (size_t)MAXLW * MAX_JB) == hipSuccess;
-        if (ok && d == 0) ok = hipEventCreateWithFlags(&ms.gathered, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&ms.gathered[d], hipEventDisableTiming) == hipSuccess;
       }
       ok = ok && hipDeviceSynchronize() == hipSuccess;
     }
@@ -314,7 +353,21 @@ int msm_hip_mgpu_create_curve(msm_hip_mgpu** out, const int* device_ids, int n_d
     }
     m->rccl = ok;  // AUTO: fall back to the pinned-buffer gather
   }
+  if (const char* e = getenv("MSM_HIP_FAULT_DEVICE")) {  // rehearsal of a failing device: its first launch fails (msm_hip_mgpu_inject_fault)
+    const int d = atoi(e);
+    if (d >= 0 && d < n_devices) {
+      m->fault_device = d;
+      m->fault_left = 1;
+    }
+  }
   *out = m;
+  return MSM_HIP_OK;
+}
+
+int msm_hip_mgpu_inject_fault(msm_hip_mgpu* m, int device_index, int launches) {
+  if (!m || device_index < 0 || device_index >= m->n || launches < 0) return MSM_HIP_ERR_INVALID_ARG;
+  m->fault_device = device_index;
+  m->fault_left = launches;
   return MSM_HIP_OK;
 }
 
@@ -360,25 +413,36 @@ int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz)
     m->worker[d]->wait(ms.ticket[d]);
     if (ms.rc[d] && !rc) rc = ms.rc[d];
   }
-  // 2. the gather is complete (RCCL: device 0's copy of the gathered blocks; every device's part of the collective with it)
+  // 2. RCCL: every device's call of THIS launch's all-gather has completed (device 0: and its copy of the gathered blocks) -- the slot's
+  //    send / gather buffers are free again.  The calls were issued in lock-step whatever the devices' own launches did, so this wait
+  //    ends even when the launch failed somewhere; only a collective that could not be ISSUED (broken) may never complete: not waited for.
+  //    (Per-slot events: the gather streams also carry the all-gathers of the launches behind this one.)
   bool hip_ok = true;
-  if (m->rccl && !rc && ms.n) {
-    DeviceGuard guard(m->device[0]);
-    hip_ok = guard.ok && hipEventSynchronize(ms.gathered) == hipSuccess;
-  }
-  // 3. collect every context slot (error words; leaves the slots free whatever happened)
-  bool parts = false;
-  for (int d = 0; d < G; d++) {
-    if (!ms.launched[d]) continue;
-    const int r = msm_hip_slot_sync(m->ctx[d], slot);
-    if (r && !rc) rc = r;
-    parts = parts || m->ctx[d]->slot[slot].parts;
-  }
-  if (m->rccl)  // a later launch may reuse the slot's send / gather buffers: the devices' collectives have left them
-    for (int d = 1; d < G; d++) {
+  if (m->rccl && ms.n && !m->broken)
+    for (int d = 0; d < G; d++) {
       DeviceGuard guard(m->device[d]);
-      if (!guard.ok || hipStreamSynchronize(m->gather_stream[d]) != hipSuccess) hip_ok = false;
+      if (!guard.ok || hipEventSynchronize(ms.gathered[d]) != hipSuccess) hip_ok = false;
     }
+  // 3. collect every context slot (error words; leaves the slots free whatever happened) -- on the device's own worker thread, which
+  //    is the only thread that touches its context while launches are in flight
+  bool parts = false;
+  {
+    int r[MGPU_MAX] = {};
+    bool p[MGPU_MAX] = {};
+    uint64_t ticket[MGPU_MAX] = {};
+    for (int d = 0; d < G; d++)
+      if (ms.launched[d]) ticket[d] = m->worker[d]->post([m, d, slot, &r, &p] {
+        r[d] = msm_hip_slot_sync(m->ctx[d], slot);
+        p[d] = m->ctx[d]->slot[slot].parts;
+      });
+    for (int d = 0; d < G; d++) {
+      if (!ms.launched[d]) continue;
+      m->worker[d]->wait(ticket[d]);
+      if (r[d] && !rc) rc = r[d];
+      parts = parts || p[d];
+    }
+  }
+  if (m->broken && !rc) rc = MSM_HIP_ERR_HIP;
   ms.pending = false;
   if (rc) return rc;
   if (!hip_ok) return MSM_HIP_ERR_HIP;

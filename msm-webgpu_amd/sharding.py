@@ -143,10 +143,17 @@ class ShardedMsmPipeline:
 
     SLOTS = 4
 
-    def __init__(self, ctx, rank, world_size, group=None, num_windows=None, depth=3, msms_per_issue=1, emulate_world=0, halves=False):
+    def __init__(self, ctx, rank, world_size, group=None, num_windows=None, depth=3, msms_per_issue=1, emulate_world=0, halves=False,
+                 combine="all"):
         """halves: the context's bases carry their endomorphism images (set_bases(..., endomorphism=True)); the ranks then share the 8
-        HALF-length windows of the 2n-point problem (msm_hip_launch_half_windows_batch_device_bn254) instead of the 16 full-length ones."""
+        HALF-length windows of the 2n-point problem (msm_hip_launch_half_windows_batch_device_bn254) instead of the 16 full-length ones.
+        combine: who runs the host window combine (src/cuzk/msm.rs:411-416) of a launch's MSMs -- every rank holds all window sums after
+        the all-gather.  "all": every rank combines every MSM (every rank returns every result; world x the host work).  "spread": vector v
+        of a launch is combined ONCE, by rank v % world -- complete() returns None in the other ranks' places (the throughput form: each
+        result exists once, on a known rank).  "rank0": rank 0 combines everything, the others return None."""
         assert 1 <= depth < self.SLOTS
+        assert combine in ("all", "spread", "rank0")
+        self.combine = combine
         self.depth = depth
         self.halves = halves
         if num_windows is None:
@@ -225,9 +232,13 @@ class ShardedMsmPipeline:
                     pass
         return out if self.g > 1 else out[0]
 
+    def owner(self, v):
+        """rank that combines vector v of a launch (None: every rank does)"""
+        return None if self.combine == "all" or self.emulate else (0 if self.combine == "rank0" else v % self.world)
+
     def _combine(self, slot, nvec):
-        """The launch's window sums (pinned host buffer: rank r's block holds [nvec][its windows] records) -> one G1 per MSM.
-        All Horner chains of the launch go through ONE library call (host pool: side by side)."""
+        """The launch's window sums (pinned host buffer: rank r's block holds [nvec][its windows] records) -> one G1 per MSM this rank
+        owns (None for the others').  All Horner chains of the launch go through ONE library call (host pool: side by side)."""
         host = self.host_np[slot]
         if self.emulate:  # partial sums over this rank's windows only (tuning aid)
             nw = self.w_end - self.w_begin
@@ -235,4 +246,12 @@ class ShardedMsmPipeline:
         else:
             nw = self.num_windows
             sums = gathered_window_sums(host, nvec, self.world, nw)
-        return MsmContext.combine_windows_batch(sums, nw, self.ctx.curve)
+        mine = [v for v in range(nvec) if self.owner(v) in (None, self.rank)]
+        if len(mine) == nvec:
+            return MsmContext.combine_windows_batch(sums, nw, self.ctx.curve)
+        out = [None] * nvec
+        if mine:
+            picked = np.ascontiguousarray(sums.reshape(nvec, nw, -1)[mine])
+            for v, g in zip(mine, MsmContext.combine_windows_batch(picked, nw, self.ctx.curve)):
+                out[v] = g
+        return out

@@ -80,3 +80,35 @@ def test_checker_sees_a_long_branch_through_a_live_register_pair():
     bad = live("4:5", 4, 5)  # the saved exec mask is read at the target
     assert len(bad) == 1 and bad[0][0] == "k_demo2" and bad[0][3] == [4, 5]
     assert live("6:7", 6, 7) == []
+
+
+def test_machine_verifier_report_is_parsed():
+    """the third gate's parser: LLVM's machine-verifier report -> (function, message)"""
+    import check_machine_verifier as mv
+
+    class P:
+        returncode = 1
+        stdout = ("# After Register Coalescer\n*** Bad machine code: Live range continues after dead def flag ***\n"
+                  "- function:    k_demo\n- basic block: %bb.34\n- instruction: 34736B\tdead undef %4299.sub0:vreg_128_align2 = V_ADD3_U32_e64\n"
+                  "*** Bad machine code: A Subrange is not covered by the main range ***\n- function:    k_demo\nLLVM ERROR: Found 2 machine code errors.\n")
+
+    real = mv.subprocess.run
+    mv.subprocess.run = lambda *a, **k: P
+    try:
+        found = mv.verify_unit("msm_hip.hip", [])
+    finally:
+        mv.subprocess.run = real
+    assert found == [("k_demo", "Live range continues after dead def flag"), ("k_demo", "A Subrange is not covered by the main range")]
+
+
+def test_product_device_code_passes_the_machine_verifier():
+    """LLVM's machine verifier over every translation unit, compiled with the build's own flags (tools/check_machine_verifier.py): the
+    register-coalescer miscompile that made the all-assembly diagnostic build return wrong bucket sums (round 3: "cause not isolated";
+    profiles/r04_asm_everywhere_rootcause.txt) is reported by it, and the product must be free of it.  Cached under build/ by the sources'
+    hash: about three minutes after a change of csrc/, nothing otherwise."""
+    import check_machine_verifier as mv
+
+    reports = mv.check()
+    assert len(reports) >= 4
+    for unit, found in reports.items():
+        assert found == [], (unit, found)

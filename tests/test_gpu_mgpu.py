@@ -93,6 +93,35 @@ def test_mgpu_grouped_asynchronous_launches(data, ids, gather, endo):
         mg.close()
 
 
+@pytest.mark.parametrize("ids,gather,fault", [([0], "rccl", 0), ([0, 0, 0], "host", 1), ([0] * 8, "host", 7)])
+def test_mgpu_a_failing_device_is_reported_within_a_bound_and_the_next_launch_succeeds(data, ids, gather, fault):
+    """One device's launch fails (msm_hip_mgpu_inject_fault: before anything is queued there, as a busy slot, an allocation failure or a HIP
+    error would).  RCCL gather: that device still issues its call of the launch's all-gather (zeroed block), so the collective completes,
+    finish returns the error in bounded time, launches already in flight behind it are unaffected and the next launch succeeds.  (With one
+    rank the collective cannot hang -- what this checks is the lock-step bookkeeping; two real GPUs: the test below.)"""
+    import time
+
+    n, points, scalars, want = data
+    mg = m.MultiGpuMsm(ids, gather)
+    try:
+        mg.set_bases(points)
+        mg.launch_batch(scalars, n, 0)
+        assert mg.finish_batch(0, 1)[0].to_affine_bytes() == want
+        mg.inject_fault(fault, 1)
+        t0 = time.monotonic()
+        mg.launch_batch(scalars, n, 1)   # fails on device `fault`
+        mg.launch_batch(scalars, n, 2)   # queued behind it: must be unaffected
+        with pytest.raises(m.MsmHipError) as e:
+            mg.finish_batch(1, 1)
+        assert e.value.code == -7 and time.monotonic() - t0 < 10.0
+        assert mg.finish_batch(2, 1)[0].to_affine_bytes() == want
+        mg.launch_batch(scalars, n, 1)   # the failed launch's slot is free again
+        assert mg.finish_batch(1, 1)[0].to_affine_bytes() == want
+        assert mg.msm(scalars).to_affine_bytes() == want
+    finally:
+        mg.close()
+
+
 def test_mgpu_two_distinct_devices_over_rccl(data):
     """The in-process RCCL gather on two real GPUs (skipped on a one-GPU box; the driver's multi-GPU node runs it)."""
     import torch
@@ -111,6 +140,17 @@ def test_mgpu_two_distinct_devices_over_rccl(data):
                 mg.launch_batch(scalars * g, n, k)
             for k in range(3):
                 assert all(r.to_affine_bytes() == want for r in mg.finish_batch(k, g))
+            # a failing device must not hang its peer's collective, nor shift the pairing of the launches behind it
+            import time
+
+            mg.inject_fault(1, 1)
+            t0 = time.monotonic()
+            mg.launch_batch(scalars * g, n, 0)
+            mg.launch_batch(scalars * g, n, 1)
+            with pytest.raises(m.MsmHipError):
+                mg.finish_batch(0, g)
+            assert time.monotonic() - t0 < 20.0
+            assert all(r.to_affine_bytes() == want for r in mg.finish_batch(1, g))
         finally:
             mg.close()
 

@@ -198,3 +198,41 @@ def test_gathered_blocks_to_per_msm_window_sums(built, world, num_windows):
         assert got[v].to_affine_bytes() == cpu.to_affine64(want)
         assert m.MsmContext.combine_windows(recs[96 * num_windows * v:96 * num_windows * (v + 1)]).to_affine_bytes() == cpu.to_affine64(want)
     assert m.MsmContext.combine_windows_batch(b"", num_windows) == []
+
+
+@pytest.mark.parametrize("mode", ["all", "spread", "rank0"])
+def test_pipeline_combines_every_msm_once_across_the_ranks(built, mode):
+    """ShardedMsmPipeline's host combine (after the all-gather every rank holds all window sums): "spread" -- vector v by rank v % world --
+    and "rank0" run each Horner chain ONCE across the ranks instead of once per rank; the owners' results are the oracle's.  Host only:
+    the object is filled in by hand (its constructor allocates device buffers)."""
+    from msm_webgpu_amd.sharding import ShardedMsmPipeline, max_windows_per_rank, window_range
+
+    world, nvec, nw = 3, 4, 16
+    per = max_windows_per_rank(world, nw)
+    recs = cpu.g1_scalar_mul(cpu.sample_points(15, nvec * nw), cpu.sample_scalars(16, nvec * nw))
+    host = np.zeros((world, nvec * per, 96), dtype=np.uint8)
+    for r in range(world):
+        b, e = window_range(r, world, nw)
+        for v in range(nvec):
+            for w in range(b, e):
+                host[r, v * (e - b) + (w - b)] = np.frombuffer(recs[96 * (v * nw + w):96 * (v * nw + w) + 96], dtype=np.uint8)
+    want = [cpu.to_affine64(cpu.horner(recs[96 * nw * v:96 * nw * (v + 1)])) for v in range(nvec)]
+
+    class Ctx:
+        curve = "bn254"
+
+    owners = []
+    for rank in range(world):
+        p = ShardedMsmPipeline.__new__(ShardedMsmPipeline)
+        p.combine, p.emulate, p.world, p.rank, p.num_windows, p.ctx = mode, 0, world, rank, nw, Ctx()
+        p.w_begin, p.w_end = window_range(rank, world, nw)
+        p.host_np = [host]
+        out = p._combine(0, nvec)
+        assert len(out) == nvec
+        for v, g in enumerate(out):
+            if g is not None:
+                owners.append(v)
+                assert g.to_affine_bytes() == want[v]
+            else:
+                assert p.owner(v) != rank
+    assert sorted(owners) == (sorted(list(range(nvec)) * world) if mode == "all" else list(range(nvec)))
