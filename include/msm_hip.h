@@ -67,6 +67,12 @@ extern "C" {
                                           MSM_HIP_BASES_PRECOMPUTE; the window-sharding entry points ignore it (records 0 .. n-1 are the
                                           plain set). */
 
+#define MSM_HIP_BASES_PLAIN 16u        /* hold the n bases only and run the reference's exact shape -- 16 windows of full-length scalars over n points
+                                          (src/cuzk/msm.rs:79-82).  WITHOUT this flag, MSM_HIP_BASES_PRECOMPUTE or MSM_HIP_BASES_ENDOMORPHISM a
+                                          base set takes the fastest mode the curve has (round 4: the drop-in default is the headline's mode):
+                                          the endomorphism mode on the curves that have one (up to 2^27 points), else the plain shape.
+                                          Same group element either way; what the flag decides is memory (n or 2n records) and speed. */
+
 typedef struct msm_hip_ctx msm_hip_ctx;
 
 /* ---- context: replaces get_adapter/get_device + per-call buffer/pipeline creation (src/cuzk/gpu.rs:11-54,

@@ -261,9 +261,13 @@ class MsmContext:
         """points: bytes (host, n x 64 B wire format) or a CUDA uint8 tensor holding the same bytes.
         mont256: the coordinates are x * 2^256 mod p (4 x 64-bit Montgomery limbs, R = 2^256) instead of canonical integers.
         precompute: fixed-base tables 2^(16 w) P_i (16 x the memory): whole MSMs then use one bucket set for all windows.
-        endomorphism: also store phi(P_i) (2 x the memory): whole MSMs split every scalar into two 127-bit halves and need
-        half the windows."""
+        endomorphism: True: also store phi(P_i) (2 x the memory): whole MSMs split every scalar into two 127-bit halves and need
+        half the windows.  False (this wrapper's default: the stage-level parity tests read the reference's 16-window shape):
+        MSM_HIP_BASES_PLAIN.  None: the C ABI's own default (flags = 0) -- the fastest mode the curve has, which is what the
+        reference-shaped calls (compute_msm / run_webgpu_msm below, msm_hip_msm_bn254_g1) use."""
         flags = (1 if check_on_curve else 0) | (2 if mont256 else 0) | (4 if precompute else 0) | (8 if endomorphism else 0)
+        if endomorphism is False and not precompute:
+            flags |= 16
         if isinstance(points, torch.Tensor) and points.is_cuda:
             t, n = _as_device_u8(points, self.pb, "points")
             self._order_after_torch(t)
@@ -585,10 +589,11 @@ class MultiGpuMsm:
         return lib().msm_hip_mgpu_uses_rccl(self._h) == 1
 
     def set_bases(self, points, check_on_curve=False, endomorphism=False):
-        """Replicated on every device.  endomorphism: MSM_HIP_BASES_ENDOMORPHISM -- msm_batch runs whole MSMs over the 2n points, and
-        the window-sharded calls shard the 8 half-length windows."""
+        """Replicated on every device.  endomorphism: True: MSM_HIP_BASES_ENDOMORPHISM -- msm_batch runs whole MSMs over the 2n points, and
+        the window-sharded calls shard the 8 half-length windows; False: MSM_HIP_BASES_PLAIN; None: the C ABI's default (flags = 0: whole
+        MSMs take the curve's fastest mode, the window-sharded calls the 16 full-length windows)."""
         b = bytes(points)
-        flags = (1 if check_on_curve else 0) | (8 if endomorphism else 0)
+        flags = (1 if check_on_curve else 0) | (8 if endomorphism else 0) | (16 if endomorphism is False else 0)
         _check(lib().msm_hip_mgpu_set_bases_bn254(self._h, b, len(b) // self.pb, flags), "msm_hip_mgpu_set_bases_bn254")
         return len(b) // self.pb
 
@@ -669,7 +674,7 @@ def _ctx(device=0):
 def compute_msm(points, scalars, device=0):
     """≙ compute_msm (src/cuzk/msm.rs:75): one-shot MSM including base upload; returns G1."""
     ctx = _ctx(device)
-    n = ctx.set_bases(points)
+    n = ctx.set_bases(points, endomorphism=None)  # the ABI's default: the curve's fastest mode (same group element as the reference's shape)
     ns = (scalars.numel() if isinstance(scalars, torch.Tensor) else len(scalars)) // 32
     if ns != n:
         raise ValueError("points and scalars differ in length (%d vs %d)" % (n, ns))

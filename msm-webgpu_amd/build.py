@@ -44,10 +44,10 @@ def compile_flags():
     flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
     if os.environ.get("MSM_HIP_SLP") != "1":
         flags.append("-fno-slp-vectorize")
-    if os.environ.get("MSM_HIP_NO_ASM") == "1":  # the C++ multipliers everywhere (the inline-assembly ones are only in g1_madd)
+    if os.environ.get("MSM_HIP_NO_ASM") == "1":  # the C++ multipliers everywhere
         flags.append("-DFQ29_NO_ASM")
-    if os.environ.get("MSM_HIP_ASM_EVERYWHERE") == "1":  # diagnostic: the inline-assembly multipliers in every kernel
-        flags.append("-DFQ29_ASM_EVERYWHERE")
+    if os.environ.get("MSM_HIP_ASM_SMVP_ONLY") == "1":  # rounds 1 - 3: the inline-assembly multipliers only in the SMVP's mixed addition, C++ elsewhere
+        flags.append("-DFQ29_ASM_SMVP_ONLY")
     return flags + os.environ.get("MSM_HIP_EXTRA_FLAGS", "").split()
 
 

@@ -135,7 +135,7 @@ inline bool fq_check_below_2p(const fq& r) {
 // Montgomery product a*b/R mod p, R = 2^261.  Operand limbs <= 2^30 + 16; value(a)*value(b) <= 169 p^2.
 // Result exact (limbs < 2^29), value < 2p.
 FQ_HD fq fq_mul(const fq& a, const fq& b) {
-#if defined(FQ29_ASM) && defined(FQ29_ASM_EVERYWHERE)  // diagnostic build: the assembly multipliers in every kernel
+#if defined(FQ29_ASM) && !defined(FQ29_ASM_SMVP_ONLY)  // the assembly multipliers in every kernel (round 4; -DFQ29_ASM_SMVP_ONLY: only in the SMVP's mixed addition, as rounds 1 - 3)
   return fq_mul_asm(a, b);
 #endif
   uint64_t c[2 * FQ_L];
@@ -168,7 +168,7 @@ FQ_HD fq fq_mul(const fq& a, const fq& b) {
 // < 2^58.01 and 9 reduction terms < 2^58, together < 2^63.2.  value(a)*value(b) + value(c)*value(d) <= 169 p^2.
 // Result exact, < 2p.
 FQ_HD fq fq_mul2(const fq& a, const fq& b, const fq& c_, const fq& d) {
-#if defined(FQ29_ASM) && defined(FQ29_ASM_EVERYWHERE)
+#if defined(FQ29_ASM) && !defined(FQ29_ASM_SMVP_ONLY)
   return fq_mul2_asm(a, b, c_, d);
 #endif
   uint64_t c[2 * FQ_L];
@@ -201,7 +201,7 @@ FQ_HD fq fq_mul2(const fq& a, const fq& b, const fq& c_, const fq& d) {
 
 // Montgomery square: 45 products instead of 81 (cross terms doubled once).
 FQ_HD fq fq_sqr(const fq& a) {
-#if defined(FQ29_ASM) && defined(FQ29_ASM_EVERYWHERE)
+#if defined(FQ29_ASM) && !defined(FQ29_ASM_SMVP_ONLY)
   return fq_sqr_asm(a);
 #endif
   uint64_t c[2 * FQ_L];

@@ -654,10 +654,22 @@ int check_run_args(msm_hip_ctx* ctx, const void* scalars, size_t n) {
 // room for n bases; no run may still be reading the old ones (the SMVP on the main stream)
 constexpr size_t MAX_PRECOMPUTE_POINTS = (size_t)1 << 24;  // 16 tables: 16 GiB, and table indices stay below 2^28
 
+// The mode a base set is held in.  Asked for explicitly (tables, endomorphism images, or MSM_HIP_BASES_PLAIN: the reference's 16 windows
+// over n points), or -- none of the three -- the fastest the curve has: the drop-in call shape (flags = 0; msm_hip_msm_bn254_g1 ≙ compute_msm,
+// src/cuzk/msm.rs:75-94) runs the mode the headline figure is measured in (656 vs 701 - 714 MSM/s at 2^20 in round 3, when it did not).
+constexpr uint32_t BASE_FLAGS_ALL = MSM_HIP_CHECK_ON_CURVE | MSM_HIP_BASES_MONT256 | MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_ENDOMORPHISM | MSM_HIP_BASES_PLAIN;
+inline uint32_t resolve_base_flags(const msm_hip_ctx* ctx, size_t n, uint32_t flags) {
+  static const bool auto_endo = [] { const char* e = getenv("MSM_HIP_BASES_AUTO"); return !e || atoi(e) != 0; }();  // MSM_HIP_BASES_AUTO=0: flags = 0 means plain (rounds 1 - 3)
+  if (flags & (MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_ENDOMORPHISM | MSM_HIP_BASES_PLAIN)) return flags;
+  if (auto_endo && ctx->ops->glv && n <= MAX_POINTS / 2) return flags | MSM_HIP_BASES_ENDOMORPHISM;
+  return flags;
+}
+
 int reserve_bases(msm_hip_ctx* ctx, size_t n, uint32_t flags) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   const bool tables = (flags & MSM_HIP_BASES_PRECOMPUTE) != 0, endo = (flags & MSM_HIP_BASES_ENDOMORPHISM) != 0;
   if (n > MAX_POINTS || (tables && n > MAX_PRECOMPUTE_POINTS) || (endo && n > MAX_POINTS / 2) || (tables && endo)) return MSM_HIP_ERR_INVALID_ARG;
+  if ((flags & ~BASE_FLAGS_ALL) || ((flags & MSM_HIP_BASES_PLAIN) && (tables || endo))) return MSM_HIP_ERR_INVALID_ARG;
   if ((endo && !ctx->ops->glv) || (tables && !ctx->ops->precompute_tables)) return MSM_HIP_ERR_INVALID_ARG;  // (a G2 context has neither)
   ctx->n_bases = 0;
   ctx->precomputed = false;
@@ -859,6 +871,7 @@ int msm_hip_wait_stream(msm_hip_ctx* ctx, void* producer_stream) {
 int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t n, uint32_t flags) {
   if (!ctx || (!xy_dev && n)) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
+  flags = resolve_base_flags(ctx, n, flags);
   int rc = reserve_bases(ctx, n, flags);
   if (rc) return rc;
   return set_bases_from_device(ctx, static_cast<const uint32_t*>(xy_dev), n, flags);
@@ -867,6 +880,7 @@ int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t 
 int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, uint32_t flags) {
   if (!ctx || (!xy_host && n)) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
+  flags = resolve_base_flags(ctx, n, flags);
   int rc = reserve_bases(ctx, n, flags);
   if (rc) return rc;
   // the wire bytes land in the bases array itself and are converted in place (same 64 B per point): no staging buffer

@@ -584,6 +584,11 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
                                                         uint32_t* __restrict__ tmp_val,
                                                         uint8_t* __restrict__ tmp_fine, size_t merge_nb, uint32_t half_n, uint32_t half_shift,
                                                         uint32_t chunks, uint32_t host_chunk_len, uint32_t* __restrict__ chunk_len_dev) {
+  // scalars a thread holds (biased, in registers) per block iteration: 8 halves of 4 words, or 4 full scalars of 8 words -- 8 of those cost
+  // 282 VGPRs + 26 AGPRs at 16 bits (one wave per SIMD) and a 304-byte scratch object at 12 bits (round 3)
+  constexpr int PER = SW == 8 ? 4 : 8;
+  constexpr int SUB = 256 * PER;
+  static_assert(SUB <= SCAT_SUB, "LDS staging arrays");
   // SW = 4 (endomorphism halves, interleaved by k_count<C, 4, true>): input 2 j is k1 of scalar j and multiplies base j; input 2 j + 1 is
   // k2 and multiplies phi(P_j), record half_shift = n_bases + j
   __shared__ uint32_t gpos[MAXLW * NCOARSE];  // global write cursor of every (window, coarse bin) run of this tile
@@ -627,13 +632,13 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
   const size_t tile_base = (size_t)blockIdx.x * tile_len;
   const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
   for (int v = 0; v < nvec; v++)
-  for (size_t sub = tile_base; sub < tile_end; sub += SCAT_SUB) {
-    // this thread's 8 biased scalars stay in registers; every window's digit code is read from them
+  for (size_t sub = tile_base; sub < tile_end; sub += SUB) {
+    // this thread's PER biased scalars stay in registers; every window's digit code is read from them
     const uint32_t* sv = scalars + (size_t)v * vec_stride;
-    uint32_t sc[8][WinCfg<C, SW>::WORDS];
+    uint32_t sc[PER][WinCfg<C, SW>::WORDS];
     uint32_t negs = 0;  // bit j: scalar j is a negative half (its digits' signs are flipped)
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < PER; j++) {
       const size_t i = sub + (size_t)j * 256 + tid;
       uint32_t raw[SW], neg = 0;
 #pragma unroll
@@ -650,9 +655,9 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
       const uint32_t idx_base = merge_nb ? (uint32_t)(w * merge_nb) : 0u;
       if (tid < NCOARSE) hist[tid] = 0;
       __syncthreads();
-      uint32_t rank[8];
+      uint32_t rank[PER];
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
+      for (int j = 0; j < PER; j++) {
         const uint32_t code = code_of_window<C>(sc[j], w);
         rank[j] = code ? atomicAdd(&hist[(code & 0x7fffu) >> 8], 1u) : 0u;
       }
@@ -663,7 +668,7 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
       __syncthreads();
       const uint32_t total = lstart[NCOARSE - 1] + hist[NCOARSE - 1];
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
+      for (int j = 0; j < PER; j++) {
         const uint32_t code = code_of_window<C>(sc[j], w);
         if (code) {
           const uint32_t slot = code & 0x7fffu, bin = slot >> 8;

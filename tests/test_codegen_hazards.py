@@ -112,3 +112,22 @@ def test_product_device_code_passes_the_machine_verifier():
     assert len(reports) >= 4
     for unit, found in reports.items():
         assert found == [], (unit, found)
+
+
+def test_machine_verifier_fires_on_the_miscompiled_variant():
+    """... and the gate does fire on the build that was wrong on the GPU: the assembly multipliers in every kernel (since round 4 the
+    product's shape) compiled WITH the SLP vectoriser (MSM_HIP_SLP=1: the compiler's default, which rounds 1 - 3 used) -- the 14-limb
+    unit's k_smvp_stitch, exactly the kernel whose P + P path returned garbage (profiles/r03_ab_asm_everywhere.txt)."""
+    import check_machine_verifier as mv
+
+    old = os.environ.get("MSM_HIP_SLP")
+    os.environ["MSM_HIP_SLP"] = "1"
+    try:
+        found = mv.check(units=["curve_bls12_381.hip"])["curve_bls12_381.hip"]
+    finally:
+        if old is None:
+            del os.environ["MSM_HIP_SLP"]
+        else:
+            os.environ["MSM_HIP_SLP"] = old
+    assert found and all("k_smvp_stitch" in fn for fn, _ in found), found
+    assert any("dead def" in msg for _, msg in found), found

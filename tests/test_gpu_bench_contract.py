@@ -45,3 +45,19 @@ def test_emulated_share_line_and_native_multi_gpu_mode(built):
     assert d["emulated_world"] == 8 and d["config"]["msms_per_launch"] == 8 and d["config"]["windows_per_gpu"] == 2 and "cpu_baseline" not in d
     n = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--logn", "14"], BENCH_MGPU_NATIVE="1", BENCH_MGPU_IDS="0,0", BENCH_STEADY_MSMS="4")
     assert n["native_mgpu"] is True and n["n_gpus"] == 2 and n["sharded_result_equals_single_gpu"] is True
+
+
+def test_multi_rank_line_carries_the_native_c_abi_figure(built):
+    """`bench.py --gpus N` (N > 1): rank 0's ONE line has the torch.distributed figure (`value`) and, from one fresh child process, the same
+    workload through the in-process multi-GPU C ABI (`value_native_mgpu`, `native_rccl_ranks`).  Rehearsed on the one GPU of this box: two
+    ranks over gloo on GPU 0, the child with two contexts on GPU 0 (pinned-buffer gather, hence 0 RCCL ranks); every MSM is combined once
+    across the ranks and each rank checks its own."""
+    d = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--logn", "14"], BENCH_ALL_ON_GPU0="1", BENCH_DIST_BACKEND="gloo", BENCH_STEADY_MSMS="4")
+    assert d["n_gpus"] == 2 and d["dist_ranks"] == 2 and d["value"] > 0 and d["sharded_result_equals_single_gpu"] is True
+    assert d["value_native_mgpu"] > 0 and abs(d["value_native_mgpu"] - 1e3 / d["ms_per_step_native_mgpu"]) < 1e-6 * d["value_native_mgpu"]
+    assert d["native_rccl_ranks"] == 0 and d["native_mgpu"]["result_equals_single_gpu"] is True
+    assert d["native_mgpu"]["config"]["device_ids"] == [0, 0]
+    # a failing child: null fields and its error, the torch figure unaffected
+    e = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--logn", "14"], BENCH_ALL_ON_GPU0="1", BENCH_DIST_BACKEND="gloo", BENCH_STEADY_MSMS="4",
+               BENCH_NATIVE_TIMEOUT_S="0.01")
+    assert e["value"] > 0 and e["value_native_mgpu"] is None and e["native_rccl_ranks"] is None and "error" in e["native_mgpu"]

@@ -247,3 +247,33 @@ def test_sharded_pipeline_over_half_length_windows(ctx):
             assert part[k] == m.MsmContext.combine_windows(host[k:k + 1]), k
     finally:
         ctx.set_bases(points)
+
+
+def test_the_drop_in_default_is_the_fast_mode_and_the_same_group_element(ctx):
+    """Round 4: a base set handed over WITHOUT flags (the C ABI's flags = 0, the one-shot msm_hip_msm_bn254_g1 ≙ compute_msm, the Python
+    compute_msm / run_webgpu_msm) takes the curve's endomorphism mode -- the mode the headline figure is measured in -- and
+    MSM_HIP_BASES_PLAIN asks for the reference's 16-window shape.  Same result in every mode, against the oracle."""
+    import ctypes as C
+
+    n = 5000
+    points, sc = cpu.sample_points(96, n), cpu.sample_scalars(97, n)
+    want = cpu.to_affine64(cpu.cpu_msm(points, sc))
+    ctx.set_bases(points, endomorphism=None)  # flags = 0
+    assert ctx.uses_endomorphism() and ctx.msm(sc).to_affine_bytes() == want
+    ctx.set_bases(points)                     # this wrapper's default: MSM_HIP_BASES_PLAIN
+    assert not ctx.uses_endomorphism() and ctx.msm(sc).to_affine_bytes() == want
+    ctx.set_bases(points, check_on_curve=True, endomorphism=None)  # other flags do not switch the default off
+    assert ctx.uses_endomorphism() and ctx.msm(sc).to_affine_bytes() == want
+    # the reference-shaped calls
+    assert m.compute_msm(points, sc).to_affine_bytes() == want and m.run_webgpu_msm(points, sc).to_affine_bytes() == want
+    out = C.create_string_buffer(96)
+    assert m.lib().msm_hip_msm_bn254_g1(points, sc, n, out) == 0
+    assert m.G1(out.raw, ref.P).to_affine_bytes() == want
+    m.lib().msm_hip_oneshot_release()
+    # plain and an explicit mode exclude each other; unknown flag bits are rejected
+    for flags in (16 | 8, 16 | 4, 32, 1 << 31):
+        assert m.lib().msm_hip_set_bases_bn254(ctx._h, points, n, flags) == -2
+    # fixed-base tables stay what they were; a G2 context (no endomorphism yet) takes the plain shape by default
+    ctx.set_bases(points, precompute=True)
+    assert not ctx.uses_endomorphism() and ctx.msm(sc).to_affine_bytes() == want
+    ctx.set_bases(points)
