@@ -70,7 +70,9 @@ extern "C" {
 #define MSM_HIP_BASES_PLAIN 16u        /* hold the n bases only and run the reference's exact shape -- 16 windows of full-length scalars over n points
                                           (src/cuzk/msm.rs:79-82).  WITHOUT this flag, MSM_HIP_BASES_PRECOMPUTE or MSM_HIP_BASES_ENDOMORPHISM a
                                           base set takes the fastest mode the curve has (round 4: the drop-in default is the headline's mode):
-                                          the endomorphism mode on the curves that have one (up to 2^27 points), else the plain shape.
+                                          the endomorphism mode on the curves of prime order that have one (BN254 G1, Grumpkin, Pallas, Vesta; up to
+                                          2^27 points), else the plain shape (on a curve with a cofactor -- BLS12-381, the G2 twists -- the mode
+                                          needs bases of order r and therefore stays an explicit choice).
                                           Same group element either way; what the flag decides is memory (n or 2n records) and speed. */
 
 typedef struct msm_hip_ctx msm_hip_ctx;
@@ -104,8 +106,10 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx);
                                     A coordinate is an Fq2 element c0 || c1, each 32 B canonical little-endian: 64 bytes; points n x 128 B (x || y), results
                                     and window sums 192 B Jacobian records, scalars 32 B; every `[96]` / `[64]` / "x 96 B" of this header reads 192 / 128.
                                     Device arithmetic: csrc/fq2.h on the 9 x 29-bit prime field (csrc/curve_bn254_g2.hip).  Window sizes, window shards,
-                                    batches, grouped launches, fixed-base tables, Montgomery-form inputs, the multi-GPU calls: as for curve 0.  NOT available
-                                    (MSM_HIP_ERR_INVALID_ARG): MSM_HIP_BASES_ENDOMORPHISM (G2's endomorphism is psi, not (beta x, y)) and the device point sampler. */
+                                    batches, grouped launches, fixed-base tables, Montgomery-form inputs, the multi-GPU calls: as for curve 0.
+                                    MSM_HIP_BASES_ENDOMORPHISM (round 4): the twist has j = 0 like the curve, so (beta x, y) with beta in the PRIME field is the
+                                    multiplication by the same lambda on G2 -- same split, half-length scalars over 2n points; the bases must have order r (G2
+                                    proper), which is why the mode is never the default here.  NOT available (MSM_HIP_ERR_INVALID_ARG): the device point sampler. */
 #define MSM_HIP_CURVE_BLS12_381_G2 6 /* G2 of BLS12-381: the twist y^2 = x^3 + 4 (1 + u) over Fq2, scalars modulo the same r as curve 4.  As curve 5 with 48-byte
                                         components: coordinates 96 B (c0 || c1), points 192 B, results and window sums 288 B Jacobian records.  The same
                                         options are unavailable.  Inputs are expected in the order-r subgroup (as every valid G2 point is); points outside

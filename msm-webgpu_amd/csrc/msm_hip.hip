@@ -522,8 +522,16 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   hipLaunchKernelGGL(k_sort_fine, dim3(ncoarse, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
                      s.d_col_ptr, ctx->d_val, chunks, d_chunk_len, ctx->d_chunk_slot, part_hist);
   AFTER_KERNEL(ctx, "k_sort_fine", st);
+  if (ctx->debug) {  // deterministic transpose for the stage read-back: every slot's run in ascending order
+    hipLaunchKernelGGL(k_order_runs, dim3(blocks_for(n_entries, 256), w_count), dim3(256), 0, st, s.d_col_ptr, ctx->d_val, ctx->d_tmp_val, stride, half);
+    hipLaunchKernelGGL(k_copy_runs, dim3(blocks_for(n_entries, 256), w_count), dim3(256), 0, st, s.d_col_ptr, ctx->d_tmp_val, ctx->d_val, stride, half);
+    AFTER_KERNEL(ctx, "k_order_runs", st);
+  }
   HIP_TRY(ctx, mark(4, true));
-  hipLaunchKernelGGL(ctx->ops->smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), 0, st, ctx->d_bases, s.d_col_ptr, ctx->d_val, stride,
+  // MSM_HIP_SMVP_LDS_PAD=<bytes> (diagnostic): unused dynamic LDS per SMVP workgroup -- 65536 lets two instead of three workgroups share a CU
+  // (2 waves per SIMD): tells a latency-bound launch (slower with fewer waves) from a multiplier- or bandwidth-bound one
+  static const unsigned smvp_lds_pad = [] { const char* e = getenv("MSM_HIP_SMVP_LDS_PAD"); const long v = e ? atol(e) : 0; return v > 0 && v <= 65536 ? (unsigned)v : 0u; }();
+  hipLaunchKernelGGL(ctx->ops->smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), smvp_lds_pad, st, ctx->d_bases, s.d_col_ptr, ctx->d_val, stride,
                      chunks, d_chunk_len, ctx->d_chunk_slot, s.d_buckets, s.d_heads, s.d_tails, half);
   AFTER_KERNEL(ctx, "k_smvp_chunks", st);
   HIP_TRY(ctx, mark(5, true));
@@ -661,7 +669,11 @@ constexpr uint32_t BASE_FLAGS_ALL = MSM_HIP_CHECK_ON_CURVE | MSM_HIP_BASES_MONT2
 inline uint32_t resolve_base_flags(const msm_hip_ctx* ctx, size_t n, uint32_t flags) {
   static const bool auto_endo = [] { const char* e = getenv("MSM_HIP_BASES_AUTO"); return !e || atoi(e) != 0; }();  // MSM_HIP_BASES_AUTO=0: flags = 0 means plain (rounds 1 - 3)
   if (flags & (MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_ENDOMORPHISM | MSM_HIP_BASES_PLAIN)) return flags;
-  if (auto_endo && ctx->ops->glv && n <= MAX_POINTS / 2) return flags | MSM_HIP_BASES_ENDOMORPHISM;
+  // ... on the curves of prime order only: phi(P) = lambda P holds on the subgroup of order r, and a base set of a curve with a cofactor
+  // (BLS12-381, the G2 twists) may hold points outside it, for which the plain MSM is still defined -- there the mode stays an opt-in
+  const bool prime_order = ctx->curve == MSM_HIP_CURVE_BN254_G1 || ctx->curve == MSM_HIP_CURVE_GRUMPKIN || ctx->curve == MSM_HIP_CURVE_PALLAS ||
+                           ctx->curve == MSM_HIP_CURVE_VESTA;
+  if (auto_endo && prime_order && ctx->ops->glv && n <= MAX_POINTS / 2) return flags | MSM_HIP_BASES_ENDOMORPHISM;
   return flags;
 }
 
@@ -670,7 +682,7 @@ int reserve_bases(msm_hip_ctx* ctx, size_t n, uint32_t flags) {
   const bool tables = (flags & MSM_HIP_BASES_PRECOMPUTE) != 0, endo = (flags & MSM_HIP_BASES_ENDOMORPHISM) != 0;
   if (n > MAX_POINTS || (tables && n > MAX_PRECOMPUTE_POINTS) || (endo && n > MAX_POINTS / 2) || (tables && endo)) return MSM_HIP_ERR_INVALID_ARG;
   if ((flags & ~BASE_FLAGS_ALL) || ((flags & MSM_HIP_BASES_PLAIN) && (tables || endo))) return MSM_HIP_ERR_INVALID_ARG;
-  if ((endo && !ctx->ops->glv) || (tables && !ctx->ops->precompute_tables)) return MSM_HIP_ERR_INVALID_ARG;  // (a G2 context has neither)
+  if ((endo && !ctx->ops->glv) || (tables && !ctx->ops->precompute_tables)) return MSM_HIP_ERR_INVALID_ARG;
   ctx->n_bases = 0;
   ctx->precomputed = false;
   ctx->endo = false;

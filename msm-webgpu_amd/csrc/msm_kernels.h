@@ -209,8 +209,8 @@ __global__ void __launch_bounds__(256) k_convert_points(const uint32_t* in, uint
   st_fq(out + i * PT_WORDS + CW, y);
 }
 
-#ifndef MSM_FQ2
 // The endomorphism's point half (csrc/glv.h): record n + i = phi(P_i) = (beta x_i, y_i) behind the n plain bases
+// (a G2 unit: beta is the element (beta, 0) of Fq2 -- the twist has j = 0 like the curve, tools/gen_constants.py emit_g2)
 __global__ void __launch_bounds__(256) k_endo_points(uint32_t* __restrict__ bases, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -223,7 +223,6 @@ __global__ void __launch_bounds__(256) k_endo_points(uint32_t* __restrict__ base
 #pragma unroll
   for (int k = 0; k < CW / 4; k++) o[k] = y[k];
 }
-#endif  // MSM_FQ2
 
 // Fixed-base tables (reference README.md "Future work": the Elastic-MSM precomputation trade-off): with
 // T_w[i] = 2^(16 w) P_i stored for every window, sum_i s_i P_i = sum_i sum_w d_{i,w} T_w[i] needs ONE bucket set for all
@@ -1021,6 +1020,44 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
     gpos[tid] += hist[tid];
     __syncthreads();
   }
+}
+
+// Deterministic mode of the transpose (the reference's stage test asserts the exact val_idxs,
+// tests/transpose_shader.rs:198-199): the order inside a slot is the arrival order of LDS atomics -- the group sum does not depend on it,
+// but a stage-level comparison does.  With the debug switch on (msm_hip_set_debug), every slot's run is put into ascending order of its
+// entries (index | sign << 31: the positive digits' points by index, then the negative digits') by a rank sort: one lane per entry finds
+// its slot (binary search of col_ptr), counts the entries of its run that are smaller (they are distinct) and writes itself to that
+// position of a scratch copy (`tmp`, the coarse-order array, free by then); a second kernel copies the scratch back.  O(sum of run
+// length^2): runs beyond ORDER_RUN_MAX entries (heavily skewed inputs) keep their arrival order.
+constexpr uint32_t ORDER_RUN_MAX = 1u << 17;
+__global__ void __launch_bounds__(256) k_order_runs(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ val_idxs, uint32_t* __restrict__ tmp,
+                                                    size_t stride, uint32_t half) {
+  const int lw = blockIdx.y;
+  const uint32_t* cp = col_ptr + (size_t)lw * (half + 1);
+  const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= cp[half]) return;
+  uint32_t lo = 0, hi = half - 1;  // the slot whose run holds entry e: cp[s] <= e < cp[s + 1]
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (cp[mid + 1] > e) hi = mid;
+    else lo = mid + 1;
+  }
+  const uint32_t b = cp[lo], end = cp[lo + 1];
+  const uint32_t* v = val_idxs + (size_t)lw * stride;
+  const uint32_t x = v[e];
+  uint32_t pos = e;
+  if (end - b <= ORDER_RUN_MAX) {
+    uint32_t rank = 0;
+    for (uint32_t j = b; j < end; j++) rank += v[j] < x ? 1u : 0u;
+    pos = b + rank;
+  }
+  tmp[(size_t)lw * stride + pos] = x;
+}
+__global__ void __launch_bounds__(256) k_copy_runs(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ tmp, uint32_t* __restrict__ val_idxs,
+                                                   size_t stride, uint32_t half) {
+  const int lw = blockIdx.y;
+  const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e < col_ptr[(size_t)lw * (half + 1) + half]) val_idxs[(size_t)lw * stride + e] = tmp[(size_t)lw * stride + e];
 }
 
 // ------------------------------------------------------------------------------------------------ stage 3: SMVP

@@ -308,3 +308,30 @@ def sample_points(n, seed=1):
         zi2 = f2_sqr(zi)
         out[i] = (f2_mul(jac[i][0], zi2), f2_mul(jac[i][1], f2_mul(zi2, zi)))
     return out
+
+
+# ---- the curve endomorphism on G2 (round 4; csrc/glv.h, tools/gen_constants.py emit_g2): the twist has j = 0, so phi(x, y) = (beta x, y) with
+# beta a cube root of unity of the PRIME field is an endomorphism of the twist, and on the order-r subgroup it is the multiplication by the
+# SAME lambda as on G1 (the split and its constants are the G1 model's) -- with the beta that belongs to lambda on G2
+_glv_cache = {}
+
+
+def glv_params():
+    """-> the G1 model's dict (lam, v1, v2, g1, g2, s1, s2) with `beta` replaced by the cube root of unity mod p for which lambda G = (beta x_G, y_G) on G2"""
+    key = (P, R, G)
+    if key not in _glv_cache:
+        q = dict(_g1.glv_params())
+        lg = mul(q["lam"], G)
+        b1 = q["beta"]
+        q["beta"] = next(b for b in (b1, b1 * b1 % P) if lg == (f2_scale(G[0], b), G[1]))
+        _glv_cache[key] = q
+    return _glv_cache[key]
+
+
+def glv_split(k):
+    return _g1.glv_split(k)
+
+
+def endo(pt):
+    """phi(P) = (beta x, y) = lambda P for P of order r"""
+    return None if pt is None else (f2_scale(pt[0], glv_params()["beta"]), pt[1])

@@ -306,11 +306,65 @@ def test_window_sharded_pipeline_on_this_curve(ctx):
     assert m.MsmContext.combine_windows(torch.cat([mine, rest], dim=0), curve=ctx.curve).to_affine_bytes() == want
 
 
+@pytest.mark.parametrize("n", [1, 2, 65, 257, 2049])
+def test_endomorphism_mode_on_g2(ctx, n):
+    """MSM_HIP_BASES_ENDOMORPHISM on G2 (round 4): the twist has j = 0, so phi(x, y) = (beta x, y), beta a cube root of unity of the prime field,
+    is the multiplication by lambda on the order-r subgroup; every scalar is split k = k1 + k2 lambda on the device (the G1 unit's split) and
+    the MSM runs over the 2n points P_i, phi(P_i) with half the windows.  Against the model's plain MSM, for every window size and entry point,
+    with the adversarial scalars of the G1 test; the model's own phi and split are checked against lambda P first."""
+    q = g2.glv_params()
+    lam = q["lam"]
+    pts = g2.sample_points(n, 44)
+    assert all(g2.endo(pt) == g2.mul(lam, pt) for pt in pts[:3])
+    sc = [g2.sample_scalar(45, i) for i in range(n)]
+    special = [0, 1, g2.R - 1, lam, g2.R - lam, 0x8000, (0x8000 * lam) % g2.R, g2.R - 0x8000, (1 << 253) + 0x80008000]
+    for i, v in enumerate(special[: n]):
+        sc[i] = v
+    for k in sc[:12]:
+        k1, k2 = g2.glv_split(k)
+        assert (k1 + k2 * lam) % g2.R == k % g2.R and abs(k1) < 1 << 127 and abs(k2) < 1 << 127
+    if n > 40:  # duplicates / negated duplicates: P_i meets itself (or phi(P_i) does) in a bucket
+        pts[20], sc[20] = pts[21], sc[21]
+        pts[23], sc[23] = g2.neg(pts[22]), sc[22]
+    want = g2.msm_pippenger(pts, sc, c=10)
+    points, scb = g2.points_to_bytes(pts), g2.scalars_to_bytes(sc)
+    dev = torch.frombuffer(bytearray(scb), dtype=torch.uint8).cuda()
+    ctx.set_bases(points, check_on_curve=True, endomorphism=True)
+    assert ctx.uses_endomorphism()
+    try:
+        for bits in (0, 12, 14, 16):
+            ctx.set_window_bits(bits)
+            assert ctx.msm(scb).to_affine() == want, (n, bits)
+        ctx.set_window_bits(0)
+        assert ctx.msm(dev).to_affine() == want
+        assert [g.to_affine() for g in ctx.msm_batch(scb * 3, n)] == [want] * 3
+        ctx.launch(dev, 0)
+        ctx.launch_host(scb, 1)
+        assert ctx.finish(1).to_affine() == want and ctx.finish(0).to_affine() == want
+        # the plain window shards still work on the same base set (records 0 .. n - 1), and so do the half-length shards
+        parts = [ctx.msm_windows(dev, 0, 6), ctx.msm_windows(dev, 6, 16)]
+        assert m.MsmContext.combine_windows(torch.cat(parts, dim=0), curve=ctx.curve).to_affine() == want
+        mg = m.MultiGpuMsm([0, 0, 0], "host", curve=ctx.curve)
+        try:
+            mg.set_bases(points, endomorphism=True)
+            assert mg.msm(scb).to_affine() == want
+            mg.launch_batch(scb * 2, n, 1)
+            assert [g.to_affine() for g in mg.finish_batch(1, 2)] == [want] * 2
+        finally:
+            mg.close()
+    finally:
+        ctx.set_window_bits(0)
+        ctx.set_bases(points)
+    assert not ctx.uses_endomorphism() and ctx.msm(scb).to_affine() == want
+
+
 def test_options_the_g2_unit_does_not_have_and_input_errors(ctx):
     pts = g2.points_to_bytes(g2.sample_points(4, 38))
-    with pytest.raises(m.MsmHipError) as e:  # (the G2 endomorphism is psi, not (beta x, y): no such mode)
-        ctx.set_bases(pts, endomorphism=True)
+    with pytest.raises(m.MsmHipError) as e:  # the endomorphism images and the fixed-base tables exclude each other, as on G1
+        ctx.set_bases(pts, endomorphism=True, precompute=True)
     assert e.value.code == -2
+    ctx.set_bases(pts, endomorphism=None)  # the ABI's default (flags = 0) on a curve with a cofactor: the plain shape
+    assert not ctx.uses_endomorphism()
     with pytest.raises(m.MsmHipError):  # (no device sampler: it would need a square root in Fq2)
         ctx.sample_points(4, 1)
     with pytest.raises(m.MsmHipError):  # a component >= p (c1 of x)

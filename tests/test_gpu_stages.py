@@ -71,6 +71,13 @@ def test_transpose_matches_cpu_model_rows(run):
             neg = set(ref_val[ref_cp[neg_row]:ref_cp[neg_row + 1]].tolist())
             assert {int(v) for v in got if not (v >> 31)} == pos
             assert {int(v & 0x7FFFFFFF) for v in got if v >> 31} == neg
+            # ... and, in the debug mode this fixture runs in, in a DETERMINISTIC order (k_order_runs): the reference's stage test asserts
+            # the exact val_idxs (tests/transpose_shader.rs:198-199); here a slot is the reference's row h + k (ascending point index, as
+            # its serial loop leaves it) followed by its row h - k with bit 31 set
+            ref_pos = [] if k == 0 else ref_val[ref_cp[H + k]:ref_cp[H + k + 1]].tolist()
+            ref_neg = ref_val[ref_cp[neg_row]:ref_cp[neg_row + 1]].tolist()
+            assert ref_pos == sorted(ref_pos) and ref_neg == sorted(ref_neg)
+            assert [int(v) for v in got] == ref_pos + [int(v) | 0x80000000 for v in ref_neg]
 
 
 def test_smvp_buckets_match_cpu_model(run):

@@ -32,24 +32,142 @@ if len(sys.argv) > 1 and sys.argv[1] in ("pallas", "vesta"):
 W, L, WORDS = 29, 9, 8  # limb bits, limbs, packed 32-bit words per field element
 
 
+def cube_root_of_unity(mod):
+    g = 2
+    while pow(g, (mod - 1) // 3, mod) == 1:
+        g += 1
+    return pow(g, (mod - 1) // 3, mod)
+
+
+def glv_lattice(rmod, lam, shift=320):
+    """The scalar split's constants (csrc/glv.h) for a cube root of unity `lam` modulo `rmod`: a short basis (a1, b1), (a2, b2) of
+    {(x, y): x + y lam = 0 mod r} from the extended Euclidean sequence r_i = s_i r + t_i lam around sqrt(r) (Guide to Elliptic Curve
+    Cryptography, algorithm 3.74), and from it  c1 = round(k b2 / r), c2 = round(-k b1 / r)  taken as sign * ((k * G + 2^(shift - 1)) >> shift)
+    with G = round(2^shift |b| / r), and  (k1, k2) = (k, 0) - c1 V1 - c2 V2  modulo 2^160 in two's complement:
+    k1 = k + m1 N11 + m2 N12, k2 = m1 N21 + m2 N22.  -> dict(V1, V2, G1, G2, N11, N12, N21, N22, ok)"""
+    seq = [(rmod, 0), (lam, 1)]
+    while seq[-1][0]:
+        q = seq[-2][0] // seq[-1][0]
+        seq.append((seq[-2][0] - q * seq[-1][0], seq[-2][1] - q * seq[-1][1]))
+    l = max(i for i, (rem, _) in enumerate(seq) if rem * rem >= rmod)
+    v1 = (seq[l + 1][0], -seq[l + 1][1])
+    cands = [(seq[l][0], -seq[l][1]), (seq[l + 2][0], -seq[l + 2][1])]
+    v2 = min(cands, key=lambda v: v[0] * v[0] + v[1] * v[1])
+    if v1[0] * v2[1] - v2[0] * v1[1] < 0:
+        v2 = (-v2[0], -v2[1])
+    assert v1[0] * v2[1] - v2[0] * v1[1] == rmod
+    for v in (v1, v2):
+        assert (v[0] + v[1] * lam) % rmod == 0
+    s1, s2 = (1 if v2[1] >= 0 else -1), (1 if -v1[1] >= 0 else -1)
+    g1 = ((abs(v2[1]) << shift) + rmod // 2) // rmod
+    g2 = ((abs(v1[1]) << shift) + rmod // 2) // rmod
+    m160 = (1 << 160) - 1
+    # |k1| <= (|a1| + |a2|) / 2 + (rounding slack), |k2| likewise; the recode of a 128-bit half needs < 2^127 - 2^112
+    half_bound = max(abs(v1[0]) + abs(v2[0]), abs(v1[1]) + abs(v2[1])) * 513 // 1024 + 2
+    ok = half_bound < (1 << 127) - (1 << 112) and g1 < 1 << 224 and g2 < 1 << 224
+    return {"V1": v1, "V2": v2, "G1": g1, "G2": g2, "N11": (-s1 * v1[0]) & m160, "N12": (-s2 * v2[0]) & m160, "N21": (-s1 * v1[1]) & m160,
+            "N22": (-s2 * v2[1]) & m160, "ok": ok}
+
+
 def emit_g2(which):
     """msm-webgpu_amd/csrc/<curve>_g2_constants.h: the constants of a G2 unit at the level of its coordinate field Fq2 = Fq[u] / (u^2 + 1)
     (csrc/fq2.h; the prime field underneath is the G1 unit's <curve>_constants.h, instantiated in a namespace of its own).
     bn254: the twist y^2 = x^3 + 3 / (9 + u);  bls12_381: the twist y^2 = x^3 + 4 (1 + u).  Scalars modulo the same r as the curve's G1.
-    No endomorphism mode (GLV_SUPPORTED = false: the G2 endomorphism is psi, not (beta x, y)), no fixed-base tables, no device sampler."""
+    Endomorphism mode (round 4): the twist has j-invariant 0 like the curve itself, so phi(x, y) = (beta x, y) with beta a cube root of unity of
+    the PRIME field is an endomorphism of the twist too, and on G2 (order r) it is the multiplication by a cube root of unity lambda mod r --
+    the same split k = k1 + k2 lambda, |k1|, |k2| < 2^127, and the same device code as G1 (csrc/glv.h), with the beta that belongs to lambda ON
+    G2 (found here by checking lambda G = (beta x_G, y_G) on the subgroup's generator).  (The Frobenius-based psi is the other candidate; its
+    eigenvalue t - 1 is 127 bits on BN254 but 64 bits on BLS12-381, where a balanced two-dimensional split needs psi^2 = (omega x, -y) -- the
+    same map as phi up to sign.)  No device sampler."""
     if which == "bn254":
         p, rmod, w, l, nw = P, RMOD, 29, 9, 8
         n9 = pow(9 * 9 + 1, -1, p)  # 1 / (9 + u) = (9 - u) / 82
         b0, b1 = 3 * 9 * n9 % p, (-3 * n9) % p
         assert ((b0 * 9 - b1) % p, (b0 + 9 * b1) % p) == (3, 0)
         text = "BN254 G2: the twist y^2 = x^3 + 3 / (9 + u)"
+        # the standard generator of G2 (EIP-197 / arkworks bn254; oracle/bn254_g2_ref.py pins it: on the twist, of order r)
+        gen = ((10857046999023057135944570762232829481370756359578518086990519993285655852781, 11559732032986387107991004021392285783925812861821192530917403151452391805634),
+               (8495653923123431417604973247489272438418190587263600148770280649306958101930, 4082367875863433681332203403145435568316851327593401208105741076214120093531))
     else:
         p = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
         rmod = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
         w, l, nw = 28, 14, 12
         b0, b1 = 4, 4
         text = "BLS12-381 G2: the twist y^2 = x^3 + 4 (1 + u)"
+        gen = ((0x024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8,
+                0x13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e),
+               (0x0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801,
+                0x0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be))
     assert p % 4 == 3  # u^2 = -1 is irreducible
+    # affine arithmetic on the twist over Fq2 (elements (c0, c1)), for the one check below
+    f2mul = lambda a, b_: ((a[0] * b_[0] - a[1] * b_[1]) % p, (a[0] * b_[1] + a[1] * b_[0]) % p)
+    f2sub = lambda a, b_: ((a[0] - b_[0]) % p, (a[1] - b_[1]) % p)
+
+    def f2inv(a):
+        n = pow(a[0] * a[0] + a[1] * a[1], -1, p)
+        return (a[0] * n % p, -a[1] * n % p)
+
+    def g2add(a, b_):
+        if a is None:
+            return b_
+        if b_ is None:
+            return a
+        if a[0] == b_[0]:
+            if f2sub(a[1], b_[1]) != (0, 0):
+                return None
+            x2 = f2mul(a[0], a[0])
+            lam_ = f2mul((3 * x2[0] % p, 3 * x2[1] % p), f2inv((2 * a[1][0] % p, 2 * a[1][1] % p)))
+        else:
+            lam_ = f2mul(f2sub(b_[1], a[1]), f2inv(f2sub(b_[0], a[0])))
+        x3 = f2sub(f2sub(f2mul(lam_, lam_), a[0]), b_[0])
+        return (x3, f2sub(f2mul(lam_, f2sub(a[0], x3)), a[1]))
+
+    def g2mul(k, pt):
+        acc = None
+        while k:
+            if k & 1:
+                acc = g2add(acc, pt)
+            pt = g2add(pt, pt)
+            k >>= 1
+        return acc
+
+    assert f2sub(f2mul(gen[1], gen[1]), f2mul(f2mul(gen[0], gen[0]), gen[0])) == (b0 % p, b1 % p) and g2mul(rmod, gen) is None
+    # lambda: the SAME cube root of unity mod r as the curve's G1 unit uses (so that the split constants are the G1 unit's, bit for bit);
+    # beta: the cube root of unity mod p that belongs to it on G2
+    beta1 = cube_root_of_unity(p)
+    lam = cube_root_of_unity(rmod)
+    g1gen = {"bn254": (1, 2)}.get(which) or (0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,
+                                             0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1)
+
+    def g1mul(k, pt):  # (x, y) over the prime field, y^2 = x^3 + b: only lambda's choice needs it
+        def add(a, b_):
+            if a is None:
+                return b_
+            if b_ is None:
+                return a
+            if a[0] == b_[0]:
+                if (a[1] + b_[1]) % p == 0:
+                    return None
+                l_ = 3 * a[0] * a[0] * pow(2 * a[1], -1, p) % p
+            else:
+                l_ = (b_[1] - a[1]) * pow(b_[0] - a[0], -1, p) % p
+            x = (l_ * l_ - a[0] - b_[0]) % p
+            return (x, (l_ * (a[0] - x) - a[1]) % p)
+        acc = None
+        while k:
+            if k & 1:
+                acc = add(acc, pt)
+            pt = add(pt, pt)
+            k >>= 1
+        return acc
+
+    if g1mul(lam, g1gen) != (beta1 * g1gen[0] % p, g1gen[1]):
+        lam = lam * lam % rmod
+    assert g1mul(lam, g1gen) == (beta1 * g1gen[0] % p, g1gen[1])  # (the G1 unit's choice: tools/gen_constants.py without _g2)
+    lg = g2mul(lam, gen)
+    beta = next(bb for bb in (beta1, beta1 * beta1 % p) if lg == ((bb * gen[0][0] % p, bb * gen[0][1] % p), gen[1]))
+    glv = glv_lattice(rmod, lam)
+    assert glv["ok"]
     m = (1 << w) - 1
     rr = 1 << (w * l)
     hl = nw // 2
@@ -68,7 +186,9 @@ def emit_g2(which):
     print(a("FQ2_2P29", lim(2 * p)) + "  // 2p, exact limbs: the reduced additions of fq2.h")
     print(a("FQ_ONE29", lim(rr % p) + [0] * l) + "  // 1 = (R mod p, 0)")
     print(a("FQ_B29", lim(b0 * rr % p) + lim(b1 * rr % p)) + "  // the twist's constant, Montgomery form")
-    print(a("FQ_BETA29", [0] * (2 * l)) + "  // (no endomorphism mode)")
+    print("// endomorphism phi(x, y) = (beta x, y) = lambda (x, y) on G2, beta in the prime field; k = k1 + k2 lambda (mod r), |k1|, |k2| < 2^127: csrc/glv.h")
+    print("// lambda = %d (the G1 unit's); beta = %d (%s the G1 unit's)" % (lam, beta, "=" if beta == beta1 else "the square of"))
+    print(a("FQ_BETA29", lim(beta * rr % p) + [0] * l) + "  // (beta, 0), Montgomery form")
     print("// p as %d x 32-bit words: each component of a coordinate is compared with it" % nw)
     print(a("FQ_P32", words(p, 32, nw)))
     print("// host finalisation, prime-field level: %d x 64-bit limbs, R = 2^%d" % (hl, 64 * hl))
@@ -83,10 +203,10 @@ def emit_g2(which):
     print("static constexpr uint32_t FR_N0_29 = 0x%08xu;" % ((-pow(rmod, -1, 1 << w)) % (1 << w)))
     print(a("FQ_PM2_32", words(p - 2, 32, nw)) + "  // p - 2 : the prime field's inversion exponent (the norm's inverse in an Fq2 inversion)")
     print("constexpr int FQ_BITS = %d;" % p.bit_length())
-    print("constexpr bool GLV_SUPPORTED = false;  // MSM_HIP_BASES_ENDOMORPHISM is not available for G2")
+    print("constexpr bool GLV_SUPPORTED = true;  // MSM_HIP_BASES_ENDOMORPHISM available (bases of order r: the mode is an explicit choice on a curve with a cofactor)")
     print("constexpr int GLV_SHIFT = 320;")
-    for name, n in (("GLV_G1_32", 7), ("GLV_G2_32", 7), ("GLV_N11_32", 5), ("GLV_N12_32", 5), ("GLV_N21_32", 5), ("GLV_N22_32", 5)):
-        print(a(name, [0] * n))
+    for name, n in (("G1", 7), ("G2", 7), ("N11", 5), ("N12", 5), ("N21", 5), ("N22", 5)):
+        print(a("GLV_%s_32" % name, words(glv[name], 32, n)))
     print("}  // namespace MSM_FIELD_NS")
 
 
@@ -228,45 +348,14 @@ def ec_mul(k, pt):
     return acc
 
 
-def cube_root_of_unity(mod):
-    g = 2
-    while pow(g, (mod - 1) // 3, mod) == 1:
-        g += 1
-    return pow(g, (mod - 1) // 3, mod)
-
-
 BETA = cube_root_of_unity(P)
 LAMBDA = cube_root_of_unity(RMOD)
 if ec_mul(LAMBDA, GEN) != (BETA * GEN[0] % P, GEN[1]):
     LAMBDA = LAMBDA * LAMBDA % RMOD
 assert ec_mul(LAMBDA, GEN) == (BETA * GEN[0] % P, GEN[1])
-# short basis (a1, b1), (a2, b2) of {(x, y): x + y lambda = 0 mod r}: the extended Euclidean sequence r_i = s_i r + t_i lambda
-# around sqrt(r) (Guide to Elliptic Curve Cryptography, algorithm 3.74)
-seq = [(RMOD, 0), (LAMBDA, 1)]
-while seq[-1][0]:
-    q = seq[-2][0] // seq[-1][0]
-    seq.append((seq[-2][0] - q * seq[-1][0], seq[-2][1] - q * seq[-1][1]))
-l = max(i for i, (rem, _) in enumerate(seq) if rem * rem >= RMOD)
-V1 = (seq[l + 1][0], -seq[l + 1][1])
-cands = [(seq[l][0], -seq[l][1]), (seq[l + 2][0], -seq[l + 2][1])]
-V2 = min(cands, key=lambda v: v[0] * v[0] + v[1] * v[1])
-if V1[0] * V2[1] - V2[0] * V1[1] < 0:
-    V2 = (-V2[0], -V2[1])
-assert V1[0] * V2[1] - V2[0] * V1[1] == RMOD
-for v in (V1, V2):
-    assert (v[0] + v[1] * LAMBDA) % RMOD == 0
+_glv = glv_lattice(RMOD, LAMBDA)
+V1, V2, G1, G2, N11, N12, N21, N22, GLV_OK = (_glv[k] for k in ("V1", "V2", "G1", "G2", "N11", "N12", "N21", "N22", "ok"))
 GLV_SHIFT = 320
-# c1 = round(k b2 / r), c2 = round(-k b1 / r), taken as sign * ((k * G + 2^(SHIFT - 1)) >> SHIFT) with G = round(2^SHIFT |b| / r)
-S1, S2 = (1 if V2[1] >= 0 else -1), (1 if -V1[1] >= 0 else -1)
-G1 = ((abs(V2[1]) << GLV_SHIFT) + RMOD // 2) // RMOD
-G2 = ((abs(V1[1]) << GLV_SHIFT) + RMOD // 2) // RMOD
-M160 = (1 << 160) - 1
-# (k1, k2) = (k, 0) - c1 V1 - c2 V2, computed modulo 2^160 in two's complement: k1 = k + m1 N11 + m2 N12, k2 = m1 N21 + m2 N22
-N11, N12 = (-S1 * V1[0]) & M160, (-S2 * V2[0]) & M160
-N21, N22 = (-S1 * V1[1]) & M160, (-S2 * V2[1]) & M160
-# |k1| <= (|a1| + |a2|) / 2 + (rounding slack), |k2| likewise; the recode of a 128-bit half needs < 2^127 - 2^112
-HALF_BOUND = max(abs(V1[0]) + abs(V2[0]), abs(V1[1]) + abs(V2[1])) * 513 // 1024 + 2
-GLV_OK = HALF_BOUND < (1 << 127) - (1 << 112) and G1 < 1 << 224 and G2 < 1 << 224
 assert GLV_OK or CURVE == "bls12_381", "the halves do not fit 8 signed 16-bit windows"
 if not GLV_OK:  # BLS12-381: the 255-bit r splits into halves of up to 128 bits, one more than 8 signed 16-bit windows hold: no endomorphism mode
     G1 = G2 = N11 = N12 = N21 = N22 = 0
