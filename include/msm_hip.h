@@ -109,7 +109,8 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx);
                                     batches, grouped launches, fixed-base tables, Montgomery-form inputs, the multi-GPU calls: as for curve 0.
                                     MSM_HIP_BASES_ENDOMORPHISM (round 4): the twist has j = 0 like the curve, so (beta x, y) with beta in the PRIME field is the
                                     multiplication by the same lambda on G2 -- same split, half-length scalars over 2n points; the bases must have order r (G2
-                                    proper), which is why the mode is never the default here.  NOT available (MSM_HIP_ERR_INVALID_ARG): the device point sampler. */
+                                    proper), which is why the mode is never the default here.  msm_hip_sample_points_device draws P_i = (a + i b) G for seeded a, b
+                                    and the standard generator G of the subgroup (points of order r; oracle/bn254_g2_ref.py: sample_points). */
 #define MSM_HIP_CURVE_BLS12_381_G2 6 /* G2 of BLS12-381: the twist y^2 = x^3 + 4 (1 + u) over Fq2, scalars modulo the same r as curve 4.  As curve 5 with 48-byte
                                         components: coordinates 96 B (c0 || c1), points 192 B, results and window sums 288 B Jacobian records.  The same
                                         options are unavailable.  Inputs are expected in the order-r subgroup (as every valid G2 point is); points outside

@@ -49,11 +49,11 @@ struct CurveOps {
    K::k_bpr_w256, K::k_bpr_final, K::k_bpr_planes<false>, K::k_bpr_planes<true>, K::k_bpr_final_planes, K::BPR_USE_W256, K::CW, K::REC_WORDS, K::XYZZ_WORDS, F::GLV_SUPPORTED, K::k_sample_scalars, K::k_sample_points, K::k_export_buckets, K::k_test_fq, K::k_test_g1,                \
    K::k_test_g1_mul_u32, F::host::combine_windows, F::host::window_from_planes, F::host::to_affine64}
 
-// A G2 unit (coordinates in Fq2, csrc/fq2.h): no device point sampler -- a null entry, which the host code checks before it accepts the call
+// A G2 unit (coordinates in Fq2, csrc/fq2.h): the same table (its point sampler draws multiples of the subgroup's generator)
 #define MSM_CURVE_OPS_FQ2(K, F)                                                                                                          \
   {K::k_convert_points, K::k_precompute_tables, K::k_endo_points, {K::k_count<12, 4, true>, K::k_count<14, 4, true>, K::k_count<16, 4, true>}, K::k_scalars_from_mont256, K::k_smvp_chunks, K::k_smvp_stitch, K::k_smvp_stitch_big,       \
    K::k_bpr_rowcol<4, 8>, K::k_bpr_rowcol<2, 8>, K::k_bpr_rowcol<3, 8>, K::k_bpr_rowcol<4, 6>, K::k_bpr_rowcol<2, 6>, K::k_bpr_rowcol<2, 4>, \
-   K::k_bpr_w256, K::k_bpr_final, K::k_bpr_planes<false>, K::k_bpr_planes<true>, K::k_bpr_final_planes, K::BPR_USE_W256, K::CW, K::REC_WORDS, K::XYZZ_WORDS, F::GLV_SUPPORTED, K::k_sample_scalars, nullptr, K::k_export_buckets, K::k_test_fq, K::k_test_g1,                \
+   K::k_bpr_w256, K::k_bpr_final, K::k_bpr_planes<false>, K::k_bpr_planes<true>, K::k_bpr_final_planes, K::BPR_USE_W256, K::CW, K::REC_WORDS, K::XYZZ_WORDS, F::GLV_SUPPORTED, K::k_sample_scalars, K::k_sample_points, K::k_export_buckets, K::k_test_fq, K::k_test_g1,                \
    K::k_test_g1_mul_u32, F::host::combine_windows, F::host::window_from_planes, F::host::to_affine64}
 
 // accessors of the separately compiled units (hidden: not part of the C ABI)

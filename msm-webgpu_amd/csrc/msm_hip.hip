@@ -1232,7 +1232,7 @@ int msm_hip_sample_scalars_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, voi
 int msm_hip_sample_points_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void* xy_dev) {
   if (!ctx || (!xy_dev && n)) return MSM_HIP_ERR_INVALID_ARG;
   if (n == 0) return MSM_HIP_OK;
-  if (!ctx->ops->sample_points) return MSM_HIP_ERR_INVALID_ARG;  // no device sampler for this curve (G2: needs a square root in Fq2)
+  if (!ctx->ops->sample_points) return MSM_HIP_ERR_INVALID_ARG;  // (no device sampler for this curve: none at present)
   ON_DEVICE(ctx);
   hipLaunchKernelGGL(ctx->ops->sample_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, seed, n, static_cast<uint32_t*>(xy_dev));
   HIP_TRY(ctx, hipGetLastError());

@@ -69,9 +69,8 @@ constexpr cwords<N> make_cwords(const uint32_t (&src)[N]) {
   for (int i = 0; i < N; i++) r.w[i] = src[i];
   return r;
 }
-// MSM_FQ2 (a G2 unit, csrc/fq2.h: the coordinate field is a quadratic extension): the pieces that need a square root in Fq2 or the
-// (beta x, y) endomorphism of the prime field -- the device point sampler, endomorphism bases -- are not built; the unit's table
-// carries null entries for them and the host refuses the corresponding options.
+// MSM_FQ2 (a G2 unit, csrc/fq2.h: the coordinate field is a quadratic extension): the prime-field point sampler (try-and-increment on x
+// with a square root) is not built; a G2 unit samples multiples of the subgroup's generator instead (k_sample_points below).
 #ifndef MSM_FQ2
 __device__ __constant__ cwords<CW> c_pp1d4 = make_cwords(FQ_PP1D4_32);
 #endif
@@ -1960,6 +1959,63 @@ __global__ void __launch_bounds__(256) k_sample_points(uint64_t seed, size_t n, 
     st_fq(out + i * PT_WORDS + CW, yp);
     break;
   }
+}
+#else  // MSM_FQ2
+// G2: P_i = (a + i b) G for seeded odd a, b < r and the standard generator G of the order-r subgroup -- byte for byte what the oracle's
+// sample_points(n, seed) produces (oracle/bn254_g2_ref.py; its sample_multipliers gives every MSM over these points a closed form).  Points
+// of G2 proper, unlike try-and-increment on the twist (whose cofactor is huge): fit for the endomorphism mode.  One lane per point: a
+// double-and-add over the 288-bit integer a + i b (not reduced: G has order r), then one inversion in Fq2.
+__global__ void __launch_bounds__(256) k_sample_points(uint64_t seed, size_t n, uint32_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t ab[2][8];
+  for (int which = 0; which < 2; which++) {  // a, b = sample_scalar(seed ^ 0x6732, 0 / 1) | 1
+    for (uint64_t attempt = 0;; attempt++) {
+      draw256(seed ^ 0x6732ull, (uint64_t)which, attempt, 1, ab[which]);
+      if (!geq_modulus<1>(ab[which])) break;
+    }
+    ab[which][0] |= 1u;
+  }
+  uint32_t m[10];  // a + i b < 2^254 + 2^28 2^254
+  {
+    const uint64_t lo = (uint32_t)i, hi = (uint64_t)i >> 32;  // (i < 2^28: hi = 0; kept general)
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      uint64_t t = c + (k < 8 ? ab[0][k] : 0u);
+      uint64_t carry = t >> 32;
+      t &= 0xffffffffull;
+      if (k < 8) {
+        const uint64_t p0 = lo * ab[1][k];
+        t += p0 & 0xffffffffull;
+        carry += p0 >> 32;
+      }
+      if (k >= 1 && k < 9) {
+        const uint64_t p1 = hi * ab[1][k - 1];
+        t += p1 & 0xffffffffull;
+        carry += p1 >> 32;
+      }
+      m[k] = (uint32_t)t;
+      c = carry + (t >> 32);
+    }
+  }
+  fq gx, gy;
+#pragma unroll
+  for (int k = 0; k < FQ_L; k++) {
+    gx.v[k] = FQ_GEN_X29[k];
+    gy.v[k] = FQ_GEN_Y29[k];
+  }
+  const g1_xyzz g = g1_from_affine(gx, gy);
+  g1_xyzz acc = g1_identity();
+#pragma unroll 1
+  for (int bit = 32 * 10 - 1; bit >= 0; bit--) {
+    acc = g1_double(acc);
+    if ((m[bit >> 5] >> (bit & 31)) & 1u) acc = g1_add(acc, g);
+  }
+  // a + i b is not a multiple of r for the sizes that fit a context (a, b odd, i < 2^28): acc is a point
+  const fq t = fq_inv(fq_mul(acc.zz, acc.zzz));
+  st_fq(out + i * PT_WORDS, fq_from_mont(fq_mul(acc.x, fq_mul(t, acc.zzz))));
+  st_fq(out + i * PT_WORDS + CW, fq_from_mont(fq_mul(acc.y, fq_mul(t, acc.zz))));
 }
 #endif  // MSM_FQ2
 

@@ -358,15 +358,16 @@ def test_endomorphism_mode_on_g2(ctx, n):
     assert not ctx.uses_endomorphism() and ctx.msm(scb).to_affine() == want
 
 
-def test_options_the_g2_unit_does_not_have_and_input_errors(ctx):
+def test_options_and_input_errors_of_the_g2_unit(ctx):
     pts = g2.points_to_bytes(g2.sample_points(4, 38))
     with pytest.raises(m.MsmHipError) as e:  # the endomorphism images and the fixed-base tables exclude each other, as on G1
         ctx.set_bases(pts, endomorphism=True, precompute=True)
     assert e.value.code == -2
     ctx.set_bases(pts, endomorphism=None)  # the ABI's default (flags = 0) on a curve with a cofactor: the plain shape
     assert not ctx.uses_endomorphism()
-    with pytest.raises(m.MsmHipError):  # (no device sampler: it would need a square root in Fq2)
-        ctx.sample_points(4, 1)
+    # the device point sampler (round 4): P_i = (a + i b) G, byte for byte the model's sample_points -- points of G2 proper
+    for n, seed in ((1, 3), (70, 77)):
+        assert ctx.sample_points(n, seed).cpu().numpy().tobytes() == g2.points_to_bytes(g2.sample_points(n, seed))
     with pytest.raises(m.MsmHipError):  # a component >= p (c1 of x)
         ctx.set_bases(pts[:FB] + bf(g2.P) + pts[CB:])
     with pytest.raises(m.MsmHipError):  # not on the twist

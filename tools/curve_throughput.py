@@ -12,12 +12,12 @@ for curve in (sys.argv[2:] or ["bn254", "grumpkin", "pallas", "vesta", "bls12_38
     ctx = m.MsmContext(0, curve=curve)
     sc = [ctx.sample_scalars(n, 2 + i) for i in range(2)]
     if curve.endswith("_g2"):
-        # G2 (coordinates in Fq2: csrc/fq2.h): no device sampler and no second CPU model -- the bases are 2^14 known multiples of the generator,
-        # repeated, and the expected result is the closed form (sum_i s_i m_i mod r) G (oracle/bn254_g2_ref.py); plain bases (no endomorphism mode)
+        # G2 (coordinates in Fq2: csrc/fq2.h): the device sampler draws P_i = (a + i b) G -- points of G2 proper -- and the expected result is the
+        # closed form (sum_i s_i m_i mod r) G (oracle/bn254_g2_ref.py: sample_multipliers).  CURVE_BASES = endomorphism (default) | plain | tables
         g2 = importlib.import_module("oracle." + curve + "_ref")
-        base = min(n, 1 << 14)
-        pts = torch.frombuffer(bytearray(g2.points_to_bytes(g2.sample_points(base, 1))), dtype=torch.uint8).cuda().view(base, 2 * g2.CB).repeat(n // base, 1).contiguous()
-        ctx.set_bases(pts, precompute=os.environ.get("CURVE_BASES") == "tables")  # (G2 has no endomorphism mode; CURVE_BASES=tables: fixed-base tables)
+        pts = ctx.sample_points(n, 1)
+        mode = os.environ.get("CURVE_BASES", "endomorphism")
+        ctx.set_bases(pts, precompute=mode == "tables", endomorphism=mode == "endomorphism")
     else:
         cpu = importlib.import_module("oracle.cpu" if curve == "bn254" else "oracle.cpu_" + curve)
         pts = ctx.sample_points(n, 1)
@@ -45,7 +45,7 @@ for curve in (sys.argv[2:] or ["bn254", "grumpkin", "pallas", "vesta", "bls12_38
     for i in range(5):
         torch.cuda.synchronize(); t1 = time.perf_counter(); ctx.msm(sc[i & 1]); lat.append((time.perf_counter() - t1) * 1e3)
     if curve.endswith("_g2"):
-        want = g2.affine_to_bytes(g2.msm_by_multipliers(g2.sample_multipliers(base, 1) * (n // base), g2.bytes_to_scalars(sc[1].cpu().numpy().tobytes())))
+        want = g2.affine_to_bytes(g2.msm_by_multipliers(g2.sample_multipliers(n, 1), g2.bytes_to_scalars(sc[1].cpu().numpy().tobytes())))
     else:
         want = cpu.to_affine64(cpu.cpu_msm(pts.cpu().numpy().tobytes(), sc[1].cpu().numpy().tobytes(), min(os.cpu_count() or 1, 32)))
     print("%-12s 2^%d: %.4f ms per MSM pipelined (%.0f MSM/s), SMVP kernel %.3f ms, latency %.3f ms, bit-exact vs its oracle: %s"

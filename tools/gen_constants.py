@@ -189,6 +189,9 @@ def emit_g2(which):
     print("// endomorphism phi(x, y) = (beta x, y) = lambda (x, y) on G2, beta in the prime field; k = k1 + k2 lambda (mod r), |k1|, |k2| < 2^127: csrc/glv.h")
     print("// lambda = %d (the G1 unit's); beta = %d (%s the G1 unit's)" % (lam, beta, "=" if beta == beta1 else "the square of"))
     print(a("FQ_BETA29", lim(beta * rr % p) + [0] * l) + "  // (beta, 0), Montgomery form")
+    print("// the standard generator of G2 (order r), Montgomery form: the device point sampler's base point (P_i = (a + i b) G, oracle/bn254_g2_ref.py: sample_points)")
+    print(a("FQ_GEN_X29", lim(gen[0][0] * rr % p) + lim(gen[0][1] * rr % p)))
+    print(a("FQ_GEN_Y29", lim(gen[1][0] * rr % p) + lim(gen[1][1] * rr % p)))
     print("// p as %d x 32-bit words: each component of a coordinate is compared with it" % nw)
     print(a("FQ_P32", words(p, 32, nw)))
     print("// host finalisation, prime-field level: %d x 64-bit limbs, R = 2^%d" % (hl, 64 * hl))
