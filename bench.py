@@ -259,13 +259,20 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    # a host-side (gloo) group beside RCCL's: where ranks must WAIT for one another without occupying their GPUs -- an RCCL barrier is a
-    # kernel that spins on every GPU until the last rank arrives (rank 0's native child, below, uses all of them meanwhile)
-    host_group = None
-    if use_dist and world > 1:
+    # host-side waits beside RCCL's collectives: where ranks must WAIT for one another without occupying their GPUs -- an RCCL barrier is a
+    # kernel that spins on every GPU until the last rank arrives (rank 0's native child, below, uses all of them meanwhile) -- they meet at
+    # the rendezvous store (counters and keys; no second process group, no second transport)
+    def host_wait(tag):
         import datetime
 
-        host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=30)) if dist.get_backend() != "gloo" else dist.group.WORLD
+        store = dist.distributed_c10d._get_default_store()
+        store.add("bench_%s_arrived" % tag, 1)
+        if rank == 0:
+            while store.add("bench_%s_arrived" % tag, 0) < world:
+                time.sleep(0.005)
+            store.set("bench_%s_go" % tag, "1")
+        else:
+            store.wait(["bench_%s_go" % tag], datetime.timedelta(minutes=30))
 
     # ranks that really take part in the collectives: every rank contributes its id to one all-gather
     dist_ranks, dist_backend = None, None
@@ -505,18 +512,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # single-MSM latency (no pipelining, stages not overlapped) -- reported beside the throughput figure
-    latency_ms, isolated = None, None
-    ctx.set_stage_timing(2)
+    # single-MSM latency (no pipelining, stages not overlapped) -- reported beside the throughput figure.  Measured WITHOUT stage events (what
+    # a caller of the synchronous entry point sees: every HIP event between two kernels costs queue time, ~45 us over the twelve kernels of a
+    # 2^16 MSM); a second pass with the events on gives the per-stage breakdown and its own, longer, latency.
+    latency_ms, latency_events_ms, isolated = None, None, None
     if world == 1 and emulate <= 1:
-        lat = []
-        for i in range(5):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            ctx.msm(scalar_sets[i & 1])
-            lat.append((time.perf_counter() - t1) * 1e3)
-            isolated = ctx.stage_ms()
-        latency_ms = sorted(lat)[len(lat) // 2]
+        for level in (0, 2):
+            ctx.set_stage_timing(level)
+            lat = []
+            for i in range(9 if level == 0 else 5):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ctx.msm(scalar_sets[i & 1])
+                lat.append((time.perf_counter() - t1) * 1e3)
+                if level:
+                    isolated = ctx.stage_ms()
+            if level == 0:
+                latency_ms = sorted(lat[2:])[len(lat[2:]) // 2]
+            else:
+                latency_events_ms = sorted(lat)[len(lat) // 2]
+    ctx.set_stage_timing(2)
 
     # sharded runs: check the gathered + combined results of the last launch against this rank's own whole MSM (outside the timed region);
     # a rank checks the vectors it combined ("spread": vector v on rank v % world), the verdict is the AND over the ranks
@@ -605,6 +620,7 @@ def main():
         "emulated_world": emulate if emulate > 1 else None,
         "sharded_result_equals_single_gpu": sharded_ok,
         "latency_ms_single_msm": latency_ms if not sharded else sharded_latency_ms,
+        "latency_ms_single_msm_with_stage_events": latency_events_ms,
         "stage_ms_single_msm": isolated,
         "scope_ms": scope_ms,
         "ms_per_step_cold_protocol": cold_elapsed * 1e3 / args.steps,
@@ -618,7 +634,8 @@ def main():
     # N > 1: the same workload through the in-process multi-GPU C ABI (what a Rust caller of src/lib.rs:76-82 links against), timed by ONE
     # fresh child of rank 0 while every rank of this job idles in a host-side wait -- value stays the torch.distributed figure
     if use_dist and world > 1 and emulate <= 1 and os.environ.get("BENCH_NATIVE_CHILD", "1") != "0":
-        dist.barrier(group=host_group)
+        host_wait("timed_region_left")  # every rank has left its timed region: the GPUs are idle
+        child, err = None, None
         if rank == 0:
             child, err = run_native_child(args, bases_mode, world)
             out["value_native_mgpu"] = child["value"] if child else None
@@ -626,7 +643,7 @@ def main():
             out["native_rccl_ranks"] = child.get("rccl_ranks") if child else None
             out["native_mgpu"] = ({"config": child["config"], "result_equals_single_gpu": child["sharded_result_equals_single_gpu"],
                                    "pre_timed_msms": child.get("pre_timed_msms")} if child else {"error": err})
-        dist.barrier(group=host_group)
+        host_wait("native_child_done")
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu as oracle_cpu  # the checker + the timed CPU baseline; never on the product path

@@ -56,7 +56,7 @@ CBY = ctx.cb  # bytes per coordinate (48 on BLS12-381)
 # BLS12-381's cofactor is not 1: the samplers' points are outside the order-r subgroup, where the endomorphism modes are not exact (and the
 # R = 2^256 input format is the 4-limb curves')
 MODES = ["host", "device", "windows", "batch", "group", "hostbatch", "mont", "bits", "tables", "tables_batch", "hostpipe", "mgpu", "endo", "endo_batch",
-         "group_halves", "mgpu_batch", "mgpu_batch_endo"]
+         "group_halves", "mgpu_batch", "mgpu_batch_endo", "auto"]
 if curve == "bls12_381":
     MODES = [x for x in MODES if x not in ("mont", "endo", "endo_batch", "group_halves", "mgpu_batch_endo")]
 if curve.endswith("_g2"):  # (the "mont" case below writes G1 coordinates; the pool's points are multiples of G2's generator: the endomorphism modes are exact)
@@ -96,7 +96,8 @@ for case in range(cases):
     sb = ref.scalars_to_bytes(sc)
     want = cpu.to_affine64(cpu.cpu_msm(points, sb))
     mode = rnd.choice(MODES)
-    ctx.set_bases(points, precompute=mode.startswith("tables"), endomorphism=mode.startswith("endo") or mode == "group_halves")
+    # ("auto": the C ABI's flags = 0 -- the curve's fastest mode on a curve of prime order, the plain shape otherwise)
+    ctx.set_bases(points, precompute=mode.startswith("tables"), endomorphism=None if mode == "auto" else (mode.startswith("endo") or mode == "group_halves"))
     if mode == "mont":
         # both inputs as R = 2^256 Montgomery words (MSM_HIP_BASES_MONT256, MSM_HIP_SCALARS_MONT256)
         PM, RM = ref.P, ref.R
@@ -108,7 +109,7 @@ for case in range(cases):
             got = ctx.msm(sm)
         finally:
             ctx.set_scalar_format(False)
-    elif mode == "host" or mode == "tables":
+    elif mode == "host" or mode == "tables" or mode == "auto":
         got = ctx.msm(sb)
     elif mode == "bits":
         # every window size, host and device scalars
