@@ -25,10 +25,10 @@ struct CurveOps {
   void (*rowcol_2_6)(const uint32_t*, uint32_t*, uint32_t*);
   void (*rowcol_2_4)(const uint32_t*, uint32_t*, uint32_t*);
   void (*bpr_w256)(const uint32_t*, const uint32_t*, uint32_t*, int);
-  void (*bpr_final)(const uint32_t*, int, uint32_t*, uint32_t*);
-  void (*bpr_planes)(const uint32_t*, const uint32_t*, uint32_t*, int, uint32_t*);
-  void (*bpr_planes_xyzz)(const uint32_t*, const uint32_t*, uint32_t*, int, uint32_t*);
-  void (*bpr_final_planes)(const uint32_t*, int, uint32_t*, uint32_t*);
+  void (*bpr_final)(const uint32_t*, int, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+  void (*bpr_planes)(const uint32_t*, const uint32_t*, uint32_t*, int, uint32_t*, uint32_t*, uint32_t*);
+  void (*bpr_planes_xyzz)(const uint32_t*, const uint32_t*, uint32_t*, int, uint32_t*, uint32_t*, uint32_t*);
+  void (*bpr_final_planes)(const uint32_t*, int, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
   bool use_w256;    // the narrow reduce tail fits a workgroup's LDS (k_bpr_w256); else k_bpr_planes<true> + k_bpr_final_planes
   int coord_words;  // 32-bit words per coordinate on the wire: 8 (254 / 255-bit fields) or 12 (BLS12-381); point = 2, Jacobian record = 3 of them
   int rec_words, xyzz_words;  // device bucket record / scratch record sizes (words)

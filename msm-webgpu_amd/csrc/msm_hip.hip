@@ -127,6 +127,7 @@ struct msm_hip_ctx {
   uint64_t* d_negbits = nullptr; // with the planes of a launch: one sign bit per input of every vector
   size_t cap_planes = 0;         // capacity (u16 entries) of d_digits; d_negbits holds cap_planes / 64 + 2 MAXLW words
   bool debug = false;
+  bool sync_call = false;  // set by the synchronous entry points (run = launch + finish at once) around their launch: nothing will be pipelined behind it
   int timing_level = 2;  // 0: no stage events, 1: only around the SMVP kernel, 2: every stage boundary
   uint32_t* d_counts = nullptr;      // [W][tiles][128]
   uint32_t* d_bin_total = nullptr;   // [W][128]
@@ -441,6 +442,15 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   // everything after the two scalar-reading kernels only sees w_count = nvec * w_count_vec local windows
   const int w_count = merge ? nvec : nvec * w_count_vec;
   hipStream_t st = ctx->stream, rs = ctx->reduce_stream[(&s - ctx->slot) % NREDUCE];
+  // a synchronous call with nothing else in flight (msm_hip_run_*: the caller waits for this launch before it issues another): the stitch and
+  // the bucket reduce follow the SMVP on the MAIN stream -- no cross-stream hand-off (an event wait costs ~10 us more than an in-stream kernel
+  // boundary), and no next launch exists whose sort the separate stream would let overlap.  MSM_HIP_INLINE_REDUCE=0: always the reduce stream.
+  static const bool inline_reduce = [] { const char* e = getenv("MSM_HIP_INLINE_REDUCE"); return !e || atoi(e) != 0; }();
+  if (inline_reduce && ctx->sync_call) {
+    bool others = false;
+    for (const Slot& o : ctx->slot) others = others || (&o != &s && o.pending);
+    if (!others) rs = st;
+  }
   // tiles of scalars for the two global sort passes: >= 2048 scalars each, at most MAX_TILES of them
   uint32_t tile_len = 2048;
   if ((n_sc + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n_sc + MAX_TILES - 1) / MAX_TILES) + 255) / 256 * 256);
@@ -535,10 +545,10 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
                      chunks, d_chunk_len, ctx->d_chunk_slot, s.d_buckets, s.d_heads, s.d_tails, half);
   AFTER_KERNEL(ctx, "k_smvp_chunks", st);
   HIP_TRY(ctx, mark(5, true));
-  HIP_TRY(ctx, hipEventRecord(s.smvp_done, st));
+  if (rs != st) HIP_TRY(ctx, hipEventRecord(s.smvp_done, st));
 
   // stitch + bucket reduce on the slot's reduce stream: few waves, long dependent chains
-  HIP_TRY(ctx, hipStreamWaitEvent(rs, s.smvp_done, 0));
+  if (rs != st) HIP_TRY(ctx, hipStreamWaitEvent(rs, s.smvp_done, 0));
   hipLaunchKernelGGL(ctx->ops->smvp_stitch, dim3(half / 256, w_count), dim3(256), 0, rs, s.d_col_ptr, chunks, d_chunk_len, s.d_heads, s.d_tails,
                      s.d_buckets, s.d_big_queue);
   AFTER_KERNEL(ctx, "k_smvp_stitch", rs);
@@ -581,26 +591,27 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   // and 29 operations per window on the host (0.3 us each).  Sums that stay on the device (window shards for the gather), grouped launches
   // (their host thread is on the critical path: several MSMs' worth of host work per launch) and debug read-backs get finished sums.
   const bool parts_mode = to_host && nvec == 1 && !ctx->debug && wsums_out == reinterpret_cast<uint32_t*>(s.d_wsums) && w_count <= 24;
+  // the kernel that ends the chain writes the launch's error word into the slot's pinned buffer itself and clears it (no copy, no fill); a
+  // single MSM's bit-plane sums go to the pinned buffer directly as well (12 KB of stores over the host link instead of a copy behind the kernel)
+  uint32_t* h_err = reinterpret_cast<uint32_t*>(s.h_wsums + WSUM_BYTES);
   if (parts_mode) {
-    hipLaunchKernelGGL(ctx->ops->bpr_planes, dim3(PLANES_PER_WINDOW, w_count), dim3(256), 0, rs, d_rows, d_cols, wsums_out, (int)(half / BPR_COLS),
-                       s.d_big_queue);
+    hipLaunchKernelGGL(ctx->ops->bpr_planes, dim3(PLANES_PER_WINDOW, w_count), dim3(256), 0, rs, d_rows, d_cols, reinterpret_cast<uint32_t*>(s.h_wsums),
+                       (int)(half / BPR_COLS), s.d_big_queue, d_err, h_err);
     AFTER_KERNEL(ctx, "k_bpr_planes", rs);
   } else if (ctx->ops->use_w256) {
     hipLaunchKernelGGL(ctx->ops->bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts, (int)(half / BPR_COLS));
     AFTER_KERNEL(ctx, "k_bpr_w256", rs);
-    hipLaunchKernelGGL(ctx->ops->bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue);
+    hipLaunchKernelGGL(ctx->ops->bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue, d_err, h_err);
     AFTER_KERNEL(ctx, "k_bpr_final", rs);
   } else {  // a field too wide for k_bpr_w256's LDS footprint (BLS12-381): the same bit-plane sums, finished on the device
     hipLaunchKernelGGL(ctx->ops->bpr_planes_xyzz, dim3(PLANES_PER_WINDOW, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts, (int)(half / BPR_COLS),
-                       s.d_big_queue);
+                       s.d_big_queue, d_err, h_err);
     AFTER_KERNEL(ctx, "k_bpr_planes<xyzz>", rs);
-    hipLaunchKernelGGL(ctx->ops->bpr_final_planes, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue);
+    hipLaunchKernelGGL(ctx->ops->bpr_final_planes, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue, d_err, h_err);
     AFTER_KERNEL(ctx, "k_bpr_final_planes", rs);
   }
   if (tl >= 2) HIP_TRY(ctx, hipEventRecord(s.red1, rs));
-  if (to_host) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * (parts_mode ? PLANES_PER_WINDOW : 1) * ctx->jb, hipMemcpyDeviceToHost, rs));
-  HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums + WSUM_BYTES, d_err, 4, hipMemcpyDeviceToHost, rs));
-  HIP_TRY(ctx, hipMemsetAsync(d_err, 0, 4, rs));  // ready for the slot's next occupant
+  if (to_host && !parts_mode) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * ctx->jb, hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipEventRecord(s.done, rs));
   HIP_TRY(ctx, hipGetLastError());
 
@@ -1039,8 +1050,10 @@ int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]) {
 }
 
 int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]) {
-  if (!out_xyz) return MSM_HIP_ERR_INVALID_ARG;
+  if (!out_xyz || !ctx) return MSM_HIP_ERR_INVALID_ARG;
+  ctx->sync_call = true;
   int rc = msm_hip_launch_device_bn254(ctx, scalars_dev, n, 0);
+  ctx->sync_call = false;
   if (rc) return rc;
   return msm_hip_finish_bn254(ctx, 0, out_xyz);
 }
@@ -1085,8 +1098,10 @@ int msm_hip_launch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n
 }
 
 int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
-  if (!out_xyz) return MSM_HIP_ERR_INVALID_ARG;
+  if (!out_xyz || !ctx) return MSM_HIP_ERR_INVALID_ARG;
+  ctx->sync_call = true;
   int rc = msm_hip_launch_bn254(ctx, scalars_host, n, 0);
+  ctx->sync_call = false;
   if (rc) return rc;
   return msm_hip_finish_bn254(ctx, 0, out_xyz);
 }
@@ -1354,10 +1369,12 @@ int msm_hip_read_window_sums(msm_hip_ctx* ctx, uint8_t* out, size_t cap_bytes) {
   // the last launch handed its window sums to the host as bit-plane sums (k_bpr_planes): finish them here
   const size_t w = (size_t)ctx->last_w_count;
   if (!out || w * ctx->jb > cap_bytes || w > 24) return MSM_HIP_ERR_INVALID_ARG;
-  uint8_t planes[WSUM_BYTES];
   const size_t plane_bytes = PLANES_PER_WINDOW * ctx->jb;
-  int rc = read_back(ctx, planes, s.d_wsums, w * plane_bytes, sizeof planes);
-  if (rc) return rc;
+  {  // (the plane sums were written into the slot's pinned buffer by the launch's last kernel: complete once its reduce stream has drained)
+    ON_DEVICE(ctx);
+    for (hipStream_t r : ctx->reduce_stream) HIP_TRY(ctx, hipStreamSynchronize(r));
+  }
+  const uint8_t* planes = s.h_wsums;
   bool ok = true;
   for (size_t k = 0; k < w; k++) ok &= ctx->ops->window_from_planes(planes + k * plane_bytes, out + k * ctx->jb);
   return ok ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;

@@ -1785,10 +1785,19 @@ __global__ void __launch_bounds__(256) k_bpr_w256(const uint32_t* __restrict__ r
 
 // one lane per window: S = 128 * W(R) + W(C) + sum(C), emitted as canonical Jacobian bytes.  (Operands stay in registers
 // here, which measured faster than the cooperative LDS form: 52 vs 71 us.)
+// (every kernel that ends a launch's reduce chain also hands the launch's error word to the host -- err_host is the slot's pinned word, written
+//  directly -- and clears it for the slot's next occupant: two copies and a fill less at the end of every chain)
+__device__ __forceinline__ void finish_error_word(uint32_t* __restrict__ err_dev, uint32_t* __restrict__ err_host) {
+  *err_host = *err_dev;
+  *err_dev = 0;
+}
 __global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ parts, int w_count, uint32_t* __restrict__ wsums,
-                                                  uint32_t* __restrict__ big_queue) {
+                                                  uint32_t* __restrict__ big_queue, uint32_t* __restrict__ err_dev, uint32_t* __restrict__ err_host) {
   const int w = threadIdx.x;
-  if (w == 0) big_queue[0] = 0;  // the stitch's queue of big buckets, consumed earlier on this stream: empty for the next launch
+  if (w == 0) {
+    big_queue[0] = 0;  // the stitch's queue of big buckets, consumed earlier on this stream: empty for the next launch
+    finish_error_word(err_dev, err_host);
+  }
   if (w >= w_count) return;
   g1_xyzz acc = ld_xyzz(parts + ((size_t)w * 3 + 0) * XYZZ_WORDS);
   for (int i = 0; i < 7; i++) acc = g1_double(acc);
@@ -1807,10 +1816,14 @@ __global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ p
 constexpr int PLANES_PER_WINDOW = 16;
 template <bool XYZZ_OUT>
 __global__ void __launch_bounds__(256) k_bpr_planes(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ cols, uint32_t* __restrict__ out,
-                                                    int nrows, uint32_t* __restrict__ big_queue) {
+                                                    int nrows, uint32_t* __restrict__ big_queue, uint32_t* __restrict__ err_dev,
+                                                    uint32_t* __restrict__ err_host) {
   __shared__ uint32_t x[256 * XYZZ_WORDS];
   const int w = blockIdx.y, plane = blockIdx.x, t = threadIdx.x;
-  if (!XYZZ_OUT && w == 0 && plane == 0 && t == 0) big_queue[0] = 0;  // as k_bpr_final: the stitch's queue is empty for the slot's next launch
+  if (!XYZZ_OUT && w == 0 && plane == 0 && t == 0) {  // as k_bpr_final: this kernel ends the chain (`out` may be the slot's pinned host buffer itself)
+    big_queue[0] = 0;
+    finish_error_word(err_dev, err_host);
+  }
   const bool is_row = plane < 8;
   const int bit = is_row ? plane : plane - 8;  // 7 for the column total: bit 7 of a column index is never set -> handled by `all`
   const bool all = plane == PLANES_PER_WINDOW - 1;
@@ -1839,9 +1852,12 @@ __global__ void __launch_bounds__(256) k_bpr_planes(const uint32_t* __restrict__
 // one lane per window: S_w = sum_b 2^(b+7) PR_b + sum_b 2^b PC_b + TC from the plane sums (XYZZ records), as canonical Jacobian bytes --
 // the device-side counterpart of host_g1.h: window_sum_from_planes, for sums that stay on the device
 __global__ void __launch_bounds__(64) k_bpr_final_planes(const uint32_t* __restrict__ planes, int w_count, uint32_t* __restrict__ wsums,
-                                                         uint32_t* __restrict__ big_queue) {
+                                                         uint32_t* __restrict__ big_queue, uint32_t* __restrict__ err_dev, uint32_t* __restrict__ err_host) {
   const int w = threadIdx.x;
-  if (w == 0) big_queue[0] = 0;
+  if (w == 0) {
+    big_queue[0] = 0;
+    finish_error_word(err_dev, err_host);
+  }
   if (w >= w_count) return;
   const uint32_t* pw = planes + (size_t)w * PLANES_PER_WINDOW * XYZZ_WORDS;
   g1_xyzz acc = g1_identity();
