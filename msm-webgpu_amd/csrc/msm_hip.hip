@@ -13,6 +13,7 @@
 // on their own stream lets the sort + SMVP of the NEXT launch (other slot) run meanwhile.  The host window combine of a
 // slot (src/cuzk/msm.rs:411-416) runs in the caller's thread inside msm_hip_finish_bn254 / msm_hip_finish_batch_bn254.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <chrono>
 #include <cstdio>
@@ -537,14 +538,17 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     hipLaunchKernelGGL(k_copy_runs, dim3(blocks_for(n_entries, 256), w_count), dim3(256), 0, st, s.d_col_ptr, ctx->d_tmp_val, ctx->d_val, stride, half);
     AFTER_KERNEL(ctx, "k_order_runs", st);
   }
-  HIP_TRY(ctx, mark(4, true));
-  // MSM_HIP_SMVP_LDS_PAD=<bytes> (diagnostic): unused dynamic LDS per SMVP workgroup -- 65536 lets two instead of three workgroups share a CU
-  // (2 waves per SIMD): tells a latency-bound launch (slower with fewer waves) from a multiplier- or bandwidth-bound one
+  // the SMVP's own begin / end timestamps: attached to its dispatch (hipExtLaunchKernelGGL) instead of two event packets around it -- a
+  // packet between two kernels costs a few microseconds of queue time, and these two sat between every launch's sort and its SMVP and
+  // between the SMVP and the next launch (bench.py times every launch's SMVP for the roofline figure).  Level 2 keeps the packets: its
+  // stage boundaries are read as differences of consecutive events.
   static const unsigned smvp_lds_pad = [] { const char* e = getenv("MSM_HIP_SMVP_LDS_PAD"); const long v = e ? atol(e) : 0; return v > 0 && v <= 65536 ? (unsigned)v : 0u; }();
-  hipLaunchKernelGGL(ctx->ops->smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), smvp_lds_pad, st, ctx->d_bases, s.d_col_ptr, ctx->d_val, stride,
-                     chunks, d_chunk_len, ctx->d_chunk_slot, s.d_buckets, s.d_heads, s.d_tails, half);
+  HIP_TRY(ctx, tl >= 2 ? hipEventRecord(s.ev[4], st) : hipSuccess);
+  hipExtLaunchKernelGGL(ctx->ops->smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), smvp_lds_pad, st, tl == 1 ? s.ev[4] : nullptr,
+                        tl == 1 ? s.ev[5] : nullptr, 0, (const uint32_t*)ctx->d_bases, (const uint32_t*)s.d_col_ptr, (const uint32_t*)ctx->d_val, stride, chunks,
+                        (const uint32_t*)d_chunk_len, (const uint32_t*)ctx->d_chunk_slot, s.d_buckets, s.d_heads, s.d_tails, half);
   AFTER_KERNEL(ctx, "k_smvp_chunks", st);
-  HIP_TRY(ctx, mark(5, true));
+  HIP_TRY(ctx, tl >= 2 ? hipEventRecord(s.ev[5], st) : hipSuccess);
   if (rs != st) HIP_TRY(ctx, hipEventRecord(s.smvp_done, st));
 
   // stitch + bucket reduce on the slot's reduce stream: few waves, long dependent chains
