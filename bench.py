@@ -592,6 +592,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "untimed_steps_before_timed_region": steady + max(args.warmup, 1),  # the W warm-up steps and, in front of them, BENCH_STEADY_MSMS steps of the same workload
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
         "scaling": "strong",

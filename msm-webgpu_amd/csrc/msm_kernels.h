@@ -1028,7 +1028,7 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
 // its slot (binary search of col_ptr), counts the entries of its run that are smaller (they are distinct) and writes itself to that
 // position of a scratch copy (`tmp`, the coarse-order array, free by then); a second kernel copies the scratch back.  O(sum of run
 // length^2): runs beyond ORDER_RUN_MAX entries (heavily skewed inputs) keep their arrival order.
-constexpr uint32_t ORDER_RUN_MAX = 1u << 17;
+constexpr uint32_t ORDER_RUN_MAX = 1u << 15;  // (2^30 comparisons for one such run)
 __global__ void __launch_bounds__(256) k_order_runs(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ val_idxs, uint32_t* __restrict__ tmp,
                                                     size_t stride, uint32_t half) {
   const int lw = blockIdx.y;
