@@ -1154,7 +1154,10 @@ __device__ __forceinline__ void smvp_assign(g1_xyzz& acc, const g1_xyzz& src) {
 
 // 168 VGPRs hold the 9-limb loop (3 waves per SIMD); 14 limbs take up to 256 (2 waves).  Fq2 on 9 limbs (BN254 G2) wants 278: capped at 256 -- 12 words
 // of scratch -- because the second wave is worth 23 % of the kernel (4.29 -> 3.31 ms at 2^20, profiles/r03_g2_throughput.txt); Fq2 on 14 limbs: one wave
-constexpr int SMVP_WAVES_PER_SIMD = FQ_L <= 9 ? 3 : FQ_L <= 18 ? 2 : 1;
+#ifndef MSM_SMVP_WAVES_WIDE
+#define MSM_SMVP_WAVES_WIDE 1  // Fq2 on 14 limbs (BLS12-381 G2): 256 VGPRs + 130 AGPRs at one wave; two waves = a 256-register cap with scratch (A/B: profiles/r04_g2_two_waves.txt)
+#endif
+constexpr int SMVP_WAVES_PER_SIMD = FQ_L <= 9 ? 3 : FQ_L <= 18 ? 2 : MSM_SMVP_WAVES_WIDE;
 // the stitch and the row / column sums (full additions: the widest kernels after the SMVP) in a unit with 18 limbs per coordinate: two waves per
 // SIMD as well (256 VGPRs + 0.26 KB of scratch instead of 309 - 317 + AGPRs: -1.5 % per MSM)
 #ifndef MSM_REDUCE_WAVES_FQ2
