@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Third code-generation gate (round 4): LLVM's own machine verifier over the device code of every translation unit.
 
-Background (profiles/r04_asm_everywhere_rootcause.txt).  The diagnostic build with the inline-assembly multipliers in
-every kernel returned wrong bucket sums in the 14-limb (BLS12-381) and Fq2 (BN254 G2) units -- the stitch's P + P path.  Cause: a
+Background (profiles/r04_asm_everywhere_rootcause.txt).  Round 3's diagnostic build with the inline-assembly multipliers in
+every kernel (since round 4, with -fno-slp-vectorize, the product's shape) returned wrong bucket sums in the 14-limb (BLS12-381) and Fq2 (BN254 G2) units -- the stitch's P + P path.  Cause: a
 miscompile, not the assembly.  clang's SLP vectoriser packs the limb arrays of the loop-carried accumulator into <2 x i32> values, the
 AMDGPU backend keeps those as 64 / 128-bit register tuples, and LLVM's register coalescer, joining the copy of the doubling's last y limb
 (a V_ADD3_U32) into such a tuple, marks that definition `dead` although its lane is live out of the block.  The register allocator then
@@ -13,7 +13,7 @@ The check: every translation unit is compiled once more, device side only, with 
 -verify-machineinstrs`; a clean unit compiles, a miscompiled one aborts naming function and instruction.  Results are cached under
 build/ (key: the sources' and flags' hash) -- the verifier makes a unit's compile 2 - 3 x slower.
 
-usage: check_machine_verifier.py            every unit with the flags of the current environment (MSM_HIP_ASM_EVERYWHERE, MSM_HIP_EXTRA_FLAGS ...)
+usage: check_machine_verifier.py            every unit with the flags of the current environment (MSM_HIP_SLP=1: the miscompiled variant; MSM_HIP_ASM_SMVP_ONLY, MSM_HIP_EXTRA_FLAGS ...)
 exit status 0 = clean, 1 = the verifier fired.
 """
 import hashlib
