@@ -67,6 +67,17 @@ extern "C" {
                                           MSM_HIP_BASES_PRECOMPUTE; the window-sharding entry points ignore it (records 0 .. n-1 are the
                                           plain set). */
 
+#define MSM_HIP_BASES_PRECOMPUTE_WIDE 32u /* wide fixed-base tables (round 4): store 2^(19 w) P_i for w = 1 .. 12 and 2^(247 - t) P_i, t = 11 (BLS12-381: 10) -- the
+                                          top digit is used shifted by t, so that it spreads over the bucket set -- (14 x the base memory: 896 MiB at 2^20
+                                          points; at most 2^22 points) and recode every scalar into 14 signed digits of 19 bits: 14 bucket additions
+                                          per point instead of the reference's 16 (src/cuzk/msm.rs:79-82: chunk_size 16), into ONE bucket set of
+                                          2^18 slots -- the bucket count of the endomorphism mode's 8 x 2^15.  For fixed bases and large MSMs (2^20 points
+                                          and up: +3 % at 2^20, +8 % at 2^22 over the endomorphism mode); one MSM per launch; the sort arrays take 8 x 14 n entries (1 GiB at 2^20).  Whole-MSM entry
+                                          points only (run, launch / finish, batch); the window-sharding entry points ignore the tables (table 0 is
+                                          the plain set).  Same result for every scalar below the scalar field's modulus and any point (a top digit that
+                                          does not fit after its shift -- scalars of 2^254 + 2^246 and more -- is MSM_HIP_ERR_NONCANONICAL).  Not combinable
+                                          with the other two modes. */
+
 #define MSM_HIP_BASES_PLAIN 16u        /* hold the n bases only and run the reference's exact shape -- 16 windows of full-length scalars over n points
                                           (src/cuzk/msm.rs:79-82).  WITHOUT this flag, MSM_HIP_BASES_PRECOMPUTE or MSM_HIP_BASES_ENDOMORPHISM a
                                           base set takes the fastest mode the curve has (round 4: the drop-in default is the headline's mode):

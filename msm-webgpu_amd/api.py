@@ -260,12 +260,13 @@ class MsmContext:
     def set_bases(self, points, check_on_curve=False, mont256=False, precompute=False, endomorphism=False):
         """points: bytes (host, n x 64 B wire format) or a CUDA uint8 tensor holding the same bytes.
         mont256: the coordinates are x * 2^256 mod p (4 x 64-bit Montgomery limbs, R = 2^256) instead of canonical integers.
-        precompute: fixed-base tables 2^(16 w) P_i (16 x the memory): whole MSMs then use one bucket set for all windows.
+        precompute: fixed-base tables 2^(16 w) P_i (16 x the memory): whole MSMs then use one bucket set for all windows.  "wide":
+        MSM_HIP_BASES_PRECOMPUTE_WIDE -- 14 tables 2^(19 w) P_i and 19-bit digits: 14 bucket additions per point instead of 16 (large MSMs).
         endomorphism: True: also store phi(P_i) (2 x the memory): whole MSMs split every scalar into two 127-bit halves and need
         half the windows.  False (this wrapper's default: the stage-level parity tests read the reference's 16-window shape):
         MSM_HIP_BASES_PLAIN.  None: the C ABI's own default (flags = 0) -- the fastest mode the curve has, which is what the
         reference-shaped calls (compute_msm / run_webgpu_msm below, msm_hip_msm_bn254_g1) use."""
-        flags = (1 if check_on_curve else 0) | (2 if mont256 else 0) | (4 if precompute else 0) | (8 if endomorphism else 0)
+        flags = (1 if check_on_curve else 0) | (2 if mont256 else 0) | (32 if precompute == "wide" else 4 if precompute else 0) | (8 if endomorphism else 0)
         if endomorphism is False and not precompute:
             flags |= 16
         if isinstance(points, torch.Tensor) and points.is_cuda:

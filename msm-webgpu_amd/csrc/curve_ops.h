@@ -9,7 +9,7 @@
 // What differs between the curves: the kernels that do field arithmetic, and the host's window combine.  A context holds one.
 struct CurveOps {
   void (*convert_points)(const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t*);
-  void (*precompute_tables)(uint32_t*, size_t, size_t, int);
+  void (*precompute_tables)(uint32_t*, size_t, size_t, int, int, int);
   void (*endo_points)(uint32_t*, size_t);
   // k_count<C, 4, true> for C = 12 / 14 / 16: the first sort pass of endomorphism launches, which splits the scalars itself (csrc/glv.h)
   void (*count_split[3])(const uint32_t*, size_t, uint32_t, uint32_t, int, int, int, size_t, uint32_t*, uint16_t*, int, uint64_t*, uint32_t*, uint32_t*, size_t);
@@ -41,20 +41,21 @@ struct CurveOps {
   void (*test_g1_mul_u32)(const uint32_t*, const uint32_t*, uint32_t*, size_t);
   bool (*combine_windows)(const uint8_t*, int, int, uint8_t*);
   bool (*window_from_planes)(const uint8_t*, uint8_t*);
+  bool (*combine_wide)(const uint8_t*, const uint8_t*, int, uint8_t*);
   int (*to_affine64)(const uint8_t*, uint8_t*);
 };
 #define MSM_CURVE_OPS(K, F)                                                                                                              \
   {K::k_convert_points, K::k_precompute_tables, K::k_endo_points, {K::k_count<12, 4, true>, K::k_count<14, 4, true>, K::k_count<16, 4, true>}, K::k_scalars_from_mont256, K::k_smvp_chunks, K::k_smvp_stitch, K::k_smvp_stitch_big,       \
    K::k_bpr_rowcol<4, 8>, K::k_bpr_rowcol<2, 8>, K::k_bpr_rowcol<3, 8>, K::k_bpr_rowcol<4, 6>, K::k_bpr_rowcol<2, 6>, K::k_bpr_rowcol<2, 4>, \
    K::k_bpr_w256, K::k_bpr_final, K::k_bpr_planes<false>, K::k_bpr_planes<true>, K::k_bpr_final_planes, K::BPR_USE_W256, K::CW, K::REC_WORDS, K::XYZZ_WORDS, F::GLV_SUPPORTED, K::k_sample_scalars, K::k_sample_points, K::k_export_buckets, K::k_test_fq, K::k_test_g1,                \
-   K::k_test_g1_mul_u32, F::host::combine_windows, F::host::window_from_planes, F::host::to_affine64}
+   K::k_test_g1_mul_u32, F::host::combine_windows, F::host::window_from_planes, F::host::combine_wide, F::host::to_affine64}
 
 // A G2 unit (coordinates in Fq2, csrc/fq2.h): the same table (its point sampler draws multiples of the subgroup's generator)
 #define MSM_CURVE_OPS_FQ2(K, F)                                                                                                          \
   {K::k_convert_points, K::k_precompute_tables, K::k_endo_points, {K::k_count<12, 4, true>, K::k_count<14, 4, true>, K::k_count<16, 4, true>}, K::k_scalars_from_mont256, K::k_smvp_chunks, K::k_smvp_stitch, K::k_smvp_stitch_big,       \
    K::k_bpr_rowcol<4, 8>, K::k_bpr_rowcol<2, 8>, K::k_bpr_rowcol<3, 8>, K::k_bpr_rowcol<4, 6>, K::k_bpr_rowcol<2, 6>, K::k_bpr_rowcol<2, 4>, \
    K::k_bpr_w256, K::k_bpr_final, K::k_bpr_planes<false>, K::k_bpr_planes<true>, K::k_bpr_final_planes, K::BPR_USE_W256, K::CW, K::REC_WORDS, K::XYZZ_WORDS, F::GLV_SUPPORTED, K::k_sample_scalars, K::k_sample_points, K::k_export_buckets, K::k_test_fq, K::k_test_g1,                \
-   K::k_test_g1_mul_u32, F::host::combine_windows, F::host::window_from_planes, F::host::to_affine64}
+   K::k_test_g1_mul_u32, F::host::combine_windows, F::host::window_from_planes, F::host::combine_wide, F::host::to_affine64}
 
 // accessors of the separately compiled units (hidden: not part of the C ABI)
 extern "C" {

@@ -57,6 +57,8 @@ enum LaunchMode {
   MODE_PLAIN = 0,   // windows [w_begin, w_end) of 254-bit scalars over the n bases
   MODE_TABLES = 1,  // fixed-base tables: all windows of a vector feed one bucket set (MSM_HIP_BASES_PRECOMPUTE)
   MODE_HALVES = 2,  // endomorphism: 127-bit halves k1, k2 over the 2n points P_i, phi(P_i) (MSM_HIP_BASES_ENDOMORPHISM, csrc/glv.h)
+  MODE_WIDE = 3,    // wide fixed-base tables: 14 digits of 19 bits per scalar, one bucket set of 2^18 slots run as 8 virtual windows of 2^15
+                    // (MSM_HIP_BASES_PRECOMPUTE_WIDE; msm_kernels.h: k_count_wide)
 };
 
 constexpr int N_MAIN_EVENTS = 7;  // boundaries of the 6 timed stages on the main stream
@@ -93,6 +95,7 @@ struct Slot {
   bool timed = false, pending = false, to_host = false;
   bool merged = false;                        // fixed-base launch: one bucket set (one window sum) per scalar vector
   bool halves = false;                        // endomorphism launch: the windows are those of 127-bit halves
+  bool wide = false;                          // wide fixed-base launch: h_wsums holds the bit-plane sums of the 8 virtual windows (combine_wide)
   bool parts = false;                         // h_wsums holds the bit-plane sums of every window (k_bpr_planes): the host finishes the window sums
   int timing_level = 0;
   int w_begin = 0, w_count = 0, nvec = 1;  // windows [w_begin, w_begin + w_count) of nvec scalar vectors
@@ -113,6 +116,7 @@ struct msm_hip_ctx {
   uint32_t* d_bases = nullptr;  // n_bases x 16 words
   size_t n_bases = 0, cap_bases = 0;  // points per table; capacity in point records (16 x n_bases with fixed-base tables)
   bool precomputed = false;           // d_bases holds the 16 tables 2^(16 w) P_i (MSM_HIP_BASES_PRECOMPUTE)
+  bool wide_tables = false;           // d_bases holds the 14 tables 2^(19 w) P_i (MSM_HIP_BASES_PRECOMPUTE_WIDE)
   bool endo = false;                  // d_bases holds phi(P_i) behind the n bases (MSM_HIP_BASES_ENDOMORPHISM)
   uint32_t* d_halves = nullptr;       // the split scalars of one launch (main stream only): [vector][2n] x 4 words
   size_t cap_halves = 0;              // in scalars
@@ -252,6 +256,43 @@ inline size_t piece_records_for(size_t n) {
 
 inline size_t stride_for(size_t n) { return (n + 3) & ~(size_t)3; }
 
+// the top digit's shift (msm_kernels.h: wide_digit): the largest for which the top digit of every scalar below the scalar field's modulus fits
+inline int wide_top_shift(int curve) {
+  static const int forced = [] { const char* e = getenv("MSM_HIP_WIDE_TOP_SHIFT"); return e ? atoi(e) : -1; }();  // tuning aid
+  if (forced >= 0) return forced;
+  if (WIDE_BITS != 19) return curve == MSM_HIP_CURVE_BLS12_381 || curve == MSM_HIP_CURVE_BLS12_381_G2 ? 4 : 5;  // (the 20-bit build: 14- or 15-bit top digit)
+  // (r >> 247, + 1 for the carry into the digit: 232 for BLS12-381, 128 -- no carry can reach a scalar of 2^254 -- for Pallas and Vesta, 97 for BN254 and Grumpkin)
+  return curve == MSM_HIP_CURVE_BLS12_381 || curve == MSM_HIP_CURVE_BLS12_381_G2 ? 10 : 11;
+}
+// SMVP lanes and lengths of a wide fixed-base launch over n points (msm_kernels.h: k_count_wide).  For uniform scalars every virtual window
+// receives 13 n / 8 entries from the 13 full digits, and the windows the shifted top digit reaches n / (windows it spans) more: the fullest
+// window's expected count F sets the device's chunk length (smvp_chunk_len), so the lanes are planned for F (+ 0.4 % + 64 entries: its
+// fluctuation is 0.07 % at 2^20) -- planned for the mean, the length the device settles on would be one entry more than the one the host
+// searched for, 4 % at 2^20.  Skewed scalars spread any other way: the arrays' per-window stride (`worst`) and the longest chunk the
+// device may pick (`host_len`) cover one window that holds everything.
+struct WideShape {
+  size_t worst;
+  uint32_t chunk_len, chunks, host_len;
+};
+inline WideShape wide_shape(size_t n, int curve) {
+  WideShape w;
+  w.worst = n * (size_t)WIDE_TABLES;
+  // the scalar field's modulus / 2^247 (the range of the top digit of a uniform scalar): BN254 and Grumpkin 96.8, Pallas and Vesta 128, BLS12-381 231.9
+  const double top_range = curve == MSM_HIP_CURVE_BLS12_381 || curve == MSM_HIP_CURVE_BLS12_381_G2 ? 231.86
+                           : curve == MSM_HIP_CURVE_PALLAS || curve == MSM_HIP_CURVE_VESTA ? 128.0 : 96.78;
+  double span = top_range * (double)(1u << wide_top_shift(curve)) / 32768.0;  // virtual windows the top digit spreads over
+  if (span < 1.0) span = 1.0;
+  if (span > (double)WIDE_VWIN) span = (double)WIDE_VWIN;
+  static const double slack = [] { const char* e = getenv("MSM_HIP_WIDE_SLACK_PCT"); return e ? atof(e) / 100.0 : 0.004; }();  // tuning aid
+  const double fullest = (double)n * (WIDE_TABLES - 1) / WIDE_VWIN + (double)n / span;
+  const size_t typ = (size_t)(fullest * (1.0 + slack)) + 64;
+  w.chunk_len = chunk_len_for(typ, WIDE_VWIN);
+  w.chunks = chunks_for(typ, w.chunk_len);
+  w.host_len = (uint32_t)((w.worst + w.chunks - 1) / w.chunks);
+  if (w.host_len < w.chunk_len) w.host_len = w.chunk_len;
+  return w;
+}
+
 // RAII: every ABI entry point runs on its context's device and leaves the caller's current device as it found it
 struct DeviceGuard {
   int prev = -1;
@@ -305,10 +346,11 @@ int setup_slot(msm_hip_ctx* ctx, Slot& s) {
 
 // make the pools fit a launch of `w_count` local windows (vectors x windows) over n points into slot `s` (not pending)
 // (`full_windows`: the windows of one whole MSM in the launch's mode -- the sort arrays are sized for at least that many)
-int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, int full_windows, Slot& s, bool planes) {
+// (`recs_override`: the launch's own count of SMVP lanes, where it is not the one n entries per window give -- wide fixed-base launches)
+int ensure_work(msm_hip_ctx* ctx, size_t n, int w_count, int wbits, int full_windows, Slot& s, bool planes, size_t recs_override = 0) {
   int rc;
   if ((rc = setup_slot(ctx, s))) return rc;
-  const size_t need_recs = (size_t)w_count * chunks_for(n, chunk_len_for(n, w_count));
+  const size_t need_recs = recs_override ? recs_override : (size_t)w_count * chunks_for(n, chunk_len_for(n, w_count));
   const size_t need_entries = stride_for(n) * (size_t)w_count;
   if ((planes || ctx->debug) && need_entries > ctx->cap_planes) {  // digit planes (main stream only, like the sort arrays)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -419,7 +461,7 @@ int err_from_bits(uint32_t bits) {
 inline bool use_planes(const msm_hip_ctx* ctx, LaunchMode mode, int w_count_vec, int wbits) {
   static const int max_w = [] { const char* e = getenv("MSM_HIP_PLANES_MAX_W"); return e ? atoi(e) : 8; }();
   static const bool whole = [] { const char* e = getenv("MSM_HIP_PLANES_WHOLE"); return e && e[0] == '1'; }();  // A/B aid: whole MSMs too
-  if (mode == MODE_TABLES || ctx->debug) return false;
+  if (mode == MODE_TABLES || mode == MODE_WIDE || ctx->debug) return false;
   if (whole) return true;
   return w_count_vec <= max_w && w_count_vec < nwin_of(wbits, mode == MODE_HALVES);
 }
@@ -429,19 +471,21 @@ inline bool use_planes(const msm_hip_ctx* ctx, LaunchMode mode, int w_count_vec,
 // copied to the slot's pinned buffer.  Returns without waiting.
 int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count_vec, int nvec, int wbits, LaunchMode mode, Slot& s,
             uint32_t* wsums_out, bool to_host) {
-  const bool merge = mode == MODE_TABLES, halves = mode == MODE_HALVES;
+  const bool merge = mode == MODE_TABLES, halves = mode == MODE_HALVES, wide = mode == MODE_WIDE;
   const uint32_t half = 1u << (wbits - 1);   // bucket slots per window
   const unsigned ncoarse = half / FINE;      // coarse bins that can hold entries
   // fixed-base tables (`merge`): the w_count_vec windows of a vector feed one bucket set -- one local window of up to
   // n * w_count_vec entries per vector -- whose entries index the tables (window w of point i = record w * n_bases + i)
-  const size_t merge_nb = merge ? ctx->n_bases : 0;
+  // wide tables (`wide`; nvec = 1, w_count_vec = 14 digits of 19 bits): the same indexing; the bucket set of 2^18 slots is run as 8 local
+  // ("virtual") windows of 2^15, into which the entries fall by the top 3 bits of their digit's magnitude (msm_kernels.h: k_count_wide)
+  const size_t merge_nb = merge || wide ? ctx->n_bases : 0;
   // endomorphism (`halves`): the recode runs over 2n halves of 16 B (the first pass splits the scalars) against 2n points -- P_i and, n_bases records
   // further on, phi(P_i) -- in half as many windows
   const size_t n_sc = halves ? 2 * n : n;  // inputs of the recode
-  const size_t n_entries = merge ? n * (size_t)w_count_vec : n_sc;
+  const size_t n_entries = merge || wide ? n * (size_t)w_count_vec : n_sc;  // (wide: what ONE virtual window may receive)
   // `nvec` scalar vectors (contiguous, n x 32 B each) share this launch: local window lw = v * w_count_vec + (w - w_begin);
   // everything after the two scalar-reading kernels only sees w_count = nvec * w_count_vec local windows
-  const int w_count = merge ? nvec : nvec * w_count_vec;
+  const int w_count = merge ? nvec : wide ? WIDE_VWIN : nvec * w_count_vec;
   hipStream_t st = ctx->stream, rs = ctx->reduce_stream[(&s - ctx->slot) % NREDUCE];
   // a synchronous call with nothing else in flight (msm_hip_run_*: the caller waits for this launch before it issues another): the stitch and
   // the bucket reduce follow the SMVP on the MAIN stream -- no cross-stream hand-off (an event wait costs ~10 us more than an in-stream kernel
@@ -456,11 +500,12 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   uint32_t tile_len = 2048;
   if ((n_sc + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n_sc + MAX_TILES - 1) / MAX_TILES) + 255) / 256 * 256);
   const uint32_t tiles = (uint32_t)((n_sc + tile_len - 1) / tile_len);
-  const uint32_t chunk_len = chunk_len_for(n_entries, w_count);
-  const uint32_t chunks = chunks_for(n_entries, chunk_len);
+  const WideShape ws = wide ? wide_shape(n, ctx->curve) : WideShape{};
+  const uint32_t chunk_len = wide ? ws.host_len : chunk_len_for(n_entries, w_count);  // (the longest the device may pick: smvp_chunk_len)
+  const uint32_t chunks = wide ? ws.chunks : chunks_for(n_entries, chunk_len);
   const size_t stride = stride_for(n_entries);
   ctx->last_stride = stride;
-  uint16_t* digits = ctx->debug && !merge ? ctx->d_digits : nullptr;
+  uint16_t* digits = ctx->debug && !merge && !wide ? ctx->d_digits : nullptr;
   // window shares (a few of a scalar's windows per vector): the first pass leaves digit planes, the second reads them (k_scatter_planes)
   const bool planes = use_planes(ctx, mode, w_count_vec, wbits);
   uint32_t* d_err = reinterpret_cast<uint32_t*>(s.d_wsums + WSUM_BYTES);
@@ -495,7 +540,9 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   // k2; a vector's 2n halves take the room of its n scalars, vector stride n * 8 words either way) for a scalar-reading second pass.
   uint16_t* plane_out = planes ? ctx->d_digits : digits;
   const int plane_mode = planes ? 2 : (digits ? 1 : 0);
-  if (halves) {
+  if (wide) {
+    hipLaunchKernelGGL(k_count_wide<8>, dim3(tiles), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, ctx->d_counts, d_err, wide_top_shift(ctx->curve));
+  } else if (halves) {
     hipLaunchKernelGGL(ctx->ops->count_split[wbits == 16 ? 2 : wbits == 14 ? 1 : 0], dim3(tiles), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, w_begin,
                        w_count_vec, nvec, n * 8, ctx->d_counts, plane_out, plane_mode, planes ? ctx->d_negbits : nullptr,
                        planes ? nullptr : ctx->d_halves, d_err, merge_nb);
@@ -509,7 +556,10 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   hipLaunchKernelGGL(k_scan_tiles, dim3(NCOARSE / 4, w_count), dim3(256), 0, st, ctx->d_counts, tiles, ctx->d_bin_total);  // all 128 bins: the scatter scans them
   AFTER_KERNEL(ctx, "k_scan_tiles", st);
   HIP_TRY(ctx, mark(2, false));
-  if (planes) {
+  if (wide) {
+    hipLaunchKernelGGL(k_scatter_wide<8>, dim3(tiles), dim3(WIDE_THREADS), 0, st, d_scalars, n_sc, stride, tile_len, tiles, ctx->d_counts, ctx->d_bin_total,
+                       ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, chunks, chunk_len, d_chunk_len, wide_top_shift(ctx->curve));
+  } else if (planes) {
     hipLaunchKernelGGL(k_scatter_planes, dim3(tiles), dim3(256), 0, st, ctx->d_digits, halves ? ctx->d_negbits : (const uint64_t*)nullptr, n_sc, stride, tile_len,
                        tiles, w_count, w_count_vec, ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine,
                        (uint32_t)ctx->n_bases, chunks, chunk_len, d_chunk_len);
@@ -594,7 +644,9 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   // operations at ~7 us each in k_bpr_w256 / k_bpr_final -- is replaced by 16 independent masked tree sums per window (k_bpr_planes, 8 deep)
   // and 29 operations per window on the host (0.3 us each).  Sums that stay on the device (window shards for the gather), grouped launches
   // (their host thread is on the critical path: several MSMs' worth of host work per launch) and debug read-backs get finished sums.
-  const bool parts_mode = to_host && nvec == 1 && !ctx->debug && wsums_out == reinterpret_cast<uint32_t*>(s.d_wsums) && w_count <= 24;
+  // (a wide fixed-base launch always leaves the plane sums: its finish needs every virtual window's plain total, which is one of them)
+  const bool parts_mode = to_host && nvec == 1 && (!ctx->debug || wide) && wsums_out == reinterpret_cast<uint32_t*>(s.d_wsums) && w_count <= 24;
+  if (wide && !parts_mode) return MSM_HIP_ERR_INVALID_ARG;
   // the kernel that ends the chain writes the launch's error word into the slot's pinned buffer itself and clears it (no copy, no fill); a
   // single MSM's bit-plane sums go to the pinned buffer directly as well (12 KB of stores over the host link instead of a copy behind the kernel)
   uint32_t* h_err = reinterpret_cast<uint32_t*>(s.h_wsums + WSUM_BYTES);
@@ -625,6 +677,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   s.wbits = wbits;
   s.merged = merge;
   s.halves = halves;
+  s.wide = wide;
   s.parts = parts_mode;
   s.n = n;
   s.timed = tl >= 1;
@@ -680,10 +733,12 @@ constexpr size_t MAX_PRECOMPUTE_POINTS = (size_t)1 << 24;  // 16 tables: 16 GiB,
 // The mode a base set is held in.  Asked for explicitly (tables, endomorphism images, or MSM_HIP_BASES_PLAIN: the reference's 16 windows
 // over n points), or -- none of the three -- the fastest the curve has: the drop-in call shape (flags = 0; msm_hip_msm_bn254_g1 ≙ compute_msm,
 // src/cuzk/msm.rs:75-94) runs the mode the headline figure is measured in (656 vs 701 - 714 MSM/s at 2^20 in round 3, when it did not).
-constexpr uint32_t BASE_FLAGS_ALL = MSM_HIP_CHECK_ON_CURVE | MSM_HIP_BASES_MONT256 | MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_ENDOMORPHISM | MSM_HIP_BASES_PLAIN;
+constexpr uint32_t BASE_FLAGS_ALL = MSM_HIP_CHECK_ON_CURVE | MSM_HIP_BASES_MONT256 | MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_ENDOMORPHISM | MSM_HIP_BASES_PLAIN |
+                                    MSM_HIP_BASES_PRECOMPUTE_WIDE;
+constexpr size_t MAX_WIDE_POINTS = (size_t)1 << 22;  // 14 tables: 3.5 GiB; sort arrays of 8 x 14 n entries: 4.2 GiB
 inline uint32_t resolve_base_flags(const msm_hip_ctx* ctx, size_t n, uint32_t flags) {
   static const bool auto_endo = [] { const char* e = getenv("MSM_HIP_BASES_AUTO"); return !e || atoi(e) != 0; }();  // MSM_HIP_BASES_AUTO=0: flags = 0 means plain (rounds 1 - 3)
-  if (flags & (MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_ENDOMORPHISM | MSM_HIP_BASES_PLAIN)) return flags;
+  if (flags & (MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_PRECOMPUTE_WIDE | MSM_HIP_BASES_ENDOMORPHISM | MSM_HIP_BASES_PLAIN)) return flags;
   // ... on the curves of prime order only: phi(P) = lambda P holds on the subgroup of order r, and a base set of a curve with a cofactor
   // (BLS12-381, the G2 twists) may hold points outside it, for which the plain MSM is still defined -- there the mode stays an opt-in
   const bool prime_order = ctx->curve == MSM_HIP_CURVE_BN254_G1 || ctx->curve == MSM_HIP_CURVE_GRUMPKIN || ctx->curve == MSM_HIP_CURVE_PALLAS ||
@@ -694,14 +749,18 @@ inline uint32_t resolve_base_flags(const msm_hip_ctx* ctx, size_t n, uint32_t fl
 
 int reserve_bases(msm_hip_ctx* ctx, size_t n, uint32_t flags) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const bool tables = (flags & MSM_HIP_BASES_PRECOMPUTE) != 0, endo = (flags & MSM_HIP_BASES_ENDOMORPHISM) != 0;
-  if (n > MAX_POINTS || (tables && n > MAX_PRECOMPUTE_POINTS) || (endo && n > MAX_POINTS / 2) || (tables && endo)) return MSM_HIP_ERR_INVALID_ARG;
-  if ((flags & ~BASE_FLAGS_ALL) || ((flags & MSM_HIP_BASES_PLAIN) && (tables || endo))) return MSM_HIP_ERR_INVALID_ARG;
+  const bool wide = (flags & MSM_HIP_BASES_PRECOMPUTE_WIDE) != 0;
+  const bool tables = (flags & MSM_HIP_BASES_PRECOMPUTE) != 0 || wide, endo = (flags & MSM_HIP_BASES_ENDOMORPHISM) != 0;
+  if (n > MAX_POINTS || (tables && n > MAX_PRECOMPUTE_POINTS) || (wide && n > MAX_WIDE_POINTS) || (endo && n > MAX_POINTS / 2) || (tables && endo))
+    return MSM_HIP_ERR_INVALID_ARG;
+  if ((flags & ~BASE_FLAGS_ALL) || ((flags & MSM_HIP_BASES_PLAIN) && (tables || endo)) || (wide && (flags & MSM_HIP_BASES_PRECOMPUTE)))
+    return MSM_HIP_ERR_INVALID_ARG;
   if ((endo && !ctx->ops->glv) || (tables && !ctx->ops->precompute_tables)) return MSM_HIP_ERR_INVALID_ARG;
   ctx->n_bases = 0;
   ctx->precomputed = false;
+  ctx->wide_tables = false;
   ctx->endo = false;
-  const size_t records = tables ? n * NWIN : endo ? 2 * n : n;
+  const size_t records = wide ? n * WIDE_TABLES : tables ? n * NWIN : endo ? 2 * n : n;
   if (records > ctx->cap_bases) {
     ctx->cap_bases = 0;
     int rc = dev_alloc(ctx, ctx->d_bases, records * 2 * (size_t)ctx->ops->coord_words);
@@ -722,11 +781,14 @@ int set_bases_from_device(msm_hip_ctx* ctx, const uint32_t* d_xy, size_t n, uint
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   int rc = err_from_bits(bits);
   if (rc) return rc;
-  if (flags & MSM_HIP_BASES_PRECOMPUTE) {  // tables 1 .. 15 behind the plain set: T_w[i] = 2^(16 w) P_i
-    hipLaunchKernelGGL(ctx->ops->precompute_tables, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_bases, n, n, NWIN);
+  if (flags & (MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_PRECOMPUTE_WIDE)) {  // tables 1 .. 15 behind the plain set: T_w[i] = 2^(16 w) P_i (wide: 1 .. 13, 2^(19 w) P_i, the last one top_shift doublings short)
+    const bool wide = (flags & MSM_HIP_BASES_PRECOMPUTE_WIDE) != 0;
+    hipLaunchKernelGGL(ctx->ops->precompute_tables, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_bases, n, n, wide ? (int)WIDE_TABLES : (int)NWIN,
+                       wide ? (int)WIDE_BITS : (int)WBITS, wide ? (int)WIDE_BITS - wide_top_shift(ctx->curve) : (int)WBITS);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->precomputed = true;
+    ctx->precomputed = !wide;
+    ctx->wide_tables = wide;
   }
   if (flags & MSM_HIP_BASES_ENDOMORPHISM) {  // phi(P_i) = (beta x_i, y_i) behind the plain set
     hipLaunchKernelGGL(ctx->ops->endo_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_bases, n);
@@ -746,7 +808,8 @@ namespace {
 size_t batch_group(msm_hip_ctx* ctx, size_t n, size_t batch) {
   // 4 at 16 bits, 3 at 14, 2 at 12 (8 / 6 / 5 with the endomorphism's half-length scalars); with fixed-base tables every MSM is one local window
   // (window size of a grouped launch: pick_window_bits with nvec > 1)
-  const size_t fit = ctx->precomputed ? (size_t)MAXLW : (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 2, ctx->endo), ctx->endo));
+  // (wide tables: one MSM per launch -- its bucket set already is 8 local windows, and the mode is meant for large MSMs)
+  const size_t fit = ctx->wide_tables ? (size_t)1 : ctx->precomputed ? (size_t)MAXLW : (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 2, ctx->endo), ctx->endo));
   size_t g = n ? ((size_t)1 << 20) / n : 1;
   if (g > fit) g = fit;
   if (g > batch) g = batch;
@@ -921,12 +984,15 @@ namespace {
 // windows [w_begin, w_end) -- in units of `wbits`-bit windows -- of `nvec` scalar vectors into `slot`
 int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end, int wbits, int slot,
                 void* window_sums_dev, LaunchMode mode = MODE_PLAIN) {
-  const bool merge = mode == MODE_TABLES, halves = mode == MODE_HALVES;
+  // (MODE_WIDE: called with wbits = 19 and all 14 windows; everything behind the recode sees 8 local windows of 16 bits)
+  const bool merge = mode == MODE_TABLES, halves = mode == MODE_HALVES, wide = mode == MODE_WIDE;
   int rc = check_run_args(ctx, scalars_dev, n);
   if (rc) return rc;
   if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > nwin_of(wbits, halves) || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
+  if (wide && (nvec != 1 || window_sums_dev || w_begin != 0 || w_end != WIDE_TABLES || wbits != WIDE_BITS)) return MSM_HIP_ERR_INVALID_ARG;
+  if (wide) wbits = WBITS;
   const int w_count = w_end - w_begin;
-  const int w_local = merge ? nvec : nvec * w_count;  // bucket sets of the launch
+  const int w_local = merge ? nvec : wide ? WIDE_VWIN : nvec * w_count;  // bucket sets of the launch
   if (nvec < 1 || w_local > MAXLW) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   Slot& s = ctx->slot[slot];
@@ -939,6 +1005,7 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
   s.wbits = wbits;
   s.merged = merge;
   s.halves = halves;
+  s.wide = wide;
   s.parts = false;
   s.to_host = window_sums_dev == nullptr;
   if (n == 0) {  // identity window sums, nothing to compute
@@ -951,8 +1018,11 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
     }
     return MSM_HIP_OK;
   }
-  if ((rc = ensure_work(ctx, merge ? n * (size_t)w_count : halves ? 2 * n : n, w_local, wbits,
-                        merge ? 1 : halves ? nwin_of(wbits, true) : NWIN, s, use_planes(ctx, mode, w_count, wbits)))) return rc;
+  if (wide) {
+    const WideShape ws = wide_shape(n, ctx->curve);
+    if ((rc = ensure_work(ctx, ws.worst, w_local, wbits, WIDE_VWIN, s, false, (size_t)w_local * ws.chunks))) return rc;
+  } else if ((rc = ensure_work(ctx, merge ? n * (size_t)w_count : halves ? 2 * n : n, w_local, wbits,
+                               merge ? 1 : halves ? nwin_of(wbits, true) : NWIN, s, use_planes(ctx, mode, w_count, wbits)))) return rc;
   if (halves && (size_t)nvec * n > ctx->cap_halves) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cap_halves = 0;
@@ -976,6 +1046,8 @@ int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scal
                                               int slot, void* window_sums_dev) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
   // whole MSMs whose sums stay in the slot (finish / finish_batch combines them): the window size follows n
+  if (w_begin == 0 && w_end == NWIN && window_sums_dev == nullptr && nvec >= 1 && ctx->wide_tables && n > 0)
+    return launch_impl(ctx, scalars_dev, n, nvec, 0, WIDE_TABLES, WIDE_BITS, slot, nullptr, MODE_WIDE);  // wide fixed-base tables (one MSM per launch)
   if (w_begin == 0 && w_end == NWIN && window_sums_dev == nullptr && nvec >= 1 && ctx->precomputed && n > 0)
     return launch_impl(ctx, scalars_dev, n, nvec, 0, NWIN, WBITS, slot, nullptr, MODE_TABLES);  // fixed-base tables: one bucket set per vector
   if (w_begin == 0 && w_end == NWIN && window_sums_dev == nullptr && nvec >= 1 && ctx->endo && n > 0 && nvec * nwin_of(16, true) <= MAXLW) {
@@ -1024,8 +1096,8 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   if (!ctx || !out_xyz || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   Slot& s = ctx->slot[slot];
   // fixed-base launches leave ONE sum per vector (every table already carries its power of two): nothing to combine but the copy
-  const int nwin = s.merged ? 1 : nwin_of(s.wbits, s.halves);
-  if (!s.pending || !s.to_host || s.w_count != nwin_of(s.wbits, s.halves)) return MSM_HIP_ERR_INVALID_ARG;
+  const int nwin = s.merged ? 1 : s.wide ? WIDE_VWIN : nwin_of(s.wbits, s.halves);
+  if (!s.pending || !s.to_host || s.w_count != (s.wide ? (int)WIDE_TABLES : nwin_of(s.wbits, s.halves))) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   int rc = wait_slot(ctx, s);
   if (rc) return rc;
@@ -1037,7 +1109,9 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
     combine_pool().run(nwin, [&](int w) {
       if (!ctx->ops->window_from_planes(s.h_wsums + (size_t)w * PLANES_PER_WINDOW * jb, sums + jb * (size_t)w)) all_ok = false;
     });
-    if (!ctx->ops->combine_windows(sums, nwin, s.wbits, out_xyz)) all_ok = false;
+    if (s.wide) {  // virtual windows: sum_hi W_hi + 2^15 sum_hi hi TC_hi (host_g1.h)
+      if (!ctx->ops->combine_wide(sums, s.h_wsums, nwin, out_xyz)) all_ok = false;
+    } else if (!ctx->ops->combine_windows(sums, nwin, s.wbits, out_xyz)) all_ok = false;
   } else {
     combine_pool().run(s.nvec, [&](int v) {  // one independent Horner chain per MSM of the launch: side by side when there are several
       if (!ctx->ops->combine_windows(s.h_wsums + (size_t)v * nwin * ctx->jb, nwin, s.wbits, out_xyz + ctx->jb * (size_t)v)) all_ok = false;

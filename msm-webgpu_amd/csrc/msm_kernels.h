@@ -47,7 +47,7 @@ constexpr int JAC_WORDS = 3 * CW;   // a Jacobian record x || y || z: 96 B (144 
 // magnitude in bits 0 .. 126, sign in bit 127).
 template <int C, int SW = 8>
 struct WinCfg {
-  static_assert(C >= 10 && C <= 16, "window bits");
+  static_assert((C >= 10 && C <= 16) || (C >= 17 && C <= 20), "window bits (17 .. 20: the digits of the wide fixed-base tables, k_count_wide)");
   static_assert(SW == 8 || SW == 4, "scalar words");
   static constexpr int BITS = C;
   static constexpr int SBITS = SW == 8 ? 254 : 127;        // bits of the scalar (magnitude)
@@ -251,14 +251,17 @@ __device__ __forceinline__ fq fq_inv(const fq& a) {  // Fq2: 1 / (a0 + a1 u) = (
   return f2_make(fpn::fq_mul(a0, acc), fpn::fq_mul(fpn::fq_sub<3>(fpn::fq_zero(), a1), acc));  // (3p - a1) / norm
 }
 #endif
-__global__ void __launch_bounds__(256) k_precompute_tables(uint32_t* __restrict__ bases, size_t n, size_t nb, int num_tables) {
+// (step_bits: doublings between two tables -- 16, or 20 for the wide tables below, whose last table is only last_step_bits above the one before)
+__global__ void __launch_bounds__(256) k_precompute_tables(uint32_t* __restrict__ bases, size_t n, size_t nb, int num_tables, int step_bits,
+                                                           int last_step_bits) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const fq px = ld_fq(bases + i * PT_WORDS), py = ld_fq(bases + i * PT_WORDS + CW);
   g1_xyzz acc = g1_from_affine(px, py);
   for (int w = 1; w < num_tables; w++) {
+    const int steps = w == num_tables - 1 ? last_step_bits : step_bits;
 #pragma unroll 1
-    for (int k = 0; k < WBITS; k++) acc = g1_double(acc);
+    for (int k = 0; k < steps; k++) acc = g1_double(acc);
     // affine again: x = X / ZZ, y = Y / ZZZ with one inversion of ZZ * ZZZ (a point of prime order never doubles to infinity)
     const fq t = fq_inv(fq_mul(acc.zz, acc.zzz));
     const fq x = fq_canonical(fq_mul(acc.x, fq_mul(t, acc.zzz)));
@@ -689,6 +692,223 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
       if (tid < NCOARSE) gpos[lw * NCOARSE + tid] += hist[tid];
       __syncthreads();
     }
+  }
+}
+
+// ---- wide fixed-base tables (round 4; SURVEY.md 8f-2, MSM_HIP_BASES_PRECOMPUTE_WIDE) ------------------------------------------------
+// With tables T_w[i] = 2^(C w) P_i the number of bucket additions of an MSM is ceil(255 / C) * n and nothing ties C to the bucket count of
+// a window any more -- there is one bucket set.  C = 19: 14 additions per point instead of 16 (-12.5 % of the SMVP, the dominant kernel) over
+// 2^18 bucket slots -- the 8 x 2^15 of the endomorphism mode: the slot of magnitude m (1 .. 2^18) is split as
+//     m = hi * 2^15 + value(slot),   hi = (m - 1) >> 15  (0 .. 7),   slot = m & 0x7fff,   value(slot) = slot, or 2^15 for slot 0
+// and `hi` is handled as a VIRTUAL WINDOW: local window hi holds the 2^15 slots of that range, so that everything behind the two
+// scalar-reading passes -- fine sort, SMVP, stitch, row / column sums -- runs unchanged on 8 local windows of 2^15 slots.  The reduce leaves,
+// per virtual window, the weighted sum W_hi = sum_slot value(slot) B[hi][slot] AND the plain total TC_hi = sum_slot B[hi][slot] (the column
+// total of the bit-plane sums, k_bpr_planes), and the host finishes  sum_hi W_hi + 2^15 * sum_hi hi * TC_hi  (host_g1.h: combine_wide).
+// The entries of virtual window hi are stored at tmp_val[hi][...]: with skewed scalars one virtual window may receive all 14 n entries, so
+// the per-window stride is 14 n (the host sizes the arrays for it); the lanes of the SMVP are sized for the uniform case and the device
+// picks the chunk length from the fullest window as always (smvp_chunk_len).
+// Why not C = 20 (13 additions, 2^19 slots = 16 virtual windows), which was built first (-DMSM_WIDE_BITS=20 still builds it;
+// profiles/r04_wide_tables.txt): its SMVP is 0.85 ms alone against 0.99, but stitching and reducing 16 bucket sets beside the next launch's
+// SMVP costs more than the additions saved -- 690 MSM/s against 721 with the endomorphism's 8 bucket sets and 727 with the one of the
+// 16-bit tables.  What an MSM costs in the pipeline is sort + SMVP + the reduce work that runs beside them, and that grows with the bucket sets.
+#ifndef MSM_WIDE_BITS
+#define MSM_WIDE_BITS 19
+#endif
+constexpr int WIDE_BITS = MSM_WIDE_BITS;
+constexpr int WIDE_TABLES = WinCfg<WIDE_BITS>::NWIN;    // 14 tables, 2^(19 w) P_i
+constexpr int WIDE_VWIN = 1 << (WIDE_BITS - WBITS);     // 8 virtual windows of 2^15 slots
+constexpr int WIDE_KEYS = WIDE_VWIN * NCOARSE;          // 1024 (virtual window, coarse bin) runs
+static_assert(WIDE_VWIN <= MAXLW, "virtual windows are local windows");
+
+//
+// The top digit.  Window 13 holds what is left of the scalar above bit 247 -- 7 or 8 bits -- so its magnitudes would all fall into virtual
+// window 0, which would then carry 2.6 n entries against 1.6 n in the others, and the SMVP's lanes are as long as the fullest window makes
+// them.  The top table is therefore 2^(247 - top_shift) P_i and the top digit is used as d << top_shift: the same product for any point
+// (exact integer arithmetic: no assumption on the point's order), spread over the virtual windows -- n entries in at most 2^8 giant
+// buckets, which the stitch handles as it handles the heavy buckets of skewed scalars.  top_shift (msm_hip.hip: wide_top_shift) is the
+// largest for which the top digit of every scalar below the scalar field's modulus r stays within 2^18: 11 where r >> 247 is 96 (BN254,
+// Grumpkin: the digit reaches 6 of the 8 virtual windows, the fullest holds 2.4 % more than the mean) or 128 (Pallas, Vesta: all 8), 10 for
+// BLS12-381 (231: 7.2 of 8).  A scalar whose shifted top digit passes 2^18 -- at or above r on every one of these curves -- is rejected like one that
+// overflows the reference's recode (ERRBIT_SCALAR_CARRY).
+// signed WIDE_BITS-bit digit of window w of the biased scalar t (WinCfg<WIDE_BITS>::WORDS words): its magnitude 1 .. 2^(WIDE_BITS - 1) (0: no entry) and sign
+__device__ __forceinline__ uint32_t wide_digit(const uint32_t* t, int w, int top_shift, uint32_t& sign, uint32_t& overflow) {
+  constexpr int C = WIDE_BITS;
+  constexpr uint32_t H = 1u << (C - 1);
+  const int bit = C * w, i = bit >> 5, sh = bit & 31;
+  uint32_t b = t[i] >> sh;
+  if (sh + C > 32) b |= t[i + 1] << (32 - sh);  // (only then is i + 1 < WORDS)
+  b &= (1u << C) - 1u;
+  sign = b < H ? 1u : 0u;
+  uint32_t mag = b >= H ? b - H : H - b;
+  if (w == WIDE_TABLES - 1) {  // (never negative: nothing above it carries into it, and its raw value is below 2^16)
+    mag <<= top_shift;
+    if (mag > H) {
+      overflow = 1;
+      mag = 0;
+    }
+  }
+  return mag;
+}
+__device__ __forceinline__ uint32_t wide_key(uint32_t mag) { return (((mag - 1u) >> 15) << 7) | ((mag & 0x7fffu) >> 8); }  // (virtual window, coarse bin)
+
+// first pass: counts[hi][tile][bin] (the layout of k_count with WIDE_VWIN local windows).  One scalar vector per launch.
+template <int SW>
+__global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles,
+                                                    uint32_t* __restrict__ counts, uint32_t* __restrict__ err, int top_shift) {
+  static_assert(SW == 8, "full-length scalars");
+  __shared__ uint32_t cnt[WIDE_KEYS];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < WIDE_KEYS; i += 256) cnt[i] = 0;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * tile_len;
+  const size_t end = base + tile_len < n ? base + tile_len : n;
+  uint32_t bad = 0;
+  for (size_t i0 = base; i0 < end; i0 += 256) {
+    const size_t i = i0 + tid;
+    if (i >= end) continue;
+    uint32_t s[SW], tb[WinCfg<WIDE_BITS, SW>::WORDS], t16[8], neg = 0;
+    ld_scalar<SW>(scalars + i * SW, s, neg);
+    bad |= bias_scalar<WIDE_BITS, SW>(s, tb);
+    bad |= bias_scalar<16>(s, t16);  // the input contract of every mode: what overflows the reference's 16-bit recode is rejected (test/utils.rs:150-152)
+#pragma unroll
+    for (int w = 0; w < WIDE_TABLES; w++) {
+      uint32_t sign;
+      const uint32_t mag = wide_digit(tb, w, top_shift, sign, bad);
+      if (mag) atomicAdd(&cnt[wide_key(mag)], 1u);
+    }
+  }
+  if (bad) atomicOr(err, ERRBIT_SCALAR_CARRY);
+  __syncthreads();
+  for (int i = tid; i < WIDE_KEYS; i += 256)
+    counts[((size_t)(i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[i];
+}
+
+// second pass: the LDS-ranked, LDS-staged scatter of k_scatter_coarse over all 1024 (virtual window, coarse bin) runs at once.  ALL 14
+// digits of the 1024 scalars of a block iteration are staged together (14 336 entries, 14 per run): ranked per window as k_scatter_coarse
+// does, a run would receive one entry per iteration and every 4-byte store would be a memory transaction of its own.
+// 112 KB of LDS: one workgroup of 512 threads per CU.
+constexpr int WIDE_THREADS = 512, WIDE_PER = 2;
+constexpr int WIDE_SUB = WIDE_THREADS * WIDE_PER;     // scalars staged per block iteration
+constexpr int WIDE_STAGE = WIDE_SUB * WIDE_TABLES;    // entries staged per block iteration
+template <int SW>
+__global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
+                                                               uint32_t tiles, const uint32_t* __restrict__ counts,
+                                                               const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr,
+                                                               uint32_t* __restrict__ tmp_val, uint8_t* __restrict__ tmp_fine, size_t table_stride,
+                                                               uint32_t chunks, uint32_t host_chunk_len, uint32_t* __restrict__ chunk_len_dev, int top_shift) {
+  static_assert(SW == 8, "full-length scalars");
+  __shared__ uint32_t gpos[WIDE_KEYS];    // write cursor of every run of this tile, relative to its virtual window's array
+  __shared__ uint32_t hist[WIDE_KEYS];
+  __shared__ uint32_t lstart[WIDE_KEYS];
+  __shared__ uint32_t st_val[WIDE_STAGE];
+  __shared__ uint16_t st_key[WIDE_STAGE];
+  __shared__ uint8_t st_fine[WIDE_STAGE];
+  __shared__ uint32_t wave_tot[WIDE_THREADS / 64];
+  __shared__ uint32_t max_total;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) max_total = 0;
+  __syncthreads();
+  // start of every run: exclusive scan of each virtual window's 128 bin totals (a pair of waves per window, four windows per step) + what
+  // earlier tiles put there; workgroup 0 publishes the bin starts (coarse_ptr[hi][0 .. 128]) and the launch's chunk length
+  for (int i0 = 0; i0 < WIDE_KEYS; i0 += WIDE_THREADS) {
+    const int i = i0 + tid, lw = i / NCOARSE, bin = i % NCOARSE;
+    const uint32_t v = bin_total[i];
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[wid] = x;
+    __syncthreads();
+    const uint32_t incl = x + ((wid & 1) ? wave_tot[wid - 1] : 0u);
+    gpos[i] = incl - v + counts[((size_t)lw * tiles + blockIdx.x) * NCOARSE + bin];
+    if (blockIdx.x == 0) {
+      coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin] = incl - v;
+      if (bin == NCOARSE - 1) {
+        coarse_ptr[(size_t)lw * (NCOARSE + 1) + NCOARSE] = incl;
+        atomicMax(&max_total, incl);
+      }
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && tid == 0) *chunk_len_dev = smvp_chunk_len(max_total, chunks, host_chunk_len);
+  const size_t tile_base = (size_t)blockIdx.x * tile_len;
+  const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
+  for (size_t sub = tile_base; sub < tile_end; sub += WIDE_SUB) {
+    for (int k = tid; k < WIDE_KEYS; k += WIDE_THREADS) hist[k] = 0;
+    uint32_t sc[WIDE_PER][WinCfg<WIDE_BITS, SW>::WORDS];
+#pragma unroll
+    for (int j = 0; j < WIDE_PER; j++) {
+      const size_t i = sub + (size_t)j * WIDE_THREADS + tid;
+      uint32_t raw[SW], neg = 0;
+#pragma unroll
+      for (int k = 0; k < SW; k++) raw[k] = 0;  // an all-zero scalar recodes to all-zero digits: no entries
+      if (i < tile_end) ld_scalar<SW>(scalars + i * SW, raw, neg);
+      (void)bias_scalar<WIDE_BITS, SW>(raw, sc[j]);
+    }
+    __syncthreads();
+    uint32_t rank[WIDE_PER][WIDE_TABLES];
+#pragma unroll
+    for (int j = 0; j < WIDE_PER; j++)
+#pragma unroll
+      for (int w = 0; w < WIDE_TABLES; w++) {
+        uint32_t sign, over = 0;
+        const uint32_t mag = wide_digit(sc[j], w, top_shift, sign, over);  // (an overflowing top digit: no entry here as in k_count_wide, which reports it)
+        rank[j][w] = mag ? atomicAdd(&hist[wide_key(mag)], 1u) : 0u;
+      }
+    __syncthreads();
+    {  // exclusive scan of the run lengths: KPT consecutive keys per thread
+      constexpr int KPT = WIDE_KEYS / WIDE_THREADS;
+      static_assert(KPT * WIDE_THREADS == WIDE_KEYS, "keys per thread");
+      uint32_t h[KPT], sum = 0;
+#pragma unroll
+      for (int k = 0; k < KPT; k++) {
+        h[k] = hist[KPT * tid + k];
+        sum += h[k];
+      }
+      uint32_t x = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+      }
+      if (lane == 63) wave_tot[wid] = x;
+      __syncthreads();
+      uint32_t run = x - sum;
+      for (int k = 0; k < wid; k++) run += wave_tot[k];
+#pragma unroll
+      for (int k = 0; k < KPT; k++) {
+        lstart[KPT * tid + k] = run;
+        run += h[k];
+      }
+    }
+    __syncthreads();
+    const uint32_t total = lstart[WIDE_KEYS - 1] + hist[WIDE_KEYS - 1];
+#pragma unroll
+    for (int j = 0; j < WIDE_PER; j++)
+#pragma unroll
+      for (int w = 0; w < WIDE_TABLES; w++) {
+        uint32_t sign, over = 0;
+        const uint32_t mag = wide_digit(sc[j], w, top_shift, sign, over);
+        if (mag) {
+          const uint32_t key = wide_key(mag), e = lstart[key] + rank[j][w];
+          const uint32_t pos = (uint32_t)(sub + (size_t)j * WIDE_THREADS + tid);
+          st_val[e] = ((uint32_t)(w * table_stride) + pos) | (sign << 31);  // window w of point i = record w * n_bases + i
+          st_key[e] = (uint16_t)key;
+          st_fine[e] = (uint8_t)(mag & 0xffu);
+        }
+      }
+    __syncthreads();
+    for (uint32_t e = tid; e < total; e += WIDE_THREADS) {
+      const uint32_t key = st_key[e];
+      const size_t d = (size_t)(key >> 7) * stride + gpos[key] + (e - lstart[key]);
+      tmp_val[d] = st_val[e];
+      tmp_fine[d] = st_fine[e];
+    }
+    __syncthreads();
+    for (int k = tid; k < WIDE_KEYS; k += WIDE_THREADS) gpos[k] += hist[k];
+    __syncthreads();
   }
 }
 

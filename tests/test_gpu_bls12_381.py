@@ -124,6 +124,8 @@ def test_msm_matches_oracle_every_window_size_and_mode(ctx, n):
     if n <= 4097:
         ctx.set_bases(points, precompute=True)
         assert ctx.msm(sc).to_affine_bytes() == want
+        ctx.set_bases(points, precompute="wide")          # 14 digits of 19 bits (top digit shifted by 10 on this curve), 8 virtual windows
+        assert ctx.msm(sc).to_affine_bytes() == want and ctx.msm(dev).to_affine_bytes() == want
         ctx.set_bases(points)
         mg = m.MultiGpuMsm([0, 0, 0], "host", curve="bls12_381")
         try:

@@ -159,6 +159,10 @@ def test_msm_matches_the_model_every_window_size_and_entry_point(ctx, n):
     ctx.set_bases(points, precompute=True)
     assert ctx.msm(scb).to_affine() == want and ctx.msm(dev).to_affine() == want
     assert [g.to_affine() for g in ctx.msm_batch(scb * 2, n)] == [want] * 2
+    # ... and the wide tables (14 digits of 19 bits into one bucket set of 2^18 slots)
+    ctx.set_bases(points, precompute="wide")
+    assert ctx.msm(scb).to_affine() == want and ctx.msm(dev).to_affine() == want
+    assert [g.to_affine() for g in ctx.msm_batch(scb * 2, n)] == [want] * 2
     # scalars handed over as s * 2^256 mod r (the in-memory words of a 4 x 64-bit Montgomery library)
     ctx.set_bases(points)
     ctx.set_scalar_format(True)

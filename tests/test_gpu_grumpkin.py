@@ -124,6 +124,8 @@ def test_device_samplers_and_every_mode(gctx):
         cp, vi = cpu.transpose(digits[w], 1 << 16)
         buckets = cpu.smvp_signed(cp, vi, pb, 1 << 16)
         assert cpu.to_affine64(wsums[96 * w:96 * w + 96]) == cpu.to_affine64(cpu.bucket_reduction("running_sum", buckets))
+    gctx.set_bases(pts, precompute="wide")                                                            # wide fixed-base tables (19-bit digits)
+    assert gctx.msm(sc).to_affine_bytes() == want
     gctx.set_bases(pts, precompute=True)                                                              # fixed-base tables
     assert gctx.msm(sc).to_affine_bytes() == want
     batch = torch.cat([sc, sc.flip(0).contiguous()], dim=0).contiguous()

@@ -1,0 +1,105 @@
+"""Wide fixed-base tables (round 4): MSM_HIP_BASES_PRECOMPUTE_WIDE stores 2^(19 w) P_i for 14 windows and recodes every scalar
+into 14 signed digits of 19 bits -- 14 bucket additions per point instead of the reference's 16 (src/cuzk/msm.rs:79-82) -- into one bucket set
+of 2^18 slots that the engine runs as 8 virtual windows of 2^15.  Same group element as the plain engine and the oracle."""
+import pytest
+
+import msm_webgpu_amd as m
+from oracle import bn254_ref as ref
+from oracle import cpu
+from tests.util import R, case_inputs, golden_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_golden_vectors_with_wide_tables(ctx):
+    for case in golden_cases():
+        points, scalars = case_inputs(case)
+        ctx.set_bases(points, check_on_curve=True, precompute="wide")
+        assert ctx.msm(scalars).to_affine_bytes().hex() == case["expected_affine"], case["name"]
+
+
+@pytest.mark.parametrize("n", [1, 2, 257, 5000, 1 << 16, (1 << 18) + 3])
+def test_wide_tables_match_oracle_and_plain_engine(ctx, n):
+    pts, sc = ctx.sample_points(n, 1400 + n), ctx.sample_scalars(n, 1401 + n)
+    pb, sb = pts.cpu().numpy().tobytes(), sc.cpu().numpy().tobytes()
+    want = cpu.to_affine64(cpu.cpu_msm(pb, sb, 8))
+    ctx.set_bases(pts, precompute="wide")
+    assert ctx.msm(sc).to_affine_bytes() == want          # device scalars
+    assert ctx.msm(sb).to_affine_bytes() == want          # host scalars
+    k = max(1, n // 3)                                    # a prefix of the bases: table stride stays n
+    assert ctx.msm(sc[:k].contiguous()).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb[: 64 * k], sb[: 32 * k], 8))
+    # the window-sharding entry points ignore the tables (table 0 is the plain base set)
+    parts = [ctx.msm_windows(sc, 0, 7), ctx.msm_windows(sc, 7, 16)]
+    import torch
+    assert m.MsmContext.combine_windows(torch.cat(parts, dim=0)).to_affine_bytes() == want
+    ctx.set_bases(pts)                                     # back to plain: the flag does not stick
+    assert ctx.msm(sc).to_affine_bytes() == want
+
+
+def test_wide_digit_edges(ctx):
+    """digits at the seams of the virtual windows (magnitude k * 2^15, k * 2^15 +- 1), the most negative digit (-2^18, with its carry), in every
+    window position (19- and 20-bit grids), beside the largest scalars the input contract admits"""
+    vals = []
+    for bits, count in ((19, 14), (20, 13)):
+        for w in range(count):
+            for d in (1, 0x7fff, 0x8000, 0x8001, 0xffff, 0x10000, 0x10001, 0x3ffff, 0x40000, 0x40001, 0x78000, 0x78001, 0x7ffff, 0x80000, 0xf8001, 0xfffff):
+                v = d << (bits * w)
+                if v < R:
+                    vals.append(v)
+    vals += [R - 1, R - 2, 0, (1 << 253) - 1, int("8000" * 15, 16), int("7ffff" * 12, 16), int("80000" * 12, 16), int("fffff" * 12, 16),
+             sum(0x3ffff << (19 * w) for w in range(13)), sum(0x40000 << (19 * w) for w in range(13)), sum(0x7ffff << (19 * w) for w in range(13))]
+    n = len(vals)
+    points = cpu.sample_points(1410, n)
+    sb = ref.scalars_to_bytes(vals)
+    want = cpu.to_affine64(cpu.cpu_msm(points, sb, 8))
+    ctx.set_bases(points, precompute="wide")
+    assert ctx.msm(sb).to_affine_bytes() == want
+    # each of them alone (a one-point MSM names the failing digit)
+    for i in range(0, n, 11):
+        one = cpu.to_affine64(cpu.cpu_msm(points[: 64 * (i + 1)], bytes(32 * i) + sb[32 * i: 32 * i + 32], 8))
+        assert ctx.msm(bytes(32 * i) + sb[32 * i: 32 * i + 32]).to_affine_bytes() == one, hex(vals[i])
+
+
+def test_wide_tables_extreme_and_skewed_scalars(ctx):
+    n = 20000
+    points = cpu.sample_points(1411, n)
+    s = 0x0FED_CBA9_8765_4321_0F1E_2D3C_4B5A_6978_8796_A5B4_C3D2_E1F0 % R
+    ctx.set_bases(points, precompute="wide")
+    # one giant bucket per window + edge digits; witness-like (zeros, ones, small values: everything in virtual window 0); duplicates of one point's worth
+    for vals in ([s] * (n - 8) + [R - 1, 0, 1, 0x8000, (1 << 253) - 1, int("8000" * 15, 16), 2, R - 2],
+                 [(i * 7919) % 3 for i in range(n)],
+                 [(i * 104729) % 70000 for i in range(n)]):
+        sb = ref.scalars_to_bytes(vals)
+        assert ctx.msm(sb).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points, sb, 8))
+    with pytest.raises(m.MsmHipError) as e:
+        ctx.msm(b"\xff" * 32)
+    assert e.value.code == -4
+    # a top digit that does not fit after its shift (a scalar of 2^254 + 2^246 or more: far above the modulus): rejected, not mis-added
+    p0 = ref.bytes_to_points(points[:64])[0]
+    for v in ((1 << 254) - 1, (1 << 254) + 5, (1 << 254) + (1 << 245)):   # top digit 128 (with the carry into it) at most: shifted by 11, 2^18
+        # (beyond the modulus, where the C oracle's Booth windows -- halo2curves' -- end: the big-integer model is the reference here)
+        assert ctx.msm(v.to_bytes(32, "little")).to_affine_bytes() == ref.affine_to_bytes64(ref.mul(v % R, p0)), hex(v)
+    with pytest.raises(m.MsmHipError) as e:
+        ctx.msm(((1 << 254) + (1 << 246)).to_bytes(32, "little"))
+    assert e.value.code == -4
+
+
+def test_wide_tables_batches_and_flags(ctx):
+    n, batch = 3000, 5
+    pts = ctx.sample_points(n, 1420)
+    sc = ctx.sample_scalars(n * batch, 1421)
+    ctx.set_bases(pts, precompute="wide")
+    assert ctx.batch_group_size(n) == 1                   # its bucket set is 8 local windows already: one MSM per launch
+    got = ctx.msm_batch(sc, n)
+    pb = pts.cpu().numpy().tobytes()
+    for k in (0, 2, 4):
+        assert got[k].to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb, sc[k * n:(k + 1) * n].cpu().numpy().tobytes())), k
+    # pipelined launches through the result slots
+    for k in range(4):
+        ctx.launch(sc[k * n:(k + 1) * n].contiguous(), slot=k)
+    assert [ctx.finish(k).to_affine_bytes() for k in range(4)] == [g.to_affine_bytes() for g in got[:4]]
+    # not combinable with the other table mode or the endomorphism
+    for flags in (32 | 4, 32 | 8, 32 | 16):
+        assert m.lib().msm_hip_set_bases_bn254(ctx._h, pb, n, flags) == -2
+    ctx.set_bases(pts)
+    assert ctx.msm(sc[:n].contiguous()).to_affine_bytes() == got[0].to_affine_bytes()

@@ -1,5 +1,5 @@
 """Single-MSM latency (median of 60 back-to-back synchronous calls, device-resident scalars, endomorphism bases) and its stage times, for the
-environment's tuning switches.  usage: latency_probe.py [logn]"""
+environment's tuning switches.  usage: latency_probe.py [logn]; LATENCY_BASES = auto | plain | endomorphism | tables | tables_wide"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,8 @@ n = 1 << logn
 ctx = m.MsmContext(0)
 pts = ctx.sample_points(n, 1)
 sc = [ctx.sample_scalars(n, 2 + i) for i in range(2)]
-ctx.set_bases(pts, endomorphism=None)
+mode = os.environ.get("LATENCY_BASES", "auto")  # auto (the ABI's default) | plain | endomorphism | tables | tables_wide
+ctx.set_bases(pts, endomorphism={"auto": None, "endomorphism": True}.get(mode, False), precompute={"tables": True, "tables_wide": "wide"}.get(mode, False))
 for level in (0, 2):
     ctx.set_stage_timing(level)
     lat = []
@@ -20,6 +21,6 @@ for level in (0, 2):
         ctx.msm(sc[i & 1])
         lat.append((time.perf_counter() - t) * 1e3)
     lat = sorted(lat[20:])
-    print("logn %d timing_level %d: median %.4f ms, best %.4f ms %s" % (logn, level, lat[len(lat) // 2], lat[0],
+    print(mode, "logn %d timing_level %d: median %.4f ms, best %.4f ms %s" % (logn, level, lat[len(lat) // 2], lat[0],
           {k: round(v, 3) for k, v in ctx.stage_ms().items()} if level else ""), flush=True)
 ctx.close()
