@@ -56,11 +56,13 @@ CBY = ctx.cb  # bytes per coordinate (48 on BLS12-381)
 # BLS12-381's cofactor is not 1: the samplers' points are outside the order-r subgroup, where the endomorphism modes are not exact (and the
 # R = 2^256 input format is the 4-limb curves')
 MODES = ["host", "device", "windows", "batch", "group", "hostbatch", "mont", "bits", "tables", "tables_batch", "hostpipe", "mgpu", "endo", "endo_batch",
-         "group_halves", "mgpu_batch", "mgpu_batch_endo", "auto"]
+         "group_halves", "mgpu_batch", "mgpu_batch_endo", "auto", "wide", "wide_batch"]
 if curve == "bls12_381":
     MODES = [x for x in MODES if x not in ("mont", "endo", "endo_batch", "group_halves", "mgpu_batch_endo")]
 if curve.endswith("_g2"):  # (the "mont" case below writes G1 coordinates; the pool's points are multiples of G2's generator: the endomorphism modes are exact)
     MODES = [x for x in MODES if x != "mont"]
+if os.environ.get("FUZZ_MODES"):  # restrict the soak to some modes, e.g. FUZZ_MODES=wide,wide_batch
+    MODES = [x for x in MODES if x in os.environ["FUZZ_MODES"].split(",")]
 combine = lambda sums: m.MsmContext.combine_windows(sums, curve=curve)
 mg = {}  # lazily created msm_hip_mgpu handles by rank count (several contexts on this one GPU, pinned-buffer gather)
 R = ref.R
@@ -97,7 +99,7 @@ for case in range(cases):
     want = cpu.to_affine64(cpu.cpu_msm(points, sb))
     mode = rnd.choice(MODES)
     # ("auto": the C ABI's flags = 0 -- the curve's fastest mode on a curve of prime order, the plain shape otherwise)
-    ctx.set_bases(points, precompute=mode.startswith("tables"), endomorphism=None if mode == "auto" else (mode.startswith("endo") or mode == "group_halves"))
+    ctx.set_bases(points, precompute="wide" if mode.startswith("wide") else mode.startswith("tables"), endomorphism=None if mode == "auto" else (mode.startswith("endo") or mode == "group_halves"))
     if mode == "mont":
         # both inputs as R = 2^256 Montgomery words (MSM_HIP_BASES_MONT256, MSM_HIP_SCALARS_MONT256)
         PM, RM = ref.P, ref.R
@@ -109,7 +111,7 @@ for case in range(cases):
             got = ctx.msm(sm)
         finally:
             ctx.set_scalar_format(False)
-    elif mode == "host" or mode == "tables" or mode == "auto":
+    elif mode in ("host", "tables", "auto", "wide"):
         got = ctx.msm(sb)
     elif mode == "bits":
         # every window size, host and device scalars
@@ -131,7 +133,7 @@ for case in range(cases):
     elif mode == "endo_batch":
         k = rnd.randrange(1, 11)
         got = ctx.msm_batch(sb * k, n)[k - 1]
-    elif mode == "tables_batch":
+    elif mode in ("tables_batch", "wide_batch"):
         k = rnd.randrange(1, 7)
         got = ctx.msm_batch(sb * k, n)[k - 1]
     elif mode == "hostpipe":
