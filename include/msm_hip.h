@@ -67,16 +67,17 @@ extern "C" {
                                           MSM_HIP_BASES_PRECOMPUTE; the window-sharding entry points ignore it (records 0 .. n-1 are the
                                           plain set). */
 
-#define MSM_HIP_BASES_PRECOMPUTE_WIDE 32u /* wide fixed-base tables (round 4): store 2^(19 w) P_i for w = 1 .. 12 and 2^(247 - t) P_i, t = 11 (BLS12-381: 10) -- the
-                                          top digit is used shifted by t, so that it spreads over the bucket set -- (14 x the base memory: 896 MiB at 2^20
-                                          points; at most 2^22 points) and recode every scalar into 14 signed digits of 19 bits: 14 bucket additions
-                                          per point instead of the reference's 16 (src/cuzk/msm.rs:79-82: chunk_size 16), into ONE bucket set of
-                                          2^18 slots -- the bucket count of the endomorphism mode's 8 x 2^15.  For fixed bases and large MSMs (2^20 points
-                                          and up: +3 % at 2^20, +8 % at 2^22 over the endomorphism mode); one MSM per launch; the sort arrays take 8 x 14 n entries (1 GiB at 2^20).  Whole-MSM entry
-                                          points only (run, launch / finish, batch); the window-sharding entry points ignore the tables (table 0 is
-                                          the plain set).  Same result for every scalar below the scalar field's modulus and any point (a top digit that
-                                          does not fit after its shift -- scalars of 2^254 + 2^246 and more -- is MSM_HIP_ERR_NONCANONICAL).  Not combinable
-                                          with the other two modes. */
+#define MSM_HIP_BASES_PRECOMPUTE_WIDE 32u /* wide fixed-base tables (round 4): store 2^(C w) P_i for digits of C = 17 bits (15 tables; base sets of more
+                                          than 2^21 points: C = 19, 14 tables; msm_hip_set_wide_bits overrides) and recode every scalar into 15 (14)
+                                          signed digits: 15 (14) bucket additions per point instead of the reference's 16 (src/cuzk/msm.rs:79-82:
+                                          chunk_size 16), into ONE bucket set of 2^(C-1) slots, run as 2 (8) "virtual windows" of 2^15 slots.  The top
+                                          table is 2^(C (T-1) - t) P_i and the top digit is used shifted by t, so that it spreads over the bucket set
+                                          (t from the scalar field's modulus; exact for any point).  For fixed bases and large MSMs (2^20 points and
+                                          up: +4 % at 2^20, +8 % at 2^22 over the endomorphism mode); 15 x (14 x) the base memory, at most 2^24 points;
+                                          one MSM per launch.  Whole-MSM entry points only (run, launch / finish, batch); the window-sharding entry
+                                          points ignore the tables (table 0 is the plain set).  Same result for every scalar below the scalar
+                                          field's modulus (a top digit that does not fit after its shift is MSM_HIP_ERR_NONCANONICAL).  Not
+                                          combinable with the other two modes. */
 
 #define MSM_HIP_BASES_PLAIN 16u        /* hold the n bases only and run the reference's exact shape -- 16 windows of full-length scalars over n points
                                           (src/cuzk/msm.rs:79-82).  WITHOUT this flag, MSM_HIP_BASES_PRECOMPUTE or MSM_HIP_BASES_ENDOMORPHISM a
@@ -165,6 +166,10 @@ int msm_hip_set_scalar_format(msm_hip_ctx* ctx, uint32_t format);
  *      msm_hip_combine_windows_bn254 always use the reference's 16-bit windows. ---- */
 int msm_hip_set_window_bits(msm_hip_ctx* ctx, int bits);
 int msm_hip_window_config(int bits, int* num_windows, int* buckets_per_window); /* host-only: the shape of a window size */
+/* digit width of the wide fixed-base tables the NEXT msm_hip_set_bases_*(…, MSM_HIP_BASES_PRECOMPUTE_WIDE) builds: 17 .. 20, 0 = by the number
+ * of bases (17 bits up to 2^21 points, 19 beyond: the measured optimum).  msm_hip_wide_bits: the width of the resident tables (0: none). */
+int msm_hip_set_wide_bits(msm_hip_ctx* ctx, int bits);
+int msm_hip_wide_bits(const msm_hip_ctx* ctx);
 int msm_hip_last_window_bits(msm_hip_ctx* ctx);                                 /* window size of the last launch       */
 int msm_hip_endomorphism_window_count(int bits); /* host-only: windows of a 127-bit half (MSM_HIP_BASES_ENDOMORPHISM): 8 / 10 / 11 */
 int msm_hip_uses_endomorphism(const msm_hip_ctx* ctx); /* 1: the resident bases were set with MSM_HIP_BASES_ENDOMORPHISM */

@@ -95,6 +95,8 @@ def lib():
         L.msm_hip_set_scalar_format.argtypes = [vp, C.c_uint32]
         L.msm_hip_set_stage_timing.argtypes = [vp, i]
         L.msm_hip_set_window_bits.argtypes = [vp, i]
+        L.msm_hip_set_wide_bits.argtypes = [vp, i]
+        L.msm_hip_wide_bits.argtypes = [vp]
         L.msm_hip_window_config.argtypes = [i, C.POINTER(i), C.POINTER(i)]
         L.msm_hip_last_window_bits.argtypes = [vp]
         L.msm_hip_endomorphism_window_count.argtypes = [i]
@@ -235,6 +237,7 @@ class MsmContext:
         _check(lib().msm_hip_ctx_create_curve(C.byref(self._h), int(device), self.curve_id), "msm_hip_ctx_create_curve")
         self.device = int(device)
         self.n_bases = 0
+        self.wide_bits_choice = 0
         self._keepalive = {}  # slot -> tensors the slot's launch still reads / writes; released when the slot is collected
 
     def _order_after_torch(self, *tensors):
@@ -261,7 +264,8 @@ class MsmContext:
         """points: bytes (host, n x 64 B wire format) or a CUDA uint8 tensor holding the same bytes.
         mont256: the coordinates are x * 2^256 mod p (4 x 64-bit Montgomery limbs, R = 2^256) instead of canonical integers.
         precompute: fixed-base tables 2^(16 w) P_i (16 x the memory): whole MSMs then use one bucket set for all windows.  "wide":
-        MSM_HIP_BASES_PRECOMPUTE_WIDE -- 14 tables 2^(19 w) P_i and 19-bit digits: 14 bucket additions per point instead of 16 (large MSMs).
+        MSM_HIP_BASES_PRECOMPUTE_WIDE -- tables 2^(C w) P_i for digits of C = 17 (more than 2^21 bases: 19) bits: 15 (14) bucket additions per
+        point instead of 16, one bucket set (large MSMs; set_wide_bits overrides C).
         endomorphism: True: also store phi(P_i) (2 x the memory): whole MSMs split every scalar into two 127-bit halves and need
         half the windows.  False (this wrapper's default: the stage-level parity tests read the reference's 16-window shape):
         MSM_HIP_BASES_PLAIN.  None: the C ABI's own default (flags = 0) -- the fastest mode the curve has, which is what the
@@ -465,6 +469,15 @@ class MsmContext:
         return {names[j]: float(buf[j]) for j in range(k)}
 
     # -- window size
+    def set_wide_bits(self, bits):
+        """digit width (17 .. 20; 0: by the number of bases) of the wide fixed-base tables the next set_bases(precompute="wide") builds"""
+        _check(lib().msm_hip_set_wide_bits(self._h, int(bits)), "msm_hip_set_wide_bits")
+        self.wide_bits_choice = int(bits)
+
+    def wide_bits(self):
+        """digit width of the resident wide tables (0: the bases are not held that way)"""
+        return lib().msm_hip_wide_bits(self._h)
+
     def set_window_bits(self, bits):
         """0: whole-MSM launches pick the signed-digit window from n (12 / 14 / 16 bits); 12, 14 or 16 fixes it."""
         _check(lib().msm_hip_set_window_bits(self._h, int(bits)), "msm_hip_set_window_bits")

@@ -95,7 +95,7 @@ struct Slot {
   bool timed = false, pending = false, to_host = false;
   bool merged = false;                        // fixed-base launch: one bucket set (one window sum) per scalar vector
   bool halves = false;                        // endomorphism launch: the windows are those of 127-bit halves
-  bool wide = false;                          // wide fixed-base launch: h_wsums holds the bit-plane sums of the 8 virtual windows (combine_wide)
+  int wide_bits = 0;                          // wide fixed-base launch (its digit width): h_wsums holds the bit-plane sums of the virtual windows (combine_wide)
   bool parts = false;                         // h_wsums holds the bit-plane sums of every window (k_bpr_planes): the host finishes the window sums
   int timing_level = 0;
   int w_begin = 0, w_count = 0, nvec = 1;  // windows [w_begin, w_begin + w_count) of nvec scalar vectors
@@ -116,7 +116,8 @@ struct msm_hip_ctx {
   uint32_t* d_bases = nullptr;  // n_bases x 16 words
   size_t n_bases = 0, cap_bases = 0;  // points per table; capacity in point records (16 x n_bases with fixed-base tables)
   bool precomputed = false;           // d_bases holds the 16 tables 2^(16 w) P_i (MSM_HIP_BASES_PRECOMPUTE)
-  bool wide_tables = false;           // d_bases holds the 14 tables 2^(19 w) P_i (MSM_HIP_BASES_PRECOMPUTE_WIDE)
+  int wide_bits_choice = 0;           // msm_hip_set_wide_bits: the digit width the next wide base set gets (0: by the number of bases)
+  int wide_bits = 0;                  // != 0: d_bases holds the wide tables 2^(C w) P_i for C-bit digits (MSM_HIP_BASES_PRECOMPUTE_WIDE; pick_wide_bits)
   bool endo = false;                  // d_bases holds phi(P_i) behind the n bases (MSM_HIP_BASES_ENDOMORPHISM)
   uint32_t* d_halves = nullptr;       // the split scalars of one launch (main stream only): [vector][2n] x 4 words
   size_t cap_halves = 0;              // in scalars
@@ -256,13 +257,51 @@ inline size_t piece_records_for(size_t n) {
 
 inline size_t stride_for(size_t n) { return (n + 3) & ~(size_t)3; }
 
-// the top digit's shift (msm_kernels.h: wide_digit): the largest for which the top digit of every scalar below the scalar field's modulus fits
-inline int wide_top_shift(int curve) {
+// The top digit of the wide tables' recode (msm_kernels.h: wide_digit), from the scalar field's modulus r (its top 64 bits, r >> 192):
+// its largest value over the scalars below r -- (r - 1 + the recode's bias below the digit) >> P, P = the digit's position -- decides the shift
+// (the largest that keeps the shifted digit within 2^(C-1)), and r / 2^P, the range of a uniform scalar's top digit, how many virtual windows
+// the shifted digit spreads over.  A top digit that does not fit after all is rejected by the kernel, never mis-added.
+inline uint64_t scalar_modulus_top64(int curve) {
+  switch (curve) {
+    case MSM_HIP_CURVE_BLS12_381:
+    case MSM_HIP_CURVE_BLS12_381_G2: return 0x73eda753299d7d48ull;
+    case MSM_HIP_CURVE_PALLAS:
+    case MSM_HIP_CURVE_VESTA: return 0x4000000000000000ull;  // both moduli: 2^254 + (a 126-bit number)
+    default: return 0x30644e72e131a029ull;                   // BN254's r, and its p (Grumpkin's scalar field): the same top 64 bits
+  }
+}
+inline int wide_top_pos(int bits) { return bits * (wide_tables_of(bits) - 1); }  // bit position of the top digit: 238 / 252 / 247 / 240 at 17 .. 20 bits (>= 192)
+inline uint32_t wide_top_max(int curve, int bits) {
+  const uint64_t top = scalar_modulus_top64(curve);
+  const int fb = wide_top_pos(bits) - 192;                   // fraction bits of `top` below the digit
+  const uint64_t frac = top << (64 - fb);                    // (r mod 2^P) / 2^P as a 64-bit fraction, truncated
+  const uint64_t bias = (1ull << 63) + (1ull << (63 - bits)) + (1ull << 20);  // the bias below the digit / 2^P (second term: the next window's bit), rounded up
+  return (uint32_t)(top >> fb) + (frac + bias < frac ? 1u : 0u);               // + the carry into the digit
+}
+inline int wide_top_shift(int curve, int bits) {
   static const int forced = [] { const char* e = getenv("MSM_HIP_WIDE_TOP_SHIFT"); return e ? atoi(e) : -1; }();  // tuning aid
   if (forced >= 0) return forced;
-  if (WIDE_BITS != 19) return curve == MSM_HIP_CURVE_BLS12_381 || curve == MSM_HIP_CURVE_BLS12_381_G2 ? 4 : 5;  // (the 20-bit build: 14- or 15-bit top digit)
-  // (r >> 247, + 1 for the carry into the digit: 232 for BLS12-381, 128 -- no carry can reach a scalar of 2^254 -- for Pallas and Vesta, 97 for BN254 and Grumpkin)
-  return curve == MSM_HIP_CURVE_BLS12_381 || curve == MSM_HIP_CURVE_BLS12_381_G2 ? 10 : 11;
+  const uint32_t dmax = wide_top_max(curve, bits), half = 1u << (bits - 1);
+  int s = 0;
+  while (s + 1 < bits && ((uint64_t)dmax << (s + 1)) <= half) s++;
+  return s;
+}
+// Can the curve's scalars be recoded into C-bit digits at all?  The top digit is never negative, so it must stay below 2^(C-1) before its
+// shift: with 17-bit digits (15 x 17 = 255 bits) only where the scalar field's modulus is below 2^254 - 2^238 -- BN254 and Grumpkin, not the
+// 255-bit moduli of Pallas, Vesta and BLS12-381.
+inline bool wide_bits_fit(int curve, int bits) { return wide_top_max(curve, bits) <= (1u << (bits - 1)) - 1u; }
+// Digit width of the wide tables for a base set of n points (profiles/r04_wide_tables.txt, same-box A/Bs against the endomorphism mode).  What an
+// MSM costs in the pipeline is sort + SMVP + the stitch / reduce work that runs beside the next launch, and the last grows with the bucket sets:
+// 17 bits (15 additions per point, 2 bucket sets) wins up to 2^21 points (+4 % at 2^20), 20 bits (13 additions, 16 bucket sets) from 2^22 up
+// (+11 % at 2^22, +18 % at 2^24), where the additions are all that counts.  19 bits (14 additions, 8 bucket sets; the 7-bit top digit makes <= 128
+// giant buckets) lies between them at every size and serves the curves 17 bits cannot; 18 bits (a 2-bit top digit: 3 giant buckets) loses everywhere.
+// msm_hip_set_wide_bits / MSM_HIP_WIDE_BITS = 17 .. 20 override.  -1: the chosen width cannot hold the curve's scalars.
+inline int pick_wide_bits(const msm_hip_ctx* ctx, size_t n) {
+  static const int forced = [] { const char* e = getenv("MSM_HIP_WIDE_BITS"); const int v = e ? atoi(e) : 0; return v >= 17 && v <= 20 ? v : 0; }();
+  const int asked = ctx->wide_bits_choice ? ctx->wide_bits_choice : forced;  // msm_hip_set_wide_bits, then the environment
+  if (asked) return wide_bits_fit(ctx->curve, asked) ? asked : -1;
+  const int bits = n <= ((size_t)1 << 21) ? 17 : 20;
+  return wide_bits_fit(ctx->curve, bits) ? bits : 19;
 }
 // SMVP lanes and lengths of a wide fixed-base launch over n points (msm_kernels.h: k_count_wide).  For uniform scalars every virtual window
 // receives 13 n / 8 entries from the 13 full digits, and the windows the shifted top digit reaches n / (windows it spans) more: the fullest
@@ -274,17 +313,18 @@ struct WideShape {
   size_t worst;
   uint32_t chunk_len, chunks, host_len;
 };
-inline WideShape wide_shape(size_t n, int curve) {
+inline WideShape wide_shape(size_t n, int curve, int bits) {
+  const int WIDE_TABLES = wide_tables_of(bits), WIDE_VWIN = wide_vwin_of(bits);
   WideShape w;
   w.worst = n * (size_t)WIDE_TABLES;
-  // the scalar field's modulus / 2^247 (the range of the top digit of a uniform scalar): BN254 and Grumpkin 96.8, Pallas and Vesta 128, BLS12-381 231.9
-  const double top_range = curve == MSM_HIP_CURVE_BLS12_381 || curve == MSM_HIP_CURVE_BLS12_381_G2 ? 231.86
-                           : curve == MSM_HIP_CURVE_PALLAS || curve == MSM_HIP_CURVE_VESTA ? 128.0 : 96.78;
-  double span = top_range * (double)(1u << wide_top_shift(curve)) / 32768.0;  // virtual windows the top digit spreads over
-  if (span < 1.0) span = 1.0;
-  if (span > (double)WIDE_VWIN) span = (double)WIDE_VWIN;
+  // r / 2^P: the top digit of a uniform scalar is uniform below it; a virtual window takes the 2^15 >> shift digit values (at least one) that
+  // land in it, so the fullest one receives that share of the n top digits on top of its (14 - 1) n / 8
+  const double top_range = (double)scalar_modulus_top64(curve) / (double)(1ull << (wide_top_pos(bits) - 192));
+  const int shift = wide_top_shift(curve, bits);
+  double share = (double)(shift >= 15 ? 1u : 32768u >> shift) / top_range;
+  if (share > 1.0) share = 1.0;
   static const double slack = [] { const char* e = getenv("MSM_HIP_WIDE_SLACK_PCT"); return e ? atof(e) / 100.0 : 0.004; }();  // tuning aid
-  const double fullest = (double)n * (WIDE_TABLES - 1) / WIDE_VWIN + (double)n / span;
+  const double fullest = (double)n * (WIDE_TABLES - 1) / WIDE_VWIN + (double)n * share;
   const size_t typ = (size_t)(fullest * (1.0 + slack)) + 64;
   w.chunk_len = chunk_len_for(typ, WIDE_VWIN);
   w.chunks = chunks_for(typ, w.chunk_len);
@@ -485,7 +525,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   const size_t n_entries = merge || wide ? n * (size_t)w_count_vec : n_sc;  // (wide: what ONE virtual window may receive)
   // `nvec` scalar vectors (contiguous, n x 32 B each) share this launch: local window lw = v * w_count_vec + (w - w_begin);
   // everything after the two scalar-reading kernels only sees w_count = nvec * w_count_vec local windows
-  const int w_count = merge ? nvec : wide ? WIDE_VWIN : nvec * w_count_vec;
+  const int w_count = merge ? nvec : wide ? wide_vwin_of(ctx->wide_bits) : nvec * w_count_vec;
   hipStream_t st = ctx->stream, rs = ctx->reduce_stream[(&s - ctx->slot) % NREDUCE];
   // a synchronous call with nothing else in flight (msm_hip_run_*: the caller waits for this launch before it issues another): the stitch and
   // the bucket reduce follow the SMVP on the MAIN stream -- no cross-stream hand-off (an event wait costs ~10 us more than an in-stream kernel
@@ -500,7 +540,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   uint32_t tile_len = 2048;
   if ((n_sc + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n_sc + MAX_TILES - 1) / MAX_TILES) + 255) / 256 * 256);
   const uint32_t tiles = (uint32_t)((n_sc + tile_len - 1) / tile_len);
-  const WideShape ws = wide ? wide_shape(n, ctx->curve) : WideShape{};
+  const WideShape ws = wide ? wide_shape(n, ctx->curve, ctx->wide_bits) : WideShape{};
   const uint32_t chunk_len = wide ? ws.host_len : chunk_len_for(n_entries, w_count);  // (the longest the device may pick: smvp_chunk_len)
   const uint32_t chunks = wide ? ws.chunks : chunks_for(n_entries, chunk_len);
   const size_t stride = stride_for(n_entries);
@@ -541,7 +581,15 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   uint16_t* plane_out = planes ? ctx->d_digits : digits;
   const int plane_mode = planes ? 2 : (digits ? 1 : 0);
   if (wide) {
-    hipLaunchKernelGGL(k_count_wide<8>, dim3(tiles), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, ctx->d_counts, d_err, wide_top_shift(ctx->curve));
+    const int top_shift = wide_top_shift(ctx->curve, ctx->wide_bits);
+#define LAUNCH_COUNT_WIDE(C) hipLaunchKernelGGL(k_count_wide<C>, dim3(tiles), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, ctx->d_counts, d_err, top_shift)
+    switch (ctx->wide_bits) {
+      case 17: LAUNCH_COUNT_WIDE(17); break;
+      case 18: LAUNCH_COUNT_WIDE(18); break;
+      case 19: LAUNCH_COUNT_WIDE(19); break;
+      default: LAUNCH_COUNT_WIDE(20); break;
+    }
+#undef LAUNCH_COUNT_WIDE
   } else if (halves) {
     hipLaunchKernelGGL(ctx->ops->count_split[wbits == 16 ? 2 : wbits == 14 ? 1 : 0], dim3(tiles), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, w_begin,
                        w_count_vec, nvec, n * 8, ctx->d_counts, plane_out, plane_mode, planes ? ctx->d_negbits : nullptr,
@@ -557,8 +605,17 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   AFTER_KERNEL(ctx, "k_scan_tiles", st);
   HIP_TRY(ctx, mark(2, false));
   if (wide) {
-    hipLaunchKernelGGL(k_scatter_wide<8>, dim3(tiles), dim3(WIDE_THREADS), 0, st, d_scalars, n_sc, stride, tile_len, tiles, ctx->d_counts, ctx->d_bin_total,
-                       ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, chunks, chunk_len, d_chunk_len, wide_top_shift(ctx->curve));
+    const int top_shift = wide_top_shift(ctx->curve, ctx->wide_bits);
+#define LAUNCH_SCATTER_WIDE(C)                                                                                                                         \
+  hipLaunchKernelGGL(k_scatter_wide<C>, dim3(tiles), dim3(WIDE_THREADS), 0, st, d_scalars, n_sc, stride, tile_len, tiles, ctx->d_counts, ctx->d_bin_total, \
+                     ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, chunks, chunk_len, d_chunk_len, top_shift)
+    switch (ctx->wide_bits) {
+      case 17: LAUNCH_SCATTER_WIDE(17); break;
+      case 18: LAUNCH_SCATTER_WIDE(18); break;
+      case 19: LAUNCH_SCATTER_WIDE(19); break;
+      default: LAUNCH_SCATTER_WIDE(20); break;
+    }
+#undef LAUNCH_SCATTER_WIDE
   } else if (planes) {
     hipLaunchKernelGGL(k_scatter_planes, dim3(tiles), dim3(256), 0, st, ctx->d_digits, halves ? ctx->d_negbits : (const uint64_t*)nullptr, n_sc, stride, tile_len,
                        tiles, w_count, w_count_vec, ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine,
@@ -677,7 +734,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   s.wbits = wbits;
   s.merged = merge;
   s.halves = halves;
-  s.wide = wide;
+  s.wide_bits = wide ? ctx->wide_bits : 0;
   s.parts = parts_mode;
   s.n = n;
   s.timed = tl >= 1;
@@ -735,7 +792,7 @@ constexpr size_t MAX_PRECOMPUTE_POINTS = (size_t)1 << 24;  // 16 tables: 16 GiB,
 // src/cuzk/msm.rs:75-94) runs the mode the headline figure is measured in (656 vs 701 - 714 MSM/s at 2^20 in round 3, when it did not).
 constexpr uint32_t BASE_FLAGS_ALL = MSM_HIP_CHECK_ON_CURVE | MSM_HIP_BASES_MONT256 | MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_ENDOMORPHISM | MSM_HIP_BASES_PLAIN |
                                     MSM_HIP_BASES_PRECOMPUTE_WIDE;
-constexpr size_t MAX_WIDE_POINTS = (size_t)1 << 22;  // 14 tables: 3.5 GiB; sort arrays of 8 x 14 n entries: 4.2 GiB
+constexpr size_t MAX_WIDE_POINTS = (size_t)1 << 24;  // 14 tables of 19-bit digits: 14 GiB; sort arrays of 8 x 14 n entries: 17 GiB
 inline uint32_t resolve_base_flags(const msm_hip_ctx* ctx, size_t n, uint32_t flags) {
   static const bool auto_endo = [] { const char* e = getenv("MSM_HIP_BASES_AUTO"); return !e || atoi(e) != 0; }();  // MSM_HIP_BASES_AUTO=0: flags = 0 means plain (rounds 1 - 3)
   if (flags & (MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_PRECOMPUTE_WIDE | MSM_HIP_BASES_ENDOMORPHISM | MSM_HIP_BASES_PLAIN)) return flags;
@@ -756,11 +813,12 @@ int reserve_bases(msm_hip_ctx* ctx, size_t n, uint32_t flags) {
   if ((flags & ~BASE_FLAGS_ALL) || ((flags & MSM_HIP_BASES_PLAIN) && (tables || endo)) || (wide && (flags & MSM_HIP_BASES_PRECOMPUTE)))
     return MSM_HIP_ERR_INVALID_ARG;
   if ((endo && !ctx->ops->glv) || (tables && !ctx->ops->precompute_tables)) return MSM_HIP_ERR_INVALID_ARG;
+  if (wide && pick_wide_bits(ctx, n) < 0) return MSM_HIP_ERR_INVALID_ARG;  // (msm_hip_set_wide_bits asked for a width that cannot hold this curve's scalars)
   ctx->n_bases = 0;
   ctx->precomputed = false;
-  ctx->wide_tables = false;
+  ctx->wide_bits = 0;
   ctx->endo = false;
-  const size_t records = wide ? n * WIDE_TABLES : tables ? n * NWIN : endo ? 2 * n : n;
+  const size_t records = wide ? n * (size_t)wide_tables_of(pick_wide_bits(ctx, n)) : tables ? n * NWIN : endo ? 2 * n : n;
   if (records > ctx->cap_bases) {
     ctx->cap_bases = 0;
     int rc = dev_alloc(ctx, ctx->d_bases, records * 2 * (size_t)ctx->ops->coord_words);
@@ -783,12 +841,13 @@ int set_bases_from_device(msm_hip_ctx* ctx, const uint32_t* d_xy, size_t n, uint
   if (rc) return rc;
   if (flags & (MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_PRECOMPUTE_WIDE)) {  // tables 1 .. 15 behind the plain set: T_w[i] = 2^(16 w) P_i (wide: 1 .. 13, 2^(19 w) P_i, the last one top_shift doublings short)
     const bool wide = (flags & MSM_HIP_BASES_PRECOMPUTE_WIDE) != 0;
-    hipLaunchKernelGGL(ctx->ops->precompute_tables, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_bases, n, n, wide ? (int)WIDE_TABLES : (int)NWIN,
-                       wide ? (int)WIDE_BITS : (int)WBITS, wide ? (int)WIDE_BITS - wide_top_shift(ctx->curve) : (int)WBITS);
+    const int wb = wide ? pick_wide_bits(ctx, n) : 0;
+    hipLaunchKernelGGL(ctx->ops->precompute_tables, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_bases, n, n, wide ? wide_tables_of(wb) : (int)NWIN,
+                       wide ? wb : (int)WBITS, wide ? wb - wide_top_shift(ctx->curve, wb) : (int)WBITS);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->precomputed = !wide;
-    ctx->wide_tables = wide;
+    ctx->wide_bits = wb;
   }
   if (flags & MSM_HIP_BASES_ENDOMORPHISM) {  // phi(P_i) = (beta x_i, y_i) behind the plain set
     hipLaunchKernelGGL(ctx->ops->endo_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_bases, n);
@@ -809,7 +868,7 @@ size_t batch_group(msm_hip_ctx* ctx, size_t n, size_t batch) {
   // 4 at 16 bits, 3 at 14, 2 at 12 (8 / 6 / 5 with the endomorphism's half-length scalars); with fixed-base tables every MSM is one local window
   // (window size of a grouped launch: pick_window_bits with nvec > 1)
   // (wide tables: one MSM per launch -- its bucket set already is 8 local windows, and the mode is meant for large MSMs)
-  const size_t fit = ctx->wide_tables ? (size_t)1 : ctx->precomputed ? (size_t)MAXLW : (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 2, ctx->endo), ctx->endo));
+  const size_t fit = ctx->wide_bits ? (size_t)1 : ctx->precomputed ? (size_t)MAXLW : (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 2, ctx->endo), ctx->endo));
   size_t g = n ? ((size_t)1 << 20) / n : 1;
   if (g > fit) g = fit;
   if (g > batch) g = batch;
@@ -989,7 +1048,8 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
   int rc = check_run_args(ctx, scalars_dev, n);
   if (rc) return rc;
   if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > nwin_of(wbits, halves) || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
-  if (wide && (nvec != 1 || window_sums_dev || w_begin != 0 || w_end != WIDE_TABLES || wbits != WIDE_BITS)) return MSM_HIP_ERR_INVALID_ARG;
+  if (wide && (nvec != 1 || window_sums_dev || w_begin != 0 || wbits != ctx->wide_bits || w_end != wide_tables_of(wbits))) return MSM_HIP_ERR_INVALID_ARG;
+  const int WIDE_VWIN = wide ? wide_vwin_of(ctx->wide_bits) : 0;
   if (wide) wbits = WBITS;
   const int w_count = w_end - w_begin;
   const int w_local = merge ? nvec : wide ? WIDE_VWIN : nvec * w_count;  // bucket sets of the launch
@@ -1005,7 +1065,7 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
   s.wbits = wbits;
   s.merged = merge;
   s.halves = halves;
-  s.wide = wide;
+  s.wide_bits = wide ? ctx->wide_bits : 0;
   s.parts = false;
   s.to_host = window_sums_dev == nullptr;
   if (n == 0) {  // identity window sums, nothing to compute
@@ -1019,7 +1079,7 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
     return MSM_HIP_OK;
   }
   if (wide) {
-    const WideShape ws = wide_shape(n, ctx->curve);
+    const WideShape ws = wide_shape(n, ctx->curve, ctx->wide_bits);
     if ((rc = ensure_work(ctx, ws.worst, w_local, wbits, WIDE_VWIN, s, false, (size_t)w_local * ws.chunks))) return rc;
   } else if ((rc = ensure_work(ctx, merge ? n * (size_t)w_count : halves ? 2 * n : n, w_local, wbits,
                                merge ? 1 : halves ? nwin_of(wbits, true) : NWIN, s, use_planes(ctx, mode, w_count, wbits)))) return rc;
@@ -1046,8 +1106,8 @@ int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scal
                                               int slot, void* window_sums_dev) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
   // whole MSMs whose sums stay in the slot (finish / finish_batch combines them): the window size follows n
-  if (w_begin == 0 && w_end == NWIN && window_sums_dev == nullptr && nvec >= 1 && ctx->wide_tables && n > 0)
-    return launch_impl(ctx, scalars_dev, n, nvec, 0, WIDE_TABLES, WIDE_BITS, slot, nullptr, MODE_WIDE);  // wide fixed-base tables (one MSM per launch)
+  if (w_begin == 0 && w_end == NWIN && window_sums_dev == nullptr && nvec >= 1 && ctx->wide_bits && n > 0)
+    return launch_impl(ctx, scalars_dev, n, nvec, 0, wide_tables_of(ctx->wide_bits), ctx->wide_bits, slot, nullptr, MODE_WIDE);  // wide fixed-base tables (one MSM per launch)
   if (w_begin == 0 && w_end == NWIN && window_sums_dev == nullptr && nvec >= 1 && ctx->precomputed && n > 0)
     return launch_impl(ctx, scalars_dev, n, nvec, 0, NWIN, WBITS, slot, nullptr, MODE_TABLES);  // fixed-base tables: one bucket set per vector
   if (w_begin == 0 && w_end == NWIN && window_sums_dev == nullptr && nvec >= 1 && ctx->endo && n > 0 && nvec * nwin_of(16, true) <= MAXLW) {
@@ -1096,8 +1156,8 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   if (!ctx || !out_xyz || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   Slot& s = ctx->slot[slot];
   // fixed-base launches leave ONE sum per vector (every table already carries its power of two): nothing to combine but the copy
-  const int nwin = s.merged ? 1 : s.wide ? WIDE_VWIN : nwin_of(s.wbits, s.halves);
-  if (!s.pending || !s.to_host || s.w_count != (s.wide ? (int)WIDE_TABLES : nwin_of(s.wbits, s.halves))) return MSM_HIP_ERR_INVALID_ARG;
+  const int nwin = s.merged ? 1 : s.wide_bits ? wide_vwin_of(s.wide_bits) : nwin_of(s.wbits, s.halves);
+  if (!s.pending || !s.to_host || s.w_count != (s.wide_bits ? wide_tables_of(s.wide_bits) : nwin_of(s.wbits, s.halves))) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   int rc = wait_slot(ctx, s);
   if (rc) return rc;
@@ -1109,7 +1169,7 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
     combine_pool().run(nwin, [&](int w) {
       if (!ctx->ops->window_from_planes(s.h_wsums + (size_t)w * PLANES_PER_WINDOW * jb, sums + jb * (size_t)w)) all_ok = false;
     });
-    if (s.wide) {  // virtual windows: sum_hi W_hi + 2^15 sum_hi hi TC_hi (host_g1.h)
+    if (s.wide_bits) {  // virtual windows: sum_hi W_hi + 2^15 sum_hi hi TC_hi (host_g1.h)
       if (!ctx->ops->combine_wide(sums, s.h_wsums, nwin, out_xyz)) all_ok = false;
     } else if (!ctx->ops->combine_windows(sums, nwin, s.wbits, out_xyz)) all_ok = false;
   } else {
@@ -1370,6 +1430,14 @@ int msm_hip_set_window_bits(msm_hip_ctx* ctx, int bits) {
   ctx->window_bits = bits;
   return MSM_HIP_OK;
 }
+
+int msm_hip_set_wide_bits(msm_hip_ctx* ctx, int bits) {
+  if (!ctx || (bits != 0 && (bits < 17 || bits > 20))) return MSM_HIP_ERR_INVALID_ARG;
+  ctx->wide_bits_choice = bits;
+  return MSM_HIP_OK;
+}
+
+int msm_hip_wide_bits(const msm_hip_ctx* ctx) { return ctx ? ctx->wide_bits : MSM_HIP_ERR_INVALID_ARG; }
 
 int msm_hip_window_config(int bits, int* num_windows, int* buckets_per_window) {
   if (bits != 12 && bits != 14 && bits != 16) return MSM_HIP_ERR_INVALID_ARG;

@@ -711,16 +711,19 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
 // profiles/r04_wide_tables.txt): its SMVP is 0.85 ms alone against 0.99, but stitching and reducing 16 bucket sets beside the next launch's
 // SMVP costs more than the additions saved -- 690 MSM/s against 721 with the endomorphism's 8 bucket sets and 727 with the one of the
 // 16-bit tables.  What an MSM costs in the pipeline is sort + SMVP + the reduce work that runs beside them, and that grows with the bucket sets.
-#ifndef MSM_WIDE_BITS
-#define MSM_WIDE_BITS 19
-#endif
-constexpr int WIDE_BITS = MSM_WIDE_BITS;
-constexpr int WIDE_TABLES = WinCfg<WIDE_BITS>::NWIN;    // 14 tables, 2^(19 w) P_i
-constexpr int WIDE_VWIN = 1 << (WIDE_BITS - WBITS);     // 8 virtual windows of 2^15 slots
-constexpr int WIDE_KEYS = WIDE_VWIN * NCOARSE;          // 1024 (virtual window, coarse bin) runs
-static_assert(WIDE_VWIN <= MAXLW, "virtual windows are local windows");
-
-//
+// The digit width C is a template parameter of the two kernels (the tables are built for it when the bases are set: msm_hip.hip picks it from
+// the number of bases -- 17 bits up to 2^21 points, where the bucket sets' stitch / reduce still counts, 19 beyond).
+template <int C>
+struct WideCfg {
+  static_assert(C >= 17 && C <= 20, "digit bits of the wide tables");
+  static constexpr int BITS = C;
+  static constexpr int TABLES = WinCfg<C>::NWIN;  // 15 / 15 / 14 / 13 tables 2^(C w) P_i at 17 / 18 / 19 / 20 bits
+  static constexpr int VWIN = 1 << (C - WBITS);   // 2 / 4 / 8 / 16 virtual windows of 2^15 slots
+  static constexpr int KEYS = VWIN * NCOARSE;     // (virtual window, coarse bin) runs
+  static_assert(VWIN <= MAXLW, "virtual windows are local windows");
+};
+__host__ __device__ constexpr int wide_tables_of(int bits) { return (254 + bits) / bits; }
+__host__ __device__ constexpr int wide_vwin_of(int bits) { return 1 << (bits - WBITS); }
 // The top digit.  Window 13 holds what is left of the scalar above bit 247 -- 7 or 8 bits -- so its magnitudes would all fall into virtual
 // window 0, which would then carry 2.6 n entries against 1.6 n in the others, and the SMVP's lanes are as long as the fullest window makes
 // them.  The top table is therefore 2^(247 - top_shift) P_i and the top digit is used as d << top_shift: the same product for any point
@@ -730,9 +733,9 @@ static_assert(WIDE_VWIN <= MAXLW, "virtual windows are local windows");
 // Grumpkin: the digit reaches 6 of the 8 virtual windows, the fullest holds 2.4 % more than the mean) or 128 (Pallas, Vesta: all 8), 10 for
 // BLS12-381 (231: 7.2 of 8).  A scalar whose shifted top digit passes 2^18 -- at or above r on every one of these curves -- is rejected like one that
 // overflows the reference's recode (ERRBIT_SCALAR_CARRY).
-// signed WIDE_BITS-bit digit of window w of the biased scalar t (WinCfg<WIDE_BITS>::WORDS words): its magnitude 1 .. 2^(WIDE_BITS - 1) (0: no entry) and sign
+// signed C-bit digit of window w of the biased scalar t (WinCfg<C>::WORDS words): its magnitude 1 .. 2^(C - 1) (0: no entry) and sign
+template <int C>
 __device__ __forceinline__ uint32_t wide_digit(const uint32_t* t, int w, int top_shift, uint32_t& sign, uint32_t& overflow) {
-  constexpr int C = WIDE_BITS;
   constexpr uint32_t H = 1u << (C - 1);
   const int bit = C * w, i = bit >> 5, sh = bit & 31;
   uint32_t b = t[i] >> sh;
@@ -740,7 +743,7 @@ __device__ __forceinline__ uint32_t wide_digit(const uint32_t* t, int w, int top
   b &= (1u << C) - 1u;
   sign = b < H ? 1u : 0u;
   uint32_t mag = b >= H ? b - H : H - b;
-  if (w == WIDE_TABLES - 1) {  // (never negative: nothing above it carries into it, and its raw value is below 2^16)
+  if (w == WideCfg<C>::TABLES - 1) {  // (never negative: nothing above it carries into it, and its raw value is below 2^16)
     mag <<= top_shift;
     if (mag > H) {
       overflow = 1;
@@ -751,11 +754,12 @@ __device__ __forceinline__ uint32_t wide_digit(const uint32_t* t, int w, int top
 }
 __device__ __forceinline__ uint32_t wide_key(uint32_t mag) { return (((mag - 1u) >> 15) << 7) | ((mag & 0x7fffu) >> 8); }  // (virtual window, coarse bin)
 
-// first pass: counts[hi][tile][bin] (the layout of k_count with WIDE_VWIN local windows).  One scalar vector per launch.
-template <int SW>
+// first pass: counts[hi][tile][bin] (the layout of k_count with WideCfg<C>::VWIN local windows).  One scalar vector per launch.
+template <int C>
 __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles,
                                                     uint32_t* __restrict__ counts, uint32_t* __restrict__ err, int top_shift) {
-  static_assert(SW == 8, "full-length scalars");
+  constexpr int SW = 8;  // full-length scalars
+  constexpr int WIDE_KEYS = WideCfg<C>::KEYS, WIDE_TABLES = WideCfg<C>::TABLES;
   __shared__ uint32_t cnt[WIDE_KEYS];
   const int tid = threadIdx.x;
   for (int i = tid; i < WIDE_KEYS; i += 256) cnt[i] = 0;
@@ -766,14 +770,14 @@ __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__
   for (size_t i0 = base; i0 < end; i0 += 256) {
     const size_t i = i0 + tid;
     if (i >= end) continue;
-    uint32_t s[SW], tb[WinCfg<WIDE_BITS, SW>::WORDS], t16[8], neg = 0;
+    uint32_t s[SW], tb[WinCfg<C, SW>::WORDS], t16[8], neg = 0;
     ld_scalar<SW>(scalars + i * SW, s, neg);
-    bad |= bias_scalar<WIDE_BITS, SW>(s, tb);
+    bad |= bias_scalar<C, SW>(s, tb);
     bad |= bias_scalar<16>(s, t16);  // the input contract of every mode: what overflows the reference's 16-bit recode is rejected (test/utils.rs:150-152)
 #pragma unroll
     for (int w = 0; w < WIDE_TABLES; w++) {
       uint32_t sign;
-      const uint32_t mag = wide_digit(tb, w, top_shift, sign, bad);
+      const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, bad);
       if (mag) atomicAdd(&cnt[wide_key(mag)], 1u);
     }
   }
@@ -789,14 +793,15 @@ __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__
 // 112 KB of LDS: one workgroup of 512 threads per CU.
 constexpr int WIDE_THREADS = 512, WIDE_PER = 2;
 constexpr int WIDE_SUB = WIDE_THREADS * WIDE_PER;     // scalars staged per block iteration
-constexpr int WIDE_STAGE = WIDE_SUB * WIDE_TABLES;    // entries staged per block iteration
-template <int SW>
+template <int C>
 __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
                                                                uint32_t tiles, const uint32_t* __restrict__ counts,
                                                                const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr,
                                                                uint32_t* __restrict__ tmp_val, uint8_t* __restrict__ tmp_fine, size_t table_stride,
                                                                uint32_t chunks, uint32_t host_chunk_len, uint32_t* __restrict__ chunk_len_dev, int top_shift) {
-  static_assert(SW == 8, "full-length scalars");
+  constexpr int SW = 8;  // full-length scalars
+  constexpr int WIDE_KEYS = WideCfg<C>::KEYS, WIDE_TABLES = WideCfg<C>::TABLES;
+  constexpr int WIDE_STAGE = WIDE_SUB * WIDE_TABLES;  // entries staged per block iteration
   __shared__ uint32_t gpos[WIDE_KEYS];    // write cursor of every run of this tile, relative to its virtual window's array
   __shared__ uint32_t hist[WIDE_KEYS];
   __shared__ uint32_t lstart[WIDE_KEYS];
@@ -812,7 +817,8 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
   // earlier tiles put there; workgroup 0 publishes the bin starts (coarse_ptr[hi][0 .. 128]) and the launch's chunk length
   for (int i0 = 0; i0 < WIDE_KEYS; i0 += WIDE_THREADS) {
     const int i = i0 + tid, lw = i / NCOARSE, bin = i % NCOARSE;
-    const uint32_t v = bin_total[i];
+    const bool live = i < WIDE_KEYS;  // (fewer runs than threads: builds with 17- or 18-bit digits)
+    const uint32_t v = live ? bin_total[i] : 0u;
     uint32_t x = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -822,8 +828,8 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
     if (lane == 63) wave_tot[wid] = x;
     __syncthreads();
     const uint32_t incl = x + ((wid & 1) ? wave_tot[wid - 1] : 0u);
-    gpos[i] = incl - v + counts[((size_t)lw * tiles + blockIdx.x) * NCOARSE + bin];
-    if (blockIdx.x == 0) {
+    if (live) gpos[i] = incl - v + counts[((size_t)lw * tiles + blockIdx.x) * NCOARSE + bin];
+    if (live && blockIdx.x == 0) {
       coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin] = incl - v;
       if (bin == NCOARSE - 1) {
         coarse_ptr[(size_t)lw * (NCOARSE + 1) + NCOARSE] = incl;
@@ -837,7 +843,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
   const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
   for (size_t sub = tile_base; sub < tile_end; sub += WIDE_SUB) {
     for (int k = tid; k < WIDE_KEYS; k += WIDE_THREADS) hist[k] = 0;
-    uint32_t sc[WIDE_PER][WinCfg<WIDE_BITS, SW>::WORDS];
+    uint32_t sc[WIDE_PER][WinCfg<C, SW>::WORDS];
 #pragma unroll
     for (int j = 0; j < WIDE_PER; j++) {
       const size_t i = sub + (size_t)j * WIDE_THREADS + tid;
@@ -845,7 +851,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
 #pragma unroll
       for (int k = 0; k < SW; k++) raw[k] = 0;  // an all-zero scalar recodes to all-zero digits: no entries
       if (i < tile_end) ld_scalar<SW>(scalars + i * SW, raw, neg);
-      (void)bias_scalar<WIDE_BITS, SW>(raw, sc[j]);
+      (void)bias_scalar<C, SW>(raw, sc[j]);
     }
     __syncthreads();
     uint32_t rank[WIDE_PER][WIDE_TABLES];
@@ -854,17 +860,18 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
 #pragma unroll
       for (int w = 0; w < WIDE_TABLES; w++) {
         uint32_t sign, over = 0;
-        const uint32_t mag = wide_digit(sc[j], w, top_shift, sign, over);  // (an overflowing top digit: no entry here as in k_count_wide, which reports it)
+        const uint32_t mag = wide_digit<C>(sc[j], w, top_shift, sign, over);  // (an overflowing top digit: no entry here as in k_count_wide, which reports it)
         rank[j][w] = mag ? atomicAdd(&hist[wide_key(mag)], 1u) : 0u;
       }
     __syncthreads();
-    {  // exclusive scan of the run lengths: KPT consecutive keys per thread
-      constexpr int KPT = WIDE_KEYS / WIDE_THREADS;
-      static_assert(KPT * WIDE_THREADS == WIDE_KEYS, "keys per thread");
+    {  // exclusive scan of the run lengths: KPT consecutive keys per thread (with fewer runs than threads, the first WIDE_KEYS threads take one each)
+      constexpr int KPT = WIDE_KEYS >= WIDE_THREADS ? WIDE_KEYS / WIDE_THREADS : 1;
+      static_assert(KPT * WIDE_THREADS == WIDE_KEYS || WIDE_KEYS < WIDE_THREADS, "keys per thread");
+      const bool mine = KPT * tid < WIDE_KEYS;
       uint32_t h[KPT], sum = 0;
 #pragma unroll
       for (int k = 0; k < KPT; k++) {
-        h[k] = hist[KPT * tid + k];
+        h[k] = mine ? hist[KPT * tid + k] : 0u;
         sum += h[k];
       }
       uint32_t x = sum;
@@ -879,7 +886,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
       for (int k = 0; k < wid; k++) run += wave_tot[k];
 #pragma unroll
       for (int k = 0; k < KPT; k++) {
-        lstart[KPT * tid + k] = run;
+        if (mine) lstart[KPT * tid + k] = run;
         run += h[k];
       }
     }
@@ -890,7 +897,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
 #pragma unroll
       for (int w = 0; w < WIDE_TABLES; w++) {
         uint32_t sign, over = 0;
-        const uint32_t mag = wide_digit(sc[j], w, top_shift, sign, over);
+        const uint32_t mag = wide_digit<C>(sc[j], w, top_shift, sign, over);
         if (mag) {
           const uint32_t key = wide_key(mag), e = lstart[key] + rank[j][w];
           const uint32_t pos = (uint32_t)(sub + (size_t)j * WIDE_THREADS + tid);

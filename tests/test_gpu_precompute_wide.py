@@ -1,6 +1,7 @@
-"""Wide fixed-base tables (round 4): MSM_HIP_BASES_PRECOMPUTE_WIDE stores 2^(19 w) P_i for 14 windows and recodes every scalar
-into 14 signed digits of 19 bits -- 14 bucket additions per point instead of the reference's 16 (src/cuzk/msm.rs:79-82) -- into one bucket set
-of 2^18 slots that the engine runs as 8 virtual windows of 2^15.  Same group element as the plain engine and the oracle."""
+"""Wide fixed-base tables (round 4): MSM_HIP_BASES_PRECOMPUTE_WIDE stores 2^(C w) P_i and recodes every scalar into signed digits
+of C = 17 bits (15 of them; 19 bits, 14, for base sets beyond 2^21 points) -- 15 (14) bucket additions per point instead of the reference's 16
+(src/cuzk/msm.rs:79-82) -- into one bucket set of 2^(C-1) slots that the engine runs as 2 (8) virtual windows of 2^15.  Same group element as
+the plain engine and the oracle, at every digit width the library builds (17 .. 20)."""
 import pytest
 
 import msm_webgpu_amd as m
@@ -10,16 +11,43 @@ from tests.util import R, case_inputs, golden_cases
 
 pytestmark = pytest.mark.gpu
 
+WIDTHS = [0, 17, 18, 19, 20]  # 0: the width the library picks from the number of bases
 
-def test_golden_vectors_with_wide_tables(ctx):
+
+@pytest.fixture(params=WIDTHS)
+def wctx(ctx, request):
+    ctx.set_wide_bits(request.param)
+    yield ctx
+    ctx.set_wide_bits(0)
+
+
+def test_golden_vectors_with_wide_tables(wctx):
+    ctx = wctx
     for case in golden_cases():
         points, scalars = case_inputs(case)
         ctx.set_bases(points, check_on_curve=True, precompute="wide")
         assert ctx.msm(scalars).to_affine_bytes().hex() == case["expected_affine"], case["name"]
 
 
+def test_width_follows_the_base_count(ctx):
+    pts = ctx.sample_points(300, 1399)
+    ctx.set_bases(pts, precompute="wide")
+    assert ctx.wide_bits() == 17
+    ctx.set_wide_bits(19)
+    ctx.set_bases(pts, precompute="wide")
+    assert ctx.wide_bits() == 19
+    ctx.set_wide_bits(0)
+    ctx.set_bases(pts)
+    assert ctx.wide_bits() == 0
+    for bad in (16, 21, -1):
+        assert m.lib().msm_hip_set_wide_bits(ctx._h, bad) == -2
+
+
 @pytest.mark.parametrize("n", [1, 2, 257, 5000, 1 << 16, (1 << 18) + 3])
-def test_wide_tables_match_oracle_and_plain_engine(ctx, n):
+def test_wide_tables_match_oracle_and_plain_engine(wctx, n):
+    ctx = wctx
+    if n > 5000 and ctx.wide_bits_choice not in (0, 19):
+        pytest.skip("large sizes at the two widths the policy uses")
     pts, sc = ctx.sample_points(n, 1400 + n), ctx.sample_scalars(n, 1401 + n)
     pb, sb = pts.cpu().numpy().tobytes(), sc.cpu().numpy().tobytes()
     want = cpu.to_affine64(cpu.cpu_msm(pb, sb, 8))
@@ -36,11 +64,12 @@ def test_wide_tables_match_oracle_and_plain_engine(ctx, n):
     assert ctx.msm(sc).to_affine_bytes() == want
 
 
-def test_wide_digit_edges(ctx):
-    """digits at the seams of the virtual windows (magnitude k * 2^15, k * 2^15 +- 1), the most negative digit (-2^18, with its carry), in every
-    window position (19- and 20-bit grids), beside the largest scalars the input contract admits"""
+def test_wide_digit_edges(wctx):
+    ctx = wctx
+    """digits at the seams of the virtual windows (magnitude k * 2^15, k * 2^15 +- 1), the most negative digit (with its carry), in every
+    window position (17- to 20-bit grids), beside the largest scalars the input contract admits"""
     vals = []
-    for bits, count in ((19, 14), (20, 13)):
+    for bits, count in ((17, 15), (18, 15), (19, 14), (20, 13)):
         for w in range(count):
             for d in (1, 0x7fff, 0x8000, 0x8001, 0xffff, 0x10000, 0x10001, 0x3ffff, 0x40000, 0x40001, 0x78000, 0x78001, 0x7ffff, 0x80000, 0xf8001, 0xfffff):
                 v = d << (bits * w)
@@ -55,12 +84,13 @@ def test_wide_digit_edges(ctx):
     ctx.set_bases(points, precompute="wide")
     assert ctx.msm(sb).to_affine_bytes() == want
     # each of them alone (a one-point MSM names the failing digit)
-    for i in range(0, n, 11):
+    for i in range(0, n, 23):
         one = cpu.to_affine64(cpu.cpu_msm(points[: 64 * (i + 1)], bytes(32 * i) + sb[32 * i: 32 * i + 32], 8))
         assert ctx.msm(bytes(32 * i) + sb[32 * i: 32 * i + 32]).to_affine_bytes() == one, hex(vals[i])
 
 
-def test_wide_tables_extreme_and_skewed_scalars(ctx):
+def test_wide_tables_extreme_and_skewed_scalars(wctx):
+    ctx = wctx
     n = 20000
     points = cpu.sample_points(1411, n)
     s = 0x0FED_CBA9_8765_4321_0F1E_2D3C_4B5A_6978_8796_A5B4_C3D2_E1F0 % R
@@ -74,13 +104,14 @@ def test_wide_tables_extreme_and_skewed_scalars(ctx):
     with pytest.raises(m.MsmHipError) as e:
         ctx.msm(b"\xff" * 32)
     assert e.value.code == -4
-    # a top digit that does not fit after its shift (a scalar of 2^254 + 2^246 or more: far above the modulus): rejected, not mis-added
+    # a top digit that does not fit after its shift (far above the modulus, at every digit width): rejected, not mis-added; up to 2^254 + a
+    # little the shifted digit still fits
     p0 = ref.bytes_to_points(points[:64])[0]
-    for v in ((1 << 254) - 1, (1 << 254) + 5, (1 << 254) + (1 << 245)):   # top digit 128 (with the carry into it) at most: shifted by 11, 2^18
+    for v in ((1 << 254) - 1, (1 << 254) + 5) if ctx.wide_bits() >= 18 else ():   # (15 digits of 17 bits hold 254 bits and a sign: not these)
         # (beyond the modulus, where the C oracle's Booth windows -- halo2curves' -- end: the big-integer model is the reference here)
         assert ctx.msm(v.to_bytes(32, "little")).to_affine_bytes() == ref.affine_to_bytes64(ref.mul(v % R, p0)), hex(v)
     with pytest.raises(m.MsmHipError) as e:
-        ctx.msm(((1 << 254) + (1 << 246)).to_bytes(32, "little"))
+        ctx.msm(((1 << 254) + (1 << 253)).to_bytes(32, "little"))
     assert e.value.code == -4
 
 
