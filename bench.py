@@ -297,8 +297,8 @@ def main():
     #                 (default on one GPU: the same bucket additions, half the buckets to reduce; 2 x the base memory)
     #   plain         the reference's shape: 16 windows over n points
     #   tables        fixed-base tables 2^(16 w) P_i: one bucket set per MSM (16 x the base memory)
-    #   tables_wide   fixed-base tables 2^(19 w) P_i, 19-bit digits: 14 bucket additions per point into one bucket set of 2^18 slots, run as
-    #                 8 virtual windows of 2^15 (14 x the base memory)
+    #   tables_wide   fixed-base tables 2^(C w) P_i, C-bit digits (17 up to 2^21 points: 15 bucket additions per point into 2 virtual windows of 2^15
+    #                 slots; 20 beyond: 13 additions, 16 virtual windows)
     #   (window-sharded runs: plain by default -- with endomorphism bases the ranks share the 8 half-length windows, one per rank at
     #    8 GPUs, measured 8 % slower per MSM than two full-length windows per rank: every rank splits every scalar, profiles/r03_share_ab.txt)
     bases_mode = os.environ.get("BENCH_BASES") or ("plain" if sharded else "endomorphism")
@@ -317,7 +317,8 @@ def main():
         if bases_mode == "tables":
             return NUM_WINDOWS * n, 1, buckets
         if bases_mode == "tables_wide":
-            return 14 * n / 8, 8, buckets
+            wb = ctx.wide_bits()
+            return ((254 + wb) // wb) * n / (1 << (wb - 16)), 1 << (wb - 16), buckets
         return n, nwin, buckets
 
     def sync_all():
@@ -607,8 +608,8 @@ def main():
                    "bases": {"plain": "n points, 16 windows (the reference's shape)",
                              "endomorphism": "P and phi(P) resident: scalars split into two 127-bit halves on the device, 8 windows over 2n points",
                              "tables": "fixed-base tables 2^(16 w) P resident: one bucket set per MSM",
-                             "tables_wide": "fixed-base tables 2^(19 w) P resident: 14 digits of 19 bits per scalar, one bucket set of 2^18 slots "
-                                            "(8 virtual windows of 2^15)"}[bases_mode],
+                             "tables_wide": "fixed-base tables 2^(C w) P resident: ceil(255 / C) digits of C bits per scalar (C = 17 up to 2^21 points, 20 beyond), "
+                                            "one bucket set of 2^(C-1) slots run as virtual windows of 2^15"}[bases_mode],
                    "window_bits": bits_main,
                    "windows_per_gpu": w_local if sharded else smvp_shape(bits_main)[1], "msms_per_launch": group if sharded else group1,
                    "parallelism": "%s windows/%d + RCCL all-gather" % ("8 half-length" if halves else "16", world) if sharded else "single GPU",

@@ -67,17 +67,18 @@ extern "C" {
                                           MSM_HIP_BASES_PRECOMPUTE; the window-sharding entry points ignore it (records 0 .. n-1 are the
                                           plain set). */
 
-#define MSM_HIP_BASES_PRECOMPUTE_WIDE 32u /* wide fixed-base tables (round 4): store 2^(C w) P_i for digits of C = 17 bits (15 tables; base sets of more
-                                          than 2^21 points: C = 19, 14 tables; msm_hip_set_wide_bits overrides) and recode every scalar into 15 (14)
-                                          signed digits: 15 (14) bucket additions per point instead of the reference's 16 (src/cuzk/msm.rs:79-82:
-                                          chunk_size 16), into ONE bucket set of 2^(C-1) slots, run as 2 (8) "virtual windows" of 2^15 slots.  The top
-                                          table is 2^(C (T-1) - t) P_i and the top digit is used shifted by t, so that it spreads over the bucket set
-                                          (t from the scalar field's modulus; exact for any point).  For fixed bases and large MSMs (2^20 points and
-                                          up: +4 % at 2^20, +8 % at 2^22 over the endomorphism mode); 15 x (14 x) the base memory, at most 2^24 points;
-                                          one MSM per launch.  Whole-MSM entry points only (run, launch / finish, batch); the window-sharding entry
-                                          points ignore the tables (table 0 is the plain set).  Same result for every scalar below the scalar
-                                          field's modulus (a top digit that does not fit after its shift is MSM_HIP_ERR_NONCANONICAL).  Not
-                                          combinable with the other two modes. */
+#define MSM_HIP_BASES_PRECOMPUTE_WIDE 32u /* wide fixed-base tables (round 4): store 2^(C w) P_i for signed digits of C bits and recode every scalar into
+                                          ceil(255 / C) of them -- 15 bucket additions per point at C = 17, 14 at 19, 13 at 20, instead of the reference's
+                                          16 (src/cuzk/msm.rs:79-82: chunk_size 16) -- into ONE bucket set of 2^(C-1) slots, run as 2^(C-16) "virtual
+                                          windows" of 2^15 slots.  C by the number of bases: 17 up to 2^21 points (19 on the curves whose 255-bit scalar
+                                          field 15 digits of 17 bits cannot hold: Pallas, Vesta, BLS12-381), 20 beyond; msm_hip_set_wide_bits overrides.
+                                          The top table is 2^(C (T-1) - t) P_i and the top digit is used shifted by t, so that it spreads over the bucket
+                                          set (t from the scalar field's modulus; exact for any point).  For fixed bases and large MSMs: +4 % at 2^20,
+                                          +11 % at 2^22, +18 % at 2^24 over the endomorphism mode; 15 x (13 x) the base memory, at most 2^24 points; one MSM
+                                          per launch; sort arrays sized for a skewed vector (2^(C-16) x T x n entries: 0.3 GiB at 2^20, 31 GiB at 2^24).
+                                          Whole-MSM entry points only (run, launch / finish, batch); the window-sharding entry points ignore the tables
+                                          (table 0 is the plain set).  Same result for every scalar below the scalar field's modulus (a top digit that
+                                          does not fit after its shift is MSM_HIP_ERR_NONCANONICAL).  Not combinable with the other two modes. */
 
 #define MSM_HIP_BASES_PLAIN 16u        /* hold the n bases only and run the reference's exact shape -- 16 windows of full-length scalars over n points
                                           (src/cuzk/msm.rs:79-82).  WITHOUT this flag, MSM_HIP_BASES_PRECOMPUTE or MSM_HIP_BASES_ENDOMORPHISM a
@@ -167,7 +168,8 @@ int msm_hip_set_scalar_format(msm_hip_ctx* ctx, uint32_t format);
 int msm_hip_set_window_bits(msm_hip_ctx* ctx, int bits);
 int msm_hip_window_config(int bits, int* num_windows, int* buckets_per_window); /* host-only: the shape of a window size */
 /* digit width of the wide fixed-base tables the NEXT msm_hip_set_bases_*(…, MSM_HIP_BASES_PRECOMPUTE_WIDE) builds: 17 .. 20, 0 = by the number
- * of bases (17 bits up to 2^21 points, 19 beyond: the measured optimum).  msm_hip_wide_bits: the width of the resident tables (0: none). */
+ * of bases and the curve (see the flag).  A width that cannot hold the curve's scalars (17 on a 255-bit scalar field) makes that call fail with
+ * MSM_HIP_ERR_INVALID_ARG.  msm_hip_wide_bits: the width of the resident tables (0: none). */
 int msm_hip_set_wide_bits(msm_hip_ctx* ctx, int bits);
 int msm_hip_wide_bits(const msm_hip_ctx* ctx);
 int msm_hip_last_window_bits(msm_hip_ctx* ctx);                                 /* window size of the last launch       */

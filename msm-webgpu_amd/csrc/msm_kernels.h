@@ -697,20 +697,19 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
 
 // ---- wide fixed-base tables (round 4; SURVEY.md 8f-2, MSM_HIP_BASES_PRECOMPUTE_WIDE) ------------------------------------------------
 // With tables T_w[i] = 2^(C w) P_i the number of bucket additions of an MSM is ceil(255 / C) * n and nothing ties C to the bucket count of
-// a window any more -- there is one bucket set.  C = 19: 14 additions per point instead of 16 (-12.5 % of the SMVP, the dominant kernel) over
-// 2^18 bucket slots -- the 8 x 2^15 of the endomorphism mode: the slot of magnitude m (1 .. 2^18) is split as
-//     m = hi * 2^15 + value(slot),   hi = (m - 1) >> 15  (0 .. 7),   slot = m & 0x7fff,   value(slot) = slot, or 2^15 for slot 0
+// a window any more -- there is one bucket set of 2^(C-1) slots.  C = 17 / 19 / 20: 15 / 14 / 13 additions per point instead of 16 (the SMVP,
+// the dominant kernel, shrinks by that much).  The slot of magnitude m (1 .. 2^(C-1)) is split as
+//     m = hi * 2^15 + value(slot),   hi = (m - 1) >> 15,   slot = m & 0x7fff,   value(slot) = slot, or 2^15 for slot 0
 // and `hi` is handled as a VIRTUAL WINDOW: local window hi holds the 2^15 slots of that range, so that everything behind the two
-// scalar-reading passes -- fine sort, SMVP, stitch, row / column sums -- runs unchanged on 8 local windows of 2^15 slots.  The reduce leaves,
+// scalar-reading passes -- fine sort, SMVP, stitch, row / column sums -- runs unchanged on 2^(C-16) local windows of 2^15 slots.  The reduce leaves,
 // per virtual window, the weighted sum W_hi = sum_slot value(slot) B[hi][slot] AND the plain total TC_hi = sum_slot B[hi][slot] (the column
 // total of the bit-plane sums, k_bpr_planes), and the host finishes  sum_hi W_hi + 2^15 * sum_hi hi * TC_hi  (host_g1.h: combine_wide).
-// The entries of virtual window hi are stored at tmp_val[hi][...]: with skewed scalars one virtual window may receive all 14 n entries, so
-// the per-window stride is 14 n (the host sizes the arrays for it); the lanes of the SMVP are sized for the uniform case and the device
+// The entries of virtual window hi are stored at tmp_val[hi][...]: with skewed scalars one virtual window may receive all T n entries, so
+// the per-window stride is T n (the host sizes the arrays for it); the lanes of the SMVP are sized for the uniform case and the device
 // picks the chunk length from the fullest window as always (smvp_chunk_len).
-// Why not C = 20 (13 additions, 2^19 slots = 16 virtual windows), which was built first (-DMSM_WIDE_BITS=20 still builds it;
-// profiles/r04_wide_tables.txt): its SMVP is 0.85 ms alone against 0.99, but stitching and reducing 16 bucket sets beside the next launch's
-// SMVP costs more than the additions saved -- 690 MSM/s against 721 with the endomorphism's 8 bucket sets and 727 with the one of the
-// 16-bit tables.  What an MSM costs in the pipeline is sort + SMVP + the reduce work that runs beside them, and that grows with the bucket sets.
+// Which C (profiles/r04_wide_tables.txt): what an MSM costs in the pipeline is sort + SMVP + the stitch / reduce work that runs beside the
+// next launch, and that grows with the bucket sets -- 20 bits (16 of them) loses to the endomorphism mode at 2^20 although its SMVP is 0.85 ms
+// alone against 0.99, and wins by 18 % at 2^24; 17 bits (2 of them) wins at 2^20.
 // The digit width C is a template parameter of the two kernels (the tables are built for it when the bases are set: msm_hip.hip picks it from
 // the number of bases -- 17 bits up to 2^21 points, where the bucket sets' stitch / reduce still counts, 19 beyond).
 template <int C>
@@ -724,15 +723,13 @@ struct WideCfg {
 };
 __host__ __device__ constexpr int wide_tables_of(int bits) { return (254 + bits) / bits; }
 __host__ __device__ constexpr int wide_vwin_of(int bits) { return 1 << (bits - WBITS); }
-// The top digit.  Window 13 holds what is left of the scalar above bit 247 -- 7 or 8 bits -- so its magnitudes would all fall into virtual
-// window 0, which would then carry 2.6 n entries against 1.6 n in the others, and the SMVP's lanes are as long as the fullest window makes
-// them.  The top table is therefore 2^(247 - top_shift) P_i and the top digit is used as d << top_shift: the same product for any point
-// (exact integer arithmetic: no assumption on the point's order), spread over the virtual windows -- n entries in at most 2^8 giant
-// buckets, which the stitch handles as it handles the heavy buckets of skewed scalars.  top_shift (msm_hip.hip: wide_top_shift) is the
-// largest for which the top digit of every scalar below the scalar field's modulus r stays within 2^18: 11 where r >> 247 is 96 (BN254,
-// Grumpkin: the digit reaches 6 of the 8 virtual windows, the fullest holds 2.4 % more than the mean) or 128 (Pallas, Vesta: all 8), 10 for
-// BLS12-381 (231: 7.2 of 8).  A scalar whose shifted top digit passes 2^18 -- at or above r on every one of these curves -- is rejected like one that
-// overflows the reference's recode (ERRBIT_SCALAR_CARRY).
+// The top digit.  The last window holds what is left of the scalar above bit C (T - 1) -- 16 / 7 / 14 bits at C = 17 / 19 / 20 -- so its
+// magnitudes would all fall into the lowest virtual windows, which would then carry far more entries than the others, and the SMVP's lanes are
+// as long as the fullest window makes them (first measurement at 20 bits: SMVP 1.06 ms instead of 0.85).  The top table is therefore
+// 2^(C (T - 1) - top_shift) P_i and the top digit is used as d << top_shift: the same product for any point (exact integer arithmetic: no
+// assumption on the point's order), spread over the virtual windows.  top_shift (msm_hip.hip: wide_top_shift) is the largest for which the top
+// digit of every scalar below the scalar field's modulus stays within 2^(C-1): for BN254 0 / 11 / 5 at 17 / 19 / 20 bits.  A scalar whose
+// shifted top digit passes that -- at or above the modulus -- is rejected like one that overflows the reference's recode (ERRBIT_SCALAR_CARRY).
 // signed C-bit digit of window w of the biased scalar t (WinCfg<C>::WORDS words): its magnitude 1 .. 2^(C - 1) (0: no entry) and sign
 template <int C>
 __device__ __forceinline__ uint32_t wide_digit(const uint32_t* t, int w, int top_shift, uint32_t& sign, uint32_t& overflow) {
@@ -787,10 +784,11 @@ __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__
     counts[((size_t)(i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[i];
 }
 
-// second pass: the LDS-ranked, LDS-staged scatter of k_scatter_coarse over all 1024 (virtual window, coarse bin) runs at once.  ALL 14
-// digits of the 1024 scalars of a block iteration are staged together (14 336 entries, 14 per run): ranked per window as k_scatter_coarse
-// does, a run would receive one entry per iteration and every 4-byte store would be a memory transaction of its own.
-// 112 KB of LDS: one workgroup of 512 threads per CU.
+// second pass: the LDS-ranked, LDS-staged scatter of k_scatter_coarse over all (virtual window, coarse bin) runs at once -- 256 / 1024 / 2048
+// of them at 17 / 19 / 20 bits.  ALL digits of the 1024 scalars of a block iteration are staged together (15 360 / 14 336 / 13 312 entries:
+// 60 / 14 / 6.5 per run): ranked per window as k_scatter_coarse does, a run would receive a fraction of that per iteration and every 4-byte
+// store would be a memory transaction of its own.  108 - 115 KB of LDS: one workgroup of 512 threads per CU.  (At 2^22 points the kernel takes
+// 244 / 351 / 471 us: the shorter the runs, the worse the stores coalesce.)
 constexpr int WIDE_THREADS = 512, WIDE_PER = 2;
 constexpr int WIDE_SUB = WIDE_THREADS * WIDE_PER;     // scalars staged per block iteration
 template <int C>
@@ -817,7 +815,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
   // earlier tiles put there; workgroup 0 publishes the bin starts (coarse_ptr[hi][0 .. 128]) and the launch's chunk length
   for (int i0 = 0; i0 < WIDE_KEYS; i0 += WIDE_THREADS) {
     const int i = i0 + tid, lw = i / NCOARSE, bin = i % NCOARSE;
-    const bool live = i < WIDE_KEYS;  // (fewer runs than threads: builds with 17- or 18-bit digits)
+    const bool live = i < WIDE_KEYS;  // (fewer runs than threads: 17-bit digits)
     const uint32_t v = live ? bin_total[i] : 0u;
     uint32_t x = v;
 #pragma unroll
