@@ -556,6 +556,31 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             sharded_ok = bool(t.item())
 
+    # The opt-in fixed-base mode beside the headline (informational, never `value`; BENCH_TABLES_WIDE=0 skips it): the same scalars through the
+    # same pipeline with the bases held as wide tables (MSM_HIP_BASES_PRECOMPUTE_WIDE: 15 bucket additions per point at 2^20 instead of 16,
+    # 13 from 2^22 up), after everything the headline needs has been measured; its result must be the headline mode's.
+    wide_line = None
+    if (world == 1 and emulate <= 1 and group1 == 1 and bases_mode != "tables_wide" and 19 <= args.logn <= 22
+            and os.environ.get("BENCH_TABLES_WIDE", "1") != "0"):
+        ctx.set_stage_timing(0)
+        want = ctx.msm(scalar_sets[(args.steps - 1) & 1])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ctx.set_bases(points, precompute="wide")
+        torch.cuda.synchronize()
+        setup_ms = (time.perf_counter() - t1) * 1e3
+        ctx.set_stage_timing(1)
+        run_steps(steady // 2 + max(args.warmup, 1), False)
+        sync_all()
+        t1 = time.perf_counter()
+        last_wide = run_steps(args.steps, False)
+        sync_all()
+        wide_elapsed = time.perf_counter() - t1
+        wide_line = {"value": args.steps / wide_elapsed, "unit": "MSM/s", "ms_per_step": wide_elapsed * 1e3 / args.steps, "digit_bits": ctx.wide_bits(),
+                     "table_setup_ms": setup_ms, "same_result_as_headline_mode": bool(last_wide == want),
+                     "note": "opt-in MSM_HIP_BASES_PRECOMPUTE_WIDE (fixed bases: 13 - 15 x the base memory); same steps / warm-up protocol, measured after the headline"}
+        ctx.set_stage_timing(2)
+
     ms_per_step = elapsed * 1e3 / args.steps
     # roofline of the SMVP accumulate kernel: algorithmic bytes of all timed launches / their summed durations
     # (geometry of every timed launch from the window size the engine reports for it: grouped small MSMs run 14-bit windows)
@@ -597,6 +622,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "fixed_base_tables_wide": wide_line,
         "untimed_steps_before_timed_region": steady + max(args.warmup, 1),  # the W warm-up steps and, in front of them, BENCH_STEADY_MSMS steps of the same workload
         "ms_per_step": ms_per_step,
         "higher_is_better": True,

@@ -13,16 +13,20 @@ for curve in (sys.argv[2:] or ["bn254", "grumpkin", "pallas", "vesta", "bls12_38
     sc = [ctx.sample_scalars(n, 2 + i) for i in range(2)]
     if curve.endswith("_g2"):
         # G2 (coordinates in Fq2: csrc/fq2.h): the device sampler draws P_i = (a + i b) G -- points of G2 proper -- and the expected result is the
-        # closed form (sum_i s_i m_i mod r) G (oracle/bn254_g2_ref.py: sample_multipliers).  CURVE_BASES = endomorphism (default) | plain | tables
+        # closed form (sum_i s_i m_i mod r) G (oracle/bn254_g2_ref.py: sample_multipliers).  CURVE_BASES = endomorphism (default) | plain | tables | tables_wide (every curve)
         g2 = importlib.import_module("oracle." + curve + "_ref")
         pts = ctx.sample_points(n, 1)
         mode = os.environ.get("CURVE_BASES", "endomorphism")
-        ctx.set_bases(pts, precompute=mode == "tables", endomorphism=mode == "endomorphism")
+        ctx.set_bases(pts, precompute="wide" if mode == "tables_wide" else mode == "tables", endomorphism=mode == "endomorphism")
     else:
         cpu = importlib.import_module("oracle.cpu" if curve == "bn254" else "oracle.cpu_" + curve)
         pts = ctx.sample_points(n, 1)
         # (BLS12-381's cofactor is not 1: the samplers' curve points are outside the order-r subgroup, where the endomorphism mode is not exact)
-        ctx.set_bases(pts, endomorphism=curve != "bls12_381")
+        mode = os.environ.get("CURVE_BASES", "endomorphism")
+        if mode in ("tables", "tables_wide"):
+            ctx.set_bases(pts, precompute="wide" if mode == "tables_wide" else True)
+        else:
+            ctx.set_bases(pts, endomorphism=curve != "bls12_381" and mode == "endomorphism")
     ctx.set_stage_timing(1)
     def run(k):
         fl, last = [], None
@@ -48,6 +52,6 @@ for curve in (sys.argv[2:] or ["bn254", "grumpkin", "pallas", "vesta", "bls12_38
         want = g2.affine_to_bytes(g2.msm_by_multipliers(g2.sample_multipliers(n, 1), g2.bytes_to_scalars(sc[1].cpu().numpy().tobytes())))
     else:
         want = cpu.to_affine64(cpu.cpu_msm(pts.cpu().numpy().tobytes(), sc[1].cpu().numpy().tobytes(), min(os.cpu_count() or 1, 32)))
-    print("%-12s 2^%d: %.4f ms per MSM pipelined (%.0f MSM/s), SMVP kernel %.3f ms, latency %.3f ms, bit-exact vs its oracle: %s"
-          % (curve, logn, step, 1e3 / step, smvp, sorted(lat)[2], last.to_affine_bytes() == want), flush=True)
+    print("%-12s %s 2^%d: %.4f ms per MSM pipelined (%.0f MSM/s), SMVP kernel %.3f ms, latency %.3f ms, bit-exact vs its oracle: %s"
+          % (curve, os.environ.get("CURVE_BASES", "endomorphism") + (" (%d-bit digits)" % ctx.wide_bits() if ctx.wide_bits() else ""), logn, step, 1e3 / step, smvp, sorted(lat)[2], last.to_affine_bytes() == want), flush=True)
     ctx.close()
