@@ -271,7 +271,7 @@ def test_the_drop_in_default_is_the_fast_mode_and_the_same_group_element(ctx):
     assert m.G1(out.raw, ref.P).to_affine_bytes() == want
     m.lib().msm_hip_oneshot_release()
     # plain and an explicit mode exclude each other; unknown flag bits are rejected
-    for flags in (16 | 8, 16 | 4, 32, 1 << 31):
+    for flags in (16 | 8, 16 | 4, 16 | 32, 64, 1 << 31):
         assert m.lib().msm_hip_set_bases_bn254(ctx._h, points, n, flags) == -2
     # fixed-base tables stay what they were; a G2 context (no endomorphism yet) takes the plain shape by default
     ctx.set_bases(points, precompute=True)
