@@ -172,6 +172,10 @@ int msm_hip_window_config(int bits, int* num_windows, int* buckets_per_window); 
  * MSM_HIP_ERR_INVALID_ARG.  msm_hip_wide_bits: the width of the resident tables (0: none). */
 int msm_hip_set_wide_bits(msm_hip_ctx* ctx, int bits);
 int msm_hip_wide_bits(const msm_hip_ctx* ctx);
+/* host-only: the shape of the wide tables for `curve` (MSM_HIP_CURVE_*) at `bits` (0: the width picked for n bases): digit width, number of
+ * tables (= bucket additions per point), virtual windows of 2^15 slots, and the shift of the top digit.  MSM_HIP_ERR_INVALID_ARG: that width
+ * cannot hold the curve's scalars. */
+int msm_hip_wide_config(int curve, int bits, size_t n, int* digit_bits, int* tables, int* virtual_windows, int* top_shift);
 int msm_hip_last_window_bits(msm_hip_ctx* ctx);                                 /* window size of the last launch       */
 int msm_hip_endomorphism_window_count(int bits); /* host-only: windows of a 127-bit half (MSM_HIP_BASES_ENDOMORPHISM): 8 / 10 / 11 */
 int msm_hip_uses_endomorphism(const msm_hip_ctx* ctx); /* 1: the resident bases were set with MSM_HIP_BASES_ENDOMORPHISM */

@@ -97,6 +97,7 @@ def lib():
         L.msm_hip_set_window_bits.argtypes = [vp, i]
         L.msm_hip_set_wide_bits.argtypes = [vp, i]
         L.msm_hip_wide_bits.argtypes = [vp]
+        L.msm_hip_wide_config.argtypes = [i, i, C.c_size_t] + [C.POINTER(C.c_int)] * 4
         L.msm_hip_window_config.argtypes = [i, C.POINTER(i), C.POINTER(i)]
         L.msm_hip_last_window_bits.argtypes = [vp]
         L.msm_hip_endomorphism_window_count.argtypes = [i]

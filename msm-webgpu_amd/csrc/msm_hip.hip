@@ -1439,6 +1439,20 @@ int msm_hip_set_wide_bits(msm_hip_ctx* ctx, int bits) {
 
 int msm_hip_wide_bits(const msm_hip_ctx* ctx) { return ctx ? ctx->wide_bits : MSM_HIP_ERR_INVALID_ARG; }
 
+int msm_hip_wide_config(int curve, int bits, size_t n, int* digit_bits, int* tables, int* virtual_windows, int* top_shift) {
+  if (curve < MSM_HIP_CURVE_BN254_G1 || curve > MSM_HIP_CURVE_BLS12_381_G2 || (bits != 0 && (bits < 17 || bits > 20))) return MSM_HIP_ERR_INVALID_ARG;
+  msm_hip_ctx probe;  // (only the two fields the policy reads)
+  probe.curve = curve;
+  probe.wide_bits_choice = bits;
+  const int wb = pick_wide_bits(&probe, n);
+  if (wb < 0) return MSM_HIP_ERR_INVALID_ARG;
+  if (digit_bits) *digit_bits = wb;
+  if (tables) *tables = wide_tables_of(wb);
+  if (virtual_windows) *virtual_windows = wide_vwin_of(wb);
+  if (top_shift) *top_shift = wide_top_shift(curve, wb);
+  return MSM_HIP_OK;
+}
+
 int msm_hip_window_config(int bits, int* num_windows, int* buckets_per_window) {
   if (bits != 12 && bits != 14 && bits != 16) return MSM_HIP_ERR_INVALID_ARG;
   if (num_windows) *num_windows = nwin_of(bits);

@@ -165,6 +165,41 @@ def test_host_only_helpers_of_window_sizes_and_curves(built):
     assert L.msm_hip_ctx_create_curve(C.byref(h), 0, 9) == -2
 
 
+def test_wide_table_shapes_follow_the_scalar_field(built):
+    """Host-only (msm_hip_wide_config): the wide fixed-base tables' digit width, table count, virtual windows and top-digit shift against an
+    independent computation from every curve's scalar-field modulus: the top digit of a C-bit signed recode is at most
+    ((r - 1 + bias) >> P) - 2^(C-1), P = C (T - 1), bias = the recode's constant; it must stay below 2^(C-1) (else the width cannot hold the
+    curve's scalars) and its shift is the largest that keeps it within 2^(C-1)."""
+    import importlib
+
+    import msm_webgpu_amd as m
+
+    L = m.lib()
+    moduli = {}
+    for cid, name in ((0, "bn254_ref"), (1, "grumpkin_ref"), (2, "pallas_ref"), (3, "vesta_ref"), (4, "bls12_381_ref"), (5, "bn254_g2_ref"), (6, "bls12_381_g2_ref")):
+        moduli[cid] = importlib.import_module("oracle." + name).R
+    out = [C.c_int() for _ in range(4)]
+    refs = [C.byref(x) for x in out]
+    for cid, r in moduli.items():
+        for bits in (17, 18, 19, 20):
+            t = (254 + bits) // bits
+            pos, half = bits * (t - 1), 1 << (bits - 1)
+            bias = sum(1 << (bits * w + bits - 1) for w in range(t))
+            dmax = ((r - 1 + bias) >> pos) - half
+            rc = L.msm_hip_wide_config(cid, bits, 1 << 20, *refs)
+            if dmax > half - 1:
+                assert rc == -2, (cid, bits)
+                continue
+            shift = max(s for s in range(bits) if (dmax << s) <= half)
+            assert (rc, [x.value for x in out]) == (0, [bits, t, 1 << (bits - 16), shift]), (cid, bits)
+        # the policy: 17 bits up to 2^21 bases where 15 digits of 17 bits hold the scalars (else 19), 20 bits beyond
+        fits17 = ((r - 1 + sum(1 << (17 * w + 16) for w in range(15))) >> 238) - (1 << 16) <= (1 << 16) - 1
+        assert fits17 == (r.bit_length() <= 254), cid
+        for n, want in ((1000, 17 if fits17 else 19), (1 << 21, 17 if fits17 else 19), ((1 << 21) + 1, 20), (1 << 24, 20)):
+            assert L.msm_hip_wide_config(cid, 0, n, *refs) == 0 and out[0].value == want, (cid, n)
+    assert L.msm_hip_wide_config(7, 0, 1, *refs) == -2 and L.msm_hip_wide_config(0, 16, 1, *refs) == -2
+
+
 def test_header_is_plain_c_and_links_from_c(built, tmp_path):
     # the boundary is a C ABI: include/msm_hip.h compiles as strict C99 and a C program links against the library (what a cgo /
     # Rust FFI binding relies on); host-only entry points run without a GPU
