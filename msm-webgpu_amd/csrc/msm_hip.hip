@@ -701,9 +701,9 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   // operations at ~7 us each in k_bpr_w256 / k_bpr_final -- is replaced by 16 independent masked tree sums per window (k_bpr_planes, 8 deep)
   // and 29 operations per window on the host (0.3 us each).  Sums that stay on the device (window shards for the gather), grouped launches
   // (their host thread is on the critical path: several MSMs' worth of host work per launch) and debug read-backs get finished sums.
-  // (a wide fixed-base launch always leaves the plane sums: its finish needs every virtual window's plain total, which is one of them)
+  // (a wide fixed-base launch always leaves the plane sums -- its finish needs every virtual window's plain total, which is one of them --: launch_impl
+  //  admits it only as one whole MSM whose sums go to the host, at most 16 virtual windows)
   const bool parts_mode = to_host && nvec == 1 && (!ctx->debug || wide) && wsums_out == reinterpret_cast<uint32_t*>(s.d_wsums) && w_count <= 24;
-  if (wide && !parts_mode) return MSM_HIP_ERR_INVALID_ARG;
   // the kernel that ends the chain writes the launch's error word into the slot's pinned buffer itself and clears it (no copy, no fill); a
   // single MSM's bit-plane sums go to the pinned buffer directly as well (12 KB of stores over the host link instead of a copy behind the kernel)
   uint32_t* h_err = reinterpret_cast<uint32_t*>(s.h_wsums + WSUM_BYTES);
