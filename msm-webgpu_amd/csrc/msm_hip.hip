@@ -313,7 +313,7 @@ struct WideShape {
   size_t worst;
   uint32_t chunk_len, chunks, host_len;
 };
-inline WideShape wide_shape(size_t n, int curve, int bits) {
+inline WideShape wide_shape(size_t n, int curve, int bits, int nvec) {  // (nvec whole MSMs in the launch: nvec x VWIN local windows share the lanes)
   const int WIDE_TABLES = wide_tables_of(bits), WIDE_VWIN = wide_vwin_of(bits);
   WideShape w;
   w.worst = n * (size_t)WIDE_TABLES;
@@ -326,7 +326,7 @@ inline WideShape wide_shape(size_t n, int curve, int bits) {
   static const double slack = [] { const char* e = getenv("MSM_HIP_WIDE_SLACK_PCT"); return e ? atof(e) / 100.0 : 0.004; }();  // tuning aid
   const double fullest = (double)n * (WIDE_TABLES - 1) / WIDE_VWIN + (double)n * share;
   const size_t typ = (size_t)(fullest * (1.0 + slack)) + 64;
-  w.chunk_len = chunk_len_for(typ, WIDE_VWIN);
+  w.chunk_len = chunk_len_for(typ, WIDE_VWIN * nvec);
   w.chunks = chunks_for(typ, w.chunk_len);
   w.host_len = (uint32_t)((w.worst + w.chunks - 1) / w.chunks);
   if (w.host_len < w.chunk_len) w.host_len = w.chunk_len;
@@ -525,7 +525,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   const size_t n_entries = merge || wide ? n * (size_t)w_count_vec : n_sc;  // (wide: what ONE virtual window may receive)
   // `nvec` scalar vectors (contiguous, n x 32 B each) share this launch: local window lw = v * w_count_vec + (w - w_begin);
   // everything after the two scalar-reading kernels only sees w_count = nvec * w_count_vec local windows
-  const int w_count = merge ? nvec : wide ? wide_vwin_of(ctx->wide_bits) : nvec * w_count_vec;
+  const int w_count = merge ? nvec : wide ? nvec * wide_vwin_of(ctx->wide_bits) : nvec * w_count_vec;
   hipStream_t st = ctx->stream, rs = ctx->reduce_stream[(&s - ctx->slot) % NREDUCE];
   // a synchronous call with nothing else in flight (msm_hip_run_*: the caller waits for this launch before it issues another): the stitch and
   // the bucket reduce follow the SMVP on the MAIN stream -- no cross-stream hand-off (an event wait costs ~10 us more than an in-stream kernel
@@ -540,7 +540,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   uint32_t tile_len = 2048;
   if ((n_sc + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n_sc + MAX_TILES - 1) / MAX_TILES) + 255) / 256 * 256);
   const uint32_t tiles = (uint32_t)((n_sc + tile_len - 1) / tile_len);
-  const WideShape ws = wide ? wide_shape(n, ctx->curve, ctx->wide_bits) : WideShape{};
+  const WideShape ws = wide ? wide_shape(n, ctx->curve, ctx->wide_bits, nvec) : WideShape{};
   const uint32_t chunk_len = wide ? ws.host_len : chunk_len_for(n_entries, w_count);  // (the longest the device may pick: smvp_chunk_len)
   const uint32_t chunks = wide ? ws.chunks : chunks_for(n_entries, chunk_len);
   const size_t stride = stride_for(n_entries);
@@ -582,7 +582,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   const int plane_mode = planes ? 2 : (digits ? 1 : 0);
   if (wide) {
     const int top_shift = wide_top_shift(ctx->curve, ctx->wide_bits);
-#define LAUNCH_COUNT_WIDE(C) hipLaunchKernelGGL(k_count_wide<C>, dim3(tiles), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, ctx->d_counts, d_err, top_shift)
+#define LAUNCH_COUNT_WIDE(C) hipLaunchKernelGGL(k_count_wide<C>, dim3(tiles), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, nvec, n * 8, ctx->d_counts, d_err, top_shift)
     switch (ctx->wide_bits) {
       case 17: LAUNCH_COUNT_WIDE(17); break;
       case 18: LAUNCH_COUNT_WIDE(18); break;
@@ -607,7 +607,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   if (wide) {
     const int top_shift = wide_top_shift(ctx->curve, ctx->wide_bits);
 #define LAUNCH_SCATTER_WIDE(C)                                                                                                                         \
-  hipLaunchKernelGGL(k_scatter_wide<C>, dim3(tiles), dim3(WIDE_THREADS), 0, st, d_scalars, n_sc, stride, tile_len, tiles, ctx->d_counts, ctx->d_bin_total, \
+  hipLaunchKernelGGL(k_scatter_wide<C>, dim3(tiles), dim3(WIDE_THREADS), 0, st, d_scalars, n_sc, stride, tile_len, tiles, nvec, n * 8, ctx->d_counts, ctx->d_bin_total, \
                      ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, chunks, chunk_len, d_chunk_len, top_shift)
     switch (ctx->wide_bits) {
       case 17: LAUNCH_SCATTER_WIDE(17); break;
@@ -702,8 +702,8 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   // and 29 operations per window on the host (0.3 us each).  Sums that stay on the device (window shards for the gather), grouped launches
   // (their host thread is on the critical path: several MSMs' worth of host work per launch) and debug read-backs get finished sums.
   // (a wide fixed-base launch always leaves the plane sums -- its finish needs every virtual window's plain total, which is one of them --: launch_impl
-  //  admits it only as one whole MSM whose sums go to the host, at most 16 virtual windows)
-  const bool parts_mode = to_host && nvec == 1 && (!ctx->debug || wide) && wsums_out == reinterpret_cast<uint32_t*>(s.d_wsums) && w_count <= 24;
+  //  admits it only as whole MSMs whose sums go to the host, at most 24 virtual windows together)
+  const bool parts_mode = to_host && (nvec == 1 || wide) && (!ctx->debug || wide) && wsums_out == reinterpret_cast<uint32_t*>(s.d_wsums) && w_count <= 24;
   // the kernel that ends the chain writes the launch's error word into the slot's pinned buffer itself and clears it (no copy, no fill); a
   // single MSM's bit-plane sums go to the pinned buffer directly as well (12 KB of stores over the host link instead of a copy behind the kernel)
   uint32_t* h_err = reinterpret_cast<uint32_t*>(s.h_wsums + WSUM_BYTES);
@@ -867,8 +867,8 @@ namespace {
 size_t batch_group(msm_hip_ctx* ctx, size_t n, size_t batch) {
   // 4 at 16 bits, 3 at 14, 2 at 12 (8 / 6 / 5 with the endomorphism's half-length scalars); with fixed-base tables every MSM is one local window
   // (window size of a grouped launch: pick_window_bits with nvec > 1)
-  // (wide tables: one MSM per launch -- its bucket set already is 8 local windows, and the mode is meant for large MSMs)
-  const size_t fit = ctx->wide_bits ? (size_t)1 : ctx->precomputed ? (size_t)MAXLW : (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 2, ctx->endo), ctx->endo));
+  // (wide tables: an MSM is 2^(C-16) local windows, and its launch leaves bit-plane sums for at most 24 of them: 12 / 3 / 1 MSMs at 17 / 19 / 20 bits)
+  const size_t fit = ctx->wide_bits ? (size_t)(24 / wide_vwin_of(ctx->wide_bits)) : ctx->precomputed ? (size_t)MAXLW : (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 2, ctx->endo), ctx->endo));
   size_t g = n ? ((size_t)1 << 20) / n : 1;
   if (g > fit) g = fit;
   if (g > batch) g = batch;
@@ -1048,11 +1048,12 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
   int rc = check_run_args(ctx, scalars_dev, n);
   if (rc) return rc;
   if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > nwin_of(wbits, halves) || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
-  if (wide && (nvec != 1 || window_sums_dev || w_begin != 0 || wbits != ctx->wide_bits || w_end != wide_tables_of(wbits))) return MSM_HIP_ERR_INVALID_ARG;
+  if (wide && (nvec < 1 || nvec * wide_vwin_of(ctx->wide_bits) > 24 || window_sums_dev || w_begin != 0 || wbits != ctx->wide_bits || w_end != wide_tables_of(wbits)))
+    return MSM_HIP_ERR_INVALID_ARG;
   const int WIDE_VWIN = wide ? wide_vwin_of(ctx->wide_bits) : 0;
   if (wide) wbits = WBITS;
   const int w_count = w_end - w_begin;
-  const int w_local = merge ? nvec : wide ? WIDE_VWIN : nvec * w_count;  // bucket sets of the launch
+  const int w_local = merge ? nvec : wide ? nvec * WIDE_VWIN : nvec * w_count;  // bucket sets of the launch
   if (nvec < 1 || w_local > MAXLW) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   Slot& s = ctx->slot[slot];
@@ -1079,7 +1080,7 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
     return MSM_HIP_OK;
   }
   if (wide) {
-    const WideShape ws = wide_shape(n, ctx->curve, ctx->wide_bits);
+    const WideShape ws = wide_shape(n, ctx->curve, ctx->wide_bits, nvec);
     if ((rc = ensure_work(ctx, ws.worst, w_local, wbits, WIDE_VWIN, s, false, (size_t)w_local * ws.chunks))) return rc;
   } else if ((rc = ensure_work(ctx, merge ? n * (size_t)w_count : halves ? 2 * n : n, w_local, wbits,
                                merge ? 1 : halves ? nwin_of(wbits, true) : NWIN, s, use_planes(ctx, mode, w_count, wbits)))) return rc;
@@ -1163,14 +1164,17 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   if (rc) return rc;
   auto t0 = std::chrono::steady_clock::now();
   std::atomic<bool> all_ok{true};
-  if (s.parts) {  // one MSM, its windows as bit-plane sums: the windows' positional sums side by side, then the Horner chain over them
+  if (s.parts) {  // one MSM (wide tables: up to 12), its windows as bit-plane sums: the windows' positional sums side by side, then the chain over them
     uint8_t sums[24 * MAX_JB];
     const size_t jb = ctx->jb;
-    combine_pool().run(nwin, [&](int w) {
+    const int total = s.wide_bits ? s.nvec * nwin : nwin;
+    combine_pool().run(total, [&](int w) {
       if (!ctx->ops->window_from_planes(s.h_wsums + (size_t)w * PLANES_PER_WINDOW * jb, sums + jb * (size_t)w)) all_ok = false;
     });
-    if (s.wide_bits) {  // virtual windows: sum_hi W_hi + 2^15 sum_hi hi TC_hi (host_g1.h)
-      if (!ctx->ops->combine_wide(sums, s.h_wsums, nwin, out_xyz)) all_ok = false;
+    if (s.wide_bits) {  // virtual windows: sum_hi W_hi + 2^15 sum_hi hi TC_hi (host_g1.h), one chain per MSM of the launch
+      combine_pool().run(s.nvec, [&](int v) {
+        if (!ctx->ops->combine_wide(sums + jb * (size_t)v * nwin, s.h_wsums + (size_t)v * nwin * PLANES_PER_WINDOW * jb, nwin, out_xyz + jb * (size_t)v)) all_ok = false;
+      });
     } else if (!ctx->ops->combine_windows(sums, nwin, s.wbits, out_xyz)) all_ok = false;
   } else {
     combine_pool().run(s.nvec, [&](int v) {  // one independent Horner chain per MSM of the launch: side by side when there are several

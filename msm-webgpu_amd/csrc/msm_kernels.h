@@ -751,24 +751,26 @@ __device__ __forceinline__ uint32_t wide_digit(const uint32_t* t, int w, int top
 }
 __device__ __forceinline__ uint32_t wide_key(uint32_t mag) { return (((mag - 1u) >> 15) << 7) | ((mag & 0x7fffu) >> 8); }  // (virtual window, coarse bin)
 
-// first pass: counts[hi][tile][bin] (the layout of k_count with WideCfg<C>::VWIN local windows).  One scalar vector per launch.
+// first pass: counts[lw][tile][bin] (the layout of k_count), local window lw = v * VWIN + hi for scalar vector v of the launch's nvec
+// (vec_stride words apart: several whole MSMs over the same tables share one kernel sequence, as in k_count)
 template <int C>
-__global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles,
-                                                    uint32_t* __restrict__ counts, uint32_t* __restrict__ err, int top_shift) {
+__global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles, int nvec,
+                                                    size_t vec_stride, uint32_t* __restrict__ counts, uint32_t* __restrict__ err, int top_shift) {
   constexpr int SW = 8;  // full-length scalars
   constexpr int WIDE_KEYS = WideCfg<C>::KEYS, WIDE_TABLES = WideCfg<C>::TABLES;
   __shared__ uint32_t cnt[WIDE_KEYS];
   const int tid = threadIdx.x;
-  for (int i = tid; i < WIDE_KEYS; i += 256) cnt[i] = 0;
-  __syncthreads();
   const size_t base = (size_t)blockIdx.x * tile_len;
   const size_t end = base + tile_len < n ? base + tile_len : n;
   uint32_t bad = 0;
+  for (int v = 0; v < nvec; v++) {
+  for (int i = tid; i < WIDE_KEYS; i += 256) cnt[i] = 0;
+  __syncthreads();
   for (size_t i0 = base; i0 < end; i0 += 256) {
     const size_t i = i0 + tid;
     if (i >= end) continue;
     uint32_t s[SW], tb[WinCfg<C, SW>::WORDS], t16[8], neg = 0;
-    ld_scalar<SW>(scalars + i * SW, s, neg);
+    ld_scalar<SW>(scalars + (size_t)v * vec_stride + i * SW, s, neg);
     bad |= bias_scalar<C, SW>(s, tb);
     bad |= bias_scalar<16>(s, t16);  // the input contract of every mode: what overflows the reference's 16-bit recode is rejected (test/utils.rs:150-152)
 #pragma unroll
@@ -778,10 +780,12 @@ __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__
       if (mag) atomicAdd(&cnt[wide_key(mag)], 1u);
     }
   }
-  if (bad) atomicOr(err, ERRBIT_SCALAR_CARRY);
   __syncthreads();
   for (int i = tid; i < WIDE_KEYS; i += 256)
-    counts[((size_t)(i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[i];
+    counts[((size_t)(v * WideCfg<C>::VWIN + i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[i];
+  __syncthreads();
+  }
+  if (bad) atomicOr(err, ERRBIT_SCALAR_CARRY);
 }
 
 // second pass: the LDS-ranked, LDS-staged scatter of k_scatter_coarse over all (virtual window, coarse bin) runs at once -- 256 / 1024 / 2048
@@ -793,7 +797,7 @@ constexpr int WIDE_THREADS = 512, WIDE_PER = 2;
 constexpr int WIDE_SUB = WIDE_THREADS * WIDE_PER;     // scalars staged per block iteration
 template <int C>
 __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
-                                                               uint32_t tiles, const uint32_t* __restrict__ counts,
+                                                               uint32_t tiles, int nvec, size_t vec_stride, const uint32_t* __restrict__ counts,
                                                                const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr,
                                                                uint32_t* __restrict__ tmp_val, uint8_t* __restrict__ tmp_fine, size_t table_stride,
                                                                uint32_t chunks, uint32_t host_chunk_len, uint32_t* __restrict__ chunk_len_dev, int top_shift) {
@@ -811,12 +815,17 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (tid == 0) max_total = 0;
   __syncthreads();
+  const size_t tile_base = (size_t)blockIdx.x * tile_len;
+  const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
+  for (int vec = 0; vec < nvec; vec++) {  // one scalar vector (one MSM of the launch) after the other: its VWIN local windows start at lw0
+  const int lw0 = vec * WideCfg<C>::VWIN;
+  const uint32_t* sv = scalars + (size_t)vec * vec_stride;
   // start of every run: exclusive scan of each virtual window's 128 bin totals (a pair of waves per window, four windows per step) + what
-  // earlier tiles put there; workgroup 0 publishes the bin starts (coarse_ptr[hi][0 .. 128]) and the launch's chunk length
+  // earlier tiles put there; workgroup 0 publishes the bin starts (coarse_ptr[lw][0 .. 128]) and, after the last vector, the launch's chunk length
   for (int i0 = 0; i0 < WIDE_KEYS; i0 += WIDE_THREADS) {
-    const int i = i0 + tid, lw = i / NCOARSE, bin = i % NCOARSE;
+    const int i = i0 + tid, lw = lw0 + i / NCOARSE, bin = i % NCOARSE;
     const bool live = i < WIDE_KEYS;  // (fewer runs than threads: 17-bit digits)
-    const uint32_t v = live ? bin_total[i] : 0u;
+    const uint32_t v = live ? bin_total[lw * NCOARSE + bin] : 0u;
     uint32_t x = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -836,9 +845,6 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
     }
     __syncthreads();
   }
-  if (blockIdx.x == 0 && tid == 0) *chunk_len_dev = smvp_chunk_len(max_total, chunks, host_chunk_len);
-  const size_t tile_base = (size_t)blockIdx.x * tile_len;
-  const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
   for (size_t sub = tile_base; sub < tile_end; sub += WIDE_SUB) {
     for (int k = tid; k < WIDE_KEYS; k += WIDE_THREADS) hist[k] = 0;
     uint32_t sc[WIDE_PER][WinCfg<C, SW>::WORDS];
@@ -848,7 +854,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
       uint32_t raw[SW], neg = 0;
 #pragma unroll
       for (int k = 0; k < SW; k++) raw[k] = 0;  // an all-zero scalar recodes to all-zero digits: no entries
-      if (i < tile_end) ld_scalar<SW>(scalars + i * SW, raw, neg);
+      if (i < tile_end) ld_scalar<SW>(sv + i * SW, raw, neg);
       (void)bias_scalar<C, SW>(raw, sc[j]);
     }
     __syncthreads();
@@ -907,7 +913,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
     __syncthreads();
     for (uint32_t e = tid; e < total; e += WIDE_THREADS) {
       const uint32_t key = st_key[e];
-      const size_t d = (size_t)(key >> 7) * stride + gpos[key] + (e - lstart[key]);
+      const size_t d = (size_t)(lw0 + (key >> 7)) * stride + gpos[key] + (e - lstart[key]);
       tmp_val[d] = st_val[e];
       tmp_fine[d] = st_fine[e];
     }
@@ -915,6 +921,8 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
     for (int k = tid; k < WIDE_KEYS; k += WIDE_THREADS) gpos[k] += hist[k];
     __syncthreads();
   }
+  }
+  if (blockIdx.x == 0 && tid == 0) *chunk_len_dev = smvp_chunk_len(max_total, chunks, host_chunk_len);
 }
 
 // The second pass of a launch whose first pass left digit planes (k_count with negbits != null): the same LDS-ranked, LDS-staged

@@ -115,16 +115,26 @@ def test_wide_tables_extreme_and_skewed_scalars(wctx):
     assert e.value.code == -4
 
 
-def test_wide_tables_batches_and_flags(ctx):
-    n, batch = 3000, 5
+def test_wide_tables_batches_and_flags(wctx):
+    ctx = wctx
+    n, batch = 3000, 14
     pts = ctx.sample_points(n, 1420)
     sc = ctx.sample_scalars(n * batch, 1421)
     ctx.set_bases(pts, precompute="wide")
-    assert ctx.batch_group_size(n) == 1                   # its bucket set is 8 local windows already: one MSM per launch
-    got = ctx.msm_batch(sc, n)
+    # an MSM is 2^(C-16) local windows, and a launch leaves bit-plane sums for at most 24: 12 / 6 / 3 / 1 whole MSMs per launch at 17 .. 20 bits
+    group = 24 >> (ctx.wide_bits() - 16)
+    assert ctx.batch_group_size(n) == group
+    got = ctx.msm_batch(sc, n)                             # groups of `group`, the last one shorter
     pb = pts.cpu().numpy().tobytes()
-    for k in (0, 2, 4):
+    for k in (0, 2, 4, 11, 12, 13):
         assert got[k].to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb, sc[k * n:(k + 1) * n].cpu().numpy().tobytes())), k
+    assert [g.to_affine_bytes() for g in ctx.msm_batch(sc.cpu().numpy().tobytes(), n)] == [g.to_affine_bytes() for g in got]
+    g2 = min(group, 5)
+    assert ctx.launch_batch(sc[: g2 * n].contiguous(), n, 2) == g2
+    assert [x.to_affine_bytes() for x in ctx.finish_batch(2, g2)] == [x.to_affine_bytes() for x in got[:g2]]
+    if group < 14:   # more whole MSMs than one launch's plane sums hold: refused, the slot stays free
+        with pytest.raises(m.MsmHipError):
+            ctx.launch_batch(sc[: (group + 1) * n].contiguous(), n, 3)
     # pipelined launches through the result slots
     for k in range(4):
         ctx.launch(sc[k * n:(k + 1) * n].contiguous(), slot=k)

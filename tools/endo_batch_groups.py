@@ -12,10 +12,10 @@ ctx.set_stage_timing(0)
 pts = ctx.sample_points(n, 1)
 sc = torch.cat([ctx.sample_scalars(n, 2 + i) for i in range(8)], dim=0).contiguous()
 total = 64
-for mode in ("plain", "endomorphism", "tables"):
-    ctx.set_bases(pts, endomorphism=mode == "endomorphism", precompute=mode == "tables")
+for mode in ("plain", "endomorphism", "tables", "tables_wide"):
+    ctx.set_bases(pts, endomorphism=mode == "endomorphism", precompute="wide" if mode == "tables_wide" else mode == "tables")
     for g in (1, 2, 4, 8):
-        if mode == "plain" and g > 4:
+        if (mode == "plain" and g > 4) or (mode == "tables_wide" and g > 24 >> (ctx.wide_bits() - 16)):
             continue
         for depth in (2, 3):
             def run(count):
