@@ -603,12 +603,16 @@ class MultiGpuMsm:
     def uses_rccl(self):
         return lib().msm_hip_mgpu_uses_rccl(self._h) == 1
 
-    def set_bases(self, points, check_on_curve=False, endomorphism=False):
+    def set_bases(self, points, check_on_curve=False, endomorphism=False, precompute=False):
         """Replicated on every device.  endomorphism: True: MSM_HIP_BASES_ENDOMORPHISM -- msm_batch runs whole MSMs over the 2n points, and
         the window-sharded calls shard the 8 half-length windows; False: MSM_HIP_BASES_PLAIN; None: the C ABI's default (flags = 0: whole
-        MSMs take the curve's fastest mode, the window-sharded calls the 16 full-length windows)."""
+        MSMs take the curve's fastest mode, the window-sharded calls the 16 full-length windows).  precompute (True / "wide": fixed-base
+        tables, as MsmContext.set_bases): the whole MSMs of msm_batch -- dealt out over the devices -- run in that mode; the window-sharded
+        calls ignore the tables."""
         b = bytes(points)
-        flags = (1 if check_on_curve else 0) | (8 if endomorphism else 0) | (16 if endomorphism is False else 0)
+        flags = (1 if check_on_curve else 0) | (8 if endomorphism else 0) | (32 if precompute == "wide" else 4 if precompute else 0)
+        if endomorphism is False and not precompute:
+            flags |= 16
         _check(lib().msm_hip_mgpu_set_bases_bn254(self._h, b, len(b) // self.pb, flags), "msm_hip_mgpu_set_bases_bn254")
         return len(b) // self.pb
 

@@ -144,3 +144,20 @@ def test_wide_tables_batches_and_flags(wctx):
         assert m.lib().msm_hip_set_bases_bn254(ctx._h, pb, n, flags) == -2
     ctx.set_bases(pts)
     assert ctx.msm(sc[:n].contiguous()).to_affine_bytes() == got[0].to_affine_bytes()
+
+
+def test_wide_tables_behind_the_multi_gpu_abi(built):
+    """BASELINE config 5's shape through msm_hip_mgpu_run_batch_bn254: whole MSMs over one fixed base dealt out over the devices (here three
+    contexts on one GPU), every device holding the wide tables; the window-sharded single MSM on the same handle ignores them."""
+    n, batch = 4000, 7
+    points = cpu.sample_points(1430, n)
+    sc = cpu.sample_scalars(1431, n * batch)
+    mg = m.MultiGpuMsm([0, 0, 0], "host")
+    try:
+        mg.set_bases(points, precompute="wide")
+        got = mg.msm_batch(sc, n)
+        for k in (0, 3, 6):
+            assert got[k].to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points, sc[32 * n * k: 32 * n * (k + 1)], 8)), k
+        assert mg.msm(sc[: 32 * n]).to_affine_bytes() == got[0].to_affine_bytes()
+    finally:
+        mg.close()
