@@ -73,8 +73,8 @@ extern "C" {
                                           windows" of 2^15 slots.  C by the number of bases: 17 up to 2^21 points (19 on the curves whose 255-bit scalar
                                           field 15 digits of 17 bits cannot hold: Pallas, Vesta, BLS12-381), 20 beyond; msm_hip_set_wide_bits overrides.
                                           The top table is 2^(C (T-1) - t) P_i and the top digit is used shifted by t, so that it spreads over the bucket
-                                          set (t from the scalar field's modulus; exact for any point).  For fixed bases: over the endomorphism mode +58 % at
-                                          2^14, +50 % at 2^16, +21 % at 2^18 (grouped launches), +4 % at 2^20, +11 % at 2^22, +18 % at 2^24; 15 x (13 x) the
+                                          set (t from the scalar field's modulus; exact for any point).  For fixed bases: over the endomorphism mode +44 ... 58 % at
+                                          2^14, +26 ... 50 % at 2^16, +20 % at 2^18 (grouped launches; 50 / 20 timed steps), +4 % at 2^20, +11 % at 2^22, +18 % at 2^24; 15 x (13 x) the
                                           base memory, at most 2^24 points; up to 12 (at 20 bits: 1) whole MSMs per launch; sort arrays sized for a skewed
                                           vector (2^(C-16) x T x n entries per MSM: 0.3 GiB at 2^20, 31 GiB at 2^24).
                                           Whole-MSM entry points only (run, launch / finish, batch); the window-sharding entry points ignore the tables
