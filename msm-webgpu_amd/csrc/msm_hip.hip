@@ -571,9 +571,9 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   }
 #define LAUNCH_BY_WBITS_SW(KERNEL, SW, ...)                                              \
   do {                                                                                   \
-    if (wbits == 16) hipLaunchKernelGGL((KERNEL<16, SW>), dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
-    else if (wbits == 14) hipLaunchKernelGGL((KERNEL<14, SW>), dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<12, SW>), dim3(tiles), dim3(256), 0, st, __VA_ARGS__); \
+    if (wbits == 16) hipLaunchKernelGGL((KERNEL<16, SW>), dim3(tiles, nvec), dim3(256), 0, st, __VA_ARGS__); \
+    else if (wbits == 14) hipLaunchKernelGGL((KERNEL<14, SW>), dim3(tiles, nvec), dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<12, SW>), dim3(tiles, nvec), dim3(256), 0, st, __VA_ARGS__); \
   } while (0)
   // first pass: recode + coarse histogram (+ digit planes: 1 = debug read-back, 2 = the second pass reads them).  Endomorphism launches:
   // the same kernel splits every scalar k = k1 + k2 lambda itself and leaves the halves (interleaved: input 2 j = k1 of scalar j, 2 j + 1 =
@@ -582,7 +582,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   const int plane_mode = planes ? 2 : (digits ? 1 : 0);
   if (wide) {
     const int top_shift = wide_top_shift(ctx->curve, ctx->wide_bits);
-#define LAUNCH_COUNT_WIDE(C) hipLaunchKernelGGL(k_count_wide<C>, dim3(tiles), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, nvec, n * 8, ctx->d_counts, d_err, top_shift)
+#define LAUNCH_COUNT_WIDE(C) hipLaunchKernelGGL(k_count_wide<C>, dim3(tiles, nvec), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, nvec, n * 8, ctx->d_counts, d_err, top_shift)
     switch (ctx->wide_bits) {
       case 17: LAUNCH_COUNT_WIDE(17); break;
       case 18: LAUNCH_COUNT_WIDE(18); break;
@@ -591,7 +591,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     }
 #undef LAUNCH_COUNT_WIDE
   } else if (halves) {
-    hipLaunchKernelGGL(ctx->ops->count_split[wbits == 16 ? 2 : wbits == 14 ? 1 : 0], dim3(tiles), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, w_begin,
+    hipLaunchKernelGGL(ctx->ops->count_split[wbits == 16 ? 2 : wbits == 14 ? 1 : 0], dim3(tiles, nvec), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, w_begin,
                        w_count_vec, nvec, n * 8, ctx->d_counts, plane_out, plane_mode, planes ? ctx->d_negbits : nullptr,
                        planes ? nullptr : ctx->d_halves, d_err, merge_nb);
     d_scalars = ctx->d_halves;
@@ -607,7 +607,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   if (wide) {
     const int top_shift = wide_top_shift(ctx->curve, ctx->wide_bits);
 #define LAUNCH_SCATTER_WIDE(C)                                                                                                                         \
-  hipLaunchKernelGGL(k_scatter_wide<C>, dim3(tiles), dim3(WIDE_THREADS), 0, st, d_scalars, n_sc, stride, tile_len, tiles, nvec, n * 8, ctx->d_counts, ctx->d_bin_total, \
+  hipLaunchKernelGGL(k_scatter_wide<C>, dim3(tiles, nvec), dim3(WIDE_THREADS), 0, st, d_scalars, n_sc, stride, tile_len, tiles, nvec, n * 8, ctx->d_counts, ctx->d_bin_total, \
                      ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, chunks, chunk_len, d_chunk_len, top_shift)
     switch (ctx->wide_bits) {
       case 17: LAUNCH_SCATTER_WIDE(17); break;

@@ -433,10 +433,14 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
                                                uint32_t* __restrict__ err, size_t merge_nb) {
   static_assert(!SPLIT || SW == 4, "the split produces 4-word halves");
   // merge_nb != 0 (fixed-base tables, see k_precompute_tables): every window of vector v feeds ONE bucket set, local window v
+  // grid (tiles, nvec): a workgroup counts one tile of ONE scalar vector (round 4: with the vectors looped over inside the workgroup a
+  // grouped launch of small MSMs kept a quarter of the CUs busy -- 64 tiles at 2^16 -- for nvec times as long)
   __shared__ uint32_t cnt[MAXLW * NCOARSE];
   const int tid = threadIdx.x;
-  const int w_eff = merge_nb ? nvec : nvec * w_count;
-  for (int i = tid; i < w_eff * NCOARSE; i += 256) cnt[i] = 0;
+  const int v = blockIdx.y;
+  const int le0 = merge_nb ? v : v * w_count, le_n = merge_nb ? 1 : w_count;  // this vector's local windows
+  (void)nvec;
+  for (int i = tid; i < le_n * NCOARSE; i += 256) cnt[le0 * NCOARSE + i] = 0;
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * tile_len;
   const size_t end = base + tile_len < n ? base + tile_len : n;
@@ -454,7 +458,7 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
       }
     }
   };
-  for (int v = 0; v < nvec; v++) {
+  {
     const uint32_t* sv = scalars + (size_t)v * vec_stride;
     if constexpr (SPLIT) {
       const size_t nsc = n / 2, neg_words = (nsc + 63) / 64;
@@ -509,8 +513,8 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ scal
   if (bad) atomicOr(err, ERRBIT_SCALAR_CARRY);
   __syncthreads();
   // counts[lw][tile][bin]
-  for (int i = tid; i < w_eff * NCOARSE; i += 256)
-    counts[((size_t)(i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[i];
+  for (int i = tid; i < le_n * NCOARSE; i += 256)
+    counts[((size_t)(le0 + i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[le0 * NCOARSE + i];
 }
 
 // One wave per (window, coarse bin): in place, counts[lw][tile][bin] becomes the number of entries of that bin in earlier
@@ -605,12 +609,17 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
   __syncthreads();
   // start of every (window, coarse bin): exclusive scan of the window's 128 bin totals -- a pair of waves per window, two
   // windows per step; workgroup 0 also publishes them as coarse_ptr[lw][0..128] for k_sort_fine
+  // grid (tiles, nvec): a workgroup scatters one tile of ONE scalar vector and needs the starts of that vector's windows only; workgroup (0, 0)
+  // scans the windows of every vector: it publishes all of them and the launch's chunk length
   const int w_eff = merge_nb ? nvec : nvec * w_count;  // local windows of all vectors of this launch
-  for (int i0 = 0; i0 < w_eff * NCOARSE; i0 += 256) {
+  const int v = blockIdx.y;
+  const bool publisher = blockIdx.x == 0 && blockIdx.y == 0;
+  const int le0 = publisher ? 0 : (merge_nb ? v : v * w_count), le1 = publisher ? w_eff : le0 + (merge_nb ? 1 : w_count);
+  for (int i0 = le0 * NCOARSE; i0 < le1 * NCOARSE; i0 += 256) {
     const int i = i0 + tid, lw = i / NCOARSE, bin = i % NCOARSE, lane = tid & 63;
-    const bool live = i < w_eff * NCOARSE;  // odd window counts: the last step has one idle pair of waves
-    const uint32_t v = live ? bin_total[i] : 0u;
-    uint32_t x = v;
+    const bool live = i < le1 * NCOARSE;  // odd window counts: the last step has one idle pair of waves
+    const uint32_t bt = live ? bin_total[i] : 0u;
+    uint32_t x = bt;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t y = __shfl_up(x, off);
@@ -619,9 +628,9 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
     if (lane == 63) wave_tot[tid >> 6] = x;
     __syncthreads();
     const uint32_t incl = x + ((tid >> 6) & 1 ? wave_tot[(tid >> 6) - 1] : 0u);
-    if (live) gpos[i] = incl - v + counts[((size_t)lw * tiles + blockIdx.x) * NCOARSE + bin];
-    if (live && blockIdx.x == 0) {
-      coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin] = incl - v;
+    if (live) gpos[i] = incl - bt + counts[((size_t)lw * tiles + blockIdx.x) * NCOARSE + bin];
+    if (live && publisher) {
+      coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin] = incl - bt;
       if (bin == NCOARSE - 1) {
         coarse_ptr[(size_t)lw * (NCOARSE + 1) + NCOARSE] = incl;
         atomicMax(&max_total, incl);
@@ -629,10 +638,9 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
     }
     __syncthreads();
   }
-  if (blockIdx.x == 0 && tid == 0) *chunk_len_dev = smvp_chunk_len(max_total, chunks, host_chunk_len);
+  if (publisher && tid == 0) *chunk_len_dev = smvp_chunk_len(max_total, chunks, host_chunk_len);
   const size_t tile_base = (size_t)blockIdx.x * tile_len;
   const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
-  for (int v = 0; v < nvec; v++)
   for (size_t sub = tile_base; sub < tile_end; sub += SUB) {
     // this thread's PER biased scalars stay in registers; every window's digit code is read from them
     const uint32_t* sv = scalars + (size_t)v * vec_stride;
@@ -763,7 +771,8 @@ __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__
   const size_t base = (size_t)blockIdx.x * tile_len;
   const size_t end = base + tile_len < n ? base + tile_len : n;
   uint32_t bad = 0;
-  for (int v = 0; v < nvec; v++) {
+  const int v = blockIdx.y;  // grid (tiles, nvec): one tile of one scalar vector per workgroup (as k_count)
+  (void)nvec;
   for (int i = tid; i < WIDE_KEYS; i += 256) cnt[i] = 0;
   __syncthreads();
   for (size_t i0 = base; i0 < end; i0 += 256) {
@@ -783,8 +792,6 @@ __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__
   __syncthreads();
   for (int i = tid; i < WIDE_KEYS; i += 256)
     counts[((size_t)(v * WideCfg<C>::VWIN + i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[i];
-  __syncthreads();
-  }
   if (bad) atomicOr(err, ERRBIT_SCALAR_CARRY);
 }
 
@@ -817,13 +824,16 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
   __syncthreads();
   const size_t tile_base = (size_t)blockIdx.x * tile_len;
   const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
-  for (int vec = 0; vec < nvec; vec++) {  // one scalar vector (one MSM of the launch) after the other: its VWIN local windows start at lw0
-  const int lw0 = vec * WideCfg<C>::VWIN;
-  const uint32_t* sv = scalars + (size_t)vec * vec_stride;
-  // start of every run: exclusive scan of each virtual window's 128 bin totals (a pair of waves per window, four windows per step) + what
-  // earlier tiles put there; workgroup 0 publishes the bin starts (coarse_ptr[lw][0 .. 128]) and, after the last vector, the launch's chunk length
+  // grid (tiles, nvec): a workgroup scatters one tile of ONE scalar vector (one MSM of the launch), whose VWIN local windows start at lw0.
+  // Start of every run: exclusive scan of each virtual window's 128 bin totals (a pair of waves per window, four windows per step) + what
+  // earlier tiles put there.  Workgroup (0, 0) does this for every vector of the launch (its own last: gpos keeps the last one scanned): it
+  // publishes all bin starts (coarse_ptr[lw][0 .. 128]) and the launch's chunk length.
+  const bool publisher = blockIdx.x == 0 && blockIdx.y == 0;
+  const int lw0 = (int)blockIdx.y * WideCfg<C>::VWIN;
+  const uint32_t* sv = scalars + (size_t)blockIdx.y * vec_stride;
+  for (int pv = publisher ? nvec - 1 : (int)blockIdx.y; pv >= (int)blockIdx.y; pv--)
   for (int i0 = 0; i0 < WIDE_KEYS; i0 += WIDE_THREADS) {
-    const int i = i0 + tid, lw = lw0 + i / NCOARSE, bin = i % NCOARSE;
+    const int i = i0 + tid, lw = pv * WideCfg<C>::VWIN + i / NCOARSE, bin = i % NCOARSE;
     const bool live = i < WIDE_KEYS;  // (fewer runs than threads: 17-bit digits)
     const uint32_t v = live ? bin_total[lw * NCOARSE + bin] : 0u;
     uint32_t x = v;
@@ -836,7 +846,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
     __syncthreads();
     const uint32_t incl = x + ((wid & 1) ? wave_tot[wid - 1] : 0u);
     if (live) gpos[i] = incl - v + counts[((size_t)lw * tiles + blockIdx.x) * NCOARSE + bin];
-    if (live && blockIdx.x == 0) {
+    if (live && publisher) {
       coarse_ptr[(size_t)lw * (NCOARSE + 1) + bin] = incl - v;
       if (bin == NCOARSE - 1) {
         coarse_ptr[(size_t)lw * (NCOARSE + 1) + NCOARSE] = incl;
@@ -845,6 +855,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
     }
     __syncthreads();
   }
+  if (publisher && tid == 0) *chunk_len_dev = smvp_chunk_len(max_total, chunks, host_chunk_len);
   for (size_t sub = tile_base; sub < tile_end; sub += WIDE_SUB) {
     for (int k = tid; k < WIDE_KEYS; k += WIDE_THREADS) hist[k] = 0;
     uint32_t sc[WIDE_PER][WinCfg<C, SW>::WORDS];
@@ -921,8 +932,6 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
     for (int k = tid; k < WIDE_KEYS; k += WIDE_THREADS) gpos[k] += hist[k];
     __syncthreads();
   }
-  }
-  if (blockIdx.x == 0 && tid == 0) *chunk_len_dev = smvp_chunk_len(max_total, chunks, host_chunk_len);
 }
 
 // The second pass of a launch whose first pass left digit planes (k_count with negbits != null): the same LDS-ranked, LDS-staged
