@@ -146,6 +146,31 @@ def test_wide_tables_batches_and_flags(wctx):
     assert ctx.msm(sc[:n].contiguous()).to_affine_bytes() == got[0].to_affine_bytes()
 
 
+@pytest.mark.parametrize("n,bits", [(1 << 20, 17), ((1 << 21) + 8, 20)])
+def test_wide_tables_at_full_sizes_equal_the_other_modes(ctx, n, bits):
+    """BASELINE config 2's size (and the first size the policy gives 20-bit digits): the wide tables' result is the endomorphism mode's and the
+    16-bit tables' -- three independent paths through the sort and the finish -- for uniform and for skewed scalars; at 2^20 the endomorphism
+    mode itself is checked bit-exactly against the CPU oracle by bench.py and tests/test_gpu_baseline_configs.py."""
+    import torch
+
+    pts = ctx.sample_points(n, 1440)
+    uniform = ctx.sample_scalars(n, 1441)
+    skew = uniform.clone()
+    skew[: n // 2, 2:] = 0                       # half of the scalars below 2^16: one virtual window takes far more than its share
+    skew[n // 2: n // 2 + n // 8] = uniform[7]   # and an eighth of them equal: giant buckets in every digit position
+    want = {}
+    for mode in ("endomorphism", "tables", "wide"):
+        ctx.set_bases(pts, endomorphism=mode == "endomorphism", precompute="wide" if mode == "wide" else mode == "tables")
+        if mode == "wide":
+            assert ctx.wide_bits() == bits
+        for name, sc in (("uniform", uniform), ("skew", skew)):
+            got = ctx.msm(sc).to_affine_bytes()
+            assert want.setdefault(name, got) == got, (mode, name)
+    del skew, uniform, pts
+    torch.cuda.empty_cache()
+    ctx.set_bases(ctx.sample_points(16, 1))      # give the tables' memory back
+
+
 def test_wide_tables_behind_the_multi_gpu_abi(built):
     """BASELINE config 5's shape through msm_hip_mgpu_run_batch_bn254: whole MSMs over one fixed base dealt out over the devices (here three
     contexts on one GPU), every device holding the wide tables; the window-sharded single MSM on the same handle ignores them."""
