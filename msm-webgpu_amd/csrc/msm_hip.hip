@@ -57,7 +57,7 @@ enum LaunchMode {
   MODE_PLAIN = 0,   // windows [w_begin, w_end) of 254-bit scalars over the n bases
   MODE_TABLES = 1,  // fixed-base tables: all windows of a vector feed one bucket set (MSM_HIP_BASES_PRECOMPUTE)
   MODE_HALVES = 2,  // endomorphism: 127-bit halves k1, k2 over the 2n points P_i, phi(P_i) (MSM_HIP_BASES_ENDOMORPHISM, csrc/glv.h)
-  MODE_WIDE = 3,    // wide fixed-base tables: 14 digits of 19 bits per scalar, one bucket set of 2^18 slots run as 8 virtual windows of 2^15
+  MODE_WIDE = 3,    // wide fixed-base tables: ceil(255 / C) digits of C = 17 .. 20 bits per scalar, one bucket set of 2^(C-1) slots run as 2^(C-16) virtual windows of 2^15
                     // (MSM_HIP_BASES_PRECOMPUTE_WIDE; msm_kernels.h: k_count_wide)
 };
 
@@ -304,7 +304,7 @@ inline int pick_wide_bits(const msm_hip_ctx* ctx, size_t n) {
   return wide_bits_fit(ctx->curve, bits) ? bits : 19;
 }
 // SMVP lanes and lengths of a wide fixed-base launch over n points (msm_kernels.h: k_count_wide).  For uniform scalars every virtual window
-// receives 13 n / 8 entries from the 13 full digits, and the windows the shifted top digit reaches n / (windows it spans) more: the fullest
+// receives (T - 1) n / VWIN entries from the T - 1 full digits, and the windows the shifted top digit reaches their share of its n more: the fullest
 // window's expected count F sets the device's chunk length (smvp_chunk_len), so the lanes are planned for F (+ 0.4 % + 64 entries: its
 // fluctuation is 0.07 % at 2^20) -- planned for the mean, the length the device settles on would be one entry more than the one the host
 // searched for, 4 % at 2^20.  Skewed scalars spread any other way: the arrays' per-window stride (`worst`) and the longest chunk the
@@ -318,7 +318,7 @@ inline WideShape wide_shape(size_t n, int curve, int bits, int nvec) {  // (nvec
   WideShape w;
   w.worst = n * (size_t)WIDE_TABLES;
   // r / 2^P: the top digit of a uniform scalar is uniform below it; a virtual window takes the 2^15 >> shift digit values (at least one) that
-  // land in it, so the fullest one receives that share of the n top digits on top of its (14 - 1) n / 8
+  // land in it, so the fullest one receives that share of the n top digits on top of its (T - 1) n / VWIN
   const double top_range = (double)scalar_modulus_top64(curve) / (double)(1ull << (wide_top_pos(bits) - 192));
   const int shift = wide_top_shift(curve, bits);
   double share = (double)(shift >= 15 ? 1u : 32768u >> shift) / top_range;
@@ -516,8 +516,8 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   const unsigned ncoarse = half / FINE;      // coarse bins that can hold entries
   // fixed-base tables (`merge`): the w_count_vec windows of a vector feed one bucket set -- one local window of up to
   // n * w_count_vec entries per vector -- whose entries index the tables (window w of point i = record w * n_bases + i)
-  // wide tables (`wide`; nvec = 1, w_count_vec = 14 digits of 19 bits): the same indexing; the bucket set of 2^18 slots is run as 8 local
-  // ("virtual") windows of 2^15, into which the entries fall by the top 3 bits of their digit's magnitude (msm_kernels.h: k_count_wide)
+  // wide tables (`wide`; w_count_vec = the T digits of C bits): the same indexing; each vector's bucket set of 2^(C-1) slots is run as 2^(C-16) local
+  // ("virtual") windows of 2^15, into which the entries fall by the top bits of their digit's magnitude (msm_kernels.h: k_count_wide)
   const size_t merge_nb = merge || wide ? ctx->n_bases : 0;
   // endomorphism (`halves`): the recode runs over 2n halves of 16 B (the first pass splits the scalars) against 2n points -- P_i and, n_bases records
   // further on, phi(P_i) -- in half as many windows
@@ -792,7 +792,7 @@ constexpr size_t MAX_PRECOMPUTE_POINTS = (size_t)1 << 24;  // 16 tables: 16 GiB,
 // src/cuzk/msm.rs:75-94) runs the mode the headline figure is measured in (656 vs 701 - 714 MSM/s at 2^20 in round 3, when it did not).
 constexpr uint32_t BASE_FLAGS_ALL = MSM_HIP_CHECK_ON_CURVE | MSM_HIP_BASES_MONT256 | MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_ENDOMORPHISM | MSM_HIP_BASES_PLAIN |
                                     MSM_HIP_BASES_PRECOMPUTE_WIDE;
-constexpr size_t MAX_WIDE_POINTS = (size_t)1 << 24;  // 14 tables of 19-bit digits: 14 GiB; sort arrays of 8 x 14 n entries: 17 GiB
+constexpr size_t MAX_WIDE_POINTS = (size_t)1 << 24;  // 13 tables of 20-bit digits: 13 GiB; sort arrays of 16 x 13 n entries: 31 GiB
 inline uint32_t resolve_base_flags(const msm_hip_ctx* ctx, size_t n, uint32_t flags) {
   static const bool auto_endo = [] { const char* e = getenv("MSM_HIP_BASES_AUTO"); return !e || atoi(e) != 0; }();  // MSM_HIP_BASES_AUTO=0: flags = 0 means plain (rounds 1 - 3)
   if (flags & (MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_PRECOMPUTE_WIDE | MSM_HIP_BASES_ENDOMORPHISM | MSM_HIP_BASES_PLAIN)) return flags;
