@@ -286,15 +286,15 @@ inline int wide_top_shift(int curve, int bits) {
   while (s + 1 < bits && ((uint64_t)dmax << (s + 1)) <= half) s++;
   return s;
 }
-// Can the curve's scalars be recoded into C-bit digits at all?  The top digit is never negative, so it must stay below 2^(C-1) before its
-// shift: with 17-bit digits (15 x 17 = 255 bits) only where the scalar field's modulus is below 2^254 - 2^238 -- BN254 and Grumpkin, not the
-// 255-bit moduli of Pallas, Vesta and BLS12-381.
-inline bool wide_bits_fit(int curve, int bits) { return wide_top_max(curve, bits) <= (1u << (bits - 1)) - 1u; }
+// Can the curve's scalars be recoded into C-bit digits at all?  The top digit is never negative and becomes a bucket magnitude, so it must not
+// pass 2^(C-1): with 17-bit digits (15 x 17 = 255 bits) that holds for BN254, Grumpkin and -- just: their moduli are 2^254 + a 126-bit number, the
+// top digit of their largest scalars is exactly 2^16 -- Pallas and Vesta, not for BLS12-381's modulus of 1.8 x 2^254.
+inline bool wide_bits_fit(int curve, int bits) { return wide_top_max(curve, bits) <= (1u << (bits - 1)); }
 // Digit width of the wide tables for a base set of n points (profiles/r04_wide_tables.txt, same-box A/Bs against the endomorphism mode).  What an
 // MSM costs in the pipeline is sort + SMVP + the stitch / reduce work that runs beside the next launch, and the last grows with the bucket sets:
 // 17 bits (15 additions per point, 2 bucket sets) wins up to 2^21 points (+4 % at 2^20), 20 bits (13 additions, 16 bucket sets) from 2^22 up
 // (+11 % at 2^22, +18 % at 2^24), where the additions are all that counts.  19 bits (14 additions, 8 bucket sets; the 7-bit top digit makes <= 128
-// giant buckets) lies between them at every size and serves the curves 17 bits cannot; 18 bits (a 2-bit top digit: 3 giant buckets) loses everywhere.
+// giant buckets) lies between them at every size and serves the curve 17 bits cannot (BLS12-381); 18 bits (a 2-bit top digit: 3 giant buckets) loses everywhere.
 // msm_hip_set_wide_bits / MSM_HIP_WIDE_BITS = 17 .. 20 override.  -1: the chosen width cannot hold the curve's scalars.
 inline int pick_wide_bits(const msm_hip_ctx* ctx, size_t n) {
   static const int forced = [] { const char* e = getenv("MSM_HIP_WIDE_BITS"); const int v = e ? atoi(e) : 0; return v >= 17 && v <= 20 ? v : 0; }();

@@ -744,18 +744,22 @@ __device__ __forceinline__ uint32_t wide_digit(const uint32_t* t, int w, int top
   constexpr uint32_t H = 1u << (C - 1);
   const int bit = C * w, i = bit >> 5, sh = bit & 31;
   uint32_t b = t[i] >> sh;
-  if (sh + C > 32) b |= t[i + 1] << (32 - sh);  // (only then is i + 1 < WORDS)
+  if (sh + C > 32 && i + 1 < WinCfg<C>::WORDS) b |= t[i + 1] << (32 - sh);
+  if (w == WideCfg<C>::TABLES - 1) {
+    // the top digit: never negative (nothing above it carries into it), so its field is read with everything above it -- a digit of exactly
+    // 2^(C-1), which the C-bit field cannot hold (17-bit digits of a scalar of 2^254 or more: Pallas, Vesta), is the bucket magnitude 2^(C-1) like
+    // any other; beyond that, or beyond it after the shift, the scalar is rejected
+    sign = 0;
+    const uint32_t d = b - H;  // (b >= H: the bias bit of this window is set and the digit is not negative)
+    if (d > (H >> top_shift)) {
+      overflow = 1;
+      return 0;
+    }
+    return d << top_shift;
+  }
   b &= (1u << C) - 1u;
   sign = b < H ? 1u : 0u;
-  uint32_t mag = b >= H ? b - H : H - b;
-  if (w == WideCfg<C>::TABLES - 1) {  // (never negative: nothing above it carries into it, and its raw value is below 2^16)
-    mag <<= top_shift;
-    if (mag > H) {
-      overflow = 1;
-      mag = 0;
-    }
-  }
-  return mag;
+  return b >= H ? b - H : H - b;
 }
 __device__ __forceinline__ uint32_t wide_key(uint32_t mag) { return (((mag - 1u) >> 15) << 7) | ((mag & 0x7fffu) >> 8); }  // (virtual window, coarse bin)
 
@@ -780,8 +784,8 @@ __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__
     if (i >= end) continue;
     uint32_t s[SW], tb[WinCfg<C, SW>::WORDS], t16[8], neg = 0;
     ld_scalar<SW>(scalars + (size_t)v * vec_stride + i * SW, s, neg);
-    bad |= bias_scalar<C, SW>(s, tb);
-    bad |= bias_scalar<16>(s, t16);  // the input contract of every mode: what overflows the reference's 16-bit recode is rejected (test/utils.rs:150-152)
+    (void)bias_scalar<C, SW>(s, tb);  // (a top digit beyond the recode's range is caught where it is read: wide_digit)
+    bad |= bias_scalar<16>(s, t16);   // the input contract of every mode: what overflows the reference's 16-bit recode is rejected (test/utils.rs:150-152)
 #pragma unroll
     for (int w = 0; w < WIDE_TABLES; w++) {
       uint32_t sign;

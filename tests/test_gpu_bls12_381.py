@@ -126,7 +126,7 @@ def test_msm_matches_oracle_every_window_size_and_mode(ctx, n):
         assert ctx.msm(sc).to_affine_bytes() == want
         ctx.set_bases(points, precompute="wide")          # 14 digits of 19 bits (top digit shifted by 10 on this curve), 8 virtual windows
         assert ctx.msm(sc).to_affine_bytes() == want and ctx.msm(dev).to_affine_bytes() == want
-        assert ctx.wide_bits() == 19                      # 15 digits of 17 bits cannot hold a 255-bit scalar field: the policy's fallback
+        assert ctx.wide_bits() == 19                      # 15 digits of 17 bits cannot hold this scalar field (1.8 x 2^254): the policy's fallback
         ctx.set_wide_bits(17)
         try:
             with pytest.raises(m.MsmHipError) as e:

@@ -107,7 +107,7 @@ def test_wide_tables_extreme_and_skewed_scalars(wctx):
     # a top digit that does not fit after its shift (far above the modulus, at every digit width): rejected, not mis-added; up to 2^254 + a
     # little the shifted digit still fits
     p0 = ref.bytes_to_points(points[:64])[0]
-    for v in ((1 << 254) - 1, (1 << 254) + 5) if ctx.wide_bits() >= 18 else ():   # (15 digits of 17 bits hold 254 bits and a sign: not these)
+    for v in ((1 << 254) - 1, (1 << 254) + 5):   # (at 17 bits the top digit is exactly 2^16 here: the largest bucket magnitude, beyond the 17-bit field)
         # (beyond the modulus, where the C oracle's Booth windows -- halo2curves' -- end: the big-integer model is the reference here)
         assert ctx.msm(v.to_bytes(32, "little")).to_affine_bytes() == ref.affine_to_bytes64(ref.mul(v % R, p0)), hex(v)
     with pytest.raises(m.MsmHipError) as e:
