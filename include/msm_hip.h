@@ -70,8 +70,9 @@ extern "C" {
 #define MSM_HIP_BASES_PRECOMPUTE_WIDE 32u /* wide fixed-base tables (round 4): store 2^(C w) P_i for signed digits of C bits and recode every scalar into
                                           ceil(255 / C) of them -- 15 bucket additions per point at C = 17, 14 at 19, 13 at 20, instead of the reference's
                                           16 (src/cuzk/msm.rs:79-82: chunk_size 16) -- into ONE bucket set of 2^(C-1) slots, run as 2^(C-16) "virtual
-                                          windows" of 2^15 slots.  C by the number of bases: 17 up to 2^21 points (19 on BLS12-381, whose scalar field 15
-                                          digits of 17 bits cannot hold), 20 beyond; msm_hip_set_wide_bits overrides.
+                                          windows" of 2^15 slots.  C by the number of bases: 16 up to 2^16 points (the 16-bit tables behind this mode's sort),
+                                          17 up to 2^21 (19 on BLS12-381, whose scalar field 15 digits of 17 bits cannot hold), 20 beyond;
+                                          msm_hip_set_wide_bits overrides.
                                           The top table is 2^(C (T-1) - t) P_i and the top digit is used shifted by t, so that it spreads over the bucket
                                           set (t from the scalar field's modulus; exact for any point).  For fixed bases: over the endomorphism mode +44 ... 58 % at
                                           2^14, +26 ... 50 % at 2^16, +20 % at 2^18 (grouped launches; 50 / 20 timed steps), +4 % at 2^20, +11 % at 2^22, +18 % at 2^24; 15 x (13 x) the
@@ -168,7 +169,7 @@ int msm_hip_set_scalar_format(msm_hip_ctx* ctx, uint32_t format);
  *      msm_hip_combine_windows_bn254 always use the reference's 16-bit windows. ---- */
 int msm_hip_set_window_bits(msm_hip_ctx* ctx, int bits);
 int msm_hip_window_config(int bits, int* num_windows, int* buckets_per_window); /* host-only: the shape of a window size */
-/* digit width of the wide fixed-base tables the NEXT msm_hip_set_bases_*(…, MSM_HIP_BASES_PRECOMPUTE_WIDE) builds: 17 .. 20, 0 = by the number
+/* digit width of the wide fixed-base tables the NEXT msm_hip_set_bases_*(…, MSM_HIP_BASES_PRECOMPUTE_WIDE) builds: 16 .. 20, 0 = by the number
  * of bases and the curve (see the flag).  A width that cannot hold the curve's scalars (17 on BLS12-381) makes that call fail with
  * MSM_HIP_ERR_INVALID_ARG.  msm_hip_wide_bits: the width of the resident tables (0: none). */
 int msm_hip_set_wide_bits(msm_hip_ctx* ctx, int bits);

@@ -57,7 +57,7 @@ enum LaunchMode {
   MODE_PLAIN = 0,   // windows [w_begin, w_end) of 254-bit scalars over the n bases
   MODE_TABLES = 1,  // fixed-base tables: all windows of a vector feed one bucket set (MSM_HIP_BASES_PRECOMPUTE)
   MODE_HALVES = 2,  // endomorphism: 127-bit halves k1, k2 over the 2n points P_i, phi(P_i) (MSM_HIP_BASES_ENDOMORPHISM, csrc/glv.h)
-  MODE_WIDE = 3,    // wide fixed-base tables: ceil(255 / C) digits of C = 17 .. 20 bits per scalar, one bucket set of 2^(C-1) slots run as 2^(C-16) virtual windows of 2^15
+  MODE_WIDE = 3,    // wide fixed-base tables: ceil(255 / C) digits of C = 16 .. 20 bits per scalar, one bucket set of 2^(C-1) slots run as 2^(C-16) virtual windows of 2^15
                     // (MSM_HIP_BASES_PRECOMPUTE_WIDE; msm_kernels.h: k_count_wide)
 };
 
@@ -270,7 +270,7 @@ inline uint64_t scalar_modulus_top64(int curve) {
     default: return 0x30644e72e131a029ull;                   // BN254's r, and its p (Grumpkin's scalar field): the same top 64 bits
   }
 }
-inline int wide_top_pos(int bits) { return bits * (wide_tables_of(bits) - 1); }  // bit position of the top digit: 238 / 252 / 247 / 240 at 17 .. 20 bits (>= 192)
+inline int wide_top_pos(int bits) { return bits * (wide_tables_of(bits) - 1); }  // bit position of the top digit: 240 / 238 / 252 / 247 / 240 at 16 .. 20 bits (>= 192)
 inline uint32_t wide_top_max(int curve, int bits) {
   const uint64_t top = scalar_modulus_top64(curve);
   const int fb = wide_top_pos(bits) - 192;                   // fraction bits of `top` below the digit
@@ -292,15 +292,17 @@ inline int wide_top_shift(int curve, int bits) {
 inline bool wide_bits_fit(int curve, int bits) { return wide_top_max(curve, bits) <= (1u << (bits - 1)); }
 // Digit width of the wide tables for a base set of n points (profiles/r04_wide_tables.txt, same-box A/Bs against the endomorphism mode).  What an
 // MSM costs in the pipeline is sort + SMVP + the stitch / reduce work that runs beside the next launch, and the last grows with the bucket sets:
-// 17 bits (15 additions per point, 2 bucket sets) wins up to 2^21 points (+4 % at 2^20), 20 bits (13 additions, 16 bucket sets) from 2^22 up
-// (+11 % at 2^22, +18 % at 2^24), where the additions are all that counts.  19 bits (14 additions, 8 bucket sets; the 7-bit top digit makes <= 128
+// 16 bits (16 additions per point like every other mode, but ONE bucket set: the 16-bit tables' shape behind these kernels' all-digits-at-once
+// scatter) wins up to 2^16 points, where grouped launches and latencies are all stitch / reduce; 17 bits (15 additions per point, 2 bucket sets)
+// up to 2^21 points (+4 % at 2^20), 20 bits (13 additions, 16 bucket sets) from 2^22 up (+11 % at 2^22, +18 % at 2^24), where the additions are
+// all that counts.  19 bits (14 additions, 8 bucket sets; the 7-bit top digit makes <= 128
 // giant buckets) lies between them at every size and serves the curve 17 bits cannot (BLS12-381); 18 bits (a 2-bit top digit: 3 giant buckets) loses everywhere.
-// msm_hip_set_wide_bits / MSM_HIP_WIDE_BITS = 17 .. 20 override.  -1: the chosen width cannot hold the curve's scalars.
+// msm_hip_set_wide_bits / MSM_HIP_WIDE_BITS = 16 .. 20 override.  -1: the chosen width cannot hold the curve's scalars.
 inline int pick_wide_bits(const msm_hip_ctx* ctx, size_t n) {
-  static const int forced = [] { const char* e = getenv("MSM_HIP_WIDE_BITS"); const int v = e ? atoi(e) : 0; return v >= 17 && v <= 20 ? v : 0; }();
+  static const int forced = [] { const char* e = getenv("MSM_HIP_WIDE_BITS"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 20 ? v : 0; }();
   const int asked = ctx->wide_bits_choice ? ctx->wide_bits_choice : forced;  // msm_hip_set_wide_bits, then the environment
   if (asked) return wide_bits_fit(ctx->curve, asked) ? asked : -1;
-  const int bits = n <= ((size_t)1 << 21) ? 17 : 20;
+  const int bits = n <= ((size_t)1 << 16) ? 16 : n <= ((size_t)1 << 21) ? 17 : 20;
   return wide_bits_fit(ctx->curve, bits) ? bits : 19;
 }
 // SMVP lanes and lengths of a wide fixed-base launch over n points (msm_kernels.h: k_count_wide).  For uniform scalars every virtual window
@@ -584,6 +586,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     const int top_shift = wide_top_shift(ctx->curve, ctx->wide_bits);
 #define LAUNCH_COUNT_WIDE(C) hipLaunchKernelGGL(k_count_wide<C>, dim3(tiles, nvec), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, nvec, n * 8, ctx->d_counts, d_err, top_shift)
     switch (ctx->wide_bits) {
+      case 16: LAUNCH_COUNT_WIDE(16); break;
       case 17: LAUNCH_COUNT_WIDE(17); break;
       case 18: LAUNCH_COUNT_WIDE(18); break;
       case 19: LAUNCH_COUNT_WIDE(19); break;
@@ -610,6 +613,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   hipLaunchKernelGGL(k_scatter_wide<C>, dim3(tiles, nvec), dim3(WIDE_THREADS), 0, st, d_scalars, n_sc, stride, tile_len, tiles, nvec, n * 8, ctx->d_counts, ctx->d_bin_total, \
                      ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, chunks, chunk_len, d_chunk_len, top_shift)
     switch (ctx->wide_bits) {
+      case 16: LAUNCH_SCATTER_WIDE(16); break;
       case 17: LAUNCH_SCATTER_WIDE(17); break;
       case 18: LAUNCH_SCATTER_WIDE(18); break;
       case 19: LAUNCH_SCATTER_WIDE(19); break;
@@ -867,7 +871,7 @@ namespace {
 size_t batch_group(msm_hip_ctx* ctx, size_t n, size_t batch) {
   // 4 at 16 bits, 3 at 14, 2 at 12 (8 / 6 / 5 with the endomorphism's half-length scalars); with fixed-base tables every MSM is one local window
   // (window size of a grouped launch: pick_window_bits with nvec > 1)
-  // (wide tables: an MSM is 2^(C-16) local windows, and its launch leaves bit-plane sums for at most 24 of them: 12 / 3 / 1 MSMs at 17 / 19 / 20 bits)
+  // (wide tables: an MSM is 2^(C-16) local windows, and its launch leaves bit-plane sums for at most 24 of them: 24 / 12 / 3 / 1 MSMs at 16 / 17 / 19 / 20 bits)
   const size_t fit = ctx->wide_bits ? (size_t)(24 / wide_vwin_of(ctx->wide_bits)) : ctx->precomputed ? (size_t)MAXLW : (size_t)(MAXLW / nwin_of(pick_window_bits(ctx, n, 2, ctx->endo), ctx->endo));
   size_t g = n ? ((size_t)1 << 20) / n : 1;
   if (g > fit) g = fit;
@@ -1436,7 +1440,7 @@ int msm_hip_set_window_bits(msm_hip_ctx* ctx, int bits) {
 }
 
 int msm_hip_set_wide_bits(msm_hip_ctx* ctx, int bits) {
-  if (!ctx || (bits != 0 && (bits < 17 || bits > 20))) return MSM_HIP_ERR_INVALID_ARG;
+  if (!ctx || (bits != 0 && (bits < 16 || bits > 20))) return MSM_HIP_ERR_INVALID_ARG;
   ctx->wide_bits_choice = bits;
   return MSM_HIP_OK;
 }
@@ -1444,7 +1448,7 @@ int msm_hip_set_wide_bits(msm_hip_ctx* ctx, int bits) {
 int msm_hip_wide_bits(const msm_hip_ctx* ctx) { return ctx ? ctx->wide_bits : MSM_HIP_ERR_INVALID_ARG; }
 
 int msm_hip_wide_config(int curve, int bits, size_t n, int* digit_bits, int* tables, int* virtual_windows, int* top_shift) {
-  if (curve < MSM_HIP_CURVE_BN254_G1 || curve > MSM_HIP_CURVE_BLS12_381_G2 || (bits != 0 && (bits < 17 || bits > 20))) return MSM_HIP_ERR_INVALID_ARG;
+  if (curve < MSM_HIP_CURVE_BN254_G1 || curve > MSM_HIP_CURVE_BLS12_381_G2 || (bits != 0 && (bits < 16 || bits > 20))) return MSM_HIP_ERR_INVALID_ARG;
   msm_hip_ctx probe;  // (only the two fields the policy reads)
   probe.curve = curve;
   probe.wide_bits_choice = bits;

@@ -719,13 +719,13 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
 // next launch, and that grows with the bucket sets -- 20 bits (16 of them) loses to the endomorphism mode at 2^20 although its SMVP is 0.85 ms
 // alone against 0.99, and wins by 18 % at 2^24; 17 bits (2 of them) wins at 2^20.
 // The digit width C is a template parameter of the two kernels (the tables are built for it when the bases are set: msm_hip.hip picks it from
-// the number of bases -- 17 bits up to 2^21 points, where the bucket sets' stitch / reduce still counts, 19 beyond).
+// the number of bases -- 16 bits up to 2^16 points and 17 up to 2^21, where the bucket sets' stitch / reduce still counts, 20 beyond).
 template <int C>
 struct WideCfg {
-  static_assert(C >= 17 && C <= 20, "digit bits of the wide tables");
+  static_assert(C >= 16 && C <= 20, "digit bits of the wide tables");
   static constexpr int BITS = C;
-  static constexpr int TABLES = WinCfg<C>::NWIN;  // 15 / 15 / 14 / 13 tables 2^(C w) P_i at 17 / 18 / 19 / 20 bits
-  static constexpr int VWIN = 1 << (C - WBITS);   // 2 / 4 / 8 / 16 virtual windows of 2^15 slots
+  static constexpr int TABLES = WinCfg<C>::NWIN;  // 16 / 15 / 15 / 14 / 13 tables 2^(C w) P_i at 16 / 17 / 18 / 19 / 20 bits
+  static constexpr int VWIN = 1 << (C - WBITS);   // 1 / 2 / 4 / 8 / 16 virtual windows of 2^15 slots
   static constexpr int KEYS = VWIN * NCOARSE;     // (virtual window, coarse bin) runs
   static_assert(VWIN <= MAXLW, "virtual windows are local windows");
 };

@@ -181,7 +181,7 @@ def test_wide_table_shapes_follow_the_scalar_field(built):
     out = [C.c_int() for _ in range(4)]
     refs = [C.byref(x) for x in out]
     for cid, r in moduli.items():
-        for bits in (17, 18, 19, 20):
+        for bits in (16, 17, 18, 19, 20):
             t = (254 + bits) // bits
             pos, half = bits * (t - 1), 1 << (bits - 1)
             bias = sum(1 << (bits * w + bits - 1) for w in range(t))
@@ -192,12 +192,12 @@ def test_wide_table_shapes_follow_the_scalar_field(built):
                 continue
             shift = max(s for s in range(bits) if (dmax << s) <= half)
             assert (rc, [x.value for x in out]) == (0, [bits, t, 1 << (bits - 16), shift]), (cid, bits)
-        # the policy: 17 bits up to 2^21 bases where 15 digits of 17 bits hold the scalars (else 19), 20 bits beyond
+        # the policy: 16 bits up to 2^16 bases, 17 up to 2^21 where 15 digits of 17 bits hold the scalars (else 19), 20 bits beyond
         fits17 = ((r - 1 + sum(1 << (17 * w + 16) for w in range(15))) >> 238) - (1 << 16) <= 1 << 16
         assert fits17 == (r < (1 << 254) + (1 << 200)), cid   # BN254, Grumpkin; Pallas and Vesta (2^254 + a 126-bit number); not BLS12-381
-        for n, want in ((1000, 17 if fits17 else 19), (1 << 21, 17 if fits17 else 19), ((1 << 21) + 1, 20), (1 << 24, 20)):
+        for n, want in ((1000, 16), (1 << 16, 16), ((1 << 16) + 1, 17 if fits17 else 19), (1 << 21, 17 if fits17 else 19), ((1 << 21) + 1, 20), (1 << 24, 20)):
             assert L.msm_hip_wide_config(cid, 0, n, *refs) == 0 and out[0].value == want, (cid, n)
-    assert L.msm_hip_wide_config(7, 0, 1, *refs) == -2 and L.msm_hip_wide_config(0, 16, 1, *refs) == -2
+    assert L.msm_hip_wide_config(7, 0, 1, *refs) == -2 and L.msm_hip_wide_config(0, 15, 1, *refs) == -2
 
 
 def test_header_is_plain_c_and_links_from_c(built, tmp_path):

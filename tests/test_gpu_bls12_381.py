@@ -126,15 +126,16 @@ def test_msm_matches_oracle_every_window_size_and_mode(ctx, n):
         assert ctx.msm(sc).to_affine_bytes() == want
         ctx.set_bases(points, precompute="wide")          # 14 digits of 19 bits (top digit shifted by 10 on this curve), 8 virtual windows
         assert ctx.msm(sc).to_affine_bytes() == want and ctx.msm(dev).to_affine_bytes() == want
-        assert ctx.wide_bits() == 19                      # 15 digits of 17 bits cannot hold this scalar field (1.8 x 2^254): the policy's fallback
-        ctx.set_wide_bits(17)
+        assert ctx.wide_bits() == 16                      # (the policy's width for a small base set; beyond 2^16 points 19 bits here, not 17:)
+        ctx.set_wide_bits(17)                             # 15 digits of 17 bits cannot hold this scalar field (1.8 x 2^254)
         try:
             with pytest.raises(m.MsmHipError) as e:
                 ctx.set_bases(points, precompute="wide")
             assert e.value.code == -2
-            ctx.set_wide_bits(20)
-            ctx.set_bases(points, precompute="wide")
-            assert ctx.msm(sc).to_affine_bytes() == want
+            for bits in (19, 20):
+                ctx.set_wide_bits(bits)
+                ctx.set_bases(points, precompute="wide")
+                assert ctx.wide_bits() == bits and ctx.msm(sc).to_affine_bytes() == want
         finally:
             ctx.set_wide_bits(0)
         ctx.set_bases(points)

@@ -107,14 +107,16 @@ def test_msm_matches_oracle_every_window_size_and_mode(cv, n):
         assert ctx.msm(sc).to_affine_bytes() == want
         ctx.set_bases(points, precompute="wide")          # 14 digits of 19 bits (a 255-bit modulus: the top digit reaches 128), 8 virtual windows
         assert ctx.msm(sc).to_affine_bytes() == want and ctx.msm(dev).to_affine_bytes() == want
-        assert ctx.wide_bits() == 17                      # the moduli are 2^254 + a 126-bit number: the top digit of 15 x 17 bits reaches exactly 2^16
-        top = [ref.R - 1, ref.R - 2, 1 << 254, (1 << 254) + 12345, (1 << 254) - 1][: min(n, 5)]      # ... for these
+        assert ctx.wide_bits() == 16                      # (the policy's width for a small base set)
+        # 17 bits: the moduli are 2^254 + a 126-bit number -- the top digit of 15 x 17 bits reaches exactly 2^16 for these:
+        top = [ref.R - 1, ref.R - 2, 1 << 254, (1 << 254) + 12345, (1 << 254) - 1][: min(n, 5)]
         tb = ref.scalars_to_bytes(top)
         assert ctx.msm(tb).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points[: 64 * len(top)], tb, 1))
-        for bits in (19, 20):
+        for bits in (17, 19, 20):
             ctx.set_wide_bits(bits)
             try:
                 ctx.set_bases(points, precompute="wide")
+                assert ctx.wide_bits() == bits
                 assert ctx.msm(sc).to_affine_bytes() == want and ctx.msm(tb).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points[: 64 * len(top)], tb, 1))
             finally:
                 ctx.set_wide_bits(0)

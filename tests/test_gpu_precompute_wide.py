@@ -11,7 +11,7 @@ from tests.util import R, case_inputs, golden_cases
 
 pytestmark = pytest.mark.gpu
 
-WIDTHS = [0, 17, 18, 19, 20]  # 0: the width the library picks from the number of bases
+WIDTHS = [0, 16, 17, 18, 19, 20]  # 0: the width the library picks from the number of bases
 
 
 @pytest.fixture(params=WIDTHS)
@@ -32,6 +32,9 @@ def test_golden_vectors_with_wide_tables(wctx):
 def test_width_follows_the_base_count(ctx):
     pts = ctx.sample_points(300, 1399)
     ctx.set_bases(pts, precompute="wide")
+    assert ctx.wide_bits() == 16
+    big = ctx.sample_points((1 << 16) + 1, 1398)
+    ctx.set_bases(big, precompute="wide")
     assert ctx.wide_bits() == 17
     ctx.set_wide_bits(19)
     ctx.set_bases(pts, precompute="wide")
@@ -39,14 +42,14 @@ def test_width_follows_the_base_count(ctx):
     ctx.set_wide_bits(0)
     ctx.set_bases(pts)
     assert ctx.wide_bits() == 0
-    for bad in (16, 21, -1):
+    for bad in (15, 21, -1):
         assert m.lib().msm_hip_set_wide_bits(ctx._h, bad) == -2
 
 
 @pytest.mark.parametrize("n", [1, 2, 257, 5000, 1 << 16, (1 << 18) + 3])
 def test_wide_tables_match_oracle_and_plain_engine(wctx, n):
     ctx = wctx
-    if n > 5000 and ctx.wide_bits_choice not in (0, 19):
+    if n > 5000 and ctx.wide_bits_choice not in (0, 16, 19):
         pytest.skip("large sizes at the two widths the policy uses")
     pts, sc = ctx.sample_points(n, 1400 + n), ctx.sample_scalars(n, 1401 + n)
     pb, sb = pts.cpu().numpy().tobytes(), sc.cpu().numpy().tobytes()
@@ -69,7 +72,7 @@ def test_wide_digit_edges(wctx):
     """digits at the seams of the virtual windows (magnitude k * 2^15, k * 2^15 +- 1), the most negative digit (with its carry), in every
     window position (17- to 20-bit grids), beside the largest scalars the input contract admits"""
     vals = []
-    for bits, count in ((17, 15), (18, 15), (19, 14), (20, 13)):
+    for bits, count in ((16, 16), (17, 15), (18, 15), (19, 14), (20, 13)):
         for w in range(count):
             for d in (1, 0x7fff, 0x8000, 0x8001, 0xffff, 0x10000, 0x10001, 0x3ffff, 0x40000, 0x40001, 0x78000, 0x78001, 0x7ffff, 0x80000, 0xf8001, 0xfffff):
                 v = d << (bits * w)
@@ -121,7 +124,7 @@ def test_wide_tables_batches_and_flags(wctx):
     pts = ctx.sample_points(n, 1420)
     sc = ctx.sample_scalars(n * batch, 1421)
     ctx.set_bases(pts, precompute="wide")
-    # an MSM is 2^(C-16) local windows, and a launch leaves bit-plane sums for at most 24: 12 / 6 / 3 / 1 whole MSMs per launch at 17 .. 20 bits
+    # an MSM is 2^(C-16) local windows, and a launch leaves bit-plane sums for at most 24: 24 / 12 / 6 / 3 / 1 whole MSMs per launch at 16 .. 20 bits
     group = 24 >> (ctx.wide_bits() - 16)
     assert ctx.batch_group_size(n) == group
     got = ctx.msm_batch(sc, n)                             # groups of `group`, the last one shorter
