@@ -800,12 +800,11 @@ __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__
 }
 
 // second pass: the LDS-ranked, LDS-staged scatter of k_scatter_coarse over all (virtual window, coarse bin) runs at once -- 256 / 1024 / 2048
-// of them at 17 / 19 / 20 bits.  ALL digits of the 1024 scalars of a block iteration are staged together (15 360 / 14 336 / 13 312 entries:
-// 60 / 14 / 6.5 per run): ranked per window as k_scatter_coarse does, a run would receive a fraction of that per iteration and every 4-byte
-// store would be a memory transaction of its own.  108 - 115 KB of LDS: one workgroup of 512 threads per CU.  (At 2^22 points the kernel takes
-// 244 / 351 / 471 us: the shorter the runs, the worse the stores coalesce.)
-constexpr int WIDE_THREADS = 512, WIDE_PER = 2;
-constexpr int WIDE_SUB = WIDE_THREADS * WIDE_PER;     // scalars staged per block iteration
+// of them at 17 / 19 / 20 bits.  ALL digits of the 2048 scalars of a block iteration are staged together (30 720 / 28 672 / 26 624 entries:
+// 120 / 28 / 13 per run): ranked per window as k_scatter_coarse does, a run would receive a fraction of that per iteration and every 4-byte
+// store would be a memory transaction of its own.  One workgroup of 512 threads per CU.  (With 1024 scalars per iteration the kernel took
+// 244 / 351 / 471 us at 2^22 points: the shorter the runs, the worse the stores coalesce.)
+constexpr int WIDE_THREADS = 512;
 template <int C>
 __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
                                                                uint32_t tiles, int nvec, size_t vec_stride, const uint32_t* __restrict__ counts,
@@ -814,11 +813,18 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
                                                                uint32_t chunks, uint32_t host_chunk_len, uint32_t* __restrict__ chunk_len_dev, int top_shift) {
   constexpr int SW = 8;  // full-length scalars
   constexpr int WIDE_KEYS = WideCfg<C>::KEYS, WIDE_TABLES = WideCfg<C>::TABLES;
+  // 5 bytes of LDS per staged entry -- its (virtual window, coarse bin) run, its fine slot, and sign | window | position within the iteration's
+  // scalars (16 bits: the record index is put together when the entry is written out) -- so that 2048 scalars (1536 at 16 bits) fit one
+  // iteration: twice the run length of the 4-byte index staged before (153 - 158 KB of the 160 KB a workgroup may hold)
+  constexpr int WIDE_PER = C == 16 ? 3 : 4;
+  constexpr int WIDE_SUB = WIDE_THREADS * WIDE_PER;   // scalars staged per block iteration
   constexpr int WIDE_STAGE = WIDE_SUB * WIDE_TABLES;  // entries staged per block iteration
+  static_assert(WIDE_SUB <= 2048 && WIDE_TABLES <= 16, "sign | window | position in 16 bits");
+  static_assert(WIDE_STAGE * 5 + WIDE_KEYS * 12 + 64 <= 160 * 1024, "LDS of a workgroup");
   __shared__ uint32_t gpos[WIDE_KEYS];    // write cursor of every run of this tile, relative to its virtual window's array
   __shared__ uint32_t hist[WIDE_KEYS];
   __shared__ uint32_t lstart[WIDE_KEYS];
-  __shared__ uint32_t st_val[WIDE_STAGE];
+  __shared__ uint16_t st_loc[WIDE_STAGE];
   __shared__ uint16_t st_key[WIDE_STAGE];
   __shared__ uint8_t st_fine[WIDE_STAGE];
   __shared__ uint32_t wave_tot[WIDE_THREADS / 64];
@@ -862,26 +868,31 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
   if (publisher && tid == 0) *chunk_len_dev = smvp_chunk_len(max_total, chunks, host_chunk_len);
   for (size_t sub = tile_base; sub < tile_end; sub += WIDE_SUB) {
     for (int k = tid; k < WIDE_KEYS; k += WIDE_THREADS) hist[k] = 0;
-    uint32_t sc[WIDE_PER][WinCfg<C, SW>::WORDS];
-#pragma unroll
-    for (int j = 0; j < WIDE_PER; j++) {
+    __syncthreads();
+    // this thread's WIDE_PER scalars are read twice -- here for the ranks, below for the entries (the second time from the L2) --: held in
+    // registers across the scan they and the ranks passed the 256 registers a wave of this workgroup size may have
+    auto biased = [&](int j, uint32_t* tb) {
       const size_t i = sub + (size_t)j * WIDE_THREADS + tid;
       uint32_t raw[SW], neg = 0;
 #pragma unroll
       for (int k = 0; k < SW; k++) raw[k] = 0;  // an all-zero scalar recodes to all-zero digits: no entries
       if (i < tile_end) ld_scalar<SW>(sv + i * SW, raw, neg);
-      (void)bias_scalar<C, SW>(raw, sc[j]);
-    }
-    __syncthreads();
-    uint32_t rank[WIDE_PER][WIDE_TABLES];
+      (void)bias_scalar<C, SW>(raw, tb);
+    };
+    uint32_t rank[WIDE_PER][(WIDE_TABLES + 1) / 2];  // two 16-bit ranks per register (a run holds fewer than 2^16 entries)
 #pragma unroll
-    for (int j = 0; j < WIDE_PER; j++)
+    for (int j = 0; j < WIDE_PER; j++) {
+      uint32_t tb[WinCfg<C, SW>::WORDS];
+      biased(j, tb);
 #pragma unroll
       for (int w = 0; w < WIDE_TABLES; w++) {
         uint32_t sign, over = 0;
-        const uint32_t mag = wide_digit<C>(sc[j], w, top_shift, sign, over);  // (an overflowing top digit: no entry here as in k_count_wide, which reports it)
-        rank[j][w] = mag ? atomicAdd(&hist[wide_key(mag)], 1u) : 0u;
+        const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, over);  // (an overflowing top digit: no entry here as in k_count_wide, which reports it)
+        const uint32_t r = mag ? atomicAdd(&hist[wide_key(mag)], 1u) : 0u;
+        if (w & 1) rank[j][w >> 1] |= r << 16;
+        else rank[j][w >> 1] = r;
       }
+    }
     __syncthreads();
     {  // exclusive scan of the run lengths: KPT consecutive keys per thread (with fewer runs than threads, the first WIDE_KEYS threads take one each)
       constexpr int KPT = WIDE_KEYS >= WIDE_THREADS ? WIDE_KEYS / WIDE_THREADS : 1;
@@ -912,24 +923,28 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
     __syncthreads();
     const uint32_t total = lstart[WIDE_KEYS - 1] + hist[WIDE_KEYS - 1];
 #pragma unroll
-    for (int j = 0; j < WIDE_PER; j++)
+    for (int j = 0; j < WIDE_PER; j++) {
+      uint32_t tb[WinCfg<C, SW>::WORDS];
+      biased(j, tb);
 #pragma unroll
       for (int w = 0; w < WIDE_TABLES; w++) {
         uint32_t sign, over = 0;
-        const uint32_t mag = wide_digit<C>(sc[j], w, top_shift, sign, over);
+        const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, over);
         if (mag) {
-          const uint32_t key = wide_key(mag), e = lstart[key] + rank[j][w];
-          const uint32_t pos = (uint32_t)(sub + (size_t)j * WIDE_THREADS + tid);
-          st_val[e] = ((uint32_t)(w * table_stride) + pos) | (sign << 31);  // window w of point i = record w * n_bases + i
+          const uint32_t key = wide_key(mag), e = lstart[key] + ((rank[j][w >> 1] >> ((w & 1) * 16)) & 0xffffu);
+          st_loc[e] = (uint16_t)((sign << 15) | ((uint32_t)w << 11) | (uint32_t)(j * WIDE_THREADS + tid));
           st_key[e] = (uint16_t)key;
           st_fine[e] = (uint8_t)(mag & 0xffu);
         }
       }
+    }
     __syncthreads();
     for (uint32_t e = tid; e < total; e += WIDE_THREADS) {
       const uint32_t key = st_key[e];
       const size_t d = (size_t)(lw0 + (key >> 7)) * stride + gpos[key] + (e - lstart[key]);
-      tmp_val[d] = st_val[e];
+      const uint32_t loc = st_loc[e];
+      // window w of point i = record w * n_bases + i
+      tmp_val[d] = ((uint32_t)(((loc >> 11) & 15u) * table_stride) + (uint32_t)sub + (loc & 2047u)) | ((loc >> 15) << 31);
       tmp_fine[d] = st_fine[e];
     }
     __syncthreads();
