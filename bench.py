@@ -297,7 +297,7 @@ def main():
     #                 (default on one GPU: the same bucket additions, half the buckets to reduce; 2 x the base memory)
     #   plain         the reference's shape: 16 windows over n points
     #   tables        fixed-base tables 2^(16 w) P_i: one bucket set per MSM (16 x the base memory)
-    #   tables_wide   fixed-base tables 2^(C w) P_i, C-bit digits (17 up to 2^21 points: 15 bucket additions per point into 2 virtual windows of 2^15
+    #   tables_wide   fixed-base tables 2^(C w) P_i, C-bit digits (17 up to 2^20 points: 15 bucket additions per point into 2 virtual windows of 2^15
     #                 slots; 20 beyond: 13 additions, 16 virtual windows)
     #   (window-sharded runs: plain by default -- with endomorphism bases the ranks share the 8 half-length windows, one per rank at
     #    8 GPUs, measured 8 % slower per MSM than two full-length windows per rank: every rank splits every scalar, profiles/r03_share_ab.txt)
@@ -645,7 +645,7 @@ def main():
                    "bases": {"plain": "n points, 16 windows (the reference's shape)",
                              "endomorphism": "P and phi(P) resident: scalars split into two 127-bit halves on the device, 8 windows over 2n points",
                              "tables": "fixed-base tables 2^(16 w) P resident: one bucket set per MSM",
-                             "tables_wide": "fixed-base tables 2^(C w) P resident: ceil(255 / C) digits of C bits per scalar (C = 17 up to 2^21 points, 20 beyond), "
+                             "tables_wide": "fixed-base tables 2^(C w) P resident: ceil(255 / C) digits of C bits per scalar (C = 16 up to 2^16 points, 17 up to 2^20, 20 beyond), "
                                             "one bucket set of 2^(C-1) slots run as virtual windows of 2^15"}[bases_mode],
                    "window_bits": bits_main,
                    "windows_per_gpu": w_local if sharded else smvp_shape(bits_main)[1], "msms_per_launch": group if sharded else group1,

@@ -71,7 +71,7 @@ extern "C" {
                                           ceil(255 / C) of them -- 15 bucket additions per point at C = 17, 14 at 19, 13 at 20, instead of the reference's
                                           16 (src/cuzk/msm.rs:79-82: chunk_size 16) -- into ONE bucket set of 2^(C-1) slots, run as 2^(C-16) "virtual
                                           windows" of 2^15 slots.  C by the number of bases: 16 up to 2^16 points (the 16-bit tables behind this mode's sort),
-                                          17 up to 2^21 (19 on BLS12-381, whose scalar field 15 digits of 17 bits cannot hold), 20 beyond;
+                                          17 up to 2^20 (19 on BLS12-381, whose scalar field 15 digits of 17 bits cannot hold), 20 beyond;
                                           msm_hip_set_wide_bits overrides.
                                           The top table is 2^(C (T-1) - t) P_i and the top digit is used shifted by t, so that it spreads over the bucket
                                           set (t from the scalar field's modulus; exact for any point).  For fixed bases: over the endomorphism mode +44 ... 58 % at

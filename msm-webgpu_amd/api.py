@@ -265,7 +265,7 @@ class MsmContext:
         """points: bytes (host, n x 64 B wire format) or a CUDA uint8 tensor holding the same bytes.
         mont256: the coordinates are x * 2^256 mod p (4 x 64-bit Montgomery limbs, R = 2^256) instead of canonical integers.
         precompute: fixed-base tables 2^(16 w) P_i (16 x the memory): whole MSMs then use one bucket set for all windows.  "wide":
-        MSM_HIP_BASES_PRECOMPUTE_WIDE -- tables 2^(C w) P_i for digits of C = 17 (more than 2^21 bases: 20) bits: 15 (13) bucket additions per
+        MSM_HIP_BASES_PRECOMPUTE_WIDE -- tables 2^(C w) P_i for digits of C = 17 (more than 2^20 bases: 20; up to 2^16: 16) bits: 15 (13) bucket additions per
         point instead of 16, one bucket set (large MSMs; set_wide_bits overrides C).
         endomorphism: True: also store phi(P_i) (2 x the memory): whole MSMs split every scalar into two 127-bit halves and need
         half the windows.  False (this wrapper's default: the stage-level parity tests read the reference's 16-window shape):

@@ -294,7 +294,8 @@ inline bool wide_bits_fit(int curve, int bits) { return wide_top_max(curve, bits
 // MSM costs in the pipeline is sort + SMVP + the stitch / reduce work that runs beside the next launch, and the last grows with the bucket sets:
 // 16 bits (16 additions per point like every other mode, but ONE bucket set: the 16-bit tables' shape behind these kernels' all-digits-at-once
 // scatter) wins up to 2^16 points, where grouped launches and latencies are all stitch / reduce; 17 bits (15 additions per point, 2 bucket sets)
-// up to 2^21 points (+4 % at 2^20), 20 bits (13 additions, 16 bucket sets) from 2^22 up (+11 % at 2^22, +18 % at 2^24), where the additions are
+// up to 2^20 points (+4 % at 2^20), 20 bits (13 additions, 16 bucket sets) beyond (2^21: 372 - 380 against 366 - 369 MSM/s with 17 bits; +11 % over the
+// endomorphism mode at 2^22, +18 % at 2^24), where the additions are
 // all that counts.  19 bits (14 additions, 8 bucket sets; the 7-bit top digit makes <= 128
 // giant buckets) lies between them at every size and serves the curve 17 bits cannot (BLS12-381); 18 bits (a 2-bit top digit: 3 giant buckets) loses everywhere.
 // msm_hip_set_wide_bits / MSM_HIP_WIDE_BITS = 16 .. 20 override.  -1: the chosen width cannot hold the curve's scalars.
@@ -302,7 +303,7 @@ inline int pick_wide_bits(const msm_hip_ctx* ctx, size_t n) {
   static const int forced = [] { const char* e = getenv("MSM_HIP_WIDE_BITS"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 20 ? v : 0; }();
   const int asked = ctx->wide_bits_choice ? ctx->wide_bits_choice : forced;  // msm_hip_set_wide_bits, then the environment
   if (asked) return wide_bits_fit(ctx->curve, asked) ? asked : -1;
-  const int bits = n <= ((size_t)1 << 16) ? 16 : n <= ((size_t)1 << 21) ? 17 : 20;
+  const int bits = n <= ((size_t)1 << 16) ? 16 : n <= ((size_t)1 << 20) ? 17 : 20;
   return wide_bits_fit(ctx->curve, bits) ? bits : 19;
 }
 // SMVP lanes and lengths of a wide fixed-base launch over n points (msm_kernels.h: k_count_wide).  For uniform scalars every virtual window

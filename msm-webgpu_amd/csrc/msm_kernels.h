@@ -719,7 +719,7 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
 // next launch, and that grows with the bucket sets -- 20 bits (16 of them) loses to the endomorphism mode at 2^20 although its SMVP is 0.85 ms
 // alone against 0.99, and wins by 18 % at 2^24; 17 bits (2 of them) wins at 2^20.
 // The digit width C is a template parameter of the two kernels (the tables are built for it when the bases are set: msm_hip.hip picks it from
-// the number of bases -- 16 bits up to 2^16 points and 17 up to 2^21, where the bucket sets' stitch / reduce still counts, 20 beyond).
+// the number of bases -- 16 bits up to 2^16 points and 17 up to 2^20, where the bucket sets' stitch / reduce still counts, 20 beyond).
 template <int C>
 struct WideCfg {
   static_assert(C >= 16 && C <= 20, "digit bits of the wide tables");

@@ -192,10 +192,10 @@ def test_wide_table_shapes_follow_the_scalar_field(built):
                 continue
             shift = max(s for s in range(bits) if (dmax << s) <= half)
             assert (rc, [x.value for x in out]) == (0, [bits, t, 1 << (bits - 16), shift]), (cid, bits)
-        # the policy: 16 bits up to 2^16 bases, 17 up to 2^21 where 15 digits of 17 bits hold the scalars (else 19), 20 bits beyond
+        # the policy: 16 bits up to 2^16 bases, 17 up to 2^20 where 15 digits of 17 bits hold the scalars (else 19), 20 bits beyond
         fits17 = ((r - 1 + sum(1 << (17 * w + 16) for w in range(15))) >> 238) - (1 << 16) <= 1 << 16
         assert fits17 == (r < (1 << 254) + (1 << 200)), cid   # BN254, Grumpkin; Pallas and Vesta (2^254 + a 126-bit number); not BLS12-381
-        for n, want in ((1000, 16), (1 << 16, 16), ((1 << 16) + 1, 17 if fits17 else 19), (1 << 21, 17 if fits17 else 19), ((1 << 21) + 1, 20), (1 << 24, 20)):
+        for n, want in ((1000, 16), (1 << 16, 16), ((1 << 16) + 1, 17 if fits17 else 19), (1 << 20, 17 if fits17 else 19), ((1 << 20) + 1, 20), (1 << 24, 20)):
             assert L.msm_hip_wide_config(cid, 0, n, *refs) == 0 and out[0].value == want, (cid, n)
     assert L.msm_hip_wide_config(7, 0, 1, *refs) == -2 and L.msm_hip_wide_config(0, 15, 1, *refs) == -2
 

@@ -1,5 +1,5 @@
 """Wide fixed-base tables (round 4): MSM_HIP_BASES_PRECOMPUTE_WIDE stores 2^(C w) P_i and recodes every scalar into signed digits
-of C = 17 bits (15 of them; 19 bits, 14, for base sets beyond 2^21 points) -- 15 (14) bucket additions per point instead of the reference's 16
+of C = 17 bits (15 of them; 16 bits up to 2^16 points, 20 bits -- 13 digits -- beyond 2^20) -- 15 (16, 13) bucket additions per point instead of the reference's 16
 (src/cuzk/msm.rs:79-82) -- into one bucket set of 2^(C-1) slots that the engine runs as 2 (8) virtual windows of 2^15.  Same group element as
 the plain engine and the oracle, at every digit width the library builds (17 .. 20)."""
 import pytest
@@ -149,9 +149,9 @@ def test_wide_tables_batches_and_flags(wctx):
     assert ctx.msm(sc[:n].contiguous()).to_affine_bytes() == got[0].to_affine_bytes()
 
 
-@pytest.mark.parametrize("n,bits", [(1 << 20, 17), ((1 << 21) + 8, 20)])
+@pytest.mark.parametrize("n,bits", [(1 << 20, 17), ((1 << 20) + 8, 20)])
 def test_wide_tables_at_full_sizes_equal_the_other_modes(ctx, n, bits):
-    """BASELINE config 2's size (and the first size the policy gives 20-bit digits): the wide tables' result is the endomorphism mode's and the
+    """BASELINE config 2's size (and just beyond it, where the policy gives 20-bit digits): the wide tables' result is the endomorphism mode's and the
     16-bit tables' -- three independent paths through the sort and the finish -- for uniform and for skewed scalars; at 2^20 the endomorphism
     mode itself is checked bit-exactly against the CPU oracle by bench.py and tests/test_gpu_baseline_configs.py."""
     import torch
