@@ -142,6 +142,13 @@ def test_wide_tables_batches_and_flags(wctx):
     for k in range(4):
         ctx.launch(sc[k * n:(k + 1) * n].contiguous(), slot=k)
     assert [ctx.finish(k).to_affine_bytes() for k in range(4)] == [g.to_affine_bytes() for g in got[:4]]
+    # scalars handed over as s * 2^256 mod r (the conversion pass sits in front of the wide recode as in front of every other)
+    vals = ref.bytes_to_scalars(sc[:n].cpu().numpy().tobytes())
+    ctx.set_scalar_format(True)
+    try:
+        assert ctx.msm(ref.scalars_to_bytes([(v << 256) % R for v in vals])).to_affine_bytes() == got[0].to_affine_bytes()
+    finally:
+        ctx.set_scalar_format(False)
     # not combinable with the other table mode or the endomorphism
     for flags in (32 | 4, 32 | 8, 32 | 16):
         assert m.lib().msm_hip_set_bases_bn254(ctx._h, pb, n, flags) == -2
