@@ -560,7 +560,10 @@ def main():
     # same pipeline with the bases held as wide tables (MSM_HIP_BASES_PRECOMPUTE_WIDE: 15 bucket additions per point at 2^20 instead of 16,
     # 13 from 2^22 up), after everything the headline needs has been measured; its result must be the headline mode's.
     wide_line = None
-    if (world == 1 and emulate <= 1 and bases_mode != "tables_wide" and os.environ.get("BENCH_TABLES_WIDE", "1") != "0"
+    # (not under rocprofv3 unless asked for -- BENCH_TABLES_WIDE=2 --: its launches would mix into the per-kernel averages of the profile this
+    #  command is compared with)
+    profiled = "ROCP_TOOL_LIBRARIES" in os.environ and os.environ.get("BENCH_TABLES_WIDE") != "2"
+    if (world == 1 and emulate <= 1 and not profiled and bases_mode != "tables_wide" and os.environ.get("BENCH_TABLES_WIDE", "1") != "0"
             and args.logn <= (24 if os.environ.get("BENCH_TABLES_WIDE") == "2" else 22)):  # (2^23, 2^24: 13 GiB of tables + 31 GiB of sort arrays, on request)
         ctx.set_stage_timing(0)
         torch.cuda.synchronize()
