@@ -44,6 +44,294 @@ def smvp_algorithmic_bytes(n, w_local, buckets=BUCKETS):
     return n * w_local * (64 + 4) + w_local * buckets * 96
 
 
+def smvp_shape(m, ctx, n, bases_mode, bits):
+    """(inputs per bucket set, bucket sets, buckets per set) of one whole MSM's SMVP launch over n points at a window size"""
+    nwin, buckets = m.MsmContext.window_config(bits)
+    if bases_mode == "endomorphism":
+        return 2 * n, m.MsmContext.endomorphism_window_count(bits), buckets
+    if bases_mode == "tables":
+        return NUM_WINDOWS * n, 1, buckets
+    if bases_mode == "tables_wide":
+        wb = ctx.wide_bits()
+        return ((254 + wb) // wb) * n / (1 << (wb - 16)), 1 << (wb - 16), buckets
+    return n, nwin, buckets
+
+
+class WholeMsmRunner:
+    """Back-to-back whole MSMs of n points on one GPU through the launch / finish halves of the C ABI: a launch holds one MSM (n >= 2^19)
+    or up to `group` whole small MSMs (as msm_hip_run_batch_* does; vector k of a launch is scalar set k & 1); `depth` launches in flight
+    over the engine's result slots, so that the host window combines (47 us per MSM) and the launch calls of one launch run under the
+    device work of the others.  Create it AFTER set_bases: the grouping follows the base mode."""
+
+    def __init__(self, m, torch, ctx, n, scalar_sets, bases_mode, depth=0):
+        self.m, self.ctx, self.n, self.sets, self.bases_mode = m, ctx, n, scalar_sets, bases_mode
+        self.group = max(1, min(ctx.batch_group_size(n), 8))
+        self.scalars = torch.cat([scalar_sets[k & 1] for k in range(self.group)], dim=0).contiguous() if self.group > 1 else None
+        # launches in flight (4 result slots): 2 where one launch is one large MSM, 3 for grouped small MSMs, whose host combines (4 per launch)
+        # would otherwise sit between launches (measured: +5 % at 2^16, +3 % at 2^18, nothing at 2^20)
+        self.depth = max(1, min(4, depth or int(os.environ.get("BENCH_PIPE_DEPTH", "0")) or (3 if self.group > 1 else 2)))
+
+    def sizes(self, count):
+        """`count` MSMs in ceil(count / group) launches: full launches and the remainder LAST when it is at least half a launch -- what
+        follows the last launch's main-stream work (bucket reduce, host combines) is not hidden by a next launch and is shorter for a
+        smaller one (measured at 2^16, 20 MSMs: 0.293 vs 0.328 ms per MSM) --, else launches of nearly equal size."""
+        g = self.group
+        k = -(-count // g)
+        rem = count % g
+        if rem and 2 * rem >= g:
+            return [g] * (count // g) + [rem]
+        return [count // k + (1 if i < count % k else 0) for i in range(k)]
+
+    def last_set(self, count):
+        """index of the scalar set the last MSM of run(count) uses"""
+        return (count - 1) & 1 if self.group == 1 else (self.sizes(count)[-1] - 1) & 1
+
+    def run(self, count, stages=None):
+        """`count` MSMs; returns the last result.  `stages` (a list) receives (smvp kernel ms, bucket sets, window bits) of every launch
+        (needs stage timing level >= 1)."""
+        ctx, n, result, pending = self.ctx, self.n, None, []
+
+        def collect():
+            slot0, gs0 = pending.pop(0)
+            res = ctx.finish(slot0) if self.group == 1 else ctx.finish_batch(slot0, gs0)[-1]
+            if stages is not None:
+                bits = ctx.last_window_bits()
+                stages.append((ctx.stage_ms()["smvp"], gs0 * smvp_shape(self.m, ctx, n, self.bases_mode, bits)[1], bits))
+            return res
+
+        for k, gs in enumerate(self.sizes(count)):
+            slot = k % self.depth
+            if self.group == 1:
+                ctx.launch(self.sets[k & 1], slot)
+            else:
+                ctx.launch_batch(self.scalars[: gs * n], n, slot)
+            pending.append((slot, gs))
+            if len(pending) == self.depth:
+                result = collect()
+        while pending:
+            result = collect()
+        return result
+
+    def roofline(self, stages):
+        """the SMVP accumulate kernel over the launches in `stages`: algorithmic bytes per launch / average duration vs HBM peak"""
+        if not stages:
+            return None
+        ms = sum(s[0] for s in stages) / len(stages)
+        alg = sum(smvp_algorithmic_bytes(smvp_shape(self.m, self.ctx, self.n, self.bases_mode, b)[0], w, 1 << (b - 1)) for _, w, b in stages) / len(stages)
+        ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"bound": "hbm", "kernel": "k_smvp_chunks", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "algorithmic_bytes": alg, "kernel_ms": ms, "launches": len(stages)}
+
+
+def measure_configs(m, torch, ctx, args, spec, points_main, sets_main):
+    """BASELINE.json's configs other than the headline's, each with its own timed region on this one GPU (inputs resident in HBM), the SMVP
+    kernel's roofline fraction from its own HIP events, and a check of its result.  Returns (configs, checks): `checks` are the comparisons
+    with the CPU oracle, run later in the cpu_baseline leg (the oracle is never imported on the measurement path).
+      c1  2^16 MSM (BASELINE: the reference's CPU-runnable case): GPU throughput and latency; the oracle's own time is its CPU figure
+      c3  2^20, windows over 8 GPUs: ONE rank's share (8 MSMs' shares per launch) timed on this GPU -- a projection, no collective --, and all
+          8 ranks' shares run one after the other, gathered in rank order and combined == the whole MSM
+      c4  2^24 MSM: >= 5 timed MSMs; whole == the 8 plain window-range shares combined; a 2^16 slice against the oracle
+      c5  64 x 2^18 over one shared base through msm_hip_run_batch_device_bn254, default (endomorphism) and wide-table bases; one vector
+          against the oracle"""
+    from msm_webgpu_amd.sharding import ShardedMsmPipeline, gathered_window_sums, window_range
+
+    spec = dict(item.split(":") for item in spec.split(",") if item)
+    cfg, checks = {}, []
+    W = max(args.warmup, 1)
+    host = lambda t: t.cpu().numpy().tobytes()
+
+    def sync():
+        torch.cuda.synchronize()
+
+    def timed_run(runner, warm, count):
+        ctx.set_stage_timing(1)
+        runner.run(warm, None)
+        st = []
+        sync()
+        t0 = time.perf_counter()
+        last = runner.run(count, st)
+        sync()
+        return time.perf_counter() - t0, last, st
+
+    if "c1" in spec:
+        logn = int(spec["c1"])
+        n = 1 << logn
+        pts = ctx.sample_points(n, 0xC10001)
+        sets = [ctx.sample_scalars(n, 0xC10100 + k) for k in range(2)]
+        ctx.set_bases(pts, endomorphism=True)
+        r = WholeMsmRunner(m, torch, ctx, n, sets, "endomorphism")
+        warm, count = r.group * r.depth + W, max(args.steps, 8 * r.group)
+        el, last, st = timed_run(r, warm, count)
+        ctx.set_stage_timing(0)
+        lat = []
+        for i in range(7):
+            sync()
+            t1 = time.perf_counter()
+            ctx.msm(sets[i & 1])
+            lat.append((time.perf_counter() - t1) * 1e3)
+        cfg["c1"] = {"workload": "2^%d BN254 G1 MSM, one GPU, bases with their endomorphism images, %d whole MSMs per launch" % (logn, r.group),
+                     "value": count / el, "unit": "MSM/s", "ms_per_msm": el * 1e3 / count, "timed_msms": count, "untimed_msms_directly_before": warm,
+                     "window_bits": st[0][2], "latency_ms_single_msm": sorted(lat)[len(lat) // 2], "roofline": r.roofline(st)}
+        checks.append({"config": "c1", "key": "verified_bit_exact_vs_cpu", "points": host(pts), "scalars": host(sets[r.last_set(count)]),
+                       "got": last.to_affine_bytes(), "threads": 1, "time_as": "cpu_path"})
+        del pts, sets, r
+
+    if "c3" in spec:
+        logn = int(spec["c3"])
+        n = 1 << logn
+        pts = points_main if points_main is not None else ctx.sample_points(n, 0xC30001)
+        sets = sets_main if points_main is not None else [ctx.sample_scalars(n, 0xC30100 + k) for k in range(2)]
+        world, c3 = 8, {"workload": "2^%d BN254 G1 MSM, windows over 8 GPUs: ONE rank's share timed on this GPU (8 MSMs' shares per launch)" % logn,
+                        "note": "a one-GPU projection -- no collective, no second GPU; the driver's SCALE run is the measurement"}
+        ctx.set_stage_timing(0)
+        for mode in [x for x in os.environ.get("BENCH_C3_MODES", "plain,tables_wide").split(",") if x]:
+            wide = mode == "tables_wide"
+            if wide:
+                ctx.set_wide_bits(int(os.environ.get("BENCH_WIDE_BITS", "19")))
+                ctx.set_bases(pts, precompute="wide")
+                nwin = 1 << (ctx.wide_bits() - 16)
+            else:
+                ctx.set_bases(pts)
+                nwin = NUM_WINDOWS
+            g = max(1, nwin // -(-nwin // world))  # as many MSMs' shares per launch as make up one MSM's worth of bucket sets
+            batch = torch.cat([sets[k & 1] for k in range(g)], dim=0).contiguous()
+            # (i) every rank's launch, one after the other; what the all-gather would deliver, combined == the whole MSM (plain bases, 16 windows)
+            per = -(-nwin // world)
+            rec = 2 if wide else 1  # wide shares: (window sum, plain total) pairs
+            gathered = torch.zeros((world, g * per * rec, ctx.jb), dtype=torch.uint8, device=batch.device)
+            for rk in range(world):
+                b, e = window_range(rk, world, nwin)
+                if e > b:
+                    (ctx.launch_vwindows_batch if wide else ctx.launch_windows_batch)(batch, n, b, e, rk % 3, gathered[rk][: g * (e - b) * rec])
+                    ctx.slot_sync(rk % 3)
+            hostg = gathered.cpu().numpy()
+            if wide:
+                got = m.MsmContext.combine_vwindows_batch(gathered_window_sums(hostg.reshape(world, g * per, rec * ctx.jb), g, world, nwin), nwin)
+                ctx.set_wide_bits(0)
+                ctx.set_bases(pts)
+            else:
+                got = m.MsmContext.combine_windows_batch(gathered_window_sums(hostg, g, world, nwin), nwin)
+            whole = [ctx.msm(sets[k]) for k in range(2)]
+            ok = all(bool(got[v] == whole[v & 1]) for v in range(g))
+            if wide:
+                ctx.set_wide_bits(int(os.environ.get("BENCH_WIDE_BITS", "19")))
+                ctx.set_bases(pts, precompute="wide")
+            # (ii) rank 0's share through the sharded pipeline, timed
+            pipe = ShardedMsmPipeline(ctx, 0, 1, depth=3, msms_per_issue=g, emulate_world=world, wide=wide)
+            ctx.set_stage_timing(1)
+
+            def run(count, st=None):
+                inflight = []
+                for _ in range(-(-count // g)):
+                    pipe.issue(batch, n, inputs_complete=True)
+                    inflight.append(1)
+                    if len(inflight) == pipe.depth:
+                        pipe.complete()
+                        inflight.pop()
+                        if st is not None:
+                            st.append(ctx.stage_ms()["smvp"])
+                while inflight:
+                    pipe.complete()
+                    inflight.pop()
+                    if st is not None:
+                        st.append(ctx.stage_ms()["smvp"])
+                return -(-count // g) * g
+
+            warm = run(3 * g + W)
+            st = []
+            sync()
+            t0 = time.perf_counter()
+            count = run(max(args.steps, 3 * g), st)
+            sync()
+            el = time.perf_counter() - t0
+            wl = pipe.w_end - pipe.w_begin
+            per_set = ((254 + ctx.wide_bits()) // ctx.wide_bits()) * n / nwin if wide else n
+            alg = smvp_algorithmic_bytes(per_set, g * wl)
+            kms = sum(st) / len(st)
+            c3[mode] = {"windows_shared": "%d virtual windows of the wide tables (%d-bit digits, %d additions per point)" % (nwin, ctx.wide_bits(), (254 + ctx.wide_bits()) // ctx.wide_bits()) if wide
+                        else "16 windows of 16 bits", "windows_per_rank": wl, "msms_per_launch": g,
+                        "ms_per_msm_one_rank_share": el * 1e3 / count, "projected_msm_per_s_at_8_gpus": count / el, "timed_msm_shares": count,
+                        "untimed_msm_shares_directly_before": warm, "all_8_shares_combined_equal_whole_msm": ok,
+                        "roofline": {"bound": "hbm", "kernel": "k_smvp_chunks", "kernel_ms": kms, "algorithmic_bytes": alg, "achieved": alg / (kms * 1e-3) / 1e9,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+            del pipe, batch, gathered
+        ctx.set_wide_bits(0)
+        ctx.set_bases(pts)
+        ctx.set_stage_timing(0)
+        w0 = ctx.msm(sets[0])
+        cfg["c3"] = c3
+        checks.append({"config": "c3", "key": "whole_msm_verified_bit_exact_vs_cpu", "points": host(pts), "scalars": host(sets[0]), "got": w0.to_affine_bytes()})
+        del pts, sets
+
+    if "c4" in spec:
+        logn = int(spec["c4"])
+        n = 1 << logn
+        pts = ctx.sample_points(n, 0xC40001)
+        sets = [ctx.sample_scalars(n, 0xC40002 + k) for k in range(2)]
+        ctx.set_bases(pts, endomorphism=True)
+        r = WholeMsmRunner(m, torch, ctx, n, sets, "endomorphism")
+        warm, count = r.group * r.depth + min(W, 3), max(5, r.group * 2)
+        el, last, st = timed_run(r, warm, count)
+        ctx.set_stage_timing(0)
+        whole = ctx.msm(sets[0])
+        # the 8 window ranges an 8-GPU run would take (16 full-length windows over the n plain records: no endomorphism split on this path)
+        parts = [ctx.msm_windows(sets[0], *window_range(rk, 8)) for rk in range(8)]
+        shares_ok = bool(m.MsmContext.combine_windows(torch.cat(parts, dim=0)) == whole)
+        k = min(1 << 16, max(n // 4, 1))
+        off = (5 << 20) if n > (6 << 20) else n // 2
+        sl_p, sl_s = pts[off:off + k].contiguous(), sets[0][off:off + k].contiguous()
+        ctx.set_bases(sl_p, endomorphism=True)
+        got = ctx.msm(sl_s)
+        cfg["c4"] = {"workload": "2^%d BN254 G1 MSM, one GPU, bases with their endomorphism images" % logn, "value": count / el, "unit": "MSM/s",
+                     "ms_per_msm": el * 1e3 / count, "timed_msms": count, "untimed_msms_directly_before": warm, "window_bits": st[0][2],
+                     "roofline": r.roofline(st), "whole_equals_8_window_range_shares_combined": shares_ok}
+        checks.append({"config": "c4", "key": "slice_2p%d_verified_bit_exact_vs_cpu" % (k.bit_length() - 1), "points": host(sl_p), "scalars": host(sl_s),
+                       "got": got.to_affine_bytes()})
+        del pts, sets, r, parts, sl_p, sl_s
+
+    if "c5" in spec:
+        b_, l_ = spec["c5"].split("x")
+        batch, n = int(b_), 1 << int(l_)
+        pts = ctx.sample_points(n, 0xC50001)
+        sc = ctx.sample_scalars(n * batch, 0xC50002)  # `batch` independent scalar vectors, contiguous
+        c5 = {"workload": "%d x 2^%s BN254 G1 MSMs over one shared base, one GPU, msm_hip_run_batch_device_bn254" % (batch, l_),
+              "note": "at 8 GPUs whole MSMs are dealt out (no exchange on the data path): 8 x this figure is the projection, the driver's SCALE run the measurement"}
+        results = {}
+        for mode in ("endomorphism", "tables_wide"):
+            ctx.set_bases(pts, endomorphism=mode == "endomorphism", precompute="wide" if mode == "tables_wide" else False)
+            ctx.set_stage_timing(1)
+            ctx.msm_batch(sc, n)  # warm-up: one whole batch (the pools take this mode's shape)
+            passes = 2
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(passes):
+                res = ctx.msm_batch(sc, n)
+            sync()
+            el = time.perf_counter() - t0
+            g = ctx.batch_group_size(n)
+            last_g = batch % g or g
+            bits = ctx.last_window_bits()
+            shp = smvp_shape(m, ctx, n, mode, bits)
+            kms = ctx.stage_ms()["smvp"]
+            alg = smvp_algorithmic_bytes(shp[0], last_g * shp[1], 1 << (bits - 1))
+            results[mode] = [x.to_affine_bytes() for x in res]
+            c5[mode] = {"value": passes * batch / el, "unit": "MSM/s", "ms_per_msm": el * 1e3 / (passes * batch), "timed_msms": passes * batch,
+                        "untimed_msms_directly_before": batch, "msms_per_launch": g, "window_bits": bits if mode == "endomorphism" else ctx.wide_bits(),
+                        "roofline": {"bound": "hbm", "kernel": "k_smvp_chunks", "kernel_ms": kms, "kernel_ms_is": "the batch's last launch (%d MSMs)" % last_g,
+                                     "algorithmic_bytes": alg, "achieved": alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        c5["both_modes_same_results"] = results["endomorphism"] == results["tables_wide"]
+        c5["all_results_differ"] = len(set(results["endomorphism"])) == batch
+        cfg["c5"] = c5
+        kv = batch - 1
+        checks.append({"config": "c5", "key": "vector_%d_verified_bit_exact_vs_cpu" % kv, "points": host(pts), "scalars": host(sc[kv * n:(kv + 1) * n]),
+                       "got": results["endomorphism"][kv]})
+        del pts, sc
+    ctx.set_stage_timing(2)
+    torch.cuda.empty_cache()
+    return cfg, checks
+
+
 def self_launch(n_ranks):
     """`python bench.py --gpus N` without a launcher: this parent (which never touches the GPU and never execs) starts one
     child per GPU with the torch.distributed environment set, lets rank 0 print the JSON line on the shared stdout, and
@@ -143,7 +431,9 @@ def native_mgpu_main(args):
     ctx0 = m.MsmContext(ids[0])
     points = ctx0.sample_points(n, 0x6D736D5F0000 + args.logn)
     mg = m.MultiGpuMsm(ids, "auto" if distinct else "host")
-    mg.set_bases(points.cpu().numpy().tobytes(), endomorphism=bases_mode == "endomorphism")
+    if bases_mode == "tables_wide":
+        mg.set_wide_bits(int(os.environ.get("BENCH_WIDE_BITS", "19")))
+    mg.set_bases(points.cpu().numpy().tobytes(), endomorphism=bases_mode == "endomorphism", precompute="wide" if bases_mode == "tables_wide" else False)
     full = mg.group_size
     group = int(os.environ.get("BENCH_MSMS_PER_LAUNCH", "0")) or full
     per_dev = {}
@@ -188,7 +478,8 @@ def native_mgpu_main(args):
                       "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                       "config": {"workload": "2^%d BN254 G1 MSM, 16-bit signed-bucket windows, inputs resident in HBM" % args.logn,
                                  "parallelism": "in-process msm_hip_mgpu_*: %s windows over %d contexts, %s gather" % (
-                                     "8 half-length" if bases_mode == "endomorphism" else "16", len(ids), "RCCL" if mg.uses_rccl else "pinned-buffer"),
+                                     "8 half-length" if bases_mode == "endomorphism" else "the virtual (wide tables)" if bases_mode == "tables_wide" else "16", len(ids),
+                                     "RCCL" if mg.uses_rccl else "pinned-buffer"),
                                  "device_ids": ids, "msms_per_launch": group, "launches_in_flight": depth},
                       "sharded_result_equals_single_gpu": ok, "native_mgpu": True, "rccl_ranks": len(ids) if mg.uses_rccl else 0,
                       "pre_timed_msms": int(os.environ.get("BENCH_STEADY_MSMS", "40")) + max(args.warmup, 1)}))
@@ -298,28 +589,21 @@ def main():
     #   plain         the reference's shape: 16 windows over n points
     #   tables        fixed-base tables 2^(16 w) P_i: one bucket set per MSM (16 x the base memory)
     #   tables_wide   fixed-base tables 2^(C w) P_i, C-bit digits (17 up to 2^20 points: 15 bucket additions per point into 2 virtual windows of 2^15
-    #                 slots; 20 beyond: 13 additions, 16 virtual windows)
+    #                 slots; 20 beyond: 13 additions, 16 virtual windows).  Window-sharded runs: the ranks share the VIRTUAL windows
+    #                 (BENCH_WIDE_BITS, default 19: 8 of them, 14 additions per point)
     #   (window-sharded runs: plain by default -- with endomorphism bases the ranks share the 8 half-length windows, one per rank at
     #    8 GPUs, measured 8 % slower per MSM than two full-length windows per rank: every rank splits every scalar, profiles/r03_share_ab.txt)
     bases_mode = os.environ.get("BENCH_BASES") or ("plain" if sharded else "endomorphism")
-    assert bases_mode in ("plain", "endomorphism", "tables", "tables_wide") and (not bases_mode.startswith("tables") or not sharded)
+    assert bases_mode in ("plain", "endomorphism", "tables", "tables_wide") and (bases_mode != "tables" or not sharded)
+    wide_shares = sharded and bases_mode == "tables_wide"
+    if wide_shares:
+        ctx.set_wide_bits(int(os.environ.get("BENCH_WIDE_BITS", "19")))
     ctx.set_bases(points, endomorphism=bases_mode == "endomorphism", precompute="wide" if bases_mode == "tables_wide" else bases_mode == "tables")
     halves = bases_mode == "endomorphism"
-    shard_windows = NUM_WINDOWS // 2 if halves else NUM_WINDOWS  # the windows the ranks share
+    # the windows the ranks share: 16, the 8 half-length ones, or the virtual windows of the wide tables
+    shard_windows = (1 << (ctx.wide_bits() - 16)) if wide_shares else NUM_WINDOWS // 2 if halves else NUM_WINDOWS
     w_begin, w_end = window_range(rank, world, shard_windows)
     w_local = w_end - w_begin
-
-    def smvp_shape(bits):
-        """(inputs per bucket set, bucket sets, buckets per set) of one whole MSM's SMVP launch at a window size"""
-        nwin, buckets = m.MsmContext.window_config(bits)
-        if bases_mode == "endomorphism":
-            return 2 * n, m.MsmContext.endomorphism_window_count(bits), buckets
-        if bases_mode == "tables":
-            return NUM_WINDOWS * n, 1, buckets
-        if bases_mode == "tables_wide":
-            wb = ctx.wide_bits()
-            return ((254 + wb) // wb) * n / (1 << (wb - 16)), 1 << (wb - 16), buckets
-        return n, nwin, buckets
 
     def sync_all():
         torch.cuda.synchronize()
@@ -327,126 +611,86 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    smvp_ms, smvp_windows, smvp_bits = [], [], []
     # window-sharded runs put the shares of several independent MSMs through one launch (as many as make up one MSM's worth of
     # bucket sets: 8 MSMs x 2 windows -- or x 1 half-length window -- at 8 GPUs): one kernel sequence and one RCCL all-gather per
     # group.  (Smaller groups for a short run -- 5 launches of 4 instead of 3 of 7 at the driver's --steps 20 -- were measured and lose:
     # 0.235 vs 0.221 ms per MSM, profiles/r03_share_ab.txt; a launch's fixed costs outweigh the shorter exposed tail.)
     # BENCH_MSMS_PER_LAUNCH overrides.
-    group = 1
-    pipe = None
+    group, pipe, runner, combine_mode = 1, None, None, None
     if sharded:
         full = msms_per_launch(emulate if emulate > 1 else world, shard_windows)
         group = int(os.environ.get("BENCH_MSMS_PER_LAUNCH", "0")) or full
         # every MSM's host window combine runs ONCE across the ranks (vector v of a launch on rank v % world), not once per rank
         combine_mode = os.environ.get("BENCH_COMBINE", "spread")
         pipe = ShardedMsmPipeline(ctx, rank, world, depth=int(os.environ.get("BENCH_PIPE_DEPTH", "3")), msms_per_issue=group,
-                                  emulate_world=emulate, halves=halves, combine=combine_mode)
+                                  emulate_world=emulate, halves=halves, combine=combine_mode, wide=wide_shares)
         w_local = pipe.w_end - pipe.w_begin
         # vector k of a group is scalar set k & 1
         group_scalars = torch.cat([scalar_sets[k & 1] for k in range(group)], dim=0).contiguous() if group > 1 else None
+    else:
+        runner = WholeMsmRunner(m, torch, ctx, n, scalar_sets, bases_mode)
 
-    # single GPU, small MSMs: whole MSMs grouped per launch (vector k of a group is scalar set k & 1)
-    group1 = 1 if sharded else max(1, min(ctx.batch_group_size(n), 8))
-    group1_scalars = torch.cat([scalar_sets[k & 1] for k in range(group1)], dim=0).contiguous() if group1 > 1 else None
-
-    # launches in flight on one GPU (4 result slots): 2 where one launch is one large MSM, 3 for grouped small MSMs, whose host
-    # combines (4 per launch) would otherwise sit between launches (measured: +5 % at 2^16, +3 % at 2^18, nothing at 2^20)
-    depth1 = max(1, min(4, int(os.environ.get("BENCH_PIPE_DEPTH", "0")) or (3 if group1 > 1 else 2)))
-
-    def group_sizes(count, g):
-        """`count` MSMs in ceil(count / g) launches of nearly equal size (a small remainder launch would run at the
-        one-MSM-per-launch rate).  One GPU, whole small MSMs per launch: full launches and the remainder LAST when it is at least
-        half a launch -- what follows the last launch's main-stream work (bucket reduce, host combines) is not hidden by a next
-        launch and is shorter for a smaller one (measured at 2^16, 20 MSMs: 0.293 vs 0.328 ms per MSM; no difference for the
-        window-sharded pipeline: 0.266 vs 0.264)."""
-        k = -(-count // g)
-        rem = count % g
-        if not sharded and rem and 2 * rem >= g:
-            return [g] * (count // g) + [rem]
+    def sharded_sizes(count):
+        k = -(-count // group)
         return [count // k + (1 if i < count % k else 0) for i in range(k)]
 
-    def note_stages(nvec):
-        """one finished launch of `nvec` MSMs (or MSM shares): its SMVP kernel time, bucket sets and window size"""
-        smvp_ms.append(ctx.stage_ms()["smvp"])
-        bits = ctx.last_window_bits()
-        smvp_bits.append(bits)
-        smvp_windows.append(nvec * (w_local if sharded else smvp_shape(bits)[1]))
-
-    def run_steps(count, record):
-        """`count` MSMs; returns the last result.  N = 1 pipelines the host combine of MSM i with the device work of i+1."""
-        result = None
+    def run_steps(count, stages=None):
+        """`count` MSMs; returns the last result.  N = 1 pipelines the host combine of MSM i with the device work of i+1.
+        `stages` receives (smvp kernel ms, bucket sets, window bits) of every launch."""
         if not sharded:
-            # one GPU: a launch holds one MSM (n >= 2^19) or up to `group1` whole small MSMs (as msm_hip_run_batch_* does); `depth`
-            # launches in flight over the engine's result slots, so that the host window combines (47 us per MSM) and the launch
-            # calls of one launch run under the device work of the others
-            sizes = group_sizes(count, group1)
-            pending = []
-            for k, gs in enumerate(sizes):
-                slot = k % depth1
-                if group1 == 1:
-                    ctx.launch(scalar_sets[k & 1], slot)
-                else:
-                    ctx.launch_batch(group1_scalars[: gs * n], n, slot)
-                pending.append((slot, gs))
-                if len(pending) == depth1:
-                    slot0, gs0 = pending.pop(0)
-                    result = ctx.finish(slot0) if group1 == 1 else ctx.finish_batch(slot0, gs0)[-1]
-                    if record:
-                        note_stages(gs0)
-            for slot0, gs0 in pending:
-                result = ctx.finish(slot0) if group1 == 1 else ctx.finish_batch(slot0, gs0)[-1]
-                if record:
-                    note_stages(gs0)
-        else:
-            # windows sharded over the ranks; device work, RCCL all-gather, D2H and host combine all pipelined
-            sizes = group_sizes(count, group)
-            inflight = []
-            for k, gs in enumerate(sizes):
-                if group > 1:
-                    pipe.issue(group_scalars[: gs * n], n, inputs_complete=True)  # sampled and synchronised before the timed region
-                else:
-                    pipe.issue(scalar_sets[k & 1], inputs_complete=True)
-                inflight.append(gs)
-                if len(inflight) == pipe.depth:
-                    result = pipe.complete()
-                    if record:
-                        note_stages(inflight[0])
-                    inflight.pop(0)
-            while inflight:
-                result = pipe.complete()
-                if record:
-                    note_stages(inflight[0])
-                inflight.pop(0)
+            return runner.run(count, stages)
+        # windows sharded over the ranks; device work, RCCL all-gather, D2H and host combine all pipelined
+        result, inflight = None, []
+
+        def collect():
+            res = pipe.complete()
+            if stages is not None:
+                stages.append((ctx.stage_ms()["smvp"], inflight[0] * w_local, 16))
+            inflight.pop(0)
+            return res
+
+        for k, gs in enumerate(sharded_sizes(count)):
+            if group > 1:
+                pipe.issue(group_scalars[: gs * n], n, inputs_complete=True)  # sampled and synchronised before the timed region
+            else:
+                pipe.issue(scalar_sets[k & 1], inputs_complete=True)
+            inflight.append(gs)
+            if len(inflight) == pipe.depth:
+                result = collect()
+        while inflight:
+            result = collect()
         return result
 
-    # The scope measurements come BEFORE the timed region, the host-scalar pipeline (24 MSMs back to back) last: after an idle phase the
-    # GPU needs ~15 MSMs (~20 ms of this work) to reach its steady state -- with only the W = 5 warm-up steps behind an idle GPU the
-    # first half of a 20-step timed region runs ~8 % slow (tools/step_time_trend.py: first 20 MSMs 1.53 ms each after 5 warm-up steps,
-    # 1.46 after 20, 1.36 from the 21st on).  The W warm-up steps still directly precede the timed region ("pre_timed_activity" in the
-    # JSON line says what ran before them).
+    def timed(count, stages):
+        """barrier + synchronise, `count` steps, barrier + synchronise; the MAX over the ranks"""
+        sync_all()
+        t0 = time.perf_counter()
+        res = run_steps(count, stages)
+        sync_all()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, res
+
+    # ---- THE MEASUREMENT, under the literal protocol: W warm-up steps on a GPU that has done nothing but sample the inputs and convert the
+    # bases, then EXACTLY K timed steps -> `value`.  HIP events only around the SMVP accumulate kernel (the roofline figure; every extra
+    # stage event costs queue time between kernels).  (Rounds 1 - 4 reported as `value` a second timed region that followed ~45 further
+    # untimed steps: after an idle phase the GPU needs ~15 MSMs, ~20 ms of this work, to reach its steady state -- tools/step_time_trend.py:
+    # first 20 MSMs 1.53 ms each after 5 warm-up steps, 1.36 from the 21st on.  That figure is still measured below and reported as
+    # `value_steady_state`, with the number of untimed steps in front of it.)
+    ctx.set_stage_timing(1)
+    stages = []
+    run_steps(max(args.warmup, 1), None)
+    elapsed, last = timed(args.steps, stages)
+    pre_timed_msms = max(args.warmup, 1)  # MSMs (or MSM shares) run before `value`'s timed region
+    ctx.set_stage_timing(2)
+
     # timing scopes B and C of SURVEY.md section 8(d), informational (never `value`): B = scalars arrive from host memory
     # (32 MiB H2D per MSM at 2^20), bases resident -- as the latency of one call and as the throughput of three slots in rotation
     # (msm_hip_launch_bn254: the copy of MSM i+1 runs on the copy stream under the device work of MSM i); C = one-shot incl.
     # base upload (≙ the reference's compute_msm call shape): the first call also creates the context the library then keeps
-    pre_timed_msms = 0  # MSMs (or MSM shares) this process has run before the timed region starts
-
-    # The same measurement under the literal protocol first: W warm-up steps on a GPU that has done nothing but sample the inputs,
-    # then K timed steps.  Reported beside `value` as `value_cold_protocol`; the GPU is still in its post-idle ramp there (DESIGN.md 6).
-    ctx.set_stage_timing(1)
-    run_steps(max(args.warmup, 1), False)
-    sync_all()
-    t0 = time.perf_counter()
-    run_steps(args.steps, False)
-    sync_all()
-    cold_elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([cold_elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        cold_elapsed = float(t.item())
-    pre_timed_msms += max(args.warmup, 1) + args.steps
-    ctx.set_stage_timing(2)
-
     scope_ms = None
     if world == 1 and emulate <= 1 and args.logn <= 22:
         sb_host = [s.cpu().numpy().tobytes() for s in scalar_sets]
@@ -480,10 +724,10 @@ def main():
             b_pipe = (time.perf_counter() - t1) * 1e3 / k
         scope_ms = {"B_host_scalars_resident_bases_latency": sorted(tb)[2], "B_host_scalars_three_slots_pipelined": b_pipe,
                     "C_one_shot_with_base_upload": sorted(tc[1:])[1], "C_one_shot_first_call": tc[0]}
-        pre_timed_msms += 4 + 5 + 2 * k
+        del sb_host, pb_host
 
     # window-sharded runs: the latency of ONE MSM across the ranks (its window shares, the gather, the host combine; nothing in
-    # flight beside it) -- BASELINE config 3 as a single call -- median of 20, measured before the timed region for the same reason
+    # flight beside it) -- BASELINE config 3 as a single call -- median of 20
     sharded_latency_ms = None
     if sharded:
         ctx.set_stage_timing(0)
@@ -495,27 +739,16 @@ def main():
             pipe.complete()
             lat.append((time.perf_counter() - t1) * 1e3)
         sharded_latency_ms = sorted(lat)[len(lat) // 2]
-        pre_timed_msms += 20
 
-    # timed region: HIP events only around the SMVP accumulate kernel (the roofline figure); every extra stage event
-    # costs queue time between kernels.  The per-stage breakdown comes from the un-pipelined latency runs below.
-    # Steady state is made explicit: whatever informational blocks ran above (they differ with the size and the rank count), at least
-    # BENCH_STEADY_MSMS (default 40) steps of the timed workload itself run back to back right before the W warm-up steps.
+    # ---- the same K steps in the steady state (informational: `value_steady_state`): BENCH_STEADY_MSMS (default 40) steps of the timed
+    # workload itself and the W warm-up steps run back to back right before them
     ctx.set_stage_timing(1)
     steady = max(0, int(os.environ.get("BENCH_STEADY_MSMS", "40")))
+    steady_stages = []
     if steady:
-        run_steps(steady, False)
-    run_steps(max(args.warmup, 1), False)
-    pre_timed_msms += steady + max(args.warmup, 1)
-    sync_all()
-    t0 = time.perf_counter()
-    last = run_steps(args.steps, True)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        run_steps(steady, None)
+    run_steps(max(args.warmup, 1), None)
+    steady_elapsed, _ = timed(args.steps, steady_stages)
 
     # single-MSM latency (no pipelining, stages not overlapped) -- reported beside the throughput figure.  Measured WITHOUT stage events (what
     # a caller of the synchronous entry point sees: every HIP event between two kernels costs queue time, ~45 us over the twelve kernels of a
@@ -556,56 +789,72 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             sharded_ok = bool(t.item())
 
+    # (not under rocprofv3 unless asked for -- BENCH_TABLES_WIDE=2 --: the launches of the blocks below would mix into the per-kernel
+    #  averages of the profile this command is compared with)
+    profiled = "ROCP_TOOL_LIBRARIES" in os.environ and os.environ.get("BENCH_TABLES_WIDE") != "2"
+    single = world == 1 and emulate <= 1 and not profiled
+
     # The opt-in fixed-base mode beside the headline (informational, never `value`; BENCH_TABLES_WIDE=0 skips it): the same scalars through the
     # same pipeline with the bases held as wide tables (MSM_HIP_BASES_PRECOMPUTE_WIDE: 15 bucket additions per point at 2^20 instead of 16,
     # 13 from 2^22 up), after everything the headline needs has been measured; its result must be the headline mode's.
     wide_line = None
-    # (not under rocprofv3 unless asked for -- BENCH_TABLES_WIDE=2 --: its launches would mix into the per-kernel averages of the profile this
-    #  command is compared with)
-    profiled = "ROCP_TOOL_LIBRARIES" in os.environ and os.environ.get("BENCH_TABLES_WIDE") != "2"
-    if (world == 1 and emulate <= 1 and not profiled and bases_mode != "tables_wide" and os.environ.get("BENCH_TABLES_WIDE", "1") != "0"
+    if (single and bases_mode != "tables_wide" and os.environ.get("BENCH_TABLES_WIDE", "1") != "0"
             and args.logn <= (24 if os.environ.get("BENCH_TABLES_WIDE") == "2" else 22)):  # (2^23, 2^24: 13 GiB of tables + 31 GiB of sort arrays, on request)
         ctx.set_stage_timing(0)
+        want = ctx.msm(scalar_sets[0])     # the headline mode's result
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         ctx.set_bases(points, precompute="wide")
         torch.cuda.synchronize()
         setup_ms = (time.perf_counter() - t1) * 1e3
-        # the grouping of small MSMs follows the mode (run_steps reads these; the headline's values come back below): an MSM is 2 local windows here, not 8 - 10
-        headline_grouping = (group1, group1_scalars, depth1)
-        group1 = max(1, min(ctx.batch_group_size(n), 8))
-        group1_scalars = torch.cat([scalar_sets[k & 1] for k in range(group1)], dim=0).contiguous() if group1 > 1 else None
-        depth1 = max(1, min(4, int(os.environ.get("BENCH_PIPE_DEPTH", "0")) or (3 if group1 > 1 else 2)))
-        last_set = (args.steps - 1) & 1 if group1 == 1 else (group_sizes(args.steps, group1)[-1] - 1) & 1
-        ctx.set_bases(points, endomorphism=bases_mode == "endomorphism", precompute=bases_mode == "tables")
-        want = ctx.msm(scalar_sets[last_set])     # the headline mode's result for the scalar vector the timed run ends with
-        ctx.set_bases(points, precompute="wide")
+        wrun = WholeMsmRunner(m, torch, ctx, n, scalar_sets, "tables_wide")  # the grouping of small MSMs follows the mode: an MSM is 2 local windows here, not 8 - 10
+        same = bool(ctx.msm(scalar_sets[0]) == want)
         ctx.set_stage_timing(1)
-        run_steps(group1 * depth1, False)  # one full-size launch through every slot first: the pools grow to this mode's shape outside the timed region
-        run_steps(steady // 2 + max(args.warmup, 1), False)
-        sync_all()
+        wrun.run(wrun.group * wrun.depth, None)  # one full-size launch through every slot first: the pools grow to this mode's shape outside the timed region
+        wrun.run(steady // 2 + max(args.warmup, 1), None)
+        torch.cuda.synchronize()
         t1 = time.perf_counter()
-        last_wide = run_steps(args.steps, False)
-        sync_all()
+        wrun.run(args.steps, None)
+        torch.cuda.synchronize()
         wide_elapsed = time.perf_counter() - t1
         wide_line = {"value": args.steps / wide_elapsed, "unit": "MSM/s", "ms_per_step": wide_elapsed * 1e3 / args.steps, "digit_bits": ctx.wide_bits(),
-                     "msms_per_launch": group1,
-                     "table_setup_ms": setup_ms, "same_result_as_headline_mode": bool(last_wide == want),
-                     "note": "opt-in MSM_HIP_BASES_PRECOMPUTE_WIDE (fixed bases: 13 - 15 x the base memory); same steps / warm-up protocol, measured after the headline"}
+                     "msms_per_launch": wrun.group, "table_setup_ms": setup_ms, "same_result_as_headline_mode": same,
+                     "untimed_steps_before_timed_region": wrun.group * wrun.depth + steady // 2 + max(args.warmup, 1),
+                     "note": "opt-in MSM_HIP_BASES_PRECOMPUTE_WIDE (fixed bases: 13 - 15 x the base memory); steady-state protocol (compare with value_steady_state), measured after the headline"}
         ctx.set_stage_timing(2)
-        group1, group1_scalars, depth1 = headline_grouping
+        del wrun
+        ctx.set_bases(points, endomorphism=bases_mode == "endomorphism", precompute=bases_mode == "tables")  # the headline's bases again
+
+    # ---- BASELINE.json's other configs on the same line (`configs`; informational, never `value`): C1 2^16, C3 one rank's share of 8 at 2^20,
+    # C4 2^24, C5 64 x 2^18 over one base -- each with its own timed region, SMVP roofline fraction and an in-run check of its result.
+    # Default run only (--logn 20, one GPU); BENCH_CONFIGS=0 skips it, BENCH_CONFIGS="c1:10,c3:12,c4:13,c5:6x11" picks other sizes (tests).
+    configs, config_checks = None, []
+    cfg_spec = os.environ.get("BENCH_CONFIGS", "c1:16,c3:20,c4:24,c5:64x18" if args.logn == 20 else "0")
+    if single and cfg_spec != "0":
+        configs, config_checks = measure_configs(m, torch, ctx, args, cfg_spec, points if "c3:%d" % args.logn in cfg_spec else None, scalar_sets)
+        ctx.set_bases(points, endomorphism=bases_mode == "endomorphism", precompute="wide" if bases_mode == "tables_wide" else bases_mode == "tables")
 
     ms_per_step = elapsed * 1e3 / args.steps
     # roofline of the SMVP accumulate kernel: algorithmic bytes of all timed launches / their summed durations
     # (geometry of every timed launch from the window size the engine reports for it: grouped small MSMs run 14-bit windows)
-    launches = len(smvp_ms)
-    smvp_avg_ms = sum(smvp_ms) / launches
-    n_of = lambda bits: (2 * n if halves else n) if sharded else smvp_shape(bits)[0]  # inputs per bucket set
-    alg_bytes = sum(smvp_algorithmic_bytes(n_of(b), w, 1 << (b - 1)) for w, b in zip(smvp_windows, smvp_bits)) / launches
-    achieved = alg_bytes / (smvp_avg_ms * 1e-3) / 1e9
-    w_launch = max(smvp_windows)
-    lane_mads_per_s = sum(n_of(b) * w for w, b in zip(smvp_windows, smvp_bits)) * MADS_PER_MIXED_ADD / (sum(smvp_ms) * 1e-3)
-    bits_main = max(set(smvp_bits), key=smvp_bits.count)
+    def roofline_of(st):
+        launches = len(st)
+        avg_ms = sum(s[0] for s in st) / launches
+        if sharded:
+            n_in = 2 * n if halves else n  # inputs per bucket set; wide shares: the 14 n digit entries spread over the virtual windows
+            per_set = (lambda b: ((254 + ctx.wide_bits()) // ctx.wide_bits()) * n / shard_windows) if wide_shares else (lambda b: n_in)
+        else:
+            per_set = lambda b: smvp_shape(m, ctx, n, bases_mode, b)[0]
+        alg = sum(smvp_algorithmic_bytes(per_set(b), w, 1 << (b - 1)) for _, w, b in st) / launches
+        ach = alg / (avg_ms * 1e-3) / 1e9
+        mads = sum(per_set(b) * w for _, w, b in st) * MADS_PER_MIXED_ADD / (sum(s[0] for s in st) * 1e-3)
+        return avg_ms, alg, ach, mads
+
+    smvp_avg_ms, alg_bytes, achieved, lane_mads_per_s = roofline_of(stages)
+    st_ms, st_alg, st_ach, _ = roofline_of(steady_stages)
+    w_launch = max(s[1] for s in stages)
+    bits_all = [s[2] for s in stages]
+    bits_main = max(set(bits_all), key=bits_all.count)
     # the rocprofv3 --kernel-trace --stats average of the same kernel in the same command, when this round's profile is committed
     kernel_ms_rocprof, rocprof_source = None, None
     try:
@@ -628,22 +877,28 @@ def main():
     except (OSError, ValueError):
         pass
 
+    shape1 = None if sharded else smvp_shape(m, ctx, n, bases_mode, bits_main)
     out = {
         "metric": "BN254 MSM/s at 2^%d points" % args.logn,
         "value": args.steps / elapsed,
-        "value_cold_protocol": args.steps / cold_elapsed,
         "unit": "MSM/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "fixed_base_tables_wide": wide_line,
-        "untimed_steps_before_timed_region": steady + max(args.warmup, 1),  # the W warm-up steps and, in front of them, BENCH_STEADY_MSMS steps of the same workload
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
+        "protocol": "literal: inputs sampled and bases converted, W warm-up steps, barrier + synchronise, K timed steps, barrier + synchronise",
+        "untimed_steps_before_timed_region": max(args.warmup, 1),
+        "value_steady_state": args.steps / steady_elapsed,
+        "ms_per_step_steady_state": steady_elapsed * 1e3 / args.steps,
+        "steady_state": {"untimed_steps_of_this_workload_directly_before": steady + max(args.warmup, 1), "smvp_kernel_ms": st_ms, "roofline_frac": st_ach / HBM_PEAK_GBS,
+                         "note": "the same K steps after BENCH_STEADY_MSMS further steps (and the scope / latency blocks): what rounds 1 - 4 reported as value"},
+        "fixed_base_tables_wide": wide_line,
+        "configs": configs,
         "config": {"workload": "2^%d BN254 G1 MSM, 16-bit signed-bucket windows, inputs resident in HBM" % args.logn,
                    "bases": {"plain": "n points, 16 windows (the reference's shape)",
                              "endomorphism": "P and phi(P) resident: scalars split into two 127-bit halves on the device, 8 windows over 2n points",
@@ -651,10 +906,14 @@ def main():
                              "tables_wide": "fixed-base tables 2^(C w) P resident: ceil(255 / C) digits of C bits per scalar (C = 16 up to 2^16 points, 17 up to 2^20, 20 beyond), "
                                             "one bucket set of 2^(C-1) slots run as virtual windows of 2^15"}[bases_mode],
                    "window_bits": bits_main,
-                   "windows_per_gpu": w_local if sharded else smvp_shape(bits_main)[1], "msms_per_launch": group if sharded else group1,
-                   "parallelism": "%s windows/%d + RCCL all-gather" % ("8 half-length" if halves else "16", world) if sharded else "single GPU",
-                   "launches_in_flight": pipe.depth if sharded else depth1,
-                   "host_combine": "pipelined behind the device work of the following launches"},
+                   "windows_per_gpu": w_local if sharded else shape1[1], "msms_per_launch": group if sharded else runner.group,
+                   "parallelism": ("%s windows/%d + RCCL all-gather" % ("%d virtual (wide tables, %d-bit digits)" % (shard_windows, ctx.wide_bits()) if wide_shares
+                                                                       else "8 half-length" if halves else "16", world)) if sharded else "single GPU",
+                   "launches_in_flight": pipe.depth if sharded else runner.depth,
+                   "host_combine": "pipelined behind the device work of the following launches",
+                   "combine": ({"mode": combine_mode, "owner": {"spread": "vector v of a launch is combined once, on rank v % world (the other ranks return None for it)",
+                                                                "all": "every rank combines every MSM", "rank0": "rank 0 combines everything"}[combine_mode]}
+                               if sharded else None)},
         "roofline": {"bound": "hbm", "kernel": "k_smvp_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": alg_bytes,
                      "kernel_ms": smvp_avg_ms, "kernel_ms_rocprof": kernel_ms_rocprof, "kernel_ms_rocprof_source": rocprof_source},
@@ -671,12 +930,7 @@ def main():
         "latency_ms_single_msm_with_stage_events": latency_events_ms,
         "stage_ms_single_msm": isolated,
         "scope_ms": scope_ms,
-        "ms_per_step_cold_protocol": cold_elapsed * 1e3 / args.steps,
         "pre_timed_msms": pre_timed_msms,
-        "pre_timed_activity": "W + K steps under the literal protocol (value_cold_protocol); " +
-                              ("scope C and B measurements (4 one-shot calls, 5 + 2 x 24 host-scalar MSMs); " if scope_ms
-                               else "20 single-MSM latency runs across the ranks; " if sharded else "") +
-                              "%d steady-state steps; the W warm-up steps" % steady,
     }
 
     # N > 1: the same workload through the in-process multi-GPU C ABI (what a Rust caller of src/lib.rs:76-82 links against), timed by ONE
@@ -699,8 +953,7 @@ def main():
         logs = args.cpu_sample_logn if args.cpu_sample_logn is not None else min(args.logn, 20)
         ns = 1 << logs
         pb = points[:ns].cpu().numpy().tobytes()
-        last_idx = (args.steps - 1) & 1 if group1 == 1 else (group_sizes(args.steps, group1)[-1] - 1) & 1
-        last_set = scalar_sets[last_idx]
+        last_set = scalar_sets[(args.steps - 1) & 1 if sharded else runner.last_set(args.steps)]
         sb = last_set[:ns].cpu().numpy().tobytes()
         t1 = time.perf_counter()
         want = oracle_cpu.cpu_msm(pb, sb, 1)
@@ -718,6 +971,17 @@ def main():
         cpu_mt = time.perf_counter() - t1
         out["cpu_baseline_mt"] = {"value": (ns / n) / cpu_mt, "unit": "MSM/s", "cores": threads, "kind": "port", "seconds": cpu_mt,
                                   "agrees": bool(oracle_cpu.to_affine64(want_mt) == oracle_cpu.to_affine64(want))}
+        # the configs' results against the same oracle (and, for C1 -- BASELINE's CPU-path config --, the oracle's own time)
+        for chk in config_checks:
+            t1 = time.perf_counter()
+            w = oracle_cpu.to_affine64(oracle_cpu.cpu_msm(chk["points"], chk["scalars"], chk.get("threads", threads)))
+            secs = time.perf_counter() - t1
+            configs[chk["config"]][chk["key"]] = bool(w == chk["got"])
+            if chk.get("time_as"):
+                configs[chk["config"]][chk["time_as"]] = {"value": 1.0 / secs, "unit": "MSM/s", "cores": chk.get("threads", threads), "kind": "port", "seconds": secs}
+    elif configs:
+        for chk in config_checks:
+            configs[chk["config"]][chk["key"]] = None  # --no-cpu-baseline: not checked
 
     if rank == 0:
         print(json.dumps(out))
@@ -725,6 +989,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
 
 
 if __name__ == "__main__":

@@ -78,8 +78,9 @@ extern "C" {
                                           2^14, +26 ... 50 % at 2^16, +20 % at 2^18 (grouped launches; 50 / 20 timed steps), +4 % at 2^20, +11 % at 2^22, +18 % at 2^24; 15 x (13 x) the
                                           base memory, at most 2^24 points; up to 12 (at 20 bits: 1) whole MSMs per launch; sort arrays sized for a skewed
                                           vector (2^(C-16) x T x n entries per MSM: 0.3 GiB at 2^20, 31 GiB at 2^24).
-                                          Whole-MSM entry points only (run, launch / finish, batch); the window-sharding entry points ignore the tables
-                                          (table 0 is the plain set).  Same result for every scalar below the scalar field's modulus (a top digit that
+                                          Whole-MSM entry points (run, launch / finish, batch) and -- round 5 -- shares of the virtual windows for the
+                                          window-sharded / multi-GPU paths (msm_hip_launch_vwindows_batch_device, msm_hip_mgpu_*); the 16-bit
+                                          window-sharding entry points ignore the tables (table 0 is the plain set).  Same result for every scalar below the scalar field's modulus (a top digit that
                                           does not fit after its shift is MSM_HIP_ERR_NONCANONICAL).  Not combinable with the other two modes. */
 
 #define MSM_HIP_BASES_PLAIN 16u        /* hold the n bases only and run the reference's exact shape -- 16 windows of full-length scalars over n points
@@ -238,6 +239,17 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz);
  * full-length windows, src/cuzk/msm.rs:79-82. */
 int msm_hip_launch_half_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int hw_begin,
                                                    int hw_end, int slot, void* window_sums_dev);
+/* the same for a context whose bases were set with MSM_HIP_BASES_PRECOMPUTE_WIDE (round 5: the fixed-base tables behind the window-sharded paths; anchors:
+ * README.md:70-71 -- the time / space trade-off --, src/cuzk/msm.rs:79-82 -- chunk_size hard-coded --, src/cuzk/msm.rs:411-416 -- the final combine):
+ * the ranks share the 2^(C-16) VIRTUAL windows of the one bucket set (msm_hip_wide_config: 8 at 19-bit digits, 16 at 20).  Virtual windows
+ * [v_begin, v_end) of every vector: at 8 GPUs and 19 bits ONE bucket set of 2^15 slots and 14 n / 8 entries per rank and MSM, instead of two sets and
+ * 2 n entries with 16-bit windows.  `sums_dev` (device memory; NULL: the slot's pinned buffer, for msm_hip_mgpu's host gather) receives
+ * nvec x (v_end - v_begin) x 2 records, vector-major: for every virtual window its weighted sum W_hi and its plain total TC_hi.  The gathered
+ * pairs of all virtual windows finish as  sum_hi W_hi + 2^15 sum_hi hi TC_hi  (msm_hip_combine_vwindows_batch_curve; pairs_host: nvec x
+ * num_vwindows x 2 records, out_xyz: nvec records).  nvec x (v_end - v_begin) <= MSM_HIP_MAX_LOCAL_WINDOWS. */
+int msm_hip_launch_vwindows_batch_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int v_begin, int v_end, int slot,
+                                         void* sums_dev);
+int msm_hip_combine_vwindows_batch_curve(int curve, const uint8_t* pairs_host, int num_vwindows, int nvec, uint8_t* out_xyz);
 int msm_hip_slot_wait_stream(msm_hip_ctx* ctx, int slot, void* hip_stream);
 int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot);
 /* result = sum_w 2^(16 w) * S_w over num_windows records (host memory): src/cuzk/msm.rs:411-416 */
@@ -275,6 +287,10 @@ int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t 
  *   _bn254         : scalars in host memory (nvec x n x 32 B); every device uploads all of them (PCIe-bound: the latency form).  The buffer
  *                    must stay untouched until finish.
  *   _device_bn254  : scalars_dev[d] = the same nvec x n x 32 B already resident on device d (complete before the call; alive until finish).
+ * Bases (msm_hip_mgpu_set_bases_bn254): replicated; the flags decide what the devices share -- MSM_HIP_BASES_PLAIN or 0: the reference's 16 windows over
+ * the n points (flags = 0 is resolved to PLAIN here, not to a context's own default: the shares of full-length windows read only the plain records);
+ * MSM_HIP_BASES_ENDOMORPHISM: the 8 half-length windows; MSM_HIP_BASES_PRECOMPUTE_WIDE: the virtual windows of the wide tables (digit width by
+ * msm_hip_mgpu_set_wide_bits, default 19: 8 virtual windows, 14 bucket additions per point, one bucket set per device at 8 GPUs).
  * A failing launch is reported by finish, which always leaves the slot free.  RCCL gather: the devices' calls of a launch's all-gather
  * are issued in lock-step -- a device whose own launch failed (slot busy, out of memory, a HIP error) still enters the collective, with a
  * zeroed block -- so a failure on one device can neither hang the others' collectives nor shift the pairing of later launches; finish
@@ -284,6 +300,8 @@ int msm_hip_mgpu_launch_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host
 int msm_hip_mgpu_launch_batch_device_bn254(msm_hip_mgpu* m, const void* const* scalars_dev, size_t n, int nvec, int slot);
 int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz);
 int msm_hip_mgpu_group_size(const msm_hip_mgpu* m);
+/* digit width (16 .. 20; 0: 19) of the wide tables the next msm_hip_mgpu_set_bases_bn254(..., MSM_HIP_BASES_PRECOMPUTE_WIDE) builds on every device */
+int msm_hip_mgpu_set_wide_bits(msm_hip_mgpu* m, int bits);
 /* test hook: the next `launches` window-sharded launches fail on device index `device_index` (MSM_HIP_ERR_HIP, before anything is queued
  * there) -- the rehearsal of one failing GPU; MSM_HIP_FAULT_DEVICE=<index> in the environment arms one such launch at creation. */
 int msm_hip_mgpu_inject_fault(msm_hip_mgpu* m, int device_index, int launches);

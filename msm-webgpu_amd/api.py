@@ -72,6 +72,9 @@ def lib():
         L.msm_hip_finish_batch_bn254.argtypes = [vp, i, u8p]
         L.msm_hip_launch_half_windows_batch_device_bn254.argtypes = [vp, vp, sz, i, i, i, i, vp]
         L.msm_hip_combine_windows_batch_curve.argtypes = [i, vp, i, i, u8p]
+        L.msm_hip_launch_vwindows_batch_device.argtypes = [vp, vp, sz, i, i, i, i, vp]
+        L.msm_hip_combine_vwindows_batch_curve.argtypes = [i, vp, i, i, u8p]
+        L.msm_hip_mgpu_set_wide_bits.argtypes = [vp, i]
         L.msm_hip_run_batch_device_bn254.argtypes = [vp, vp, sz, sz, u8p]
         L.msm_hip_launch_device_bn254.argtypes = [vp, vp, sz, i]
         L.msm_hip_launch_bn254.argtypes = [vp, u8p, sz, i]
@@ -391,6 +394,20 @@ class MsmContext:
                "msm_hip_launch_half_windows_batch_device_bn254")
         self._keepalive[slot] = (t, out_dev)
 
+    def launch_vwindows_batch(self, scalars_dev, n, v_begin, v_end, slot, out_dev, inputs_complete=False):
+        """launch_windows_batch over the VIRTUAL windows of a context whose bases are wide fixed-base tables (set_bases(precompute="wide");
+        msm_hip_launch_vwindows_batch_device): `out_dev` (CUDA uint8 [nvec * (v_end - v_begin) * 2, jb], vector-major) receives, for every
+        virtual window, its weighted sum and its plain total."""
+        t, rows = _as_device_u8(scalars_dev, 32, "scalars")
+        if n <= 0 or rows % n:
+            raise ValueError("scalars must hold a whole number of n-element vectors")
+        if not inputs_complete:
+            self._order_after_torch(t)
+        _check(lib().msm_hip_launch_vwindows_batch_device(self._h, t.data_ptr(), n, rows // n, v_begin, v_end, slot,
+                                                          out_dev.data_ptr() if out_dev is not None else None),
+               "msm_hip_launch_vwindows_batch_device")
+        self._keepalive[slot] = (t, out_dev)
+
     def launch_batch(self, scalars_dev, n, slot=0):
         """Enqueue up to 4 WHOLE MSMs (contiguous scalar vectors, CUDA uint8 [nvec * n, 32]) as one launch; finish_batch collects."""
         self.launch_windows_batch(scalars_dev, n, 0, NUM_WINDOWS, slot, None)
@@ -445,6 +462,27 @@ class MsmContext:
         cid, p = CURVES[curve]
         _check(lib().msm_hip_combine_windows_batch_curve(cid, a.ctypes.data, num_windows, nvec, out), "msm_hip_combine_windows_batch_curve")
         return [G1(out.raw[jb * k:jb * (k + 1)], p) for k in range(nvec)]
+
+    @staticmethod
+    def combine_vwindows_batch(pairs, num_vwindows, curve="bn254"):
+        """The finish of window-sharded launches over wide tables: pairs holds nvec x num_vwindows x 2 records (bytes, numpy uint8 array or
+        CPU tensor) -- every virtual window's weighted sum and plain total, in virtual-window order -> [G1, ...]"""
+        if isinstance(pairs, torch.Tensor):
+            pairs = pairs.contiguous().numpy()
+        a = np.ascontiguousarray(np.frombuffer(pairs, dtype=np.uint8) if isinstance(pairs, (bytes, bytearray)) else pairs, dtype=np.uint8)
+        jb = 3 * coord_bytes(curve)
+        nvec = a.size // (2 * jb * num_vwindows)
+        if nvec * 2 * jb * num_vwindows != a.size:
+            raise ValueError("pairs must be nvec x num_vwindows x 2 x %d bytes" % jb)
+        out = C.create_string_buffer(max(jb * nvec, 1))
+        cid, p = CURVES[curve]
+        _check(lib().msm_hip_combine_vwindows_batch_curve(cid, a.ctypes.data, num_vwindows, nvec, out), "msm_hip_combine_vwindows_batch_curve")
+        return [G1(out.raw[jb * k:jb * (k + 1)], p) for k in range(nvec)]
+
+    def virtual_windows(self):
+        """virtual windows (of 2^15 bucket slots) of the resident wide tables: 2^(digit bits - 16); 0 without such tables"""
+        wb = self.wide_bits()
+        return (1 << (wb - 16)) if wb else 0
 
     # -- synthetic inputs in HBM
     def sample_scalars(self, n, seed):
@@ -606,9 +644,9 @@ class MultiGpuMsm:
     def set_bases(self, points, check_on_curve=False, endomorphism=False, precompute=False):
         """Replicated on every device.  endomorphism: True: MSM_HIP_BASES_ENDOMORPHISM -- msm_batch runs whole MSMs over the 2n points, and
         the window-sharded calls shard the 8 half-length windows; False: MSM_HIP_BASES_PLAIN; None: the C ABI's default (flags = 0: whole
-        MSMs take the curve's fastest mode, the window-sharded calls the 16 full-length windows).  precompute (True / "wide": fixed-base
-        tables, as MsmContext.set_bases): the whole MSMs of msm_batch -- dealt out over the devices -- run in that mode; the window-sharded
-        calls ignore the tables."""
+        object resolves it to the plain set).  precompute: True -- the 16-bit fixed-base tables for the whole MSMs of msm_batch (the
+        window-sharded calls ignore them); "wide" -- the wide tables: msm_batch runs whole MSMs on them and the window-sharded calls share
+        their virtual windows (set_wide_bits; default 19-bit digits: 8 virtual windows)."""
         b = bytes(points)
         flags = (1 if check_on_curve else 0) | (8 if endomorphism else 0) | (32 if precompute == "wide" else 4 if precompute else 0)
         if endomorphism is False and not precompute:
@@ -628,6 +666,10 @@ class MultiGpuMsm:
         out = C.create_string_buffer(max(self.jb * batch, 1))
         _check(lib().msm_hip_mgpu_run_batch_bn254(self._h, b, n, batch, out), "msm_hip_mgpu_run_batch_bn254")
         return [G1(out.raw[self.jb * k:self.jb * (k + 1)], self.modulus) for k in range(batch)]
+
+    def set_wide_bits(self, bits):
+        """digit width (16 .. 20; 0: 19) of the wide tables the next set_bases(precompute="wide") builds on every device"""
+        _check(lib().msm_hip_mgpu_set_wide_bits(self._h, int(bits)), "msm_hip_mgpu_set_wide_bits")
 
     # -- window-sharded launches of several MSMs, asynchronous (the throughput form)
     @property

@@ -314,15 +314,16 @@ inline bool window_from_planes(const uint8_t* planes, uint8_t* sum96) {
 // The wide fixed-base tables' finish (msm_kernels.h: k_count_wide): sum_hi W_hi + 2^15 * sum_hi hi * TC_hi over the `nvirt` virtual windows.
 // `sums96`: the finished W_hi (window_from_planes, made side by side by the caller); `planes`: the launch's bit-plane sums, whose record 15 of
 // every window is TC_hi.  sum_hi hi * TC_hi by running sums from the top (2 additions per virtual window), then 15 doublings.
-inline bool combine_wide(const uint8_t* sums96, const uint8_t* planes, int nvirt, uint8_t* out) {
+// (`sums` / `totals`: W_hi and TC_hi as JB-byte records, `sum_stride` / `total_stride` bytes apart)
+inline bool combine_wide_strided(const uint8_t* sums, size_t sum_stride, const uint8_t* totals, size_t total_stride, int nvirt, uint8_t* out) {
   bool ok = true;
   hg1 acc = hg1_identity(), run = hg1_identity(), weighted = hg1_identity();
   for (int hi = nvirt - 1; hi >= 0; hi--) {
     hg1 w, tc;
-    ok &= hg1_from_bytes96(w, sums96 + JB * (size_t)hi);
+    ok &= hg1_from_bytes96(w, sums + sum_stride * (size_t)hi);
     acc = hg1_add(acc, w);
     if (hi >= 1) {
-      ok &= hg1_from_bytes96(tc, planes + JB * ((size_t)hi * PLANES_PER_WINDOW + PLANES_PER_WINDOW - 1));
+      ok &= hg1_from_bytes96(tc, totals + total_stride * (size_t)hi);
       run = hg1_add(run, tc);
       weighted = hg1_add(weighted, run);
     }
@@ -330,6 +331,13 @@ inline bool combine_wide(const uint8_t* sums96, const uint8_t* planes, int nvirt
   for (int k = 0; k < 15; k++) weighted = hg1_double(weighted);
   hg1_to_bytes96(out, hg1_add(acc, weighted));
   return ok;
+}
+inline bool combine_wide(const uint8_t* sums96, const uint8_t* planes, int nvirt, uint8_t* out) {
+  return combine_wide_strided(sums96, JB, planes + JB * (size_t)(PLANES_PER_WINDOW - 1), JB * (size_t)PLANES_PER_WINDOW, nvirt, out);
+}
+// ... from the (W_hi, TC_hi) pairs the shares of a window-sharded run deliver (k_bpr_final with emit_total): pairs[hi] = W_hi || TC_hi
+inline bool combine_wide_pairs(const uint8_t* pairs, int nvirt, uint8_t* out) {
+  return combine_wide_strided(pairs, 2 * (size_t)JB, pairs + JB, 2 * (size_t)JB, nvirt, out);
 }
 
 }  // namespace host

@@ -65,7 +65,7 @@ constexpr int N_MAIN_EVENTS = 7;  // boundaries of the 6 timed stages on the mai
 constexpr uint32_t MAX_TILES = 1024;
 constexpr size_t MAX_JB = 288;  // the largest Jacobian record of any curve (BLS12-381 G2: 3 x 96 B; BN254 G2: 3 x 64 B; BLS12-381 G1: 3 x 48 B; the 254 / 255-bit G1 curves: 96 B)
 constexpr size_t WSUM_BYTES = (size_t)24 * PLANES_PER_WINDOW * MAX_JB;  // MAXLW window sums or, for one host-combined MSM, the bit-plane sums (k_bpr_planes) of its <= 22 windows
-static_assert(WSUM_BYTES >= (size_t)MAXLW * MAX_JB, "window-sum buffer");
+static_assert(WSUM_BYTES >= (size_t)2 * MAXLW * MAX_JB, "window-sum buffer (pairs of records for shares of the wide tables' virtual windows)");
 constexpr int NSLOT = MSM_HIP_NUM_SLOTS;  // result slots
 constexpr int NREDUCE = 2;  // reduce streams (slot k uses stream k % NREDUCE): two bucket reduces may be in flight when the
                             // main-stream work of one MSM is shorter than its bucket reduce (few windows per GPU).  The context
@@ -97,6 +97,7 @@ struct Slot {
   bool halves = false;                        // endomorphism launch: the windows are those of 127-bit halves
   int wide_bits = 0;                          // wide fixed-base launch (its digit width): h_wsums holds the bit-plane sums of the virtual windows (combine_wide)
   bool parts = false;                         // h_wsums holds the bit-plane sums of every window (k_bpr_planes): the host finishes the window sums
+  bool pairs = false;                         // a share of the wide tables' virtual windows: the launch leaves (window sum, plain total) record pairs
   int timing_level = 0;
   int w_begin = 0, w_count = 0, nvec = 1;  // windows [w_begin, w_begin + w_count) of nvec scalar vectors
   size_t n = 0;
@@ -316,7 +317,7 @@ struct WideShape {
   size_t worst;
   uint32_t chunk_len, chunks, host_len;
 };
-inline WideShape wide_shape(size_t n, int curve, int bits, int nvec) {  // (nvec whole MSMs in the launch: nvec x VWIN local windows share the lanes)
+inline WideShape wide_shape(size_t n, int curve, int bits, int lwin) {  // (lwin local windows share the lanes: nvec whole MSMs x VWIN, or nvec shares x their virtual windows)
   const int WIDE_TABLES = wide_tables_of(bits), WIDE_VWIN = wide_vwin_of(bits);
   WideShape w;
   w.worst = n * (size_t)WIDE_TABLES;
@@ -329,7 +330,7 @@ inline WideShape wide_shape(size_t n, int curve, int bits, int nvec) {  // (nvec
   static const double slack = [] { const char* e = getenv("MSM_HIP_WIDE_SLACK_PCT"); return e ? atof(e) / 100.0 : 0.004; }();  // tuning aid
   const double fullest = (double)n * (WIDE_TABLES - 1) / WIDE_VWIN + (double)n * share;
   const size_t typ = (size_t)(fullest * (1.0 + slack)) + 64;
-  w.chunk_len = chunk_len_for(typ, WIDE_VWIN * nvec);
+  w.chunk_len = chunk_len_for(typ, lwin);
   w.chunks = chunks_for(typ, w.chunk_len);
   w.host_len = (uint32_t)((w.worst + w.chunks - 1) / w.chunks);
   if (w.host_len < w.chunk_len) w.host_len = w.chunk_len;
@@ -512,9 +513,13 @@ inline bool use_planes(const msm_hip_ctx* ctx, LaunchMode mode, int w_count_vec,
 // Enqueue one MSM (windows [w_begin, w_begin + w_count)) into slot `s`.  Window sums (canonical Jacobian bytes) go to
 // `wsums_out` (device memory; the slot's own buffer when null); the error word and, if `to_host`, the window sums are
 // copied to the slot's pinned buffer.  Returns without waiting.
+// (MODE_WIDE: `v_count` != 0 -- a SHARE of the virtual windows, [v_begin, v_begin + v_count) of every vector; its sums are (window sum, plain
+//  total) pairs, 2 records per local window.  0: whole MSMs, all 2^(C-16) virtual windows)
 int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count_vec, int nvec, int wbits, LaunchMode mode, Slot& s,
-            uint32_t* wsums_out, bool to_host) {
+            uint32_t* wsums_out, bool to_host, int v_begin = 0, int v_count = 0) {
   const bool merge = mode == MODE_TABLES, halves = mode == MODE_HALVES, wide = mode == MODE_WIDE;
+  const bool pairs = wide && v_count != 0;
+  if (wide && !pairs) v_count = wide_vwin_of(ctx->wide_bits);
   const uint32_t half = 1u << (wbits - 1);   // bucket slots per window
   const unsigned ncoarse = half / FINE;      // coarse bins that can hold entries
   // fixed-base tables (`merge`): the w_count_vec windows of a vector feed one bucket set -- one local window of up to
@@ -528,7 +533,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   const size_t n_entries = merge || wide ? n * (size_t)w_count_vec : n_sc;  // (wide: what ONE virtual window may receive)
   // `nvec` scalar vectors (contiguous, n x 32 B each) share this launch: local window lw = v * w_count_vec + (w - w_begin);
   // everything after the two scalar-reading kernels only sees w_count = nvec * w_count_vec local windows
-  const int w_count = merge ? nvec : wide ? nvec * wide_vwin_of(ctx->wide_bits) : nvec * w_count_vec;
+  const int w_count = merge ? nvec : wide ? nvec * v_count : nvec * w_count_vec;
   hipStream_t st = ctx->stream, rs = ctx->reduce_stream[(&s - ctx->slot) % NREDUCE];
   // a synchronous call with nothing else in flight (msm_hip_run_*: the caller waits for this launch before it issues another): the stitch and
   // the bucket reduce follow the SMVP on the MAIN stream -- no cross-stream hand-off (an event wait costs ~10 us more than an in-stream kernel
@@ -543,7 +548,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   uint32_t tile_len = 2048;
   if ((n_sc + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n_sc + MAX_TILES - 1) / MAX_TILES) + 255) / 256 * 256);
   const uint32_t tiles = (uint32_t)((n_sc + tile_len - 1) / tile_len);
-  const WideShape ws = wide ? wide_shape(n, ctx->curve, ctx->wide_bits, nvec) : WideShape{};
+  const WideShape ws = wide ? wide_shape(n, ctx->curve, ctx->wide_bits, w_count) : WideShape{};
   const uint32_t chunk_len = wide ? ws.host_len : chunk_len_for(n_entries, w_count);  // (the longest the device may pick: smvp_chunk_len)
   const uint32_t chunks = wide ? ws.chunks : chunks_for(n_entries, chunk_len);
   const size_t stride = stride_for(n_entries);
@@ -585,7 +590,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   const int plane_mode = planes ? 2 : (digits ? 1 : 0);
   if (wide) {
     const int top_shift = wide_top_shift(ctx->curve, ctx->wide_bits);
-#define LAUNCH_COUNT_WIDE(C) hipLaunchKernelGGL(k_count_wide<C>, dim3(tiles, nvec), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, nvec, n * 8, ctx->d_counts, d_err, top_shift)
+#define LAUNCH_COUNT_WIDE(C) hipLaunchKernelGGL(k_count_wide<C>, dim3(tiles, nvec), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, nvec, n * 8, ctx->d_counts, d_err, top_shift, v_begin, v_count)
     switch (ctx->wide_bits) {
       case 16: LAUNCH_COUNT_WIDE(16); break;
       case 17: LAUNCH_COUNT_WIDE(17); break;
@@ -612,7 +617,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     const int top_shift = wide_top_shift(ctx->curve, ctx->wide_bits);
 #define LAUNCH_SCATTER_WIDE(C)                                                                                                                         \
   hipLaunchKernelGGL(k_scatter_wide<C>, dim3(tiles, nvec), dim3(WIDE_THREADS), 0, st, d_scalars, n_sc, stride, tile_len, tiles, nvec, n * 8, ctx->d_counts, ctx->d_bin_total, \
-                     ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, chunks, chunk_len, d_chunk_len, top_shift)
+                     ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, chunks, chunk_len, d_chunk_len, top_shift, v_begin, v_count)
     switch (ctx->wide_bits) {
       case 16: LAUNCH_SCATTER_WIDE(16); break;
       case 17: LAUNCH_SCATTER_WIDE(17); break;
@@ -708,7 +713,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   // (their host thread is on the critical path: several MSMs' worth of host work per launch) and debug read-backs get finished sums.
   // (a wide fixed-base launch always leaves the plane sums -- its finish needs every virtual window's plain total, which is one of them --: launch_impl
   //  admits it only as whole MSMs whose sums go to the host, at most 24 virtual windows together)
-  const bool parts_mode = to_host && (nvec == 1 || wide) && (!ctx->debug || wide) && wsums_out == reinterpret_cast<uint32_t*>(s.d_wsums) && w_count <= 24;
+  const bool parts_mode = to_host && !pairs && (nvec == 1 || wide) && (!ctx->debug || wide) && wsums_out == reinterpret_cast<uint32_t*>(s.d_wsums) && w_count <= 24;
   // the kernel that ends the chain writes the launch's error word into the slot's pinned buffer itself and clears it (no copy, no fill); a
   // single MSM's bit-plane sums go to the pinned buffer directly as well (12 KB of stores over the host link instead of a copy behind the kernel)
   uint32_t* h_err = reinterpret_cast<uint32_t*>(s.h_wsums + WSUM_BYTES);
@@ -719,17 +724,17 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   } else if (ctx->ops->use_w256) {
     hipLaunchKernelGGL(ctx->ops->bpr_w256, dim3(2, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts, (int)(half / BPR_COLS));
     AFTER_KERNEL(ctx, "k_bpr_w256", rs);
-    hipLaunchKernelGGL(ctx->ops->bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue, d_err, h_err);
+    hipLaunchKernelGGL(ctx->ops->bpr_final, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue, d_err, h_err, pairs ? 1 : 0);
     AFTER_KERNEL(ctx, "k_bpr_final", rs);
   } else {  // a field too wide for k_bpr_w256's LDS footprint (BLS12-381): the same bit-plane sums, finished on the device
     hipLaunchKernelGGL(ctx->ops->bpr_planes_xyzz, dim3(PLANES_PER_WINDOW, w_count), dim3(256), 0, rs, d_rows, d_cols, d_parts, (int)(half / BPR_COLS),
                        s.d_big_queue, d_err, h_err);
     AFTER_KERNEL(ctx, "k_bpr_planes<xyzz>", rs);
-    hipLaunchKernelGGL(ctx->ops->bpr_final_planes, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue, d_err, h_err);
+    hipLaunchKernelGGL(ctx->ops->bpr_final_planes, dim3(1), dim3(64), 0, rs, d_parts, w_count, wsums_out, s.d_big_queue, d_err, h_err, pairs ? 1 : 0);
     AFTER_KERNEL(ctx, "k_bpr_final_planes", rs);
   }
   if (tl >= 2) HIP_TRY(ctx, hipEventRecord(s.red1, rs));
-  if (to_host && !parts_mode) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * ctx->jb, hipMemcpyDeviceToHost, rs));
+  if (to_host && !parts_mode) HIP_TRY(ctx, hipMemcpyAsync(s.h_wsums, wsums_out, (size_t)w_count * (pairs ? 2 : 1) * ctx->jb, hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipEventRecord(s.done, rs));
   HIP_TRY(ctx, hipGetLastError());
 
@@ -741,6 +746,11 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   s.halves = halves;
   s.wide_bits = wide ? ctx->wide_bits : 0;
   s.parts = parts_mode;
+  s.pairs = pairs;
+  if (pairs) {
+    s.w_begin = v_begin;
+    s.w_count = v_count;
+  }
   s.n = n;
   s.timed = tl >= 1;
   s.timing_level = tl;
@@ -1046,16 +1056,21 @@ int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, 
 
 namespace {
 // windows [w_begin, w_end) -- in units of `wbits`-bit windows -- of `nvec` scalar vectors into `slot`
+// (MODE_WIDE, v_count != 0: a SHARE of the wide tables' virtual windows -- [v_begin, v_begin + v_count) of every vector; its sums are (window sum,
+//  plain total) pairs: 2 records per local window, to `window_sums_dev` or, when null, to the slot's pinned buffer)
 int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end, int wbits, int slot,
-                void* window_sums_dev, LaunchMode mode = MODE_PLAIN) {
+                void* window_sums_dev, LaunchMode mode = MODE_PLAIN, int v_begin = 0, int v_count = 0) {
   // (MODE_WIDE: called with wbits = 19 and all 14 windows; everything behind the recode sees 8 local windows of 16 bits)
   const bool merge = mode == MODE_TABLES, halves = mode == MODE_HALVES, wide = mode == MODE_WIDE;
+  const bool pairs = wide && v_count != 0;
   int rc = check_run_args(ctx, scalars_dev, n);
   if (rc) return rc;
   if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > nwin_of(wbits, halves) || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
-  if (wide && (nvec < 1 || nvec * wide_vwin_of(ctx->wide_bits) > 24 || window_sums_dev || w_begin != 0 || wbits != ctx->wide_bits || w_end != wide_tables_of(wbits)))
-    return MSM_HIP_ERR_INVALID_ARG;
-  const int WIDE_VWIN = wide ? wide_vwin_of(ctx->wide_bits) : 0;
+  if (wide && (nvec < 1 || w_begin != 0 || wbits != ctx->wide_bits || w_end != wide_tables_of(wbits))) return MSM_HIP_ERR_INVALID_ARG;
+  if (wide && !pairs && (nvec * wide_vwin_of(ctx->wide_bits) > 24 || window_sums_dev)) return MSM_HIP_ERR_INVALID_ARG;
+  if (pairs && (v_begin < 0 || v_count < 0 || v_begin + v_count > wide_vwin_of(ctx->wide_bits))) return MSM_HIP_ERR_INVALID_ARG;
+  if (!wide && v_count) return MSM_HIP_ERR_INVALID_ARG;
+  const int WIDE_VWIN = wide ? (pairs ? v_count : wide_vwin_of(ctx->wide_bits)) : 0;
   if (wide) wbits = WBITS;
   const int w_count = w_end - w_begin;
   const int w_local = merge ? nvec : wide ? nvec * WIDE_VWIN : nvec * w_count;  // bucket sets of the launch
@@ -1073,20 +1088,25 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
   s.halves = halves;
   s.wide_bits = wide ? ctx->wide_bits : 0;
   s.parts = false;
+  s.pairs = pairs;
+  if (pairs) {
+    s.w_begin = v_begin;
+    s.w_count = v_count;
+  }
   s.to_host = window_sums_dev == nullptr;
   if (n == 0) {  // identity window sums, nothing to compute
     s.pending = true;
     s.timed = false;
     memset(s.h_wsums, 0, WSUM_BYTES + 4);
     if (window_sums_dev) {
-      HIP_TRY(ctx, hipMemsetAsync(window_sums_dev, 0, (size_t)w_local * ctx->jb, ctx->reduce_stream[slot % NREDUCE]));
+      HIP_TRY(ctx, hipMemsetAsync(window_sums_dev, 0, (size_t)w_local * (pairs ? 2 : 1) * ctx->jb, ctx->reduce_stream[slot % NREDUCE]));
       HIP_TRY(ctx, hipEventRecord(s.done, ctx->reduce_stream[slot % NREDUCE]));
     }
     return MSM_HIP_OK;
   }
   if (wide) {
-    const WideShape ws = wide_shape(n, ctx->curve, ctx->wide_bits, nvec);
-    if ((rc = ensure_work(ctx, ws.worst, w_local, wbits, WIDE_VWIN, s, false, (size_t)w_local * ws.chunks))) return rc;
+    const WideShape ws = wide_shape(n, ctx->curve, ctx->wide_bits, w_local);
+    if ((rc = ensure_work(ctx, ws.worst, w_local, wbits, wide_vwin_of(ctx->wide_bits), s, false, (size_t)w_local * ws.chunks))) return rc;
   } else if ((rc = ensure_work(ctx, merge ? n * (size_t)w_count : halves ? 2 * n : n, w_local, wbits,
                                merge ? 1 : halves ? nwin_of(wbits, true) : NWIN, s, use_planes(ctx, mode, w_count, wbits)))) return rc;
   if (halves && (size_t)nvec * n > ctx->cap_halves) {
@@ -1102,7 +1122,7 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
     ctx->cap_scalar_conv = (size_t)nvec * n;
   }
   return enqueue(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, nvec, wbits, mode, s,
-                 static_cast<uint32_t*>(window_sums_dev), window_sums_dev == nullptr);
+                 static_cast<uint32_t*>(window_sums_dev), window_sums_dev == nullptr, v_begin, v_count);
 }
 }  // namespace
 
@@ -1134,6 +1154,14 @@ int msm_hip_launch_half_windows_batch_device_bn254(msm_hip_ctx* ctx, const void*
   return launch_impl(ctx, scalars_dev, n, nvec, hw_begin, hw_end, WBITS, slot, window_sums_dev, MODE_HALVES);
 }
 
+int msm_hip_launch_vwindows_batch_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int v_begin, int v_end, int slot,
+                                         void* sums_dev) {
+  if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
+  if (!ctx->wide_bits) return ctx->n_bases || !n ? MSM_HIP_ERR_INVALID_ARG : MSM_HIP_ERR_NO_BASES;  // needs bases set with MSM_HIP_BASES_PRECOMPUTE_WIDE
+  if (v_begin < 0 || v_end <= v_begin) return MSM_HIP_ERR_INVALID_ARG;
+  return launch_impl(ctx, scalars_dev, n, nvec, 0, wide_tables_of(ctx->wide_bits), ctx->wide_bits, slot, sums_dev, MODE_WIDE, v_begin, v_end - v_begin);
+}
+
 int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot,
                                         void* window_sums_dev) {
   return msm_hip_launch_windows_batch_device_bn254(ctx, scalars_dev, n, 1, w_begin, w_end, slot, window_sums_dev);
@@ -1163,7 +1191,7 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   Slot& s = ctx->slot[slot];
   // fixed-base launches leave ONE sum per vector (every table already carries its power of two): nothing to combine but the copy
   const int nwin = s.merged ? 1 : s.wide_bits ? wide_vwin_of(s.wide_bits) : nwin_of(s.wbits, s.halves);
-  if (!s.pending || !s.to_host || s.w_count != (s.wide_bits ? wide_tables_of(s.wide_bits) : nwin_of(s.wbits, s.halves))) return MSM_HIP_ERR_INVALID_ARG;
+  if (!s.pending || !s.to_host || s.pairs || s.w_count != (s.wide_bits ? wide_tables_of(s.wide_bits) : nwin_of(s.wbits, s.halves))) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   int rc = wait_slot(ctx, s);
   if (rc) return rc;
@@ -1314,6 +1342,18 @@ int msm_hip_combine_windows_batch_curve(int curve, const uint8_t* window_sums_ho
   // independent Horner chains (47 us each on one core): side by side on the combine pool when there are several
   combine_pool().run(nvec, [&](int v) {
     if (!ops->combine_windows(window_sums_host + (size_t)v * num_windows * jb, num_windows, WBITS, out_xyz + (size_t)v * jb)) ok = false;
+  });
+  return ok ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
+}
+
+int msm_hip_combine_vwindows_batch_curve(int curve, const uint8_t* pairs_host, int num_vwindows, int nvec, uint8_t* out_xyz) {
+  if (curve < 0 || curve >= MSM_HIP_NUM_CURVES) return MSM_HIP_ERR_INVALID_ARG;
+  if (!pairs_host || !out_xyz || num_vwindows < 1 || num_vwindows > 16 || nvec < 0) return MSM_HIP_ERR_INVALID_ARG;
+  const CurveOps* ops = curve_ops(curve);
+  const size_t jb = 12 * (size_t)ops->coord_words;
+  std::atomic<bool> ok{true};
+  combine_pool().run(nvec, [&](int v) {  // one short chain per MSM (2 additions per virtual window + 15 doublings), side by side
+    if (!ops->combine_wide_pairs(pairs_host + (size_t)v * num_vwindows * 2 * jb, num_vwindows, out_xyz + (size_t)v * jb)) ok = false;
   });
   return ok ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
 }

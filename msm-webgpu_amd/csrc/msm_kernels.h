@@ -765,9 +765,15 @@ __device__ __forceinline__ uint32_t wide_key(uint32_t mag) { return (((mag - 1u)
 
 // first pass: counts[lw][tile][bin] (the layout of k_count), local window lw = v * VWIN + hi for scalar vector v of the launch's nvec
 // (vec_stride words apart: several whole MSMs over the same tables share one kernel sequence, as in k_count)
+// Virtual-window SHARES (round 5: the wide tables behind the window-sharded / multi-GPU entry points): a launch may take only the virtual
+// windows [v_begin, v_begin + v_count) of every vector -- a rank of an 8-GPU run at 19-bit digits takes ONE of the 8: a bucket set of 2^15
+// slots and, for uniform scalars, 14 n / 8 entries instead of the 2 n entries and two bucket sets of two 16-bit windows.  Both passes still
+// recode every digit of every scalar (the carry chain runs across the digits; 32 B per scalar) and drop the digits whose magnitude falls
+// outside the range; local window lw = v * v_count + (hi - v_begin).  Whole MSMs: v_begin = 0, v_count = VWIN.
 template <int C>
 __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles, int nvec,
-                                                    size_t vec_stride, uint32_t* __restrict__ counts, uint32_t* __restrict__ err, int top_shift) {
+                                                    size_t vec_stride, uint32_t* __restrict__ counts, uint32_t* __restrict__ err, int top_shift,
+                                                    int v_begin, int v_count) {
   constexpr int SW = 8;  // full-length scalars
   constexpr int WIDE_KEYS = WideCfg<C>::KEYS, WIDE_TABLES = WideCfg<C>::TABLES;
   __shared__ uint32_t cnt[WIDE_KEYS];
@@ -777,6 +783,7 @@ __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__
   uint32_t bad = 0;
   const int v = blockIdx.y;  // grid (tiles, nvec): one tile of one scalar vector per workgroup (as k_count)
   (void)nvec;
+  const uint32_t keys = (uint32_t)v_count * NCOARSE;  // (virtual window, coarse bin) runs of this launch's share (<= WIDE_KEYS)
   for (int i = tid; i < WIDE_KEYS; i += 256) cnt[i] = 0;
   __syncthreads();
   for (size_t i0 = base; i0 < end; i0 += 256) {
@@ -790,12 +797,13 @@ __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__
     for (int w = 0; w < WIDE_TABLES; w++) {
       uint32_t sign;
       const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, bad);
-      if (mag) atomicAdd(&cnt[wide_key(mag)], 1u);
+      const uint32_t key = wide_key(mag) - ((uint32_t)v_begin << 7);  // (mag = 0: no entry, whatever the key says)
+      if (mag && key < keys) atomicAdd(&cnt[key], 1u);
     }
   }
   __syncthreads();
-  for (int i = tid; i < WIDE_KEYS; i += 256)
-    counts[((size_t)(v * WideCfg<C>::VWIN + i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[i];
+  for (int i = tid; i < (int)keys; i += 256)
+    counts[((size_t)(v * v_count + i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[i];
   if (bad) atomicOr(err, ERRBIT_SCALAR_CARRY);
 }
 
@@ -810,9 +818,12 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
                                                                uint32_t tiles, int nvec, size_t vec_stride, const uint32_t* __restrict__ counts,
                                                                const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr,
                                                                uint32_t* __restrict__ tmp_val, uint8_t* __restrict__ tmp_fine, size_t table_stride,
-                                                               uint32_t chunks, uint32_t host_chunk_len, uint32_t* __restrict__ chunk_len_dev, int top_shift) {
+                                                               uint32_t chunks, uint32_t host_chunk_len, uint32_t* __restrict__ chunk_len_dev, int top_shift,
+                                                               int v_begin, int v_count) {
   constexpr int SW = 8;  // full-length scalars
   constexpr int WIDE_KEYS = WideCfg<C>::KEYS, WIDE_TABLES = WideCfg<C>::TABLES;
+  const int keys = v_count * NCOARSE;                // runs of this launch's share of the virtual windows (k_count_wide); WIDE_KEYS for whole MSMs
+  const uint32_t key0 = (uint32_t)v_begin << 7;
   // 5 bytes of LDS per staged entry -- its (virtual window, coarse bin) run, its fine slot, and sign | window | position within the iteration's
   // scalars (16 bits: the record index is put together when the entry is written out) -- so that 2048 scalars (1536 at 16 bits) fit one
   // iteration: twice the run length of the 4-byte index staged before (153 - 158 KB of the 160 KB a workgroup may hold)
@@ -839,12 +850,12 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
   // earlier tiles put there.  Workgroup (0, 0) does this for every vector of the launch (its own last: gpos keeps the last one scanned): it
   // publishes all bin starts (coarse_ptr[lw][0 .. 128]) and the launch's chunk length.
   const bool publisher = blockIdx.x == 0 && blockIdx.y == 0;
-  const int lw0 = (int)blockIdx.y * WideCfg<C>::VWIN;
+  const int lw0 = (int)blockIdx.y * v_count;
   const uint32_t* sv = scalars + (size_t)blockIdx.y * vec_stride;
   for (int pv = publisher ? nvec - 1 : (int)blockIdx.y; pv >= (int)blockIdx.y; pv--)
-  for (int i0 = 0; i0 < WIDE_KEYS; i0 += WIDE_THREADS) {
-    const int i = i0 + tid, lw = pv * WideCfg<C>::VWIN + i / NCOARSE, bin = i % NCOARSE;
-    const bool live = i < WIDE_KEYS;  // (fewer runs than threads: 17-bit digits)
+  for (int i0 = 0; i0 < keys; i0 += WIDE_THREADS) {
+    const int i = i0 + tid, lw = pv * v_count + i / NCOARSE, bin = i % NCOARSE;
+    const bool live = i < keys;  // (fewer runs than threads: 17-bit digits, shares of a few virtual windows)
     const uint32_t v = live ? bin_total[lw * NCOARSE + bin] : 0u;
     uint32_t x = v;
 #pragma unroll
@@ -888,7 +899,8 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
       for (int w = 0; w < WIDE_TABLES; w++) {
         uint32_t sign, over = 0;
         const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, over);  // (an overflowing top digit: no entry here as in k_count_wide, which reports it)
-        const uint32_t r = mag ? atomicAdd(&hist[wide_key(mag)], 1u) : 0u;
+        const uint32_t key = wide_key(mag) - key0;                           // (outside this launch's virtual windows: no entry)
+        const uint32_t r = mag && key < (uint32_t)keys ? atomicAdd(&hist[key], 1u) : 0u;
         if (w & 1) rank[j][w >> 1] |= r << 16;
         else rank[j][w >> 1] = r;
       }
@@ -930,8 +942,9 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
       for (int w = 0; w < WIDE_TABLES; w++) {
         uint32_t sign, over = 0;
         const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, over);
-        if (mag) {
-          const uint32_t key = wide_key(mag), e = lstart[key] + ((rank[j][w >> 1] >> ((w & 1) * 16)) & 0xffffu);
+        const uint32_t key = wide_key(mag) - key0;
+        if (mag && key < (uint32_t)keys) {
+          const uint32_t e = lstart[key] + ((rank[j][w >> 1] >> ((w & 1) * 16)) & 0xffffu);
           st_loc[e] = (uint16_t)((sign << 15) | ((uint32_t)w << 11) | (uint32_t)(j * WIDE_THREADS + tid));
           st_key[e] = (uint16_t)key;
           st_fine[e] = (uint8_t)(mag & 0xffu);
@@ -2055,8 +2068,11 @@ __device__ __forceinline__ void finish_error_word(uint32_t* __restrict__ err_dev
   *err_host = *err_dev;
   *err_dev = 0;
 }
+// (emit_total: shares of the wide tables' virtual windows -- record 2 w is the window sum, record 2 w + 1 the window's PLAIN total
+//  TC_w = sum_slot B[w][slot], which the finish needs beside it: host_g1.h, combine_wide_pairs)
 __global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ parts, int w_count, uint32_t* __restrict__ wsums,
-                                                  uint32_t* __restrict__ big_queue, uint32_t* __restrict__ err_dev, uint32_t* __restrict__ err_host) {
+                                                  uint32_t* __restrict__ big_queue, uint32_t* __restrict__ err_dev, uint32_t* __restrict__ err_host,
+                                                  int emit_total) {
   const int w = threadIdx.x;
   if (w == 0) {
     big_queue[0] = 0;  // the stitch's queue of big buckets, consumed earlier on this stream: empty for the next launch
@@ -2065,8 +2081,10 @@ __global__ void __launch_bounds__(64) k_bpr_final(const uint32_t* __restrict__ p
   if (w >= w_count) return;
   g1_xyzz acc = ld_xyzz(parts + ((size_t)w * 3 + 0) * XYZZ_WORDS);
   for (int i = 0; i < 7; i++) acc = g1_double(acc);
-  acc = g1_add(acc, g1_add(ld_xyzz(parts + ((size_t)w * 3 + 1) * XYZZ_WORDS), ld_xyzz(parts + ((size_t)w * 3 + 2) * XYZZ_WORDS)));
-  st_jacobian_plain(wsums + (size_t)w * JAC_WORDS, acc);
+  const g1_xyzz total = ld_xyzz(parts + ((size_t)w * 3 + 2) * XYZZ_WORDS);
+  acc = g1_add(acc, g1_add(ld_xyzz(parts + ((size_t)w * 3 + 1) * XYZZ_WORDS), total));
+  st_jacobian_plain(wsums + (size_t)(emit_total ? 2 * w : w) * JAC_WORDS, acc);
+  if (emit_total) st_jacobian_plain(wsums + (size_t)(2 * w + 1) * JAC_WORDS, total);
 }
 
 // ... or, for a launch whose sums go to the host anyway (one MSM per launch: its LATENCY is what counts): the narrow end of the reduction
@@ -2116,7 +2134,8 @@ __global__ void __launch_bounds__(256) k_bpr_planes(const uint32_t* __restrict__
 // one lane per window: S_w = sum_b 2^(b+7) PR_b + sum_b 2^b PC_b + TC from the plane sums (XYZZ records), as canonical Jacobian bytes --
 // the device-side counterpart of host_g1.h: window_sum_from_planes, for sums that stay on the device
 __global__ void __launch_bounds__(64) k_bpr_final_planes(const uint32_t* __restrict__ planes, int w_count, uint32_t* __restrict__ wsums,
-                                                         uint32_t* __restrict__ big_queue, uint32_t* __restrict__ err_dev, uint32_t* __restrict__ err_host) {
+                                                         uint32_t* __restrict__ big_queue, uint32_t* __restrict__ err_dev, uint32_t* __restrict__ err_host,
+                                                         int emit_total) {
   const int w = threadIdx.x;
   if (w == 0) {
     big_queue[0] = 0;
@@ -2130,8 +2149,10 @@ __global__ void __launch_bounds__(64) k_bpr_final_planes(const uint32_t* __restr
     acc = g1_double(acc);
     acc = g1_add(acc, ld_xyzz(pw + (size_t)(pos >= 7 ? pos - 7 : 8 + pos) * XYZZ_WORDS));
   }
-  acc = g1_add(acc, ld_xyzz(pw + (size_t)(PLANES_PER_WINDOW - 1) * XYZZ_WORDS));
-  st_jacobian_plain(wsums + (size_t)w * JAC_WORDS, acc);
+  const g1_xyzz total = ld_xyzz(pw + (size_t)(PLANES_PER_WINDOW - 1) * XYZZ_WORDS);
+  acc = g1_add(acc, total);
+  st_jacobian_plain(wsums + (size_t)(emit_total ? 2 * w : w) * JAC_WORDS, acc);
+  if (emit_total) st_jacobian_plain(wsums + (size_t)(2 * w + 1) * JAC_WORDS, total);
 }
 
 // bucket records -> Jacobian wire records (stage read-back for the parity tests)

@@ -107,11 +107,12 @@ struct MgpuSlot {
   int nvec = 0;
   size_t n = 0;
   bool halves = false;           // the windows are the 8 half-length ones (endomorphism bases)
+  int wide_bits = 0;             // != 0: the shares are the virtual windows of the wide fixed-base tables (records come in pairs: window sum, plain total)
   uint64_t ticket[MGPU_MAX] = {};  // the launch job of every device
   int rc[MGPU_MAX] = {};           // ... and its status
   bool launched[MGPU_MAX] = {};    // the device's context slot holds an unfinished launch
-  uint8_t* d_send[MGPU_MAX] = {};    // MAXLW x 96 B: this device's window sums [nvec][its windows], then padding
-  uint8_t* d_gather[MGPU_MAX] = {};  // n x MAXLW x 96 B: every device's block after the all-gather
+  uint8_t* d_send[MGPU_MAX] = {};    // 2 MAXLW x 96 B: this device's window sums [nvec][its windows] (wide shares: record pairs), then padding
+  uint8_t* d_gather[MGPU_MAX] = {};  // n x 2 MAXLW x 96 B: every device's block after the all-gather
   uint8_t* h_gather = nullptr;       // pinned copy of device 0's gather buffer
   hipEvent_t gathered[MGPU_MAX] = {};  // device d's call of this launch's all-gather has completed (device 0: and h_gather is complete)
 };
@@ -129,6 +130,8 @@ struct msm_hip_mgpu {
   std::atomic<int> fault_device{-1};  // test hook (msm_hip_mgpu_inject_fault / MSM_HIP_FAULT_DEVICE): the next `fault_left` launches fail on this device
   std::atomic<int> fault_left{0};
   bool endo = false;  // the resident bases carry their endomorphism images: window-sharded launches use the 8 half-length windows
+  int wide_bits = 0;  // the resident bases are wide fixed-base tables of this digit width: window-sharded launches share their 2^(C-16) virtual windows
+  int wide_bits_choice = 0;  // msm_hip_mgpu_set_wide_bits (0: 19 -- as many virtual windows as a node has GPUs)
   RcclApi api;
   void* comm[MGPU_MAX] = {};
   hipStream_t gather_stream[MGPU_MAX] = {};  // the collective and the copy to the host: behind the slot's bucket reduce, beside the next one
@@ -148,8 +151,9 @@ int mgpu_for_each(msm_hip_mgpu* m, F f) {
   return MSM_HIP_OK;
 }
 
-inline int mgpu_windows(const msm_hip_mgpu* m, bool halves) { return halves ? nwin_of(WBITS, true) : NWIN; }
-inline int mgpu_per(const msm_hip_mgpu* m, bool halves) { return (mgpu_windows(m, halves) + m->n - 1) / m->n; }
+// the windows the devices share: 16, the 8 half-length ones (endomorphism bases), or the virtual windows of wide tables
+inline int mgpu_windows(bool halves, int wide_bits) { return wide_bits ? wide_vwin_of(wide_bits) : halves ? nwin_of(WBITS, true) : NWIN; }
+inline int mgpu_per(const msm_hip_mgpu* m, bool halves, int wide_bits) { return (mgpu_windows(halves, wide_bits) + m->n - 1) / m->n; }
 
 // device d's own work of a window-sharded launch: scalars up (host variant), its window range of every vector into context slot `k`
 // (`launched`: the context slot now holds an unfinished launch)
@@ -181,7 +185,8 @@ int mgpu_enqueue_on_device(msm_hip_mgpu* m, int d, int k, const void* scalars, b
     dev = s.d_host_scalars;
   }
   void* sums = m->rccl ? ms.d_send[d] : nullptr;  // host gather: the sums leave through the context slot's pinned buffer
-  rc = launch_impl(ctx, dev, n, nvec, b, e, WBITS, k, sums, halves ? MODE_HALVES : MODE_PLAIN);
+  if (ms.wide_bits) rc = launch_impl(ctx, dev, n, nvec, 0, wide_tables_of(ms.wide_bits), ms.wide_bits, k, sums, MODE_WIDE, b, e - b);
+  else rc = launch_impl(ctx, dev, n, nvec, b, e, WBITS, k, sums, halves ? MODE_HALVES : MODE_PLAIN);
   launched = rc == MSM_HIP_OK;
   return rc;
 }
@@ -195,7 +200,7 @@ int mgpu_launch_on_device(msm_hip_mgpu* m, int d, int k, const void* scalars, bo
   MgpuSlot& ms = m->slot[k];
   msm_hip_ctx* ctx = m->ctx[d];
   const bool halves = ms.halves;
-  const int W = mgpu_windows(m, halves), rows = nvec * mgpu_per(m, halves);
+  const int W = mgpu_windows(halves, ms.wide_bits), rows = nvec * mgpu_per(m, halves, ms.wide_bits) * (ms.wide_bits ? 2 : 1);
   int b, e;
   (void)msm_hip_window_range(d, m->n, W, &b, &e);
   int rc = MSM_HIP_OK;
@@ -229,13 +234,14 @@ int mgpu_launch(msm_hip_mgpu* m, const void* const* per_device, const void* host
   MgpuSlot& ms = m->slot[k];
   if (ms.pending) return MSM_HIP_ERR_SLOT_BUSY;
   const bool halves = m->endo;
-  if (nvec * mgpu_per(m, halves) > MAXLW) return MSM_HIP_ERR_INVALID_ARG;
+  if (nvec * mgpu_per(m, halves, m->wide_bits) > MAXLW) return MSM_HIP_ERR_INVALID_ARG;
   if (n && m->ctx[0]->n_bases == 0) return MSM_HIP_ERR_NO_BASES;
   if (n > m->ctx[0]->n_bases) return MSM_HIP_ERR_INVALID_ARG;
   ms.pending = true;
   ms.nvec = nvec;
   ms.n = n;
   ms.halves = halves;
+  ms.wide_bits = m->wide_bits;
   for (int d = 0; d < m->n; d++) {
     ms.launched[d] = false;
     ms.rc[d] = MSM_HIP_OK;
@@ -338,15 +344,15 @@ int msm_hip_mgpu_create_curve(msm_hip_mgpu** out, const int* device_ids, int n_d
       ok = guard.ok && hipStreamCreateWithFlags(&m->gather_stream[d], hipStreamNonBlocking) == hipSuccess;
       for (int k = 0; ok && k < NSLOT; k++) {
         MgpuSlot& ms = m->slot[k];
-        ok = hipMalloc((void**)&ms.d_send[d], (size_t)MAXLW * MAX_JB) == hipSuccess &&
-             hipMalloc((void**)&ms.d_gather[d], (size_t)n_devices * MAXLW * MAX_JB) == hipSuccess &&
-             hipMemset(ms.d_send[d], 0, (size_t)MAXLW * MAX_JB) == hipSuccess;
+        ok = hipMalloc((void**)&ms.d_send[d], (size_t)2 * MAXLW * MAX_JB) == hipSuccess &&
+             hipMalloc((void**)&ms.d_gather[d], (size_t)n_devices * 2 * MAXLW * MAX_JB) == hipSuccess &&
+             hipMemset(ms.d_send[d], 0, (size_t)2 * MAXLW * MAX_JB) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&ms.gathered[d], hipEventDisableTiming) == hipSuccess;
       }
       ok = ok && hipDeviceSynchronize() == hipSuccess;
     }
     for (int k = 0; ok && k < NSLOT; k++)
-      ok = hipHostMalloc((void**)&m->slot[k].h_gather, (size_t)n_devices * MAXLW * MAX_JB, hipHostMallocDefault) == hipSuccess;
+      ok = hipHostMalloc((void**)&m->slot[k].h_gather, (size_t)n_devices * 2 * MAXLW * MAX_JB, hipHostMallocDefault) == hipSuccess;
     if (!ok && flags == MSM_HIP_MGPU_GATHER_RCCL) {
       msm_hip_mgpu_destroy(m);
       return MSM_HIP_ERR_HIP;
@@ -378,15 +384,30 @@ int msm_hip_mgpu_set_bases_bn254(msm_hip_mgpu* m, const uint8_t* xy_host, size_t
   if (!m || (!xy_host && n)) return MSM_HIP_ERR_INVALID_ARG;
   for (const MgpuSlot& ms : m->slot)
     if (ms.pending) return MSM_HIP_ERR_SLOT_BUSY;
+  // The mode the window-sharded launches run in follows the flags: the 8 half-length windows with the endomorphism images, the virtual windows
+  // with wide tables, else the reference's 16 windows over the n plain records.  flags = 0 (the drop-in call shape) is resolved ONCE here to the
+  // plain set -- a context's own default (the endomorphism images on the prime-order curves, msm_hip.hip: resolve_base_flags) would make every
+  // device store 2n records and run k_endo_points for launches that then read only the first n.  Whole-MSM batches
+  // (msm_hip_mgpu_run_batch) run in the mode the flags name.
+  if (!(flags & (MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_PRECOMPUTE_WIDE | MSM_HIP_BASES_ENDOMORPHISM | MSM_HIP_BASES_PLAIN))) flags |= MSM_HIP_BASES_PLAIN;
+  if (flags & MSM_HIP_BASES_PRECOMPUTE_WIDE)  // shares of virtual windows: 19-bit digits unless asked otherwise (a context alone picks 17 / 20 by n: 2 or 16 virtual windows)
+    for (int d = 0; d < m->n; d++) m->ctx[d]->wide_bits_choice = m->wide_bits_choice ? m->wide_bits_choice : 19;
   const int rc = mgpu_for_each(m, [&](int d) { return msm_hip_set_bases_bn254(m->ctx[d], xy_host, n, flags); });  // replicated
-  m->endo = !rc && n && (flags & MSM_HIP_BASES_ENDOMORPHISM) != 0;
+  m->endo = !rc && n && m->ctx[0]->endo;
+  m->wide_bits = !rc && n ? m->ctx[0]->wide_bits : 0;
   return rc;
+}
+
+int msm_hip_mgpu_set_wide_bits(msm_hip_mgpu* m, int bits) {
+  if (!m || (bits != 0 && (bits < 16 || bits > 20))) return MSM_HIP_ERR_INVALID_ARG;
+  m->wide_bits_choice = bits;
+  return MSM_HIP_OK;
 }
 
 int msm_hip_mgpu_group_size(const msm_hip_mgpu* m) {
   if (!m) return MSM_HIP_ERR_INVALID_ARG;
-  const int per = mgpu_per(m, m->endo);
-  int g = (m->endo ? 8 : 16) / per;  // as many MSMs' shares as make up one MSM's worth of bucket sets per device
+  const int per = mgpu_per(m, m->endo, m->wide_bits);
+  int g = mgpu_windows(m->endo, m->wide_bits) / per;  // as many MSMs' shares as make up one MSM's worth of bucket sets per device
   return g < 1 ? 1 : g;
 }
 
@@ -406,7 +427,8 @@ int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz)
   if (!m || !out_xyz || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   MgpuSlot& ms = m->slot[slot];
   if (!ms.pending) return MSM_HIP_ERR_INVALID_ARG;
-  const int G = m->n, nvec = ms.nvec, W = mgpu_windows(m, ms.halves), rows = nvec * mgpu_per(m, ms.halves);
+  const int wide_bits = ms.wide_bits;
+  const int G = m->n, nvec = ms.nvec, W = mgpu_windows(ms.halves, wide_bits), rows = nvec * mgpu_per(m, ms.halves, wide_bits) * (wide_bits ? 2 : 1);
   int rc = MSM_HIP_OK;
   // 1. every device's launch job has run; the first failure is the launch's status
   for (int d = 0; d < G; d++) {
@@ -452,7 +474,8 @@ int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz)
   }
   // 4. one host window combine per MSM, side by side on the host pool
   const size_t jb = m->ctx[0]->jb;
-  const size_t rec = parts ? PLANES_PER_WINDOW * jb : jb;  // (one vector per launch through the pinned buffers: the windows arrive as bit-plane sums)
+  // (one vector per launch through the pinned buffers: the windows arrive as bit-plane sums; shares of virtual windows: as record pairs)
+  const size_t rec = wide_bits ? 2 * jb : parts ? PLANES_PER_WINDOW * jb : jb;
   const CurveOps* ops = curve_ops(m->curve);
   std::atomic<bool> ok{true};
   combine_pool().run(nvec, [&](int v) {
@@ -465,6 +488,10 @@ int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz)
       memcpy(all + (size_t)b * rec, block + (size_t)v * (e - b) * rec, (size_t)(e - b) * rec);
     }
     const uint8_t* records = all;
+    if (wide_bits) {  // sum_hi W_hi + 2^15 sum_hi hi TC_hi over the gathered (W_hi, TC_hi) pairs
+      if (!ops->combine_wide_pairs(all, W, out_xyz + (size_t)v * jb)) ok = false;
+      return;
+    }
     if (parts) {
       for (int w = 0; w < W; w++)
         if (!ops->window_from_planes(all + (size_t)w * rec, sums + jb * (size_t)w)) ok = false;

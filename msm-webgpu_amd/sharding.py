@@ -144,20 +144,27 @@ class ShardedMsmPipeline:
     SLOTS = 4
 
     def __init__(self, ctx, rank, world_size, group=None, num_windows=None, depth=3, msms_per_issue=1, emulate_world=0, halves=False,
-                 combine="all"):
+                 combine="all", wide=False):
         """halves: the context's bases carry their endomorphism images (set_bases(..., endomorphism=True)); the ranks then share the 8
         HALF-length windows of the 2n-point problem (msm_hip_launch_half_windows_batch_device_bn254) instead of the 16 full-length ones.
         combine: who runs the host window combine (src/cuzk/msm.rs:411-416) of a launch's MSMs -- every rank holds all window sums after
         the all-gather.  "all": every rank combines every MSM (every rank returns every result; world x the host work).  "spread": vector v
         of a launch is combined ONCE, by rank v % world -- complete() returns None in the other ranks' places (the throughput form: each
-        result exists once, on a known rank).  "rank0": rank 0 combines everything, the others return None."""
+        result exists once, on a known rank).  "rank0": rank 0 combines everything, the others return None.
+        wide: the context's bases are wide fixed-base tables (set_bases(..., precompute="wide")); the ranks share their VIRTUAL windows
+        (msm_hip_launch_vwindows_batch_device: 8 at 19-bit digits), every window's record is a (weighted sum, plain total) pair and the finish is
+        msm_hip_combine_vwindows_batch_curve."""
         assert 1 <= depth < self.SLOTS
         assert combine in ("all", "spread", "rank0")
+        assert not (halves and wide)
         self.combine = combine
         self.depth = depth
         self.halves = halves
+        self.wide = wide
+        self.rec = 2 if wide else 1  # records per window in the gathered blocks
         if num_windows is None:
-            num_windows = NUM_WINDOWS // 2 if halves else NUM_WINDOWS
+            num_windows = ctx.virtual_windows() if wide else NUM_WINDOWS // 2 if halves else NUM_WINDOWS
+        assert num_windows > 0
         self.ctx, self.rank, self.world, self.group, self.num_windows = ctx, rank, world_size, group, num_windows
         self.w_begin, self.w_end = window_range(rank, world_size, num_windows)
         self.per = max_windows_per_rank(world_size, num_windows)
@@ -170,7 +177,7 @@ class ShardedMsmPipeline:
         self.g = msms_per_issue
         assert self.g * self.per <= 64, "msms_per_issue x windows per rank must not exceed 64 local windows"
         dev = torch.device("cuda", ctx.device)
-        rows = self.g * self.per
+        rows = self.g * self.per * self.rec
         jb = ctx.jb  # bytes of a Jacobian record of the context's curve
         self.padded = [torch.zeros((rows, jb), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
         self.gathered = [torch.empty((world_size, rows, jb), dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
@@ -198,8 +205,8 @@ class ShardedMsmPipeline:
         assert 1 <= nvec <= self.g and nvec * n == rows
         self.nvec[slot] = nvec
         if w_local > 0:
-            launch = self.ctx.launch_half_windows_batch if self.halves else self.ctx.launch_windows_batch
-            launch(scalars_dev, n, self.w_begin, self.w_end, slot, self.padded[slot][: nvec * w_local], inputs_complete=inputs_complete)
+            launch = self.ctx.launch_vwindows_batch if self.wide else self.ctx.launch_half_windows_batch if self.halves else self.ctx.launch_windows_batch
+            launch(scalars_dev, n, self.w_begin, self.w_end, slot, self.padded[slot][: nvec * w_local * self.rec], inputs_complete=inputs_complete)
             # gather + copies go to the CURRENT torch stream (normally the default stream): with GPU_MAX_HW_QUEUES=8 this
             # layout -- 3 engine streams, the default stream, RCCL's own -- keeps three launches in flight; a dedicated side
             # stream (or a 4th engine stream) was measured to collapse the pipeline to one at a time
@@ -240,18 +247,22 @@ class ShardedMsmPipeline:
         """The launch's window sums (pinned host buffer: rank r's block holds [nvec][its windows] records) -> one G1 per MSM this rank
         owns (None for the others').  All Horner chains of the launch go through ONE library call (host pool: side by side)."""
         host = self.host_np[slot]
+        if self.wide:  # a window's record is its (weighted sum, plain total) pair
+            host = host.reshape(host.shape[0], host.shape[1] // 2, 2 * host.shape[2])
         if self.emulate:  # partial sums over this rank's windows only (tuning aid)
             nw = self.w_end - self.w_begin
             sums = np.ascontiguousarray(host[0, : nvec * nw])
         else:
             nw = self.num_windows
             sums = gathered_window_sums(host, nvec, self.world, nw)
+        # (wide, emulated: the pairs of virtual windows 0 .. nw-1 only -- the partial result those windows give, as in the other modes)
+        finish = MsmContext.combine_vwindows_batch if self.wide else MsmContext.combine_windows_batch
         mine = [v for v in range(nvec) if self.owner(v) in (None, self.rank)]
         if len(mine) == nvec:
-            return MsmContext.combine_windows_batch(sums, nw, self.ctx.curve)
+            return finish(sums, nw, self.ctx.curve)
         out = [None] * nvec
         if mine:
             picked = np.ascontiguousarray(sums.reshape(nvec, nw, -1)[mine])
-            for v, g in zip(mine, MsmContext.combine_windows_batch(picked, nw, self.ctx.curve)):
+            for v, g in zip(mine, finish(picked, nw, self.ctx.curve)):
                 out[v] = g
         return out

@@ -23,13 +23,16 @@ def _bench(args, **env):
 
 
 def test_single_gpu_line_has_the_contract_keys(built):
-    d = _bench(["--steps", "6", "--warmup", "2", "--logn", "14", "--cpu-sample-logn", "12"], BENCH_STEADY_MSMS="8")
+    d = _bench(["--steps", "6", "--warmup", "2", "--logn", "14", "--cpu-sample-logn", "12"], BENCH_STEADY_MSMS="8", BENCH_CONFIGS="c1:10,c3:12,c4:13,c5:6x11")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-                "roofline", "cpu_baseline", "value_cold_protocol", "pre_timed_msms"):
+                "roofline", "cpu_baseline", "value_steady_state", "pre_timed_msms", "protocol", "configs"):
         assert key in d, key
+    # `value` is the literal protocol: exactly the W warm-up steps in front of its timed region
+    assert d["untimed_steps_before_timed_region"] == 2 and d["pre_timed_msms"] == 2 and d["value_steady_state"] > 0
+    assert d["steady_state"]["untimed_steps_of_this_workload_directly_before"] == 8 + 2
     assert d["unit"] == "MSM/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"] and d["value_cold_protocol"] > 0
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel"] == "k_smvp_chunks"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1 and "traffic" in rf and "kernel_ms_rocprof" in rf
@@ -37,7 +40,19 @@ def test_single_gpu_line_has_the_contract_keys(built):
     assert d["config"]["window_bits"] == 14 and d["config"]["msms_per_launch"] > 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "MSM/s" and cb["value"] > 0 and "sample" in cb
-    assert d["pre_timed_msms"] >= 8 + 2
+    # BASELINE.json's other configs on the same line, each verified in the run (round 5)
+    cf = d["configs"]
+    assert set(cf) == {"c1", "c3", "c4", "c5"}
+    assert cf["c1"]["value"] > 0 and cf["c1"]["verified_bit_exact_vs_cpu"] is True and cf["c1"]["cpu_path"]["cores"] == 1 and 0 < cf["c1"]["roofline"]["frac"] < 1
+    for mode in ("plain", "tables_wide"):
+        assert cf["c3"][mode]["all_8_shares_combined_equal_whole_msm"] is True and cf["c3"][mode]["ms_per_msm_one_rank_share"] > 0, mode
+        assert 0 < cf["c3"][mode]["roofline"]["frac"] < 1
+    assert cf["c3"]["whole_msm_verified_bit_exact_vs_cpu"] is True
+    assert cf["c4"]["timed_msms"] >= 5 and cf["c4"]["whole_equals_8_window_range_shares_combined"] is True and 0 < cf["c4"]["roofline"]["frac"] < 1
+    assert any(k.startswith("slice_") and v is True for k, v in cf["c4"].items())
+    for mode in ("endomorphism", "tables_wide"):
+        assert cf["c5"][mode]["value"] > 0 and 0 < cf["c5"][mode]["roofline"]["frac"] < 1, mode
+    assert cf["c5"]["both_modes_same_results"] is True and cf["c5"]["all_results_differ"] is True and cf["c5"]["vector_5_verified_bit_exact_vs_cpu"] is True
 
 
 def test_emulated_share_line_and_native_multi_gpu_mode(built):

@@ -236,3 +236,66 @@ def test_pipeline_combines_every_msm_once_across_the_ranks(built, mode):
             else:
                 assert p.owner(v) != rank
     assert sorted(owners) == (sorted(list(range(nvec)) * world) if mode == "all" else list(range(nvec)))
+
+
+def _pairs_worker(rank, world, port, nvec, nwin, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from msm_webgpu_amd.sharding import gathered_window_sums, max_windows_per_rank, window_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = window_range(rank, world, nwin)
+    per = max_windows_per_rank(world, nwin)
+    # this rank's block as msm_hip_launch_vwindows_batch_device writes it: [nvec][its virtual windows][2] records, then padding
+    block = torch.zeros((nvec * per * 2, 96), dtype=torch.uint8)
+    block[: nvec * (e - b) * 2] = torch.from_numpy(_PAIRS(nvec, nwin)[:, b:e].reshape(-1, 96).copy())
+    gathered = torch.empty((world, nvec * per * 2, 96), dtype=torch.uint8)
+    dist.all_gather_into_tensor(gathered.view(-1), block.view(-1))
+    pairs = gathered_window_sums(gathered.numpy().reshape(world, nvec * per, 192), nvec, world, nwin)
+    q.put((rank, pairs.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _PAIRS(nvec, nwin):
+    """(W_hi, TC_hi) records of `nvec` synthetic MSMs: multiples of the generator, so that the finish has a closed form"""
+    from oracle import bn254_ref as ref
+
+    out = np.zeros((nvec, nwin, 2, 96), dtype=np.uint8)
+    for v in range(nvec):
+        for hi in range(nwin):
+            for k, mult in enumerate((1000 * v + 7 * hi + 1, 13 * v + hi + 2)):
+                x, y = ref.mul(mult, ref.G)
+                out[v, hi, k] = np.frombuffer(x.to_bytes(32, "little") + y.to_bytes(32, "little") + (1).to_bytes(32, "little"), dtype=np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("world,nwin", [(2, 8), (3, 8), (2, 16)])
+def test_virtual_window_pairs_gather_and_finish_gloo(built, world, nwin):
+    """the record shape of window-sharded launches over wide tables: every rank contributes (weighted sum, plain total) pairs of its virtual
+    windows; after ONE all-gather (gloo here) every rank finishes sum_hi W_hi + 2^15 sum_hi hi TC_hi (msm_hip_combine_vwindows_batch_curve)"""
+    import msm_webgpu_amd as m
+    from oracle import bn254_ref as ref
+
+    nvec = 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pairs_worker, args=(r, world, port, nvec, nwin, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(g[1] == _PAIRS(nvec, nwin).tobytes() for g in got)  # every rank holds every pair, in virtual-window order
+    res = m.MsmContext.combine_vwindows_batch(np.frombuffer(got[0][1], dtype=np.uint8), nwin)
+    for v in range(nvec):
+        mult = sum(1000 * v + 7 * hi + 1 for hi in range(nwin)) + (1 << 15) * sum(hi * (13 * v + hi + 2) for hi in range(nwin))
+        x, y = ref.mul(mult % ref.R, ref.G)
+        assert res[v].to_affine_bytes() == x.to_bytes(32, "little") + y.to_bytes(32, "little"), v
