@@ -131,7 +131,7 @@ def measure_configs(m, torch, ctx, args, spec, points_main, sets_main):
       c3  2^20, windows over 8 GPUs: ONE rank's share (8 MSMs' shares per launch) timed on this GPU -- a projection, no collective --, and all
           8 ranks' shares run one after the other, gathered in rank order and combined == the whole MSM
       c4  2^24 MSM: >= 5 timed MSMs; whole == the 8 plain window-range shares combined; a 2^16 slice against the oracle
-      c5  64 x 2^18 over one shared base through msm_hip_run_batch_device_bn254, default (endomorphism) and wide-table bases; one vector
+      c5  64 x 2^18 over one shared base through msm_hip_run_batch_device, default (endomorphism) and wide-table bases; one vector
           against the oracle"""
     from msm_webgpu_amd.sharding import ShardedMsmPipeline, gathered_window_sums, window_range
 
@@ -294,7 +294,7 @@ def measure_configs(m, torch, ctx, args, spec, points_main, sets_main):
         batch, n = int(b_), 1 << int(l_)
         pts = ctx.sample_points(n, 0xC50001)
         sc = ctx.sample_scalars(n * batch, 0xC50002)  # `batch` independent scalar vectors, contiguous
-        c5 = {"workload": "%d x 2^%s BN254 G1 MSMs over one shared base, one GPU, msm_hip_run_batch_device_bn254" % (batch, l_),
+        c5 = {"workload": "%d x 2^%s BN254 G1 MSMs over one shared base, one GPU, msm_hip_run_batch_device" % (batch, l_),
               "note": "at 8 GPUs whole MSMs are dealt out (no exchange on the data path): 8 x this figure is the projection, the driver's SCALE run the measurement"}
         results = {}
         for mode in ("endomorphism", "tables_wide"):
@@ -391,7 +391,7 @@ def self_launch(n_ranks):
 
 def run_native_child(args, bases_mode, n_ranks):
     """rank 0, after its own timed region (every rank idle in a host-side wait): ONE fresh child process times the same window-sharded
-    workload through the in-process C ABI a Rust caller gets (native_mgpu_main: msm_hip_mgpu_launch_batch_device_bn254 /
+    workload through the in-process C ABI a Rust caller gets (native_mgpu_main: msm_hip_mgpu_launch_batch_device /
     finish_batch over `n_ranks` devices, ncclAllGather per launch) -- reported beside the torch.distributed figure as value_native_mgpu.
     A failing child is a non-zero exit of the child and null fields here; nothing of it runs inside this process."""
     import subprocess
@@ -415,8 +415,8 @@ def run_native_child(args, bases_mode, n_ranks):
 
 
 def native_mgpu_main(args):
-    """BENCH_MGPU_NATIVE=1: the same window-sharded workload through the in-process multi-GPU C ABI (msm_hip_mgpu_launch_batch_device_bn254 /
-    msm_hip_mgpu_finish_batch_bn254: one host process, one engine context and one persistent host thread per GPU, one ncclAllGather per
+    """BENCH_MGPU_NATIVE=1: the same window-sharded workload through the in-process multi-GPU C ABI (msm_hip_mgpu_launch_batch_device /
+    msm_hip_mgpu_finish_batch: one host process, one engine context and one persistent host thread per GPU, one ncclAllGather per
     launch, host combines on the library's pool) instead of one process per GPU over torch.distributed -- so that the path a Rust caller
     gets can be timed next to the one the driver measures.  BENCH_MGPU_IDS=0,0,0,0,0,0,0,0 rehearses it with several contexts on one GPU
     (pinned-buffer gather; the contexts then SHARE that GPU, so the figure is a one-GPU total, not a scaling result)."""
@@ -689,7 +689,7 @@ def main():
 
     # timing scopes B and C of SURVEY.md section 8(d), informational (never `value`): B = scalars arrive from host memory
     # (32 MiB H2D per MSM at 2^20), bases resident -- as the latency of one call and as the throughput of three slots in rotation
-    # (msm_hip_launch_bn254: the copy of MSM i+1 runs on the copy stream under the device work of MSM i); C = one-shot incl.
+    # (msm_hip_launch: the copy of MSM i+1 runs on the copy stream under the device work of MSM i); C = one-shot incl.
     # base upload (≙ the reference's compute_msm call shape): the first call also creates the context the library then keeps
     scope_ms = None
     if world == 1 and emulate <= 1 and args.logn <= 22:

@@ -103,7 +103,8 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx);
 
 /* ---- other curves (the reference lists them as future work, README.md, and is hard-wired to BN254's Fq,
  *      src/cuzk/msm.rs:37-43).  The curve is a property of the context: every entry point of this header works on the curve its
- *      context was created for (their names keep the `_bn254` of the reference's only instantiation).  Supported besides BN254 G1:
+ *      context was created for (round 5: the entry points carry curve-neutral names; the `_bn254` names of rounds 1 - 4 -- the reference's only
+ *      instantiation -- remain as aliases, at the end of this header).  Supported besides BN254 G1:
  *      Grumpkin, BN254's cycle partner (y^2 = x^3 - 17 over BN254's scalar field r; scalars modulo BN254's base field p) -- its
  *      base field agrees with BN254's in the top 128 bits, so the same 9 x 29-bit lazy-limb arithmetic and the same kernels serve
  *      both, instantiated once per curve (csrc/curve_select.h); and the Pasta cycle, Pallas and Vesta (y^2 = x^3 + 5 over the
@@ -148,9 +149,9 @@ int msm_hip_wait_stream(msm_hip_ctx* ctx, void* producer_stream);
 
 /* ---- bases: upload + convert to the device's Montgomery form once (≙ the point half of the decompose shader,
  *      src/cuzk/wgsl/cuzk/decompose_scalars.template.wgsl:41-70, launched at src/cuzk/msm.rs:441-524) ---- */
-int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, uint32_t flags);
+int msm_hip_set_bases(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, uint32_t flags);
 /* same, bytes already in device memory (plain device pointer, e.g. a torch tensor's data_ptr) */
-int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t n, uint32_t flags);
+int msm_hip_set_bases_device(msm_hip_ctx* ctx, const void* xy_dev, size_t n, uint32_t flags);
 
 /* ---- scalar format of all following runs of this context: canonical little-endian integers (default, = scalars_to_bytes,
  *      src/lib.rs:50-52), or s * 2^256 mod r, little-endian -- the in-memory limbs of a 4 x 64-bit Montgomery library with
@@ -182,62 +183,62 @@ int msm_hip_wide_config(int curve, int bits, size_t n, int* digit_bits, int* tab
 int msm_hip_last_window_bits(msm_hip_ctx* ctx);                                 /* window size of the last launch       */
 int msm_hip_endomorphism_window_count(int bits); /* host-only: windows of a 127-bit half (MSM_HIP_BASES_ENDOMORPHISM): 8 / 10 / 11 */
 int msm_hip_uses_endomorphism(const msm_hip_ctx* ctx); /* 1: the resident bases were set with MSM_HIP_BASES_ENDOMORPHISM */
-/* how many whole MSMs of n points the batch entry points put through ONE launch (what msm_hip_launch_windows_batch_device_bn254
+/* how many whole MSMs of n points the batch entry points put through ONE launch (what msm_hip_launch_windows_batch_device
  * with w_begin = 0, w_end = 16, window_sums_dev = NULL should be given for best throughput): 1 from 2^20 points up, at most
  * MSM_HIP_MAX_LOCAL_WINDOWS / (windows of the size picked for n) below */
 int msm_hip_batch_group_size(msm_hip_ctx* ctx, size_t n);
 
 /* ---- run: sum_i scalars[i] * bases[i] over the first n bases (n <= number of bases set).
  *      ≙ compute_msm stages 1-5, src/cuzk/msm.rs:96-416 (decompose, transpose, SMVP, bucket reduce, Horner) ---- */
-int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
-int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]);
+int msm_hip_run(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
+int msm_hip_run_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]);
 /* asynchronous halves of run_device: `launch` enqueues all device work of one MSM into result slot `slot` (0 .. MSM_HIP_NUM_SLOTS-1)
  * and returns; `finish` waits for that slot and performs the host finalisation (src/cuzk/msm.rs:391-416).
  * Lets a caller overlap the host Horner of MSM i with the device work of MSM i+1. */
-int msm_hip_launch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot);
-int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]);
-/* `launch` with the scalars in HOST memory (msm_hip_run_bn254 = this + finish on slot 0): they are copied into the slot's own
+int msm_hip_launch_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot);
+int msm_hip_finish(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]);
+/* `launch` with the scalars in HOST memory (msm_hip_run = this + finish on slot 0): they are copied into the slot's own
  * device staging buffer on a separate copy stream, so the copy of MSM i+1 overlaps the device work of MSM i when the caller
  * alternates slots.  Pageable memory: returns once the bytes have left the caller's buffer.  Pinned memory (hipHostMalloc /
  * hipHostRegister): returns at once and the buffer must stay untouched until the slot is collected. */
-int msm_hip_launch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int slot);
+int msm_hip_launch(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int slot);
 
 /* ---- batch: `batch` independent scalar vectors (batch x n x 32 B, contiguous, device memory) over the resident bases;
  *      out: batch x 96 B.  Internally a software pipeline over the result slots (BASELINE.json config 5: many MSMs over
  *      one shared base). ---- */
-int msm_hip_run_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, size_t batch, uint8_t* out_xyz);
+int msm_hip_run_batch_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, size_t batch, uint8_t* out_xyz);
 /* same with the scalar vectors in host memory (batch x n x 32 B): each vector is copied to the device just ahead of its own
  * MSM, inside the same pipeline */
-int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz);
+int msm_hip_run_batch(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz);
 
 /* ---- window-sharded execution (multi-GPU; Pippenger windows are independent).
  *      Computes the window sums S_w for w in [w_begin, w_end) and writes (w_end - w_begin) x 96 B Jacobian
  *      canonical-LE records to `window_sums_dev` (device memory, so that RCCL can gather them in place). ---- */
-int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end,
+int msm_hip_run_windows_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end,
                                      void* window_sums_dev);
 /* asynchronous form: enqueue into a result slot and return.  window_sums_dev == NULL keeps the sums in the slot and
- * copies them to the host (then msm_hip_finish_bn254 applies when all 16 windows were run).  Afterwards:
+ * copies them to the host (then msm_hip_finish applies when all 16 windows were run).  Afterwards:
  *   msm_hip_slot_wait_stream  makes a foreign HIP stream (e.g. the one RCCL runs on) wait for the slot on the device,
  *                             without blocking the host;
  *   msm_hip_slot_sync         blocks the host until the slot is complete and returns its error status. */
-int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot,
+int msm_hip_launch_windows_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot,
                                         void* window_sums_dev);
 /* several MSMs per launch: `nvec` scalar vectors (contiguous, nvec x n x 32 B) over the resident bases, windows
  * [w_begin, w_end) of each, nvec * (w_end - w_begin) <= MSM_HIP_MAX_LOCAL_WINDOWS; window_sums_dev receives nvec x (w_end - w_begin) x 96 B
  * (vector-major).  One kernel sequence sorts, accumulates and reduces all of them: a rank of a window-sharded run whose
  * own share (2 windows of one MSM at 8 GPUs) cannot fill the GPU processes 8 MSMs' shares at once.
  * Up to MSM_HIP_MAX_LOCAL_WINDOWS = 64 local windows per launch, i.e. also up to 4 WHOLE small MSMs (w_begin = 0, w_end = 16,
- * window_sums_dev = NULL): msm_hip_finish_batch_bn254 then waits for the slot and writes nvec x 96 B results.  The batch
+ * window_sums_dev = NULL): msm_hip_finish_batch then waits for the slot and writes nvec x 96 B results.  The batch
  * entry points above group small MSMs this way on their own. */
-int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin,
+int msm_hip_launch_windows_batch_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin,
                                               int w_end, int slot, void* window_sums_dev);
-int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz);
+int msm_hip_finish_batch(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz);
 /* the same for a context whose bases were set with MSM_HIP_BASES_ENDOMORPHISM: HALF-length windows [hw_begin, hw_end) of the 8 that the
  * 127-bit halves k1, k2 of every scalar have (k = k1 + k2 lambda; the MSM runs over the 2n points P_i, phi(P_i)): at 8 GPUs one such window
  * per rank instead of two full-length ones -- the same bucket additions, half the buckets to stitch and reduce.  The 8 sums S_hw combine like
  * any window sums: result = sum_hw 2^(16 hw) S_hw (msm_hip_combine_windows_bn254 with num_windows = 8).  Anchor: the reference runs 16
  * full-length windows, src/cuzk/msm.rs:79-82. */
-int msm_hip_launch_half_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int hw_begin,
+int msm_hip_launch_half_windows_batch_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int hw_begin,
                                                    int hw_end, int slot, void* window_sums_dev);
 /* the same for a context whose bases were set with MSM_HIP_BASES_PRECOMPUTE_WIDE (round 5: the fixed-base tables behind the window-sharded paths; anchors:
  * README.md:70-71 -- the time / space trade-off --, src/cuzk/msm.rs:79-82 -- chunk_size hard-coded --, src/cuzk/msm.rs:411-416 -- the final combine):
@@ -260,10 +261,10 @@ int msm_hip_combine_windows_batch_curve(int curve, const uint8_t* window_sums_ho
 
 /* ---- multi-GPU in ONE host process (BASELINE.json north star: "independent Pippenger windows shard across the 8 GPUs of one
  *      node with a final RCCL gather/reduce of partial sums over xGMI"; the reference is single-device, src/cuzk/msm.rs:88-94).
- *      One engine context per listed device.  msm_hip_mgpu_run_bn254: device d computes the window sums of window range d
+ *      One engine context per listed device.  msm_hip_mgpu_run: device d computes the window sums of window range d
  *      (msm_hip_window_range(d, n_devices, 16, ...); bases replicated, every device receives all scalars), the sums are gathered
  *      -- ncclAllGather over RCCL (librccl is loaded at run time; not a link dependency) or through the slots' pinned result
- *      buffers -- and the host window combine (src/cuzk/msm.rs:411-416) runs once.  msm_hip_mgpu_run_batch_bn254 deals whole
+ *      buffers -- and the host window combine (src/cuzk/msm.rs:411-416) runs once.  msm_hip_mgpu_run_batch deals whole
  *      MSMs out contiguously (BASELINE config 5: many MSMs over one shared base): no exchange at all.
  *      Device ids may repeat with MSM_HIP_MGPU_GATHER_HOST (several contexts on one GPU: rehearsal on a one-GPU box). ---- */
 typedef struct msm_hip_mgpu msm_hip_mgpu;
@@ -275,8 +276,8 @@ int msm_hip_mgpu_create_curve(msm_hip_mgpu** out, const int* device_ids, int n_d
 void msm_hip_mgpu_destroy(msm_hip_mgpu* m);
 int msm_hip_mgpu_device_count(const msm_hip_mgpu* m);
 int msm_hip_mgpu_uses_rccl(const msm_hip_mgpu* m);
-int msm_hip_mgpu_set_bases_bn254(msm_hip_mgpu* m, const uint8_t* xy_host, size_t n, uint32_t flags);
-int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
+int msm_hip_mgpu_set_bases(msm_hip_mgpu* m, const uint8_t* xy_host, size_t n, uint32_t flags);
+int msm_hip_mgpu_run(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
 /* The throughput form of the same (what a Rust caller that holds many (points, scalars) jobs drives, src/lib.rs:76-82; the reference creates
  * its device per call, src/cuzk/msm.rs:88-94): `nvec` scalar vectors share ONE launch -- device d runs its window range of every vector in one
  * kernel sequence (a single MSM's share, 2 of 16 windows at 8 GPUs, cannot fill a GPU) into result slot `slot` (0 .. MSM_HIP_NUM_SLOTS-1) of its
@@ -284,10 +285,10 @@ int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t 
  * issues its calls, so several slots can be in flight.  `finish` waits for the slot and writes nvec x 96 B results (one host window combine
  * per MSM, side by side on the host pool).  nvec x (windows per device) <= MSM_HIP_MAX_LOCAL_WINDOWS; msm_hip_mgpu_group_size() is the nvec
  * that fills a device (8 at 8 GPUs).  With bases set with MSM_HIP_BASES_ENDOMORPHISM the shares are the 8 half-length windows.
- *   _bn254         : scalars in host memory (nvec x n x 32 B); every device uploads all of them (PCIe-bound: the latency form).  The buffer
+ *   launch_batch         : scalars in host memory (nvec x n x 32 B); every device uploads all of them (PCIe-bound: the latency form).  The buffer
  *                    must stay untouched until finish.
- *   _device_bn254  : scalars_dev[d] = the same nvec x n x 32 B already resident on device d (complete before the call; alive until finish).
- * Bases (msm_hip_mgpu_set_bases_bn254): replicated; the flags decide what the devices share -- MSM_HIP_BASES_PLAIN or 0: the reference's 16 windows over
+ *   launch_batch_device  : scalars_dev[d] = the same nvec x n x 32 B already resident on device d (complete before the call; alive until finish).
+ * Bases (msm_hip_mgpu_set_bases): replicated; the flags decide what the devices share -- MSM_HIP_BASES_PLAIN or 0: the reference's 16 windows over
  * the n points (flags = 0 is resolved to PLAIN here, not to a context's own default: the shares of full-length windows read only the plain records);
  * MSM_HIP_BASES_ENDOMORPHISM: the 8 half-length windows; MSM_HIP_BASES_PRECOMPUTE_WIDE: the virtual windows of the wide tables (digit width by
  * msm_hip_mgpu_set_wide_bits, default 19: 8 virtual windows, 14 bucket additions per point, one bucket set per device at 8 GPUs).
@@ -296,18 +297,15 @@ int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t 
  * zeroed block -- so a failure on one device can neither hang the others' collectives nor shift the pairing of later launches; finish
  * returns that device's error within the time of a normal launch and the next launch runs normally.  Only a collective that could not be
  * ISSUED on some device leaves the object unusable (every later call returns MSM_HIP_ERR_HIP; destroy aborts the communicator). */
-int msm_hip_mgpu_launch_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, int nvec, int slot);
-int msm_hip_mgpu_launch_batch_device_bn254(msm_hip_mgpu* m, const void* const* scalars_dev, size_t n, int nvec, int slot);
-int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz);
+int msm_hip_mgpu_launch_batch(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, int nvec, int slot);
+int msm_hip_mgpu_launch_batch_device(msm_hip_mgpu* m, const void* const* scalars_dev, size_t n, int nvec, int slot);
+int msm_hip_mgpu_finish_batch(msm_hip_mgpu* m, int slot, uint8_t* out_xyz);
 int msm_hip_mgpu_group_size(const msm_hip_mgpu* m);
-/* digit width (16 .. 20; 0: 19) of the wide tables the next msm_hip_mgpu_set_bases_bn254(..., MSM_HIP_BASES_PRECOMPUTE_WIDE) builds on every device */
+/* digit width (16 .. 20; 0: 19) of the wide tables the next msm_hip_mgpu_set_bases(..., MSM_HIP_BASES_PRECOMPUTE_WIDE) builds on every device */
 int msm_hip_mgpu_set_wide_bits(msm_hip_mgpu* m, int bits);
-/* test hook: the next `launches` window-sharded launches fail on device index `device_index` (MSM_HIP_ERR_HIP, before anything is queued
- * there) -- the rehearsal of one failing GPU; MSM_HIP_FAULT_DEVICE=<index> in the environment arms one such launch at creation. */
-int msm_hip_mgpu_inject_fault(msm_hip_mgpu* m, int device_index, int launches);
-int msm_hip_mgpu_run_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz);
+int msm_hip_mgpu_run_batch(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz);
 /* contiguous balanced partition of [0, num) over `world` ranks (the first num % world ranks take one more): the window ranges of
- * msm_hip_mgpu_run_bn254 and the MSM ranges of msm_hip_mgpu_run_batch_bn254; host-only */
+ * msm_hip_mgpu_run and the MSM ranges of msm_hip_mgpu_run_batch; host-only */
 int msm_hip_window_range(int rank, int world, int num, int* begin, int* end);
 
 /* host-only helper (≙ Curve::to_affine as used by tests/cuzk.rs:88-94): 96 B Jacobian -> 64 B canonical affine x || y.
@@ -321,6 +319,8 @@ int msm_hip_g1_to_affine_bn254(const uint8_t xyz[96], uint8_t out_xy[64]);
  *      msm_hip_oneshot_release() frees the kept contexts (call it before unloading the library or to return the device memory);
  *      MSM_HIP_ONESHOT_KEEP=0 in the environment restores create / destroy per call. ---- */
 int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
+/* the same on any curve of this library (MSM_HIP_CURVE_*; record sizes as that curve's): msm_hip_msm_bn254_g1 is curve 0 */
+int msm_hip_msm_curve(int curve, const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t* out_xyz);
 void msm_hip_oneshot_release(void);
 
 /* ---- synthetic inputs generated in HBM (≙ sample_scalars / sample_points, src/lib.rs:20-42, seeded):
@@ -340,6 +340,11 @@ int msm_hip_set_stage_timing(msm_hip_ctx* ctx, int level);
 /* the context's main stream as a hipStream_t */
 void* msm_hip_stream(msm_hip_ctx* ctx);
 
+/* ==== TEST HOOKS ========================================================================================================================
+ * Everything between here and the matching #endif exists for the parity tests and the profiling scripts only -- stage read-back, single-operation
+ * kernels, the deterministic transpose, fault injection.  A binding of the product API does not need them: they are declared only with
+ * MSM_HIP_TEST_HOOKS defined (the symbols are exported either way). */
+#ifdef MSM_HIP_TEST_HOOKS
 /* ---- stage-level read-back for parity tests (≙ read_from_gpu_test, src/cuzk/gpu.rs:137-171).  Each copies the
  *      buffer left by the last run to host memory.  Layouts:
  *      digits    : u16[num_windows_run][n]    code = sign << 15 | (|d| & 0x7fff); 0 = digit 0 (no entry);
@@ -375,10 +380,40 @@ int msm_hip_test_fq_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t
 int msm_hip_test_g1_op(msm_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
 int msm_hip_test_g1_mul_u32(msm_hip_ctx* ctx, const uint8_t* a, const uint32_t* k, uint8_t* out, size_t n);
 
+/* test hook: the next `launches` window-sharded launches fail on device index `device_index` (MSM_HIP_ERR_HIP, before anything is queued
+ * there) -- the rehearsal of one failing GPU.  Armed only through this call (round 5: no environment variable can make a deployment's launches fail). */
+int msm_hip_mgpu_inject_fault(msm_hip_mgpu* m, int device_index, int launches);
+#endif /* MSM_HIP_TEST_HOOKS */
+
 const char* msm_hip_strerror(int code);
 int msm_hip_last_hip_error(msm_hip_ctx* ctx);
 /* ABI version; bumped on any signature change */
 int msm_hip_abi_version(void);
+
+/* ---- aliases: the names of rounds 1 - 4 (the reference instantiates its generic functions with halo2curves::bn256 only, src/lib.rs:91,154). Each is
+ *      the curve-neutral entry point of the same name without `_bn254`, on whatever curve the context was created for. ---- */
+int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, uint32_t flags);
+int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t n, uint32_t flags);
+int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
+int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]);
+int msm_hip_launch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot);
+int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]);
+int msm_hip_launch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int slot);
+int msm_hip_run_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, size_t batch, uint8_t* out_xyz);
+int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz);
+int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, void* window_sums_dev);
+int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot, void* window_sums_dev);
+int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end, int slot,
+                                              void* window_sums_dev);
+int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz);
+int msm_hip_launch_half_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int hw_begin, int hw_end, int slot,
+                                                   void* window_sums_dev);
+int msm_hip_mgpu_set_bases_bn254(msm_hip_mgpu* m, const uint8_t* xy_host, size_t n, uint32_t flags);
+int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
+int msm_hip_mgpu_launch_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, int nvec, int slot);
+int msm_hip_mgpu_launch_batch_device_bn254(msm_hip_mgpu* m, const void* const* scalars_dev, size_t n, int nvec, int slot);
+int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz);
+int msm_hip_mgpu_run_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz);
 
 #ifdef __cplusplus
 }

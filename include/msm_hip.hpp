@@ -94,25 +94,25 @@ class MsmContext {
   void set_bases(const std::vector<G1Affine>& g, bool check_on_curve = false, uint32_t more_flags = 0) {
     // more_flags: MSM_HIP_BASES_ENDOMORPHISM (half-length scalars, 2 x the base memory) or MSM_HIP_BASES_PRECOMPUTE (fixed-base tables)
     const std::vector<uint8_t> b = points_to_bytes(g);
-    check(msm_hip_set_bases_bn254(ctx_, b.data(), g.size(), (check_on_curve ? MSM_HIP_CHECK_ON_CURVE : 0u) | more_flags), "msm_hip_set_bases_bn254");
+    check(msm_hip_set_bases(ctx_, b.data(), g.size(), (check_on_curve ? MSM_HIP_CHECK_ON_CURVE : 0u) | more_flags), "msm_hip_set_bases");
   }
-  /// Raw forms for callers whose field elements already sit in memory as bytes: `flags` as in msm_hip_set_bases_bn254
+  /// Raw forms for callers whose field elements already sit in memory as bytes: `flags` as in msm_hip_set_bases
   /// (e.g. MSM_HIP_BASES_MONT256 for 4 x 64-bit Montgomery limbs); scalars_mont256(true) switches the scalar format likewise.
   void set_bases_bytes(const uint8_t* xy, size_t n, uint32_t flags = 0) {
-    check(msm_hip_set_bases_bn254(ctx_, xy, n, flags), "msm_hip_set_bases_bn254");
+    check(msm_hip_set_bases(ctx_, xy, n, flags), "msm_hip_set_bases");
   }
   void scalars_mont256(bool on) {
     check(msm_hip_set_scalar_format(ctx_, on ? MSM_HIP_SCALARS_MONT256 : MSM_HIP_SCALARS_CANONICAL), "msm_hip_set_scalar_format");
   }
   G1 msm_bytes(const uint8_t* scalars, size_t n) {
     G1 r;
-    check(msm_hip_run_bn254(ctx_, scalars, n, r.xyz.data()), "msm_hip_run_bn254");
+    check(msm_hip_run(ctx_, scalars, n, r.xyz.data()), "msm_hip_run");
     return r;
   }
   G1 msm(const std::vector<Fr>& v) {
     const std::vector<uint8_t> b = scalars_to_bytes(v);
     G1 r;
-    check(msm_hip_run_bn254(ctx_, b.data(), v.size(), r.xyz.data()), "msm_hip_run_bn254");
+    check(msm_hip_run(ctx_, b.data(), v.size(), r.xyz.data()), "msm_hip_run");
     return r;
   }
   /// Many MSMs over the resident bases (BASELINE config 5), pipelined inside the library: one result per scalar vector
@@ -127,7 +127,7 @@ class MsmContext {
       all.insert(all.end(), b.begin(), b.end());
     }
     std::vector<uint8_t> out(96 * vs.size());
-    check(msm_hip_run_batch_bn254(ctx_, all.data(), n, vs.size(), out.data()), "msm_hip_run_batch_bn254");
+    check(msm_hip_run_batch(ctx_, all.data(), n, vs.size(), out.data()), "msm_hip_run_batch");
     std::vector<G1> r(vs.size());
     for (size_t k = 0; k < vs.size(); k++) std::memcpy(r[k].xyz.data(), out.data() + 96 * k, 96);
     return r;
@@ -153,14 +153,14 @@ class MultiGpuMsm {
 
   void set_bases(const std::vector<G1Affine>& g, uint32_t flags = 0) {  // replicated on every device
     const std::vector<uint8_t> b = points_to_bytes(g);
-    check(msm_hip_mgpu_set_bases_bn254(m_, b.data(), g.size(), flags), "msm_hip_mgpu_set_bases_bn254");
+    check(msm_hip_mgpu_set_bases(m_, b.data(), g.size(), flags), "msm_hip_mgpu_set_bases");
   }
   int group_size() const { return msm_hip_mgpu_group_size(m_); }
   bool uses_rccl() const { return msm_hip_mgpu_uses_rccl(m_) == 1; }
   G1 msm(const std::vector<Fr>& v) {
     const std::vector<uint8_t> b = scalars_to_bytes(v);
     G1 r;
-    check(msm_hip_mgpu_run_bn254(m_, b.data(), v.size(), r.xyz.data()), "msm_hip_mgpu_run_bn254");
+    check(msm_hip_mgpu_run(m_, b.data(), v.size(), r.xyz.data()), "msm_hip_mgpu_run");
     return r;
   }
   std::vector<G1> msm_stream(const std::vector<std::vector<Fr>>& jobs) {
@@ -185,7 +185,7 @@ class MultiGpuMsm {
         if (i >= IN_FLIGHT) {
           const size_t k = i - IN_FLIGHT, nvec = groups[k].size() / (32 * n);
           finished = k + 1;  // (finish leaves the slot free whatever it returns)
-          check(msm_hip_mgpu_finish_batch_bn254(m_, (int)(k % MSM_HIP_NUM_SLOTS), xyz.data()), "msm_hip_mgpu_finish_batch_bn254");
+          check(msm_hip_mgpu_finish_batch(m_, (int)(k % MSM_HIP_NUM_SLOTS), xyz.data()), "msm_hip_mgpu_finish_batch");
           for (size_t v = 0; v < nvec; v++) {
             G1 r;
             std::memcpy(r.xyz.data(), xyz.data() + 96 * v, 96);
@@ -193,15 +193,15 @@ class MultiGpuMsm {
           }
         }
         if (i < groups.size()) {
-          check(msm_hip_mgpu_launch_batch_bn254(m_, groups[i].data(), n, (int)(groups[i].size() / (32 * n)), (int)(i % MSM_HIP_NUM_SLOTS)),
-                "msm_hip_mgpu_launch_batch_bn254");
+          check(msm_hip_mgpu_launch_batch(m_, groups[i].data(), n, (int)(groups[i].size() / (32 * n)), (int)(i % MSM_HIP_NUM_SLOTS)),
+                "msm_hip_mgpu_launch_batch");
           launched = i + 1;
         }
       }
     } catch (...) {
       // the launches still in flight read `groups` (pageable uploads on the devices' host threads): collect every one of them before the
       // buffers go out of scope
-      for (size_t k = finished; k < launched; k++) (void)msm_hip_mgpu_finish_batch_bn254(m_, (int)(k % MSM_HIP_NUM_SLOTS), xyz.data());
+      for (size_t k = finished; k < launched; k++) (void)msm_hip_mgpu_finish_batch(m_, (int)(k % MSM_HIP_NUM_SLOTS), xyz.data());
       throw;
     }
     return out;

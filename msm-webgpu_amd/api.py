@@ -63,25 +63,25 @@ def lib():
         L.msm_hip_g1_to_affine_curve.argtypes = [i, u8p, u8p]
         L.msm_hip_ctx_destroy.argtypes = [vp]
         L.msm_hip_ctx_destroy.restype = None
-        L.msm_hip_set_bases_bn254.argtypes = [vp, u8p, sz, C.c_uint32]
-        L.msm_hip_set_bases_device_bn254.argtypes = [vp, vp, sz, C.c_uint32]
-        L.msm_hip_run_bn254.argtypes = [vp, u8p, sz, u8p]
-        L.msm_hip_run_device_bn254.argtypes = [vp, vp, sz, u8p]
-        L.msm_hip_run_batch_bn254.argtypes = [vp, u8p, sz, sz, u8p]
-        L.msm_hip_launch_windows_batch_device_bn254.argtypes = [vp, vp, sz, i, i, i, i, vp]
-        L.msm_hip_finish_batch_bn254.argtypes = [vp, i, u8p]
-        L.msm_hip_launch_half_windows_batch_device_bn254.argtypes = [vp, vp, sz, i, i, i, i, vp]
+        L.msm_hip_set_bases.argtypes = [vp, u8p, sz, C.c_uint32]
+        L.msm_hip_set_bases_device.argtypes = [vp, vp, sz, C.c_uint32]
+        L.msm_hip_run.argtypes = [vp, u8p, sz, u8p]
+        L.msm_hip_run_device.argtypes = [vp, vp, sz, u8p]
+        L.msm_hip_run_batch.argtypes = [vp, u8p, sz, sz, u8p]
+        L.msm_hip_launch_windows_batch_device.argtypes = [vp, vp, sz, i, i, i, i, vp]
+        L.msm_hip_finish_batch.argtypes = [vp, i, u8p]
+        L.msm_hip_launch_half_windows_batch_device.argtypes = [vp, vp, sz, i, i, i, i, vp]
         L.msm_hip_combine_windows_batch_curve.argtypes = [i, vp, i, i, u8p]
         L.msm_hip_launch_vwindows_batch_device.argtypes = [vp, vp, sz, i, i, i, i, vp]
         L.msm_hip_combine_vwindows_batch_curve.argtypes = [i, vp, i, i, u8p]
         L.msm_hip_mgpu_set_wide_bits.argtypes = [vp, i]
-        L.msm_hip_run_batch_device_bn254.argtypes = [vp, vp, sz, sz, u8p]
-        L.msm_hip_launch_device_bn254.argtypes = [vp, vp, sz, i]
-        L.msm_hip_launch_bn254.argtypes = [vp, u8p, sz, i]
+        L.msm_hip_run_batch_device.argtypes = [vp, vp, sz, sz, u8p]
+        L.msm_hip_launch_device.argtypes = [vp, vp, sz, i]
+        L.msm_hip_launch.argtypes = [vp, u8p, sz, i]
         L.msm_hip_wait_stream.argtypes = [vp, vp]
-        L.msm_hip_finish_bn254.argtypes = [vp, i, u8p]
-        L.msm_hip_run_windows_device_bn254.argtypes = [vp, vp, sz, i, i, vp]
-        L.msm_hip_launch_windows_device_bn254.argtypes = [vp, vp, sz, i, i, i, vp]
+        L.msm_hip_finish.argtypes = [vp, i, u8p]
+        L.msm_hip_run_windows_device.argtypes = [vp, vp, sz, i, i, vp]
+        L.msm_hip_launch_windows_device.argtypes = [vp, vp, sz, i, i, i, vp]
         L.msm_hip_slot_wait_stream.argtypes = [vp, i, vp]
         L.msm_hip_slot_sync.argtypes = [vp, i]
         L.msm_hip_combine_windows_bn254.argtypes = [u8p, i, u8p]
@@ -121,12 +121,12 @@ def lib():
         L.msm_hip_mgpu_destroy.restype = None
         L.msm_hip_mgpu_device_count.argtypes = [vp]
         L.msm_hip_mgpu_uses_rccl.argtypes = [vp]
-        L.msm_hip_mgpu_set_bases_bn254.argtypes = [vp, u8p, sz, C.c_uint32]
-        L.msm_hip_mgpu_run_bn254.argtypes = [vp, u8p, sz, u8p]
-        L.msm_hip_mgpu_run_batch_bn254.argtypes = [vp, u8p, sz, sz, u8p]
-        L.msm_hip_mgpu_launch_batch_bn254.argtypes = [vp, u8p, sz, i, i]
-        L.msm_hip_mgpu_launch_batch_device_bn254.argtypes = [vp, C.POINTER(vp), sz, i, i]
-        L.msm_hip_mgpu_finish_batch_bn254.argtypes = [vp, i, u8p]
+        L.msm_hip_mgpu_set_bases.argtypes = [vp, u8p, sz, C.c_uint32]
+        L.msm_hip_mgpu_run.argtypes = [vp, u8p, sz, u8p]
+        L.msm_hip_mgpu_run_batch.argtypes = [vp, u8p, sz, sz, u8p]
+        L.msm_hip_mgpu_launch_batch.argtypes = [vp, u8p, sz, i, i]
+        L.msm_hip_mgpu_launch_batch_device.argtypes = [vp, C.POINTER(vp), sz, i, i]
+        L.msm_hip_mgpu_finish_batch.argtypes = [vp, i, u8p]
         L.msm_hip_mgpu_group_size.argtypes = [vp]
         L.msm_hip_mgpu_inject_fault.argtypes = [vp, i, i]
         L.msm_hip_window_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
@@ -280,13 +280,13 @@ class MsmContext:
         if isinstance(points, torch.Tensor) and points.is_cuda:
             t, n = _as_device_u8(points, self.pb, "points")
             self._order_after_torch(t)
-            _check(lib().msm_hip_set_bases_device_bn254(self._h, t.data_ptr(), n, flags), "msm_hip_set_bases_device_bn254")
+            _check(lib().msm_hip_set_bases_device(self._h, t.data_ptr(), n, flags), "msm_hip_set_bases_device")
         else:
             b = bytes(points)
             if len(b) % self.pb:
                 raise ValueError("points must be n x 64 bytes")
             n = len(b) // self.pb
-            _check(lib().msm_hip_set_bases_bn254(self._h, b, n, flags), "msm_hip_set_bases_bn254")
+            _check(lib().msm_hip_set_bases(self._h, b, n, flags), "msm_hip_set_bases")
         self.n_bases = n
         return n
 
@@ -297,12 +297,12 @@ class MsmContext:
         if isinstance(scalars, torch.Tensor) and scalars.is_cuda:
             t, n = _as_device_u8(scalars, 32, "scalars")
             self._order_after_torch(t)
-            _check(lib().msm_hip_run_device_bn254(self._h, t.data_ptr(), n, out), "msm_hip_run_device_bn254")
+            _check(lib().msm_hip_run_device(self._h, t.data_ptr(), n, out), "msm_hip_run_device")
         else:
             b = bytes(scalars)
             if len(b) % 32:
                 raise ValueError("scalars must be n x 32 bytes")
-            _check(lib().msm_hip_run_bn254(self._h, b, len(b) // 32, out), "msm_hip_run_bn254")
+            _check(lib().msm_hip_run(self._h, b, len(b) // 32, out), "msm_hip_run")
         return G1(out.raw, self.modulus)
 
     def msm_batch(self, scalars_dev, n):
@@ -314,7 +314,7 @@ class MsmContext:
                 raise ValueError("scalars must hold a whole number of n-element vectors")
             batch = len(b) // (32 * n)
             out = C.create_string_buffer(self.jb * batch)
-            _check(lib().msm_hip_run_batch_bn254(self._h, b, n, batch, out), "msm_hip_run_batch_bn254")
+            _check(lib().msm_hip_run_batch(self._h, b, n, batch, out), "msm_hip_run_batch")
             return [G1(out.raw[self.jb * k:self.jb * (k + 1)], self.modulus) for k in range(batch)]
         t, rows = _as_device_u8(scalars_dev, 32, "scalars")
         if n <= 0 or rows % n:
@@ -322,14 +322,14 @@ class MsmContext:
         batch = rows // n
         out = C.create_string_buffer(self.jb * batch)
         self._order_after_torch(t)
-        _check(lib().msm_hip_run_batch_device_bn254(self._h, t.data_ptr(), n, batch, out), "msm_hip_run_batch_device_bn254")
+        _check(lib().msm_hip_run_batch_device(self._h, t.data_ptr(), n, batch, out), "msm_hip_run_batch_device")
         return [G1(out.raw[self.jb * k:self.jb * (k + 1)], self.modulus) for k in range(batch)]
 
     def launch(self, scalars_dev, slot=0):
         """Enqueue the device work of one MSM into a result slot (0..3) and return at once."""
         t, n = _as_device_u8(scalars_dev, 32, "scalars")
         self._order_after_torch(t)
-        _check(lib().msm_hip_launch_device_bn254(self._h, t.data_ptr(), n, slot), "msm_hip_launch_device_bn254")
+        _check(lib().msm_hip_launch_device(self._h, t.data_ptr(), n, slot), "msm_hip_launch_device")
         self._keepalive[slot] = t
 
     def launch_host(self, scalars_host, slot=0):
@@ -338,13 +338,13 @@ class MsmContext:
         b = bytes(scalars_host)
         if len(b) % 32:
             raise ValueError("scalars must be n x 32 bytes")
-        _check(lib().msm_hip_launch_bn254(self._h, b, len(b) // 32, slot), "msm_hip_launch_bn254")
+        _check(lib().msm_hip_launch(self._h, b, len(b) // 32, slot), "msm_hip_launch")
 
     def finish(self, slot=0):
         """Wait for the slot's device work, run the host window combine, return G1."""
         out = C.create_string_buffer(self.jb)
         try:
-            _check(lib().msm_hip_finish_bn254(self._h, slot, out), "msm_hip_finish_bn254")
+            _check(lib().msm_hip_finish(self._h, slot, out), "msm_hip_finish")
         finally:
             self._keepalive.pop(slot, None)
         return G1(out.raw, self.modulus)
@@ -356,16 +356,16 @@ class MsmContext:
         if out_dev is None:
             out_dev = torch.empty((w_end - w_begin, self.jb), dtype=torch.uint8, device=t.device)
         self._order_after_torch(t)
-        _check(lib().msm_hip_run_windows_device_bn254(self._h, t.data_ptr(), n, w_begin, w_end, out_dev.data_ptr()),
-               "msm_hip_run_windows_device_bn254")
+        _check(lib().msm_hip_run_windows_device(self._h, t.data_ptr(), n, w_begin, w_end, out_dev.data_ptr()),
+               "msm_hip_run_windows_device")
         return out_dev
 
     def launch_windows(self, scalars_dev, w_begin, w_end, slot, out_dev):
         """Asynchronous msm_windows into a result slot (0..3); `out_dev` (CUDA uint8 [w_end - w_begin, 96]) receives the sums."""
         t, n = _as_device_u8(scalars_dev, 32, "scalars")
         self._order_after_torch(t)
-        _check(lib().msm_hip_launch_windows_device_bn254(self._h, t.data_ptr(), n, w_begin, w_end, slot, out_dev.data_ptr()),
-               "msm_hip_launch_windows_device_bn254")
+        _check(lib().msm_hip_launch_windows_device(self._h, t.data_ptr(), n, w_begin, w_end, slot, out_dev.data_ptr()),
+               "msm_hip_launch_windows_device")
         self._keepalive[slot] = (t, out_dev)
 
     def launch_windows_batch(self, scalars_dev, n, w_begin, w_end, slot, out_dev, inputs_complete=False):
@@ -376,22 +376,22 @@ class MsmContext:
             raise ValueError("scalars must hold a whole number of n-element vectors")
         if not inputs_complete:  # True: the caller vouches that the scalars were complete before this call (no stream ordering needed)
             self._order_after_torch(t)
-        _check(lib().msm_hip_launch_windows_batch_device_bn254(self._h, t.data_ptr(), n, rows // n, w_begin, w_end, slot,
+        _check(lib().msm_hip_launch_windows_batch_device(self._h, t.data_ptr(), n, rows // n, w_begin, w_end, slot,
                                                                out_dev.data_ptr() if out_dev is not None else None),
-               "msm_hip_launch_windows_batch_device_bn254")
+               "msm_hip_launch_windows_batch_device")
         self._keepalive[slot] = (t, out_dev)
 
     def launch_half_windows_batch(self, scalars_dev, n, hw_begin, hw_end, slot, out_dev, inputs_complete=False):
         """launch_windows_batch over the 8 HALF-length windows of a context whose bases carry their endomorphism images
-        (msm_hip_launch_half_windows_batch_device_bn254): `out_dev` receives nvec * (hw_end - hw_begin) sums, vector-major."""
+        (msm_hip_launch_half_windows_batch_device): `out_dev` receives nvec * (hw_end - hw_begin) sums, vector-major."""
         t, rows = _as_device_u8(scalars_dev, 32, "scalars")
         if n <= 0 or rows % n:
             raise ValueError("scalars must hold a whole number of n-element vectors")
         if not inputs_complete:
             self._order_after_torch(t)
-        _check(lib().msm_hip_launch_half_windows_batch_device_bn254(self._h, t.data_ptr(), n, rows // n, hw_begin, hw_end, slot,
+        _check(lib().msm_hip_launch_half_windows_batch_device(self._h, t.data_ptr(), n, rows // n, hw_begin, hw_end, slot,
                                                                     out_dev.data_ptr() if out_dev is not None else None),
-               "msm_hip_launch_half_windows_batch_device_bn254")
+               "msm_hip_launch_half_windows_batch_device")
         self._keepalive[slot] = (t, out_dev)
 
     def launch_vwindows_batch(self, scalars_dev, n, v_begin, v_end, slot, out_dev, inputs_complete=False):
@@ -417,7 +417,7 @@ class MsmContext:
         """Wait for a launch_batch slot, run the host window combines, return the list of G1 results."""
         out = C.create_string_buffer(self.jb * nvec)
         try:
-            _check(lib().msm_hip_finish_batch_bn254(self._h, slot, out), "msm_hip_finish_batch_bn254")
+            _check(lib().msm_hip_finish_batch(self._h, slot, out), "msm_hip_finish_batch")
         finally:
             self._keepalive.pop(slot, None)
         return [G1(out.raw[self.jb * k:self.jb * (k + 1)], self.modulus) for k in range(nvec)]
@@ -651,20 +651,20 @@ class MultiGpuMsm:
         flags = (1 if check_on_curve else 0) | (8 if endomorphism else 0) | (32 if precompute == "wide" else 4 if precompute else 0)
         if endomorphism is False and not precompute:
             flags |= 16
-        _check(lib().msm_hip_mgpu_set_bases_bn254(self._h, b, len(b) // self.pb, flags), "msm_hip_mgpu_set_bases_bn254")
+        _check(lib().msm_hip_mgpu_set_bases(self._h, b, len(b) // self.pb, flags), "msm_hip_mgpu_set_bases")
         return len(b) // self.pb
 
     def msm(self, scalars):
         b = bytes(scalars)
         out = C.create_string_buffer(self.jb)
-        _check(lib().msm_hip_mgpu_run_bn254(self._h, b, len(b) // 32, out), "msm_hip_mgpu_run_bn254")
+        _check(lib().msm_hip_mgpu_run(self._h, b, len(b) // 32, out), "msm_hip_mgpu_run")
         return G1(out.raw, self.modulus)
 
     def msm_batch(self, scalars, n):
         b = bytes(scalars)
         batch = len(b) // (32 * n)
         out = C.create_string_buffer(max(self.jb * batch, 1))
-        _check(lib().msm_hip_mgpu_run_batch_bn254(self._h, b, n, batch, out), "msm_hip_mgpu_run_batch_bn254")
+        _check(lib().msm_hip_mgpu_run_batch(self._h, b, n, batch, out), "msm_hip_mgpu_run_batch")
         return [G1(out.raw[self.jb * k:self.jb * (k + 1)], self.modulus) for k in range(batch)]
 
     def set_wide_bits(self, bits):
@@ -690,7 +690,7 @@ class MultiGpuMsm:
             if not inputs_complete:  # the header wants the device scalars complete before the call: wait for whatever torch still has queued on
                 for t in ts:          # each tensor's device (the engine's streams are not ordered with torch's)
                     torch.cuda.current_stream(t.device).synchronize()
-            _check(lib().msm_hip_mgpu_launch_batch_device_bn254(self._h, ptrs, n, rows // n, slot), "msm_hip_mgpu_launch_batch_device_bn254")
+            _check(lib().msm_hip_mgpu_launch_batch_device(self._h, ptrs, n, rows // n, slot), "msm_hip_mgpu_launch_batch_device")
             self._keep = getattr(self, "_keep", {})
             self._keep[slot] = ts
             return rows // n
@@ -699,7 +699,7 @@ class MultiGpuMsm:
             raise ValueError("scalars must hold a whole number of n-element vectors")
         self._keep = getattr(self, "_keep", {})
         self._keep[slot] = b  # the library reads the buffer until finish
-        _check(lib().msm_hip_mgpu_launch_batch_bn254(self._h, b, n, len(b) // (32 * n), slot), "msm_hip_mgpu_launch_batch_bn254")
+        _check(lib().msm_hip_mgpu_launch_batch(self._h, b, n, len(b) // (32 * n), slot), "msm_hip_mgpu_launch_batch")
         return len(b) // (32 * n)
 
     def inject_fault(self, device_index, launches=1):
@@ -709,7 +709,7 @@ class MultiGpuMsm:
     def finish_batch(self, slot, nvec):
         out = C.create_string_buffer(self.jb * nvec)
         try:
-            _check(lib().msm_hip_mgpu_finish_batch_bn254(self._h, slot, out), "msm_hip_mgpu_finish_batch_bn254")
+            _check(lib().msm_hip_mgpu_finish_batch(self._h, slot, out), "msm_hip_mgpu_finish_batch")
         finally:
             getattr(self, "_keep", {}).pop(slot, None)
         return [G1(out.raw[self.jb * k:self.jb * (k + 1)], self.modulus) for k in range(nvec)]

@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # MSM_HIP_SO: load (and build into) another file, e.g. a diagnostic variant next to the product library
 SO = os.environ.get("MSM_HIP_SO") or os.path.join(HERE, "libmsm_hip.so")
-SOURCES = ["msm_hip.hip", "curve_grumpkin.hip", "curve_pallas.hip", "curve_vesta.hip", "curve_bls12_381.hip", "curve_bn254_g2.hip", "curve_bls12_381_g2.hip", "fq2.h", "bn254_g2_constants.h", "bls12_381_g2_constants.h", "fq28x14_asm.h", "bls12_381_constants.h", "curve_ops.h", "msm_kernels.h", "g1.h", "fq29.h", "fq29_asm.h", "host_g1.h", "host_pool.h", "glv.h", "msm_mgpu.h", "curve_select.h", "curve_unit.h", "grumpkin_constants.h", "bn254_constants.h", "pallas_constants.h", "vesta_constants.h"]
+SOURCES = ["msm_hip.hip", "curve_grumpkin.hip", "curve_pallas.hip", "curve_vesta.hip", "curve_bls12_381.hip", "curve_bn254_g2.hip", "curve_bls12_381_g2.hip", "fq2.h", "bn254_g2_constants.h", "bls12_381_g2_constants.h", "fq28x14_asm.h", "bls12_381_constants.h", "curve_ops.h", "msm_kernels.h", "g1.h", "fq29.h", "fq29_asm.h", "host_g1.h", "host_pool.h", "host_worker.h", "glv.h", "msm_mgpu.h", "curve_select.h", "curve_unit.h", "grumpkin_constants.h", "bn254_constants.h", "pallas_constants.h", "vesta_constants.h"]
 HEADER = os.path.join(HERE, "..", "include", "msm_hip.h")
 TEMPS = os.path.join(HERE, "..", "build", "temps" if not os.environ.get("MSM_HIP_SO") else "temps_" + os.path.basename(SO))
 
@@ -24,9 +24,54 @@ def device_asm_is_current():
     return all(os.path.getmtime(f) >= newest for f in device_asm_files())
 
 
+def build_stamp():
+    """what the library on disk must have been built FROM to be the product: a hash over the compile flags (the environment switches of the
+    diagnostic builds included -- MSM_HIP_SLP, MSM_HIP_NO_ASM, MSM_HIP_EXTRA_FLAGS ...) and the contents of every source.  Written next to the
+    library by build(); a library whose stamp differs (built once with variant flags, or from other sources) is rebuilt instead of being
+    silently reused, and the code-generation gates (tools/check_machine_verifier.py, tools/check_long_branch_hazard.py) check the stamp of the
+    library they vouch for."""
+    import hashlib
+
+    h = hashlib.sha256()
+    h.update("\0".join(compile_flags()).encode())
+    for f in sorted(SOURCES) + [HEADER]:
+        path = f if os.path.isabs(f) else os.path.join(CSRC, f)
+        if os.path.exists(path):
+            h.update(b"\0" + os.path.basename(path).encode() + b"\0")
+            with open(path, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
+def stamp_path():
+    return SO + ".stamp"
+
+
+def stamp_is_current():
+    """True if the library on disk was built from the current sources with the current flags"""
+    try:
+        with open(stamp_path()) as f:
+            return f.read().strip() == build_stamp()
+    except OSError:
+        return False
+
+
+def variant_flags():
+    """the environment switches that change the generated code (the diagnostic builds)"""
+    return [k for k in ("MSM_HIP_SLP", "MSM_HIP_NO_ASM", "MSM_HIP_ASM_SMVP_ONLY", "MSM_HIP_EXTRA_FLAGS") if os.environ.get(k)]
+
+
 def needs_build():
     if not os.path.exists(SO):
         return True
+    if os.environ.get("MSM_HIP_SO"):
+        # a diagnostic library named explicitly (built here with variant flags, run on the GPU box without them in the environment): its own
+        # modification time decides -- the stamp rule below is the PRODUCT's
+        t = os.path.getmtime(SO)
+        return any(os.path.getmtime(d) > t for d in [os.path.join(CSRC, s) for s in SOURCES] + [HEADER] if os.path.exists(d))
+    if os.path.exists(stamp_path()):
+        return not stamp_is_current()
+    # a library without a stamp (built by an older checkout): the modification times decide, as they used to
     t = os.path.getmtime(SO)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
@@ -55,6 +100,9 @@ def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950: every translation unit of csrc/ to an object (in parallel), then -shared -> msm-webgpu_amd/libmsm_hip.so"""
     if not force and not needs_build():
         return SO
+    if variant_flags() and not os.environ.get("MSM_HIP_SO"):
+        # the product library is only ever built with the gated flags: a variant build must name its own file
+        raise RuntimeError("variant build flags (%s) need MSM_HIP_SO=<another file>: libmsm_hip.so is the product" % ", ".join(variant_flags()))
     from concurrent.futures import ThreadPoolExecutor
 
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -78,6 +126,8 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=TEMPS)
     os.replace(SO + ".tmp", SO)
+    with open(stamp_path(), "w") as f:
+        f.write(build_stamp() + "\n")
     return SO
 
 

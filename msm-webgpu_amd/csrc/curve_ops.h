@@ -10,7 +10,7 @@
 struct CurveOps {
   void (*convert_points)(const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t*);
   void (*precompute_tables)(uint32_t*, size_t, size_t, int, int, int);
-  void (*endo_points)(uint32_t*, size_t);
+  void (*endo_points)(uint32_t*, size_t, size_t, size_t);
   // k_count<C, 4, true> for C = 12 / 14 / 16: the first sort pass of endomorphism launches, which splits the scalars itself (csrc/glv.h)
   void (*count_split[3])(const uint32_t*, size_t, uint32_t, uint32_t, int, int, int, size_t, uint32_t*, uint16_t*, int, uint64_t*, uint32_t*, uint32_t*, size_t);
   void (*scalars_from_mont256)(const uint32_t*, uint32_t*, size_t, uint32_t*);

@@ -198,6 +198,10 @@ inline hg1 hg1_identity() {
   return r;
 }
 inline bool hg1_is_identity(const hg1& p) { return hfq_is_zero(p.z); }
+inline hg1 hg1_neg(const hg1& p) {  // (x, -y, z): 0 - y in the coordinate field (prime field or Fq2)
+  hg1 zero = hg1_identity();
+  return {p.x, hfq_sub(zero.y, p.y), p.z};
+}
 
 inline hg1 hg1_double(const hg1& p) {  // dbl-2009-l, a = 0
   if (hg1_is_identity(p)) return p;
@@ -311,25 +315,26 @@ inline bool window_from_planes(const uint8_t* planes, uint8_t* sum96) {
   return ok;
 }
 
-// The wide fixed-base tables' finish (msm_kernels.h: k_count_wide): sum_hi W_hi + 2^15 * sum_hi hi * TC_hi over the `nvirt` virtual windows.
-// `sums96`: the finished W_hi (window_from_planes, made side by side by the caller); `planes`: the launch's bit-plane sums, whose record 15 of
-// every window is TC_hi.  sum_hi hi * TC_hi by running sums from the top (2 additions per virtual window), then 15 doublings.
-// (`sums` / `totals`: W_hi and TC_hi as JB-byte records, `sum_stride` / `total_stride` bytes apart)
+// The wide fixed-base tables' finish (msm_kernels.h: wide_key).  Magnitude m sits in virtual window vw = (m - 1) mod V at the slot of value
+// (m - 1) / V + 1, so with the windows' weighted sums W_vw and plain totals TC_vw (V = nvirt, a power of two):
+//     sum_m m B_m = V * sum_vw W_vw - sum_vw (V - 1 - vw) TC_vw = V * sum_vw W_vw - sum_{j=0}^{V-2} (TC_0 + ... + TC_j)
+// -- log2 V doublings and 2 additions per virtual window.
+// (`sums` / `totals`: W_vw and TC_vw as JB-byte records, `sum_stride` / `total_stride` bytes apart)
 inline bool combine_wide_strided(const uint8_t* sums, size_t sum_stride, const uint8_t* totals, size_t total_stride, int nvirt, uint8_t* out) {
   bool ok = true;
-  hg1 acc = hg1_identity(), run = hg1_identity(), weighted = hg1_identity();
-  for (int hi = nvirt - 1; hi >= 0; hi--) {
+  hg1 acc = hg1_identity(), run = hg1_identity(), minus = hg1_identity();
+  for (int vw = 0; vw < nvirt; vw++) {
     hg1 w, tc;
-    ok &= hg1_from_bytes96(w, sums + sum_stride * (size_t)hi);
+    ok &= hg1_from_bytes96(w, sums + sum_stride * (size_t)vw);
     acc = hg1_add(acc, w);
-    if (hi >= 1) {
-      ok &= hg1_from_bytes96(tc, totals + total_stride * (size_t)hi);
+    if (vw < nvirt - 1) {
+      ok &= hg1_from_bytes96(tc, totals + total_stride * (size_t)vw);
       run = hg1_add(run, tc);
-      weighted = hg1_add(weighted, run);
+      minus = hg1_add(minus, run);
     }
   }
-  for (int k = 0; k < 15; k++) weighted = hg1_double(weighted);
-  hg1_to_bytes96(out, hg1_add(acc, weighted));
+  for (int v = nvirt; v > 1; v >>= 1) acc = hg1_double(acc);
+  hg1_to_bytes96(out, hg1_add(acc, hg1_neg(minus)));
   return ok;
 }
 inline bool combine_wide(const uint8_t* sums96, const uint8_t* planes, int nvirt, uint8_t* out) {

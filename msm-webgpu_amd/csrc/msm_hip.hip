@@ -11,7 +11,7 @@
 //   stream "reduce" : (waits smvp_done) stitch + bucket reduce -> window sums -> D2H -> event done[slot]
 // The stitch and the bucket reduce are bound by the depth of dependent group additions and occupy few waves; putting them
 // on their own stream lets the sort + SMVP of the NEXT launch (other slot) run meanwhile.  The host window combine of a
-// slot (src/cuzk/msm.rs:411-416) runs in the caller's thread inside msm_hip_finish_bn254 / msm_hip_finish_batch_bn254.
+// slot (src/cuzk/msm.rs:411-416) runs in the caller's thread inside msm_hip_finish / msm_hip_finish_batch.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -22,6 +22,7 @@
 #include <mutex>
 #include <new>
 
+#define MSM_HIP_TEST_HOOKS 1
 #include "../../include/msm_hip.h"
 #include "curve_ops.h"
 #include "host_pool.h"
@@ -88,7 +89,7 @@ struct Slot {
   hipEvent_t smvp_done = nullptr;             // main -> reduce hand-off
   hipEvent_t done = nullptr;                  // everything of this slot finished (recorded on the reduce stream)
   hipEvent_t staged = nullptr;                // host scalars of this slot have landed in d_host_scalars (copy stream)
-  uint32_t* d_host_scalars = nullptr;         // staging of msm_hip_launch_bn254's host scalars (this slot's own: no launch of
+  uint32_t* d_host_scalars = nullptr;         // staging of msm_hip_launch's host scalars (this slot's own: no launch of
   size_t cap_host_scalars = 0;                // another slot can still be reading it), in scalars; allocated on first use
   size_t cap_recs = 0;                        // capacity (records) of d_heads / d_tails
   bool ready = false;                         // small buffers + events exist (slots are set up on first use)
@@ -123,12 +124,14 @@ struct msm_hip_ctx {
   uint32_t* d_halves = nullptr;       // the split scalars of one launch (main stream only): [vector][2n] x 4 words
   size_t cap_halves = 0;              // in scalars
 
-  hipStream_t copy_stream = nullptr;    // H2D of host scalars (created on first use by msm_hip_launch_bn254)
+  hipStream_t copy_stream = nullptr;    // H2D of host scalars (created on first use by msm_hip_launch)
   hipEvent_t input_ready = nullptr;     // a caller's producer stream -> main stream (msm_hip_wait_stream)
+  hipEvent_t bases_ready = nullptr;     // the one-shot entry point: the last chunk of the bases has been converted (conversion stream -> main stream)
+  hipEvent_t chunk_landed[8] = {};      // ... and chunk k of the wire bytes has landed (copy stream -> conversion stream)
   size_t cap_entries = 0;  // capacity of the entry arrays (tmp_val, tmp_fine, val): local windows x per-window stride
   size_t last_stride = 0;  // per-window stride of the last launch (n rounded up to a multiple of 4)
   size_t cap_chunk_slot = 0;  // capacity (records) of d_chunk_slot
-  uint8_t* d_batch_stage = nullptr;   // staging ring (NSLOT vectors) of msm_hip_run_batch_bn254, allocated on first use
+  uint8_t* d_batch_stage = nullptr;   // staging ring (NSLOT vectors) of msm_hip_run_batch, allocated on first use
   size_t cap_batch_stage = 0;
   uint16_t* d_digits = nullptr;  // digit-code planes [local window][n]: debug read-back, or the input of the second sort pass (k_scatter_planes)
   uint64_t* d_negbits = nullptr; // with the planes of a launch: one sign bit per input of every vector
@@ -143,6 +146,8 @@ struct msm_hip_ctx {
   uint8_t* d_tmp_fine = nullptr;     // [W][stride]
   uint32_t* d_val = nullptr;         // [W][stride] slot order
   uint32_t* d_chunk_slot = nullptr;  // [W][chunks] bucket slot of every SMVP chunk's first entry
+  uint32_t* d_list_len = nullptr;    // shares of the wide tables' virtual windows: [W][sub-tiles] lengths of the first pass's compact entry lists (k_count_wide_list)
+  size_t cap_list_len = 0;
   uint32_t* d_scalar_conv = nullptr;  // canonical copies of scalars handed over in R = 2^256 Montgomery form (one launch's worth)
   size_t cap_scalar_conv = 0;         // in scalars
   uint32_t scalar_format = 0;         // MSM_HIP_SCALARS_CANONICAL / MSM_HIP_SCALARS_MONT256
@@ -276,15 +281,23 @@ inline uint32_t wide_top_max(int curve, int bits) {
   const uint64_t top = scalar_modulus_top64(curve);
   const int fb = wide_top_pos(bits) - 192;                   // fraction bits of `top` below the digit
   const uint64_t frac = top << (64 - fb);                    // (r mod 2^P) / 2^P as a 64-bit fraction, truncated
-  const uint64_t bias = (1ull << 63) + (1ull << (63 - bits)) + (1ull << 20);  // the bias below the digit / 2^P (second term: the next window's bit), rounded up
+  // the bias below the digit / 2^P = 1/2 + 2^(-C-1) + 2^(-2C-1) + ... as a 64-bit fraction: every term of the series that has a bit there, + 2 units
+  // for its tail and for the truncation of `frac` -- an UPPER bound (round 4 stopped after two terms + 2^20, which the third term, 2^(63-2C),
+  // exceeds: right for the five moduli of this library, not a bound), so a width is at worst refused for a modulus on a carry boundary, never
+  // accepted wrongly; tests/test_abi.py compares with the exact big-integer value for every curve and width
+  uint64_t bias = 2;
+  for (int sh = 63; sh >= 0; sh -= bits) bias += 1ull << sh;
   return (uint32_t)(top >> fb) + (frac + bias < frac ? 1u : 0u);               // + the carry into the digit
 }
+// Round 5: with INTERLEAVED virtual windows (msm_kernels.h: wide_key) the narrow top digit spreads over the windows by itself and is used as it
+// is -- no shift.  (Round 4 shifted it by the largest amount that kept it within 2^(C-1), to spread it over contiguous magnitude ranges;
+// MSM_HIP_WIDE_TOP_SHIFT still forces a shift for A/B runs: the kernels and the tables' last step honour it.)
 inline int wide_top_shift(int curve, int bits) {
   static const int forced = [] { const char* e = getenv("MSM_HIP_WIDE_TOP_SHIFT"); return e ? atoi(e) : -1; }();  // tuning aid
-  if (forced >= 0) return forced;
+  if (forced < 0) return 0;
   const uint32_t dmax = wide_top_max(curve, bits), half = 1u << (bits - 1);
   int s = 0;
-  while (s + 1 < bits && ((uint64_t)dmax << (s + 1)) <= half) s++;
+  while (s + 1 < bits && s < forced && ((uint64_t)dmax << (s + 1)) <= half) s++;
   return s;
 }
 // Can the curve's scalars be recoded into C-bit digits at all?  The top digit is never negative and becomes a bucket magnitude, so it must not
@@ -321,14 +334,13 @@ inline WideShape wide_shape(size_t n, int curve, int bits, int lwin) {  // (lwin
   const int WIDE_TABLES = wide_tables_of(bits), WIDE_VWIN = wide_vwin_of(bits);
   WideShape w;
   w.worst = n * (size_t)WIDE_TABLES;
-  // r / 2^P: the top digit of a uniform scalar is uniform below it; a virtual window takes the 2^15 >> shift digit values (at least one) that
-  // land in it, so the fullest one receives that share of the n top digits on top of its (T - 1) n / VWIN
-  const double top_range = (double)scalar_modulus_top64(curve) / (double)(1ull << (wide_top_pos(bits) - 192));
+  // interleaved virtual windows (msm_kernels.h: wide_key): consecutive magnitudes go to consecutive windows, so every digit -- the narrow top one
+  // included -- spreads evenly: each window expects T n / VWIN entries (a forced top shift of s puts the top digit's n entries into every 2^s-th
+  // window only)
   const int shift = wide_top_shift(curve, bits);
-  double share = (double)(shift >= 15 ? 1u : 32768u >> shift) / top_range;
-  if (share > 1.0) share = 1.0;
+  const int top_windows = WIDE_VWIN >> (shift < bits - WBITS ? shift : bits - WBITS);
   static const double slack = [] { const char* e = getenv("MSM_HIP_WIDE_SLACK_PCT"); return e ? atof(e) / 100.0 : 0.004; }();  // tuning aid
-  const double fullest = (double)n * (WIDE_TABLES - 1) / WIDE_VWIN + (double)n * share;
+  const double fullest = (double)n * (WIDE_TABLES - 1) / WIDE_VWIN + (double)n / (top_windows > 0 ? top_windows : 1);
   const size_t typ = (size_t)(fullest * (1.0 + slack)) + 64;
   w.chunk_len = chunk_len_for(typ, lwin);
   w.chunks = chunks_for(typ, w.chunk_len);
@@ -515,8 +527,11 @@ inline bool use_planes(const msm_hip_ctx* ctx, LaunchMode mode, int w_count_vec,
 // copied to the slot's pinned buffer.  Returns without waiting.
 // (MODE_WIDE: `v_count` != 0 -- a SHARE of the virtual windows, [v_begin, v_begin + v_count) of every vector; its sums are (window sum, plain
 //  total) pairs, 2 records per local window.  0: whole MSMs, all 2^(C-16) virtual windows)
+// `phase`: 0 the whole launch; 1 only its recode + sort (everything that needs the scalars alone); 2 the rest, from the SMVP on (everything that
+// needs the bases) -- the one-shot entry point sorts while the bases are still being uploaded (msm_hip_msm_bn254_g1).  Phase 2 must follow
+// phase 1 of the same launch with the same arguments.
 int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, int w_count_vec, int nvec, int wbits, LaunchMode mode, Slot& s,
-            uint32_t* wsums_out, bool to_host, int v_begin = 0, int v_count = 0) {
+            uint32_t* wsums_out, bool to_host, int v_begin = 0, int v_count = 0, int phase = 0) {
   const bool merge = mode == MODE_TABLES, halves = mode == MODE_HALVES, wide = mode == MODE_WIDE;
   const bool pairs = wide && v_count != 0;
   if (wide && !pairs) v_count = wide_vwin_of(ctx->wide_bits);
@@ -545,9 +560,16 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     if (!others) rs = st;
   }
   // tiles of scalars for the two global sort passes: >= 2048 scalars each, at most MAX_TILES of them
+  // shares of at most WIDE_SHARE_VWIN_MAX virtual windows of wide tables: the first pass leaves compact lists of the share's entries per sub-tile of
+  // LIST_SUB scalars (k_count_wide_list / k_scatter_list); tiles are then whole sub-tiles.  MSM_HIP_WIDE_SHARE_LISTS=0: the two-pass shape (A/B aid)
+  static const bool share_lists = [] { const char* e = getenv("MSM_HIP_WIDE_SHARE_LISTS"); return !e || atoi(e) != 0; }();
+  const bool share_shape = pairs && v_count <= WIDE_SHARE_VWIN_MAX;
+  const bool list_path = share_shape && share_lists;
+  const uint32_t tile_unit = list_path ? (uint32_t)LIST_SUB : 256u;
   uint32_t tile_len = 2048;
-  if ((n_sc + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n_sc + MAX_TILES - 1) / MAX_TILES) + 255) / 256 * 256);
+  if ((n_sc + tile_len - 1) / tile_len > MAX_TILES) tile_len = (uint32_t)((((n_sc + MAX_TILES - 1) / MAX_TILES) + tile_unit - 1) / tile_unit * tile_unit);
   const uint32_t tiles = (uint32_t)((n_sc + tile_len - 1) / tile_len);
+  const uint32_t subtiles = (uint32_t)((n_sc + LIST_SUB - 1) / LIST_SUB);
   const WideShape ws = wide ? wide_shape(n, ctx->curve, ctx->wide_bits, w_count) : WideShape{};
   const uint32_t chunk_len = wide ? ws.host_len : chunk_len_for(n_entries, w_count);  // (the longest the device may pick: smvp_chunk_len)
   const uint32_t chunks = wide ? ws.chunks : chunks_for(n_entries, chunk_len);
@@ -569,6 +591,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     if (tl >= 2 || (tl == 1 && smvp_edge)) return hipEventRecord(s.ev[i], st);
     return hipSuccess;
   };
+  if (phase != 2) {  // ---- recode + sort
   HIP_TRY(ctx, hipStreamWaitEvent(st, s.done, 0));
   HIP_TRY(ctx, mark(0, false));
   if (ctx->scalar_format == MSM_HIP_SCALARS_MONT256) {  // Montgomery-form scalars: canonical copies first (part of stage 0)
@@ -591,14 +614,21 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   if (wide) {
     const int top_shift = wide_top_shift(ctx->curve, ctx->wide_bits);
 #define LAUNCH_COUNT_WIDE(C) hipLaunchKernelGGL(k_count_wide<C>, dim3(tiles, nvec), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, nvec, n * 8, ctx->d_counts, d_err, top_shift, v_begin, v_count)
-    switch (ctx->wide_bits) {
-      case 16: LAUNCH_COUNT_WIDE(16); break;
-      case 17: LAUNCH_COUNT_WIDE(17); break;
-      case 18: LAUNCH_COUNT_WIDE(18); break;
-      case 19: LAUNCH_COUNT_WIDE(19); break;
-      default: LAUNCH_COUNT_WIDE(20); break;
+#define LAUNCH_COUNT_WIDE_LIST(C) hipLaunchKernelGGL(k_count_wide_list<C>, dim3(tiles, nvec), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, nvec, n * 8, ctx->d_counts, d_err, top_shift, v_begin, v_count, ctx->d_val, ctx->d_list_len, stride, subtiles)
+    switch (ctx->wide_bits * 2 + (list_path ? 1 : 0)) {
+      case 32: LAUNCH_COUNT_WIDE(16); break;
+      case 33: LAUNCH_COUNT_WIDE_LIST(16); break;
+      case 34: LAUNCH_COUNT_WIDE(17); break;
+      case 35: LAUNCH_COUNT_WIDE_LIST(17); break;
+      case 36: LAUNCH_COUNT_WIDE(18); break;
+      case 37: LAUNCH_COUNT_WIDE_LIST(18); break;
+      case 38: LAUNCH_COUNT_WIDE(19); break;
+      case 39: LAUNCH_COUNT_WIDE_LIST(19); break;
+      case 40: LAUNCH_COUNT_WIDE(20); break;
+      default: LAUNCH_COUNT_WIDE_LIST(20); break;
     }
 #undef LAUNCH_COUNT_WIDE
+#undef LAUNCH_COUNT_WIDE_LIST
   } else if (halves) {
     hipLaunchKernelGGL(ctx->ops->count_split[wbits == 16 ? 2 : wbits == 14 ? 1 : 0], dim3(tiles, nvec), dim3(256), 0, st, d_scalars, n_sc, tile_len, tiles, w_begin,
                        w_count_vec, nvec, n * 8, ctx->d_counts, plane_out, plane_mode, planes ? ctx->d_negbits : nullptr,
@@ -615,9 +645,21 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   HIP_TRY(ctx, mark(2, false));
   if (wide) {
     const int top_shift = wide_top_shift(ctx->curve, ctx->wide_bits);
-#define LAUNCH_SCATTER_WIDE(C)                                                                                                                         \
-  hipLaunchKernelGGL(k_scatter_wide<C>, dim3(tiles, nvec), dim3(WIDE_THREADS), 0, st, d_scalars, n_sc, stride, tile_len, tiles, nvec, n * 8, ctx->d_counts, ctx->d_bin_total, \
+    // shares of at most WIDE_SHARE_VWIN_MAX virtual windows: from the first pass's lists, or (MSM_HIP_WIDE_SHARE_LISTS=0) the small shape of the
+    // two-pass kernel (four workgroups per CU instead of one)
+    if (list_path) {
+      hipLaunchKernelGGL(k_scatter_list, dim3(tiles, w_count), dim3(256), 0, st, (const uint32_t*)ctx->d_val, (const uint32_t*)ctx->d_list_len, stride,
+                         (uint32_t)(LIST_SUB * wide_tables_of(ctx->wide_bits)), subtiles, n_sc, tile_len, tiles, w_count, ctx->d_counts, ctx->d_bin_total,
+                         ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, chunks, chunk_len, d_chunk_len);
+    } else {
+#define LAUNCH_SCATTER_WIDE_SHAPE(C, SHARE)                                                                                                                         \
+  hipLaunchKernelGGL((k_scatter_wide<C, SHARE>), dim3(tiles, nvec), dim3(WideScatterShape<C, SHARE>::THREADS), 0, st, d_scalars, n_sc, stride, tile_len, tiles, nvec, n * 8, ctx->d_counts, ctx->d_bin_total, \
                      ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, chunks, chunk_len, d_chunk_len, top_shift, v_begin, v_count)
+#define LAUNCH_SCATTER_WIDE(C)                       \
+  do {                                               \
+    if (share_shape) LAUNCH_SCATTER_WIDE_SHAPE(C, true); \
+    else LAUNCH_SCATTER_WIDE_SHAPE(C, false);        \
+  } while (0)
     switch (ctx->wide_bits) {
       case 16: LAUNCH_SCATTER_WIDE(16); break;
       case 17: LAUNCH_SCATTER_WIDE(17); break;
@@ -625,7 +667,9 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
       case 19: LAUNCH_SCATTER_WIDE(19); break;
       default: LAUNCH_SCATTER_WIDE(20); break;
     }
+#undef LAUNCH_SCATTER_WIDE_SHAPE
 #undef LAUNCH_SCATTER_WIDE
+    }
   } else if (planes) {
     hipLaunchKernelGGL(k_scatter_planes, dim3(tiles), dim3(256), 0, st, ctx->d_digits, halves ? ctx->d_negbits : (const uint64_t*)nullptr, n_sc, stride, tile_len,
                        tiles, w_count, w_count_vec, ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine,
@@ -654,6 +698,11 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     hipLaunchKernelGGL(k_order_runs, dim3(blocks_for(n_entries, 256), w_count), dim3(256), 0, st, s.d_col_ptr, ctx->d_val, ctx->d_tmp_val, stride, half);
     hipLaunchKernelGGL(k_copy_runs, dim3(blocks_for(n_entries, 256), w_count), dim3(256), 0, st, s.d_col_ptr, ctx->d_tmp_val, ctx->d_val, stride, half);
     AFTER_KERNEL(ctx, "k_order_runs", st);
+  }
+  }  // ---- (recode + sort)
+  if (phase == 1) {
+    HIP_TRY(ctx, hipGetLastError());
+    return MSM_HIP_OK;
   }
   // the SMVP's own begin / end timestamps: attached to its dispatch (hipExtLaunchKernelGGL) instead of two event packets around it -- a
   // packet between two kernels costs a few microseconds of queue time, and these two sat between every launch's sort and its SMVP and
@@ -865,7 +914,7 @@ int set_bases_from_device(msm_hip_ctx* ctx, const uint32_t* d_xy, size_t n, uint
     ctx->wide_bits = wb;
   }
   if (flags & MSM_HIP_BASES_ENDOMORPHISM) {  // phi(P_i) = (beta x_i, y_i) behind the plain set
-    hipLaunchKernelGGL(ctx->ops->endo_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_bases, n);
+    hipLaunchKernelGGL(ctx->ops->endo_points, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_bases, n, (size_t)0, n);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->endo = true;
@@ -901,13 +950,13 @@ int run_batch_groups(msm_hip_ctx* ctx, size_t n, size_t batch, uint8_t* out_xyz,
   for (size_t j = 0; j < groups + DEPTH; j++) {
     if (j >= DEPTH) {
       const size_t k = j - DEPTH;
-      if ((rc = msm_hip_finish_batch_bn254(ctx, (int)(k % NSLOT), out_xyz + ctx->jb * k * g))) break;
+      if ((rc = msm_hip_finish_batch(ctx, (int)(k % NSLOT), out_xyz + ctx->jb * k * g))) break;
     }
     if (j < groups) {
       const size_t first = j * g, count = first + g <= batch ? g : batch - first;
       const void* dev = nullptr;
       if ((rc = stage(j, first, count, &dev))) break;
-      if ((rc = msm_hip_launch_windows_batch_device_bn254(ctx, dev, n, (int)count, 0, NWIN, (int)(j % NSLOT), nullptr))) break;
+      if ((rc = msm_hip_launch_windows_batch_device(ctx, dev, n, (int)count, 0, NWIN, (int)(j % NSLOT), nullptr))) break;
     }
   }
   if (rc) drain_slots(ctx);
@@ -1000,7 +1049,7 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   for (hipStream_t r : ctx->reduce_stream)
     if (r) (void)hipStreamSynchronize(r);
-  void* bufs[] = {ctx->d_bases,   ctx->d_halves, ctx->d_batch_stage, ctx->d_scalar_conv, ctx->d_part_hist, ctx->d_digits, ctx->d_negbits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
+  void* bufs[] = {ctx->d_list_len, ctx->d_bases,   ctx->d_halves, ctx->d_batch_stage, ctx->d_scalar_conv, ctx->d_part_hist, ctx->d_digits, ctx->d_negbits, ctx->d_counts,     ctx->d_bin_total, ctx->d_coarse_ptr,
                   ctx->d_tmp_val, ctx->d_tmp_fine, ctx->d_val,    ctx->d_chunk_slot, ctx->d_err,       ctx->d_stage};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1017,6 +1066,9 @@ void msm_hip_ctx_destroy(msm_hip_ctx* ctx) {
       if (s.ev[i]) (void)hipEventDestroy(s.ev[i]);
   }
   if (ctx->input_ready) (void)hipEventDestroy(ctx->input_ready);
+  if (ctx->bases_ready) (void)hipEventDestroy(ctx->bases_ready);
+  for (hipEvent_t e : ctx->chunk_landed)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   for (hipStream_t r : ctx->reduce_stream)
@@ -1032,7 +1084,7 @@ int msm_hip_wait_stream(msm_hip_ctx* ctx, void* producer_stream) {
   return MSM_HIP_OK;
 }
 
-int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t n, uint32_t flags) {
+int msm_hip_set_bases_device(msm_hip_ctx* ctx, const void* xy_dev, size_t n, uint32_t flags) {
   if (!ctx || (!xy_dev && n)) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   flags = resolve_base_flags(ctx, n, flags);
@@ -1041,7 +1093,7 @@ int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t 
   return set_bases_from_device(ctx, static_cast<const uint32_t*>(xy_dev), n, flags);
 }
 
-int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, uint32_t flags) {
+int msm_hip_set_bases(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, uint32_t flags) {
   if (!ctx || (!xy_host && n)) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   flags = resolve_base_flags(ctx, n, flags);
@@ -1059,7 +1111,7 @@ namespace {
 // (MODE_WIDE, v_count != 0: a SHARE of the wide tables' virtual windows -- [v_begin, v_begin + v_count) of every vector; its sums are (window sum,
 //  plain total) pairs: 2 records per local window, to `window_sums_dev` or, when null, to the slot's pinned buffer)
 int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end, int wbits, int slot,
-                void* window_sums_dev, LaunchMode mode = MODE_PLAIN, int v_begin = 0, int v_count = 0) {
+                void* window_sums_dev, LaunchMode mode = MODE_PLAIN, int v_begin = 0, int v_count = 0, int phase = 0) {
   // (MODE_WIDE: called with wbits = 19 and all 14 windows; everything behind the recode sees 8 local windows of 16 bits)
   const bool merge = mode == MODE_TABLES, halves = mode == MODE_HALVES, wide = mode == MODE_WIDE;
   const bool pairs = wide && v_count != 0;
@@ -1077,7 +1129,7 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
   if (nvec < 1 || w_local > MAXLW) return MSM_HIP_ERR_INVALID_ARG;
   ON_DEVICE(ctx);
   Slot& s = ctx->slot[slot];
-  if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;  // its result was never collected (msm_hip_finish_bn254 / msm_hip_slot_sync)
+  if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;  // its result was never collected (msm_hip_finish / msm_hip_slot_sync)
   if ((rc = setup_slot(ctx, s))) return rc;
   s.n = n;
   s.w_begin = w_begin;
@@ -1107,6 +1159,13 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
   if (wide) {
     const WideShape ws = wide_shape(n, ctx->curve, ctx->wide_bits, w_local);
     if ((rc = ensure_work(ctx, ws.worst, w_local, wbits, wide_vwin_of(ctx->wide_bits), s, false, (size_t)w_local * ws.chunks))) return rc;
+    const size_t need_len = pairs ? (size_t)w_local * ((n + LIST_SUB - 1) / LIST_SUB) : 0;  // list lengths of a share's first pass
+    if (need_len > ctx->cap_list_len) {
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->cap_list_len = 0;
+      if ((rc = dev_alloc(ctx, ctx->d_list_len, need_len))) return rc;
+      ctx->cap_list_len = need_len;
+    }
   } else if ((rc = ensure_work(ctx, merge ? n * (size_t)w_count : halves ? 2 * n : n, w_local, wbits,
                                merge ? 1 : halves ? nwin_of(wbits, true) : NWIN, s, use_planes(ctx, mode, w_count, wbits)))) return rc;
   if (halves && (size_t)nvec * n > ctx->cap_halves) {
@@ -1122,13 +1181,13 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
     ctx->cap_scalar_conv = (size_t)nvec * n;
   }
   return enqueue(ctx, static_cast<const uint32_t*>(scalars_dev), n, w_begin, w_count, nvec, wbits, mode, s,
-                 static_cast<uint32_t*>(window_sums_dev), window_sums_dev == nullptr, v_begin, v_count);
+                 static_cast<uint32_t*>(window_sums_dev), window_sums_dev == nullptr, v_begin, v_count, phase);
 }
 }  // namespace
 
 extern "C" {
 
-int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end,
+int msm_hip_launch_windows_batch_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end,
                                               int slot, void* window_sums_dev) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
   // whole MSMs whose sums stay in the slot (finish / finish_batch combines them): the window size follows n
@@ -1147,7 +1206,7 @@ int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scal
   return launch_impl(ctx, scalars_dev, n, nvec, w_begin, w_end, WBITS, slot, window_sums_dev);
 }
 
-int msm_hip_launch_half_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int hw_begin, int hw_end,
+int msm_hip_launch_half_windows_batch_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int hw_begin, int hw_end,
                                                    int slot, void* window_sums_dev) {
   if (!ctx) return MSM_HIP_ERR_INVALID_ARG;
   if (!ctx->endo && ctx->n_bases) return MSM_HIP_ERR_INVALID_ARG;  // needs bases set with MSM_HIP_BASES_ENDOMORPHISM
@@ -1162,13 +1221,13 @@ int msm_hip_launch_vwindows_batch_device(msm_hip_ctx* ctx, const void* scalars_d
   return launch_impl(ctx, scalars_dev, n, nvec, 0, wide_tables_of(ctx->wide_bits), ctx->wide_bits, slot, sums_dev, MODE_WIDE, v_begin, v_end - v_begin);
 }
 
-int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot,
+int msm_hip_launch_windows_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot,
                                         void* window_sums_dev) {
-  return msm_hip_launch_windows_batch_device_bn254(ctx, scalars_dev, n, 1, w_begin, w_end, slot, window_sums_dev);
+  return msm_hip_launch_windows_batch_device(ctx, scalars_dev, n, 1, w_begin, w_end, slot, window_sums_dev);
 }
 
-int msm_hip_launch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot) {
-  return msm_hip_launch_windows_device_bn254(ctx, scalars_dev, n, 0, NWIN, slot, nullptr);
+int msm_hip_launch_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot) {
+  return msm_hip_launch_windows_device(ctx, scalars_dev, n, 0, NWIN, slot, nullptr);
 }
 
 int msm_hip_slot_wait_stream(msm_hip_ctx* ctx, int slot, void* foreign_stream) {
@@ -1186,7 +1245,7 @@ int msm_hip_slot_sync(msm_hip_ctx* ctx, int slot) {
   return wait_slot(ctx, s);
 }
 
-int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
+int msm_hip_finish_batch(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   if (!ctx || !out_xyz || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   Slot& s = ctx->slot[slot];
   // fixed-base launches leave ONE sum per vector (every table already carries its power of two): nothing to combine but the copy
@@ -1219,18 +1278,18 @@ int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) {
   return MSM_HIP_OK;
 }
 
-int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]) {
+int msm_hip_finish(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]) {
   if (!ctx || slot < 0 || slot >= NSLOT || ctx->slot[slot].nvec != 1) return MSM_HIP_ERR_INVALID_ARG;
-  return msm_hip_finish_batch_bn254(ctx, slot, out_xyz);
+  return msm_hip_finish_batch(ctx, slot, out_xyz);
 }
 
-int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]) {
+int msm_hip_run_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]) {
   if (!out_xyz || !ctx) return MSM_HIP_ERR_INVALID_ARG;
   ctx->sync_call = true;
-  int rc = msm_hip_launch_device_bn254(ctx, scalars_dev, n, 0);
+  int rc = msm_hip_launch_device(ctx, scalars_dev, n, 0);
   ctx->sync_call = false;
   if (rc) return rc;
-  return msm_hip_finish_bn254(ctx, 0, out_xyz);
+  return msm_hip_finish(ctx, 0, out_xyz);
 }
 
 }  // extern "C"
@@ -1261,27 +1320,27 @@ int launch_host_windows(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n,
   HIP_TRY(ctx, hipMemcpyAsync(s.d_host_scalars, scalars_host, n * 32, hipMemcpyHostToDevice, ctx->copy_stream));
   HIP_TRY(ctx, hipEventRecord(s.staged, ctx->copy_stream));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.staged, 0));
-  if (auto_bits) return msm_hip_launch_windows_batch_device_bn254(ctx, s.d_host_scalars, n, 1, 0, NWIN, slot, nullptr);
+  if (auto_bits) return msm_hip_launch_windows_batch_device(ctx, s.d_host_scalars, n, 1, 0, NWIN, slot, nullptr);
   return launch_impl(ctx, s.d_host_scalars, n, 1, w_begin, w_end, WBITS, slot, window_sums_dev);
 }
 }  // namespace
 
 extern "C" {
 
-int msm_hip_launch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int slot) {
+int msm_hip_launch(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int slot) {
   return launch_host_windows(ctx, scalars_host, n, 0, NWIN, slot, nullptr, true);
 }
 
-int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
+int msm_hip_run(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
   if (!out_xyz || !ctx) return MSM_HIP_ERR_INVALID_ARG;
   ctx->sync_call = true;
-  int rc = msm_hip_launch_bn254(ctx, scalars_host, n, 0);
+  int rc = msm_hip_launch(ctx, scalars_host, n, 0);
   ctx->sync_call = false;
   if (rc) return rc;
-  return msm_hip_finish_bn254(ctx, 0, out_xyz);
+  return msm_hip_finish(ctx, 0, out_xyz);
 }
 
-int msm_hip_run_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, size_t batch, uint8_t* out_xyz) {
+int msm_hip_run_batch_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, size_t batch, uint8_t* out_xyz) {
   if (!out_xyz && batch) return MSM_HIP_ERR_INVALID_ARG;
   int rc = check_run_args(ctx, scalars_dev, n);
   if (rc) return rc;
@@ -1292,7 +1351,7 @@ int msm_hip_run_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, si
   });
 }
 
-int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz) {
+int msm_hip_run_batch(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz) {
   if (!out_xyz && batch) return MSM_HIP_ERR_INVALID_ARG;
   int rc = check_run_args(ctx, scalars_host, n);
   if (rc) return rc;
@@ -1319,10 +1378,10 @@ int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_
   });
 }
 
-int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end,
+int msm_hip_run_windows_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end,
                                      void* window_sums_dev) {
   if (!window_sums_dev) return MSM_HIP_ERR_INVALID_ARG;
-  int rc = msm_hip_launch_windows_device_bn254(ctx, scalars_dev, n, w_begin, w_end, 0, window_sums_dev);
+  int rc = msm_hip_launch_windows_device(ctx, scalars_dev, n, w_begin, w_end, 0, window_sums_dev);
   if (rc) return rc;
   return msm_hip_slot_sync(ctx, 0);
 }
@@ -1385,40 +1444,141 @@ int msm_hip_g1_to_affine_curve(int curve, const uint8_t xyz[96], uint8_t out_xy[
 namespace {
 constexpr int ONESHOT_MAX_DEVICES = 64;
 std::mutex g_oneshot_mutex;
-msm_hip_ctx* g_oneshot_ctx[ONESHOT_MAX_DEVICES] = {};
+msm_hip_ctx* g_oneshot_ctx[MSM_HIP_NUM_CURVES][ONESHOT_MAX_DEVICES] = {};
 inline bool oneshot_keep() {
   static const bool v = [] { const char* e = getenv("MSM_HIP_ONESHOT_KEEP"); return !(e && e[0] == '0'); }();
   return v;
 }
 }  // namespace
 
-int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
+}  // extern "C"
+
+namespace {
+// The one-shot call on a kept (or fresh) context, OVERLAPPED (round 5): the reference uploads everything, then dispatches (src/cuzk/msm.rs:84-94,
+// 441-480); here the 32 n bytes of scalars go first and their recode + sort (everything that needs the scalars alone: launch phase 1) runs while
+// the 64 n bytes of points are still arriving -- in chunks on the copy stream, each converted to the device form (and its endomorphism image
+// made) as soon as it has landed --, and only the SMVP (launch phase 2) waits for the last chunk.  Hidden: the sort (~0.26 ms at 2^20), the
+// conversion kernels (~0.1 ms) and one host synchronisation.  MSM_HIP_ONESHOT_OVERLAP=0: upload, convert, then run (rounds 1 - 4).
+int oneshot_overlapped(msm_hip_ctx* ctx, const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t* out_xyz) {
+  ON_DEVICE(ctx);
+  const uint32_t flags = resolve_base_flags(ctx, n, 0);
+  const bool endo = (flags & MSM_HIP_BASES_ENDOMORPHISM) != 0;
+  int rc = reserve_bases(ctx, n, flags);  // (waits for the main stream: nothing is reading the old bases)
+  if (rc) return rc;
+  Slot& s = ctx->slot[0];
+  if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;
+  if ((rc = setup_slot(ctx, s))) return rc;
+  if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (!ctx->bases_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->bases_ready, hipEventDisableTiming));
+  if (n > s.cap_host_scalars) {
+    s.cap_host_scalars = 0;
+    if ((rc = dev_alloc(ctx, s.d_host_scalars, n * 8))) return rc;
+    s.cap_host_scalars = n;
+  }
+  // 1. the scalars, and their sort
+  HIP_TRY(ctx, hipMemcpyAsync(s.d_host_scalars, scalars_host, n * 32, hipMemcpyHostToDevice, ctx->copy_stream));
+  HIP_TRY(ctx, hipEventRecord(s.staged, ctx->copy_stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.staged, 0));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0, 4, ctx->copy_stream));  // (ahead of every chunk's copy, hence of every conversion)
+  ctx->n_bases = n;  // (what the launch checks n against; the records themselves follow below)
+  ctx->endo = endo;
+  const LaunchMode mode = endo ? MODE_HALVES : MODE_PLAIN;
+  const int wbits = pick_window_bits(ctx, n, 1, endo), w_end = nwin_of(wbits, endo);
+  ctx->sync_call = true;
+  rc = launch_impl(ctx, s.d_host_scalars, n, 1, 0, w_end, wbits, 0, nullptr, mode, 0, 0, 1);
+  if (rc) {
+    ctx->sync_call = false;
+    ctx->n_bases = 0;
+    return rc;
+  }
+  // 2. the points behind the scalars on the copy stream, in a few chunks (2^18 points = 16 MiB: smaller ones cost the pageable copy path more
+  //    than they hide, profiles/r05_oneshot.txt); every chunk is converted on ANOTHER stream (the second reduce stream, idle in this call shape)
+  //    as soon as it has landed, so the copies follow each other without waiting for kernels
+  static const size_t chunk = [] {  // points per chunk (MSM_HIP_ONESHOT_CHUNK_LOG: tuning aid)
+    const char* e = getenv("MSM_HIP_ONESHOT_CHUNK_LOG");
+    const int l = e ? atoi(e) : 18;
+    return (size_t)1 << (l >= 10 && l <= 28 ? l : 18);
+  }();
+  hipStream_t conv = ctx->reduce_stream[NREDUCE - 1];
+  hipError_t he = hipSuccess;
+  int k = 0;
+  for (size_t first = 0; first < n && he == hipSuccess; first += chunk, k++) {
+    const size_t count = n - first < chunk ? n - first : chunk;
+    uint32_t* dst = ctx->d_bases + first * 2 * (size_t)ctx->ops->coord_words;
+    hipEvent_t& landed = ctx->chunk_landed[k & 7];
+    if (!landed && (he = hipEventCreateWithFlags(&landed, hipEventDisableTiming)) != hipSuccess) break;
+    if ((he = hipMemcpyAsync(dst, xy_host + first * ctx->pb, count * ctx->pb, hipMemcpyHostToDevice, ctx->copy_stream)) != hipSuccess) break;
+    if ((he = hipEventRecord(landed, ctx->copy_stream)) != hipSuccess) break;
+    if ((he = hipStreamWaitEvent(conv, landed, 0)) != hipSuccess) break;
+    hipLaunchKernelGGL(ctx->ops->convert_points, dim3(blocks_for(count, 256)), dim3(256), 0, conv, dst, dst, count, flags, ctx->d_err);
+    if (endo) hipLaunchKernelGGL(ctx->ops->endo_points, dim3(blocks_for(count, 256)), dim3(256), 0, conv, ctx->d_bases, n, first, count);
+    he = hipGetLastError();
+  }
+  if (he == hipSuccess) he = hipEventRecord(ctx->bases_ready, conv);
+  if (he == hipSuccess) he = hipStreamWaitEvent(ctx->stream, ctx->bases_ready, 0);
+  // 3. the rest of the launch (on failure above too: phase 1 left the slot's streams mid-launch -- the bases it then reads are whatever arrived,
+  //    and the result is discarded)
+  rc = launch_impl(ctx, s.d_host_scalars, n, 1, 0, w_end, wbits, 0, nullptr, mode, 0, 0, 2);
+  ctx->sync_call = false;
+  uint8_t scratch[MAX_JB];
+  const int frc = rc ? rc : msm_hip_finish(ctx, 0, he == hipSuccess ? out_xyz : scratch);
+  uint32_t base_bits = 0;  // the conversion's error word (read last: the launch was queued behind the copy stream before the host waits for anything)
+  if (he == hipSuccess) he = hipStreamSynchronize(conv);
+  if (he == hipSuccess) he = hipMemcpy(&base_bits, ctx->d_err, 4, hipMemcpyDeviceToHost);
+  if (he != hipSuccess) {
+    ctx->last_hip_error = (int)he;
+    ctx->n_bases = 0;
+    return MSM_HIP_ERR_HIP;
+  }
+  if (const int brc = err_from_bits(base_bits)) {  // a non-canonical coordinate: the bases are not usable (as msm_hip_set_bases_* reports it)
+    ctx->n_bases = 0;
+    return brc;
+  }
+  return frc;
+}
+}  // namespace
+
+extern "C" {
+
+int msm_hip_msm_curve(int curve, const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t* out_xyz) {
   int dev = 0;
+  if (curve < 0 || curve >= MSM_HIP_NUM_CURVES) return MSM_HIP_ERR_INVALID_ARG;
   if (hipGetDevice(&dev) != hipSuccess) return MSM_HIP_ERR_NO_DEVICE;  // the caller's current device (0 unless it chose another)
+  if (!out_xyz || ((!xy_host || !scalars_host) && n)) return MSM_HIP_ERR_INVALID_ARG;
   const bool keep = oneshot_keep() && dev >= 0 && dev < ONESHOT_MAX_DEVICES;
   std::unique_lock<std::mutex> lock(g_oneshot_mutex, std::defer_lock);
   msm_hip_ctx* ctx = nullptr;
   int rc = MSM_HIP_OK;
   if (keep) {
     lock.lock();
-    ctx = g_oneshot_ctx[dev];
+    ctx = g_oneshot_ctx[curve][dev];
   }
   if (!ctx) {
-    if ((rc = msm_hip_ctx_create(&ctx, dev))) return rc;
-    if (keep) g_oneshot_ctx[dev] = ctx;
+    if ((rc = msm_hip_ctx_create_curve(&ctx, dev, curve))) return rc;
+    if (keep) g_oneshot_ctx[curve][dev] = ctx;
   }
-  rc = msm_hip_set_bases_bn254(ctx, xy_host, n, 0);
-  if (!rc) rc = msm_hip_run_bn254(ctx, scalars_host, n, out_xyz);
+  static const bool overlap = [] { const char* e = getenv("MSM_HIP_ONESHOT_OVERLAP"); return !e || atoi(e) != 0; }();
+  if (overlap && n > 0 && n <= MAX_POINTS / 2) {
+    rc = oneshot_overlapped(ctx, xy_host, scalars_host, n, out_xyz);
+  } else {
+    rc = msm_hip_set_bases(ctx, xy_host, n, 0);
+    if (!rc) rc = msm_hip_run(ctx, scalars_host, n, out_xyz);
+  }
   if (!keep) msm_hip_ctx_destroy(ctx);
   return rc;
 }
 
+int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
+  return msm_hip_msm_curve(MSM_HIP_CURVE_BN254_G1, xy_host, scalars_host, n, out_xyz);
+}
+
 void msm_hip_oneshot_release(void) {
   std::lock_guard<std::mutex> lock(g_oneshot_mutex);
-  for (msm_hip_ctx*& c : g_oneshot_ctx) {
-    if (c) msm_hip_ctx_destroy(c);
-    c = nullptr;
-  }
+  for (auto& per_curve : g_oneshot_ctx)
+    for (msm_hip_ctx*& c : per_curve) {
+      if (c) msm_hip_ctx_destroy(c);
+      c = nullptr;
+    }
 }
 
 int msm_hip_sample_scalars_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void* scalars_dev) {
@@ -1653,3 +1813,47 @@ int msm_hip_test_g1_mul_u32(msm_hip_ctx* ctx, const uint8_t* a, const uint32_t* 
 }  // extern "C"
 
 #include "msm_mgpu.h"
+
+// ---- the `_bn254` names of rounds 1 - 4: aliases of the curve-neutral entry points (include/msm_hip.h, last block)
+extern "C" {
+int msm_hip_set_bases_bn254(msm_hip_ctx* ctx, const uint8_t* xy_host, size_t n, uint32_t flags) { return msm_hip_set_bases(ctx, xy_host, n, flags); }
+int msm_hip_set_bases_device_bn254(msm_hip_ctx* ctx, const void* xy_dev, size_t n, uint32_t flags) { return msm_hip_set_bases_device(ctx, xy_dev, n, flags); }
+int msm_hip_run_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) { return msm_hip_run(ctx, scalars_host, n, out_xyz); }
+int msm_hip_run_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]) { return msm_hip_run_device(ctx, scalars_dev, n, out_xyz); }
+int msm_hip_launch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int slot) { return msm_hip_launch_device(ctx, scalars_dev, n, slot); }
+int msm_hip_finish_bn254(msm_hip_ctx* ctx, int slot, uint8_t out_xyz[96]) { return msm_hip_finish(ctx, slot, out_xyz); }
+int msm_hip_launch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int slot) { return msm_hip_launch(ctx, scalars_host, n, slot); }
+int msm_hip_run_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, size_t batch, uint8_t* out_xyz) {
+  return msm_hip_run_batch_device(ctx, scalars_dev, n, batch, out_xyz);
+}
+int msm_hip_run_batch_bn254(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz) {
+  return msm_hip_run_batch(ctx, scalars_host, n, batch, out_xyz);
+}
+int msm_hip_run_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, void* window_sums_dev) {
+  return msm_hip_run_windows_device(ctx, scalars_dev, n, w_begin, w_end, window_sums_dev);
+}
+int msm_hip_launch_windows_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int w_begin, int w_end, int slot, void* window_sums_dev) {
+  return msm_hip_launch_windows_device(ctx, scalars_dev, n, w_begin, w_end, slot, window_sums_dev);
+}
+int msm_hip_launch_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int w_begin, int w_end, int slot,
+                                              void* window_sums_dev) {
+  return msm_hip_launch_windows_batch_device(ctx, scalars_dev, n, nvec, w_begin, w_end, slot, window_sums_dev);
+}
+int msm_hip_finish_batch_bn254(msm_hip_ctx* ctx, int slot, uint8_t* out_xyz) { return msm_hip_finish_batch(ctx, slot, out_xyz); }
+int msm_hip_launch_half_windows_batch_device_bn254(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, int hw_begin, int hw_end, int slot,
+                                                   void* window_sums_dev) {
+  return msm_hip_launch_half_windows_batch_device(ctx, scalars_dev, n, nvec, hw_begin, hw_end, slot, window_sums_dev);
+}
+int msm_hip_mgpu_set_bases_bn254(msm_hip_mgpu* m, const uint8_t* xy_host, size_t n, uint32_t flags) { return msm_hip_mgpu_set_bases(m, xy_host, n, flags); }
+int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) { return msm_hip_mgpu_run(m, scalars_host, n, out_xyz); }
+int msm_hip_mgpu_launch_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, int nvec, int slot) {
+  return msm_hip_mgpu_launch_batch(m, scalars_host, n, nvec, slot);
+}
+int msm_hip_mgpu_launch_batch_device_bn254(msm_hip_mgpu* m, const void* const* scalars_dev, size_t n, int nvec, int slot) {
+  return msm_hip_mgpu_launch_batch_device(m, scalars_dev, n, nvec, slot);
+}
+int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz) { return msm_hip_mgpu_finish_batch(m, slot, out_xyz); }
+int msm_hip_mgpu_run_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz) {
+  return msm_hip_mgpu_run_batch(m, scalars_host, n, batch, out_xyz);
+}
+}  // extern "C"

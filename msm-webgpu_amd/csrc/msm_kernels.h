@@ -210,9 +210,11 @@ __global__ void __launch_bounds__(256) k_convert_points(const uint32_t* in, uint
 
 // The endomorphism's point half (csrc/glv.h): record n + i = phi(P_i) = (beta x_i, y_i) behind the n plain bases
 // (a G2 unit: beta is the element (beta, 0) of Fq2 -- the twist has j = 0 like the curve, tools/gen_constants.py emit_g2)
-__global__ void __launch_bounds__(256) k_endo_points(uint32_t* __restrict__ bases, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// (records first .. first + count - 1 of the n: the one-shot entry point converts the bases chunk by chunk as they arrive)
+__global__ void __launch_bounds__(256) k_endo_points(uint32_t* __restrict__ bases, size_t n, size_t first, size_t count) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const size_t i = first + k;
   fq beta;
 #pragma unroll
   for (int k = 0; k < FQ_L; k++) beta.v[k] = FQ_BETA29[k];
@@ -761,7 +763,19 @@ __device__ __forceinline__ uint32_t wide_digit(const uint32_t* t, int w, int top
   sign = b < H ? 1u : 0u;
   return b >= H ? b - H : H - b;
 }
-__device__ __forceinline__ uint32_t wide_key(uint32_t mag) { return (((mag - 1u) >> 15) << 7) | ((mag & 0x7fffu) >> 8); }  // (virtual window, coarse bin)
+// Magnitude m (1 .. 2^(C-1)) -> virtual window and bucket slot, INTERLEAVED (round 5):  vw = (m - 1) mod VWIN,  value(slot) = (m - 1) / VWIN + 1
+// (1 .. 2^15; slot = value mod 2^15, i.e. slot 0 carries 2^15 as in every window).  Consecutive magnitudes go to consecutive virtual windows, so
+// ANY smooth distribution of magnitudes -- the narrow top digit's included -- fills the virtual windows evenly: the shares of a window-sharded
+// run (one virtual window per rank at 19 bits and 8 GPUs) are balanced, a whole MSM's windows need the same chunk length, and the top digit
+// needs no shift.  (Rounds 4's contiguous ranges, vw = (m - 1) >> 15, put the whole top digit into the lowest windows; its shift spread it as
+// multiples of 2^shift -- every 32nd slot of a 20-bit set four times as full as its neighbours, which a stitch wave pays for in all 64 lanes.)
+// The window's weighted sum W_vw = sum_slot value(slot) B[slot] and plain total TC_vw give  sum_m m B_m = VWIN W_vw - (VWIN - 1 - vw) TC_vw.
+template <int C>
+__device__ __forceinline__ uint32_t wide_slot(uint32_t mag) { return (((mag - 1u) >> (C - WBITS)) + 1u) & 0x7fffu; }
+template <int C>
+__device__ __forceinline__ uint32_t wide_key(uint32_t mag) {  // (virtual window, coarse bin); mag = 0 gives garbage: callers test mag first
+  return (((mag - 1u) & (uint32_t)(WideCfg<C>::VWIN - 1)) << 7) | (wide_slot<C>(mag) >> 8);
+}
 
 // first pass: counts[lw][tile][bin] (the layout of k_count), local window lw = v * VWIN + hi for scalar vector v of the launch's nvec
 // (vec_stride words apart: several whole MSMs over the same tables share one kernel sequence, as in k_count)
@@ -797,7 +811,7 @@ __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__
     for (int w = 0; w < WIDE_TABLES; w++) {
       uint32_t sign;
       const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, bad);
-      const uint32_t key = wide_key(mag) - ((uint32_t)v_begin << 7);  // (mag = 0: no entry, whatever the key says)
+      const uint32_t key = wide_key<C>(mag) - ((uint32_t)v_begin << 7);  // (mag = 0: no entry, whatever the key says)
       if (mag && key < keys) atomicAdd(&cnt[key], 1u);
     }
   }
@@ -807,53 +821,273 @@ __global__ void __launch_bounds__(256) k_count_wide(const uint32_t* __restrict__
   if (bad) atomicOr(err, ERRBIT_SCALAR_CARRY);
 }
 
+// ---- shares of a few virtual windows: the first pass leaves a COMPACT LIST of the share's entries (round 5) ---------------------------------
+// A rank of a window-sharded run keeps an eighth of the digits (one of 8 virtual windows at 19 bits, two of 16 at 20).  Ranking and staging
+// them where they are found -- 13 x 8 digit positions per thread, an eighth of the lanes active at each -- made the second pass the longest
+// kernel of the sort (310 - 540 us per launch of 8 vectors against 153 for the digit-plane scatter of two 16-bit windows,
+// profiles/r05_wide_shares.txt).  So the divergent work is done ONCE, here: every kept digit is appended (wave-aggregated: one LDS atomic per
+// wave, digit position and virtual window) to the list of its (local window, sub-tile of LIST_SUB scalars), and the second pass
+// (k_scatter_list) reads the lists with every lane busy.
+//   entry  = position within the sub-tile (11 bits) | table w << 11 | sign << 15 | bucket slot << 16   (the virtual window is the list's)
+//   list of (lw, sub-tile q): list[lw * stride + q * LIST_SUB * TABLES ...], list_len[lw * subtiles + q] entries -- the arrays of the final
+//   slot order (val_idxs), free until the fine sort writes them, sized for a share that receives every digit (stride >= n TABLES).
+constexpr int LIST_SUB = 2048;
+constexpr int WIDE_SHARE_VWIN_MAX = 4;  // shares of more virtual windows than this run the whole-MSM shape of the two passes
+template <int C>
+__global__ void __launch_bounds__(256) k_count_wide_list(const uint32_t* __restrict__ scalars, size_t n, uint32_t tile_len, uint32_t tiles, int nvec,
+                                                         size_t vec_stride, uint32_t* __restrict__ counts, uint32_t* __restrict__ err, int top_shift,
+                                                         int v_begin, int v_count, uint32_t* __restrict__ list, uint32_t* __restrict__ list_len,
+                                                         size_t stride, uint32_t subtiles) {
+  constexpr int SW = 8;
+  constexpr int WIDE_TABLES = WideCfg<C>::TABLES;
+  constexpr int KEYS_MAX = WIDE_SHARE_VWIN_MAX * NCOARSE;
+  __shared__ uint32_t cnt[KEYS_MAX];
+  __shared__ uint32_t lcount[WIDE_SHARE_VWIN_MAX];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const size_t base = (size_t)blockIdx.x * tile_len;  // (tile_len is a multiple of LIST_SUB or the only tile's: sub-tiles never straddle tiles)
+  const size_t end = base + tile_len < n ? base + tile_len : n;
+  uint32_t bad = 0;
+  const int v = blockIdx.y;
+  (void)nvec;
+  const uint32_t keys = (uint32_t)v_count * NCOARSE;
+  for (int i = tid; i < KEYS_MAX; i += 256) cnt[i] = 0;
+  if (tid < WIDE_SHARE_VWIN_MAX) lcount[tid] = 0;
+  __syncthreads();
+  for (size_t sub = base; sub < end; sub += LIST_SUB) {
+    const size_t sub_end = sub + LIST_SUB < end ? sub + LIST_SUB : end;
+    const uint32_t q = (uint32_t)(sub / LIST_SUB);
+    for (size_t i0 = sub; i0 < sub_end; i0 += 256) {
+      const size_t i = i0 + tid;
+      const bool valid = i < sub_end;
+      uint32_t s[SW], tb[WinCfg<C, SW>::WORDS], t16[8], neg = 0;
+#pragma unroll
+      for (int k = 0; k < SW; k++) s[k] = 0;  // (a lane beyond the end recodes zero: no entries)
+      if (valid) ld_scalar<SW>(scalars + (size_t)v * vec_stride + i * SW, s, neg);
+      (void)bias_scalar<C, SW>(s, tb);
+      bad |= bias_scalar<16>(s, t16);   // the input contract of every mode (test/utils.rs:150-152)
+      // every kept digit's entry and its place among the wave's kept digits of the same local window (ballots only: no LDS round trip) ...
+      uint32_t ent[WIDE_TABLES], place[WIDE_TABLES];  // place: local window << 28 | position within the wave's block of that window; 0xffffffff: not kept
+      uint32_t wave_cnt[WIDE_SHARE_VWIN_MAX];         // wave-uniform running counts
+#pragma unroll
+      for (int vw = 0; vw < WIDE_SHARE_VWIN_MAX; vw++) wave_cnt[vw] = 0;
+#pragma unroll
+      for (int w = 0; w < WIDE_TABLES; w++) {
+        uint32_t sign;
+        const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, bad);
+        const uint32_t key = wide_key<C>(mag) - ((uint32_t)v_begin << 7);
+        const bool keep = mag && key < keys;
+        if (keep) atomicAdd(&cnt[key], 1u);
+        ent[w] = (uint32_t)(i - sub) | ((uint32_t)w << 11) | (sign << 15) | (wide_slot<C>(mag) << 16);
+        place[w] = 0xffffffffu;
+#pragma unroll
+        for (int vw = 0; vw < WIDE_SHARE_VWIN_MAX; vw++) {
+          if (vw >= v_count) break;  // wave-uniform
+          const bool mine = keep && (key >> 7) == (uint32_t)vw;
+          const unsigned long long mm = __ballot(mine);
+          if (mine) place[w] = ((uint32_t)vw << 28) | (wave_cnt[vw] + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull)));
+          wave_cnt[vw] += (uint32_t)__popcll(mm);
+        }
+      }
+      // ... ONE reservation per wave and local window for all of them (one LDS round trip instead of one per digit position), then the stores
+      uint32_t wave_base[WIDE_SHARE_VWIN_MAX];
+#pragma unroll
+      for (int vw = 0; vw < WIDE_SHARE_VWIN_MAX; vw++) {
+        wave_base[vw] = 0;
+        if (vw < v_count && lane == 0 && wave_cnt[vw]) wave_base[vw] = atomicAdd(&lcount[vw], wave_cnt[vw]);
+      }
+#pragma unroll
+      for (int vw = 0; vw < WIDE_SHARE_VWIN_MAX; vw++) wave_base[vw] = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_base[vw]);
+#pragma unroll
+      for (int w = 0; w < WIDE_TABLES; w++) {
+        if (place[w] != 0xffffffffu) {
+          const uint32_t vw = place[w] >> 28;
+          const uint32_t b = vw == 0 ? wave_base[0] : vw == 1 ? wave_base[1] : vw == 2 ? wave_base[2] : wave_base[3];
+          list[(size_t)(v * v_count + vw) * stride + (size_t)q * (LIST_SUB * WIDE_TABLES) + b + (place[w] & 0x0fffffffu)] = ent[w];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < v_count) {
+      list_len[(size_t)(v * v_count + tid) * subtiles + q] = lcount[tid];
+      lcount[tid] = 0;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < (int)keys; i += 256)
+    counts[((size_t)(v * v_count + i / NCOARSE) * tiles + blockIdx.x) * NCOARSE + (i % NCOARSE)] = cnt[i];
+  if (bad) atomicOr(err, ERRBIT_SCALAR_CARRY);
+}
+
+// second pass of a share: grid (tiles, local windows) -- a workgroup takes the lists of ONE local window over its tile, LIST_CHUNK entries at a
+// time: histogram of the coarse bins, scan, cursor placement into the LDS staging, coalesced write-out (k_scatter_coarse's scheme with every lane
+// busy).
+constexpr int LIST_CHUNK = 4096;
+__global__ void __launch_bounds__(256) k_scatter_list(const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_len, size_t stride, uint32_t region,
+                                                      uint32_t subtiles, size_t n, uint32_t tile_len, uint32_t tiles, int w_eff,
+                                                      const uint32_t* __restrict__ counts, const uint32_t* __restrict__ bin_total,
+                                                      uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ tmp_val, uint8_t* __restrict__ tmp_fine,
+                                                      size_t table_stride, uint32_t chunks, uint32_t host_chunk_len, uint32_t* __restrict__ chunk_len_dev) {
+  __shared__ uint32_t gpos[NCOARSE];
+  __shared__ uint32_t hist[NCOARSE];
+  __shared__ uint32_t lstart[NCOARSE];
+  __shared__ uint32_t cur[NCOARSE];
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t st_val[LIST_CHUNK];
+  __shared__ uint32_t st_dst[LIST_CHUNK];
+  __shared__ uint8_t st_fine[LIST_CHUNK];
+  __shared__ uint32_t max_total;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lw = blockIdx.y;
+  if (tid == 0) max_total = 0;
+  __syncthreads();
+  // start of every coarse bin's run of this tile (exclusive scan of the window's 128 bin totals + what earlier tiles put there); workgroup
+  // (0, 0) does it for every local window of the launch (its own last): it publishes all bin starts and the launch's chunk length
+  const bool publisher = blockIdx.x == 0 && blockIdx.y == 0;
+  for (int pl = publisher ? w_eff - 1 : lw; pl >= lw; pl--) {
+    const int bin = tid;  // threads 0 .. 127: one bin each (two waves)
+    const bool live = tid < NCOARSE;
+    const uint32_t v = live ? bin_total[pl * NCOARSE + bin] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[wid] = x;
+    __syncthreads();
+    const uint32_t incl = x + ((wid & 1) ? wave_tot[wid - 1] : 0u);
+    if (live) gpos[bin] = incl - v + counts[((size_t)pl * tiles + blockIdx.x) * NCOARSE + bin];
+    if (live && publisher) {
+      coarse_ptr[(size_t)pl * (NCOARSE + 1) + bin] = incl - v;
+      if (bin == NCOARSE - 1) {
+        coarse_ptr[(size_t)pl * (NCOARSE + 1) + NCOARSE] = incl;
+        atomicMax(&max_total, incl);
+      }
+    }
+    __syncthreads();
+  }
+  if (publisher && tid == 0) *chunk_len_dev = smvp_chunk_len(max_total, chunks, host_chunk_len);
+  const size_t tile_base = (size_t)blockIdx.x * tile_len;
+  const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
+  uint32_t* ov = tmp_val + (size_t)lw * stride;
+  uint8_t* of = tmp_fine + (size_t)lw * stride;
+  for (size_t sub = tile_base; sub < tile_end; sub += LIST_SUB) {
+    const uint32_t q = (uint32_t)(sub / LIST_SUB);
+    const uint32_t len = list_len[(size_t)lw * subtiles + q];
+    const uint32_t* src = list + (size_t)lw * stride + (size_t)q * region;
+    for (uint32_t lo = 0; lo < len; lo += LIST_CHUNK) {
+      const uint32_t cnt = len - lo < (uint32_t)LIST_CHUNK ? len - lo : (uint32_t)LIST_CHUNK;
+      if (tid < NCOARSE) hist[tid] = 0;
+      __syncthreads();
+      uint32_t ent[LIST_CHUNK / 256];
+#pragma unroll
+      for (int j = 0; j < LIST_CHUNK / 256; j++) {
+        const uint32_t e = (uint32_t)j * 256 + tid;
+        ent[j] = e < cnt ? src[lo + e] : 0xffffffffu;     // (a slot is 15 bits: no entry has bit 31 set)
+        if (e < cnt) atomicAdd(&hist[ent[j] >> 24], 1u);  // coarse bin = slot >> 8 = entry >> 24
+      }
+      __syncthreads();
+      const uint32_t mine = tid < NCOARSE ? hist[tid] : 0u;
+      const uint32_t excl = block_excl_scan_256(mine, wave_tot);
+      if (tid < NCOARSE) {
+        lstart[tid] = excl;
+        cur[tid] = excl;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < LIST_CHUNK / 256; j++) {
+        if (ent[j] != 0xffffffffu) {
+          const uint32_t bin = ent[j] >> 24;
+          const uint32_t e = atomicAdd(&cur[bin], 1u);
+          // window w of point i = record w * n_bases + i
+          st_val[e] = ((uint32_t)(((ent[j] >> 11) & 15u) * table_stride) + (uint32_t)sub + (ent[j] & 2047u)) | (((ent[j] >> 15) & 1u) << 31);
+          st_fine[e] = (uint8_t)((ent[j] >> 16) & 0xffu);
+          st_dst[e] = gpos[bin] + (e - lstart[bin]);
+        }
+      }
+      __syncthreads();
+      for (uint32_t e = tid; e < cnt; e += 256) {
+        const uint32_t d = st_dst[e];
+        ov[d] = st_val[e];
+        of[d] = st_fine[e];
+      }
+      if (tid < NCOARSE) gpos[tid] += hist[tid];
+      __syncthreads();
+    }
+  }
+}
+
 // second pass: the LDS-ranked, LDS-staged scatter of k_scatter_coarse over all (virtual window, coarse bin) runs at once -- 256 / 1024 / 2048
 // of them at 17 / 19 / 20 bits.  ALL digits of the 2048 scalars of a block iteration are staged together (30 720 / 28 672 / 26 624 entries:
 // 120 / 28 / 13 per run): ranked per window as k_scatter_coarse does, a run would receive a fraction of that per iteration and every 4-byte
 // store would be a memory transaction of its own.  One workgroup of 512 threads per CU.  (With 1024 scalars per iteration the kernel took
 // 244 / 351 / 471 us at 2^22 points: the shorter the runs, the worse the stores coalesce.)
+//
+// Two shapes of the same kernel (WideShape<C, SHARE>):
+//   whole MSMs   512 threads, 4 scalars per thread and iteration (3 at 16 bits), every run of the bucket set, LDS for every entry the iteration's
+//                scalars can produce (153 - 158 KB: one workgroup per CU)
+//   shares       (round 5: a rank's virtual windows, k_count_wide) -- at most 4 virtual windows, an eighth of the entries for uniform scalars at 8
+//                ranks: with the whole-MSM shape the 4096 workgroups of a launch of 8 vectors ran one per CU, sixteen rounds of a latency-bound
+//                kernel (385 - 544 us per launch against 153 for the digit-plane scatter of two 16-bit windows, profiles/r05_wide_shares.txt).
+//                256 threads, 8 scalars per thread, LDS for WIDE_SHARE_CAP entries (38 KB: four workgroups per CU), no ranks in registers.  Skewed
+//                scalars may put EVERY digit of an iteration into the share (14 x 2048 entries): an iteration whose entries pass the staging is
+//                redone one scalar per thread at a time.
+#ifndef WIDE_SHARE_REREAD
+#define WIDE_SHARE_REREAD 1  // A/B aid (same-box pairs, profiles/r05_wide_shares.txt: 0.2198 - 0.2231 vs 0.2242 - 0.2256 ms per MSM share): 1 = the scalars are read again for the second pass (one at a time) instead of staying in registers
+#endif
 constexpr int WIDE_THREADS = 512;
-template <int C>
-__global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
+constexpr int WIDE_SHARE_THREADS = 256, WIDE_SHARE_CAP = 6144;
+template <int C, bool SHARE>
+struct WideScatterShape {
+  static constexpr int THREADS = SHARE ? WIDE_SHARE_THREADS : WIDE_THREADS;
+  static constexpr int PER = SHARE ? 8 : (C == 16 ? 3 : 4);                    // scalars per thread and block iteration
+  static constexpr int SUB = THREADS * PER;                                    // scalars staged per block iteration
+  static constexpr int KEYS = SHARE ? (WideCfg<C>::VWIN < WIDE_SHARE_VWIN_MAX ? WideCfg<C>::VWIN : WIDE_SHARE_VWIN_MAX) * NCOARSE : WideCfg<C>::KEYS;
+  static constexpr int STAGE = SHARE ? WIDE_SHARE_CAP : SUB * WideCfg<C>::TABLES;  // entries the LDS staging holds
+  static_assert(SUB <= 2048 && WideCfg<C>::TABLES <= 16, "sign | window | position in 16 bits");
+  static_assert(STAGE * 5 + KEYS * (SHARE ? 16 : 12) + 64 <= 160 * 1024, "LDS of a workgroup");
+};
+template <int C, bool SHARE>
+__global__ void __launch_bounds__((WideScatterShape<C, SHARE>::THREADS), (SHARE ? (WIDE_SHARE_REREAD ? 4 : 3) : 1)) k_scatter_wide(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
                                                                uint32_t tiles, int nvec, size_t vec_stride, const uint32_t* __restrict__ counts,
                                                                const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr,
                                                                uint32_t* __restrict__ tmp_val, uint8_t* __restrict__ tmp_fine, size_t table_stride,
                                                                uint32_t chunks, uint32_t host_chunk_len, uint32_t* __restrict__ chunk_len_dev, int top_shift,
                                                                int v_begin, int v_count) {
+  using Shape = WideScatterShape<C, SHARE>;
   constexpr int SW = 8;  // full-length scalars
-  constexpr int WIDE_KEYS = WideCfg<C>::KEYS, WIDE_TABLES = WideCfg<C>::TABLES;
+  constexpr int WIDE_KEYS = Shape::KEYS, WIDE_TABLES = WideCfg<C>::TABLES, THREADS = Shape::THREADS;
   const int keys = v_count * NCOARSE;                // runs of this launch's share of the virtual windows (k_count_wide); WIDE_KEYS for whole MSMs
   const uint32_t key0 = (uint32_t)v_begin << 7;
   // 5 bytes of LDS per staged entry -- its (virtual window, coarse bin) run, its fine slot, and sign | window | position within the iteration's
   // scalars (16 bits: the record index is put together when the entry is written out) -- so that 2048 scalars (1536 at 16 bits) fit one
   // iteration: twice the run length of the 4-byte index staged before (153 - 158 KB of the 160 KB a workgroup may hold)
-  constexpr int WIDE_PER = C == 16 ? 3 : 4;
-  constexpr int WIDE_SUB = WIDE_THREADS * WIDE_PER;   // scalars staged per block iteration
-  constexpr int WIDE_STAGE = WIDE_SUB * WIDE_TABLES;  // entries staged per block iteration
-  static_assert(WIDE_SUB <= 2048 && WIDE_TABLES <= 16, "sign | window | position in 16 bits");
-  static_assert(WIDE_STAGE * 5 + WIDE_KEYS * 12 + 64 <= 160 * 1024, "LDS of a workgroup");
+  constexpr int WIDE_PER = Shape::PER;
+  constexpr int WIDE_SUB = Shape::SUB;      // scalars staged per block iteration
+  constexpr int WIDE_STAGE = Shape::STAGE;  // entries staged at a time
   __shared__ uint32_t gpos[WIDE_KEYS];    // write cursor of every run of this tile, relative to its virtual window's array
   __shared__ uint32_t hist[WIDE_KEYS];
   __shared__ uint32_t lstart[WIDE_KEYS];
+  __shared__ uint32_t cur[SHARE ? WIDE_KEYS : 1];  // share shape: cursor of every run while an iteration's entries are staged
   __shared__ uint16_t st_loc[WIDE_STAGE];
   __shared__ uint16_t st_key[WIDE_STAGE];
   __shared__ uint8_t st_fine[WIDE_STAGE];
-  __shared__ uint32_t wave_tot[WIDE_THREADS / 64];
+  __shared__ uint32_t wave_tot[THREADS / 64];
   __shared__ uint32_t max_total;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (tid == 0) max_total = 0;
   __syncthreads();
   const size_t tile_base = (size_t)blockIdx.x * tile_len;
   const size_t tile_end = tile_base + tile_len < n ? tile_base + tile_len : n;
-  // grid (tiles, nvec): a workgroup scatters one tile of ONE scalar vector (one MSM of the launch), whose VWIN local windows start at lw0.
-  // Start of every run: exclusive scan of each virtual window's 128 bin totals (a pair of waves per window, four windows per step) + what
+  // grid (tiles, nvec): a workgroup scatters one tile of ONE scalar vector (one MSM of the launch), whose v_count local windows start at lw0.
+  // Start of every run: exclusive scan of each virtual window's 128 bin totals (a pair of waves per window) + what
   // earlier tiles put there.  Workgroup (0, 0) does this for every vector of the launch (its own last: gpos keeps the last one scanned): it
   // publishes all bin starts (coarse_ptr[lw][0 .. 128]) and the launch's chunk length.
   const bool publisher = blockIdx.x == 0 && blockIdx.y == 0;
   const int lw0 = (int)blockIdx.y * v_count;
   const uint32_t* sv = scalars + (size_t)blockIdx.y * vec_stride;
   for (int pv = publisher ? nvec - 1 : (int)blockIdx.y; pv >= (int)blockIdx.y; pv--)
-  for (int i0 = 0; i0 < keys; i0 += WIDE_THREADS) {
+  for (int i0 = 0; i0 < keys; i0 += THREADS) {
     const int i = i0 + tid, lw = pv * v_count + i / NCOARSE, bin = i % NCOARSE;
     const bool live = i < keys;  // (fewer runs than threads: 17-bit digits, shares of a few virtual windows)
     const uint32_t v = live ? bin_total[lw * NCOARSE + bin] : 0u;
@@ -877,82 +1111,48 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
     __syncthreads();
   }
   if (publisher && tid == 0) *chunk_len_dev = smvp_chunk_len(max_total, chunks, host_chunk_len);
-  for (size_t sub = tile_base; sub < tile_end; sub += WIDE_SUB) {
-    for (int k = tid; k < WIDE_KEYS; k += WIDE_THREADS) hist[k] = 0;
+  // this thread's scalar j of the block iteration at `sub`, biased for the recode.  The scalars are read twice -- for the counts and for the
+  // entries (the second time from the L2) --: held in registers across the scan they and the ranks passed the 256 registers a wave may have
+  auto biased = [&](size_t sub, int j, uint32_t* tb) {
+    const size_t i = sub + (size_t)j * THREADS + tid;
+    uint32_t raw[SW], neg = 0;
+#pragma unroll
+    for (int k = 0; k < SW; k++) raw[k] = 0;  // an all-zero scalar recodes to all-zero digits: no entries
+    if (i < tile_end) ld_scalar<SW>(sv + i * SW, raw, neg);
+    (void)bias_scalar<C, SW>(raw, tb);
+  };
+  // exclusive scan of the run lengths hist[] -> lstart[]: KPT consecutive keys per thread (with fewer runs than threads, the first WIDE_KEYS threads
+  // take one each); ends with a barrier
+  auto scan_runs = [&]() {
+    constexpr int KPT = WIDE_KEYS >= THREADS ? WIDE_KEYS / THREADS : 1;
+    static_assert(KPT * THREADS == WIDE_KEYS || WIDE_KEYS < THREADS, "keys per thread");
+    const bool mine = KPT * tid < WIDE_KEYS;
+    uint32_t h[KPT], sum = 0;
+#pragma unroll
+    for (int k = 0; k < KPT; k++) {
+      h[k] = mine ? hist[KPT * tid + k] : 0u;
+      sum += h[k];
+    }
+    uint32_t x = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[wid] = x;
     __syncthreads();
-    // this thread's WIDE_PER scalars are read twice -- here for the ranks, below for the entries (the second time from the L2) --: held in
-    // registers across the scan they and the ranks passed the 256 registers a wave of this workgroup size may have
-    auto biased = [&](int j, uint32_t* tb) {
-      const size_t i = sub + (size_t)j * WIDE_THREADS + tid;
-      uint32_t raw[SW], neg = 0;
+    uint32_t run = x - sum;
+    for (int k = 0; k < wid; k++) run += wave_tot[k];
 #pragma unroll
-      for (int k = 0; k < SW; k++) raw[k] = 0;  // an all-zero scalar recodes to all-zero digits: no entries
-      if (i < tile_end) ld_scalar<SW>(sv + i * SW, raw, neg);
-      (void)bias_scalar<C, SW>(raw, tb);
-    };
-    uint32_t rank[WIDE_PER][(WIDE_TABLES + 1) / 2];  // two 16-bit ranks per register (a run holds fewer than 2^16 entries)
-#pragma unroll
-    for (int j = 0; j < WIDE_PER; j++) {
-      uint32_t tb[WinCfg<C, SW>::WORDS];
-      biased(j, tb);
-#pragma unroll
-      for (int w = 0; w < WIDE_TABLES; w++) {
-        uint32_t sign, over = 0;
-        const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, over);  // (an overflowing top digit: no entry here as in k_count_wide, which reports it)
-        const uint32_t key = wide_key(mag) - key0;                           // (outside this launch's virtual windows: no entry)
-        const uint32_t r = mag && key < (uint32_t)keys ? atomicAdd(&hist[key], 1u) : 0u;
-        if (w & 1) rank[j][w >> 1] |= r << 16;
-        else rank[j][w >> 1] = r;
-      }
+    for (int k = 0; k < KPT; k++) {
+      if (mine) lstart[KPT * tid + k] = run;
+      run += h[k];
     }
     __syncthreads();
-    {  // exclusive scan of the run lengths: KPT consecutive keys per thread (with fewer runs than threads, the first WIDE_KEYS threads take one each)
-      constexpr int KPT = WIDE_KEYS >= WIDE_THREADS ? WIDE_KEYS / WIDE_THREADS : 1;
-      static_assert(KPT * WIDE_THREADS == WIDE_KEYS || WIDE_KEYS < WIDE_THREADS, "keys per thread");
-      const bool mine = KPT * tid < WIDE_KEYS;
-      uint32_t h[KPT], sum = 0;
-#pragma unroll
-      for (int k = 0; k < KPT; k++) {
-        h[k] = mine ? hist[KPT * tid + k] : 0u;
-        sum += h[k];
-      }
-      uint32_t x = sum;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t y = __shfl_up(x, off);
-        if (lane >= off) x += y;
-      }
-      if (lane == 63) wave_tot[wid] = x;
-      __syncthreads();
-      uint32_t run = x - sum;
-      for (int k = 0; k < wid; k++) run += wave_tot[k];
-#pragma unroll
-      for (int k = 0; k < KPT; k++) {
-        if (mine) lstart[KPT * tid + k] = run;
-        run += h[k];
-      }
-    }
-    __syncthreads();
-    const uint32_t total = lstart[WIDE_KEYS - 1] + hist[WIDE_KEYS - 1];
-#pragma unroll
-    for (int j = 0; j < WIDE_PER; j++) {
-      uint32_t tb[WinCfg<C, SW>::WORDS];
-      biased(j, tb);
-#pragma unroll
-      for (int w = 0; w < WIDE_TABLES; w++) {
-        uint32_t sign, over = 0;
-        const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, over);
-        const uint32_t key = wide_key(mag) - key0;
-        if (mag && key < (uint32_t)keys) {
-          const uint32_t e = lstart[key] + ((rank[j][w >> 1] >> ((w & 1) * 16)) & 0xffffu);
-          st_loc[e] = (uint16_t)((sign << 15) | ((uint32_t)w << 11) | (uint32_t)(j * WIDE_THREADS + tid));
-          st_key[e] = (uint16_t)key;
-          st_fine[e] = (uint8_t)(mag & 0xffu);
-        }
-      }
-    }
-    __syncthreads();
-    for (uint32_t e = tid; e < total; e += WIDE_THREADS) {
+  };
+  // the staged entries 0 .. cnt-1 (bin-major) to their runs; ends with a barrier
+  auto write_out = [&](size_t sub, uint32_t cnt) {
+    for (uint32_t e = tid; e < cnt; e += THREADS) {
       const uint32_t key = st_key[e];
       const size_t d = (size_t)(lw0 + (key >> 7)) * stride + gpos[key] + (e - lstart[key]);
       const uint32_t loc = st_loc[e];
@@ -961,8 +1161,157 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_scatter_wide(const uint32_t* _
       tmp_fine[d] = st_fine[e];
     }
     __syncthreads();
-    for (int k = tid; k < WIDE_KEYS; k += WIDE_THREADS) gpos[k] += hist[k];
+  };
+  for (size_t sub = tile_base; sub < tile_end; sub += WIDE_SUB) {
+    if constexpr (SHARE) {
+      // Share shape: no ranks are kept -- an entry's place inside its run is drawn from a cursor when it is staged (any order inside a run is as
+      // good as another) -- and the iteration's biased scalars stay in registers across both passes (8 x 9 words; their 8 loads are in flight
+      // together): nothing is read twice, and the LDS alone bounds the workgroups per CU.
+#if WIDE_SHARE_REREAD
+#define WIDE_SHARE_UNROLL _Pragma("unroll 1")
+#define WIDE_SHARE_TB(j) tb1
+#define WIDE_SHARE_LOAD(j) uint32_t tb1[WinCfg<C, SW>::WORDS]; biased(sub, j, tb1)
+#else
+#define WIDE_SHARE_UNROLL _Pragma("unroll")
+#define WIDE_SHARE_TB(j) tbs[j]
+#define WIDE_SHARE_LOAD(j)
+      uint32_t tbs[WIDE_PER][WinCfg<C, SW>::WORDS];
+#pragma unroll
+      for (int j = 0; j < WIDE_PER; j++) biased(sub, j, tbs[j]);
+#endif
+      for (int k = tid; k < WIDE_KEYS; k += THREADS) hist[k] = 0;
+      __syncthreads();
+      WIDE_SHARE_UNROLL
+      for (int j = 0; j < WIDE_PER; j++) {
+        WIDE_SHARE_LOAD(j);
+#pragma unroll
+        for (int w = 0; w < WIDE_TABLES; w++) {
+          uint32_t sign, over = 0;
+          const uint32_t mag = wide_digit<C>(WIDE_SHARE_TB(j), w, top_shift, sign, over);  // (an overflowing top digit: no entry here as in k_count_wide, which reports it)
+          const uint32_t key = wide_key<C>(mag) - key0;                            // (outside this launch's virtual windows: no entry)
+          if (mag && key < (uint32_t)keys) atomicAdd(&hist[key], 1u);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one scalar's digits at a time: hoisted together, the 8 x 14 digits and keys take 400 registers
+      }
+      __syncthreads();
+      scan_runs();
+      const uint32_t total = lstart[WIDE_KEYS - 1] + hist[WIDE_KEYS - 1];
+      if (total <= (uint32_t)WIDE_STAGE) {  // block-uniform
+        for (int k = tid; k < WIDE_KEYS; k += THREADS) cur[k] = lstart[k];
+        __syncthreads();
+        // (the digits are extracted AGAIN from the biased scalars: kept from the counting pass -- which is what the compiler does when it can
+        //  see that the values are the same -- the 8 x 14 magnitudes, keys and signs take 400 registers; the asm makes the words opaque)
+#if !WIDE_SHARE_REREAD
+#pragma unroll
+        for (int j = 0; j < WIDE_PER; j++)
+#pragma unroll
+          for (int k = 0; k < WinCfg<C, SW>::WORDS; k++) asm volatile("" : "+v"(tbs[j][k]));
+#endif
+        WIDE_SHARE_UNROLL
+        for (int j = 0; j < WIDE_PER; j++) {
+          WIDE_SHARE_LOAD(j);
+#pragma unroll
+          for (int w = 0; w < WIDE_TABLES; w++) {
+            uint32_t sign, over = 0;
+            const uint32_t mag = wide_digit<C>(WIDE_SHARE_TB(j), w, top_shift, sign, over);
+            const uint32_t key = wide_key<C>(mag) - key0;
+            if (mag && key < (uint32_t)keys) {
+              const uint32_t e = atomicAdd(&cur[key], 1u);
+              st_loc[e] = (uint16_t)((sign << 15) | ((uint32_t)w << 11) | (uint32_t)(j * THREADS + tid));
+              st_key[e] = (uint16_t)key;
+              st_fine[e] = (uint8_t)(wide_slot<C>(mag) & 0xffu);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        write_out(sub, total);
+        for (int k = tid; k < WIDE_KEYS; k += THREADS) gpos[k] += hist[k];
+        __syncthreads();
+      } else {
+        // Skewed scalars put more of the iteration's digits into this share than the staging holds (every digit, at worst): the iteration is
+        // redone one scalar per thread at a time (THREADS x TABLES entries at most), each read again (the rare path keeps nothing in registers)
+        static_assert(THREADS * WIDE_TABLES <= WIDE_STAGE, "one scalar per thread fits the staging");
+        __syncthreads();  // (everyone has read `total` before hist / lstart are rebuilt)
+#pragma unroll 1
+        for (int j = 0; j < WIDE_PER; j++) {
+          for (int k = tid; k < WIDE_KEYS; k += THREADS) hist[k] = 0;
+          __syncthreads();
+          uint32_t tb[WinCfg<C, SW>::WORDS];
+          biased(sub, j, tb);
+#pragma unroll 1
+          for (int w = 0; w < WIDE_TABLES; w++) {
+            uint32_t sign, over = 0;
+            const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, over);
+            const uint32_t key = wide_key<C>(mag) - key0;
+            if (mag && key < (uint32_t)keys) atomicAdd(&hist[key], 1u);
+          }
+          __syncthreads();
+          scan_runs();
+          const uint32_t part = lstart[WIDE_KEYS - 1] + hist[WIDE_KEYS - 1];
+          for (int k = tid; k < WIDE_KEYS; k += THREADS) cur[k] = lstart[k];
+          __syncthreads();
+#pragma unroll 1
+          for (int w = 0; w < WIDE_TABLES; w++) {
+            uint32_t sign, over = 0;
+            const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, over);
+            const uint32_t key = wide_key<C>(mag) - key0;
+            if (mag && key < (uint32_t)keys) {
+              const uint32_t e = atomicAdd(&cur[key], 1u);
+              st_loc[e] = (uint16_t)((sign << 15) | ((uint32_t)w << 11) | (uint32_t)(j * THREADS + tid));
+              st_key[e] = (uint16_t)key;
+              st_fine[e] = (uint8_t)(wide_slot<C>(mag) & 0xffu);
+            }
+          }
+          __syncthreads();
+          write_out(sub, part);
+          for (int k = tid; k < WIDE_KEYS; k += THREADS) gpos[k] += hist[k];
+          __syncthreads();
+        }
+      }
+    } else {
+    for (int k = tid; k < WIDE_KEYS; k += THREADS) hist[k] = 0;
     __syncthreads();
+    uint32_t rank[WIDE_PER][(WIDE_TABLES + 1) / 2];  // two 16-bit ranks per register (a run holds fewer than 2^16 entries)
+#pragma unroll
+    for (int j = 0; j < WIDE_PER; j++) {
+      uint32_t tb[WinCfg<C, SW>::WORDS];
+      biased(sub, j, tb);
+#pragma unroll
+      for (int w = 0; w < WIDE_TABLES; w++) {
+        uint32_t sign, over = 0;
+        const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, over);  // (an overflowing top digit: no entry here as in k_count_wide, which reports it)
+        const uint32_t key = wide_key<C>(mag) - key0;                           // (outside this launch's virtual windows: no entry)
+        const uint32_t r = mag && key < (uint32_t)keys ? atomicAdd(&hist[key], 1u) : 0u;
+        if (w & 1) rank[j][w >> 1] |= r << 16;
+        else rank[j][w >> 1] = r;
+      }
+    }
+    __syncthreads();
+    scan_runs();
+    const uint32_t total = lstart[WIDE_KEYS - 1] + hist[WIDE_KEYS - 1];
+#pragma unroll
+    for (int j = 0; j < WIDE_PER; j++) {
+      uint32_t tb[WinCfg<C, SW>::WORDS];
+      biased(sub, j, tb);
+#pragma unroll
+      for (int w = 0; w < WIDE_TABLES; w++) {
+        uint32_t sign, over = 0;
+        const uint32_t mag = wide_digit<C>(tb, w, top_shift, sign, over);
+        const uint32_t key = wide_key<C>(mag) - key0;
+        if (mag && key < (uint32_t)keys) {
+          const uint32_t e = lstart[key] + ((rank[j][w >> 1] >> ((w & 1) * 16)) & 0xffffu);
+          st_loc[e] = (uint16_t)((sign << 15) | ((uint32_t)w << 11) | (uint32_t)(j * THREADS + tid));
+          st_key[e] = (uint16_t)key;
+          st_fine[e] = (uint8_t)(wide_slot<C>(mag) & 0xffu);
+        }
+      }
+    }
+    __syncthreads();
+    write_out(sub, total);
+    for (int k = tid; k < WIDE_KEYS; k += THREADS) gpos[k] += hist[k];
+    __syncthreads();
+    }
   }
 }
 

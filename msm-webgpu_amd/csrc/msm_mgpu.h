@@ -3,7 +3,7 @@
 // The reference is single-device (src/cuzk/msm.rs:88-94 creates one wgpu device per call); BASELINE.json's north star shards
 // the independent Pippenger windows over the GPUs of a node "with a final RCCL gather/reduce of partial sums over xGMI".
 //
-//   window-sharded launches (msm_hip_mgpu_launch_batch_* / msm_hip_mgpu_finish_batch_bn254; msm_hip_mgpu_run_bn254 = one vector, slot 0):
+//   window-sharded launches (msm_hip_mgpu_launch_batch_* / msm_hip_mgpu_finish_batch; msm_hip_mgpu_run = one vector, slot 0):
 //     device d computes the window sums of ITS window range for every scalar vector of the launch -- `nvec` MSMs' shares go through
 //     one kernel sequence per device, because one MSM's share (2 of 16 windows at 8 GPUs) cannot fill a GPU -- into result slot
 //     `slot` of its context; the shares are gathered with ONE ncclAllGather per launch, in stream order behind each device's bucket
@@ -11,16 +11,14 @@
 //     (src/cuzk/msm.rs:411-416), spread over the host pool.  With endomorphism bases the windows are the 8 half-length ones.
 //     Launches are asynchronous: every device has a persistent host thread that issues its HIP / RCCL calls, so the caller can keep
 //     several result slots in flight (launch k + 1 and k + 2 run while launch k is gathered and combined).
-//   many whole MSMs (msm_hip_mgpu_run_batch_bn254): dealt out contiguously (BASELINE config 5); no exchange at all.
+//   many whole MSMs (msm_hip_mgpu_run_batch): dealt out contiguously (BASELINE config 5); no exchange at all.
 // Included by msm_hip.hip (same translation unit: it uses the context internals).
 #pragma once
 #include <dlfcn.h>
 
-#include <condition_variable>
-#include <deque>
-#include <functional>
-#include <thread>
 #include <vector>
+
+#include "host_worker.h"
 
 namespace {
 
@@ -53,54 +51,6 @@ struct RcclApi {
 };
 constexpr int NCCL_UINT8 = 1;  // ncclUint8 (rccl.h)
 
-// One persistent host thread per device: runs the closures posted to it in order.  H2D copies from pageable memory block their
-// thread, and a launch is ~100 us of HIP calls: with a thread per device the devices' uploads and launches proceed side by side,
-// and the caller's thread stays free (round 2 spawned the threads per call).
-class DeviceWorker {
- public:
-  DeviceWorker() : th_([this] { loop(); }) {}
-  ~DeviceWorker() {
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      stop_ = true;
-    }
-    cv_.notify_all();
-    th_.join();
-  }
-  uint64_t post(std::function<void()> f) {  // returns the ticket wait() takes
-    std::lock_guard<std::mutex> lk(mu_);
-    q_.push_back(std::move(f));
-    cv_.notify_all();
-    return ++posted_;
-  }
-  void wait(uint64_t ticket) {
-    std::unique_lock<std::mutex> lk(mu_);
-    cv_.wait(lk, [&] { return done_ >= ticket; });
-  }
-
- private:
-  void loop() {
-    std::unique_lock<std::mutex> lk(mu_);
-    for (;;) {
-      cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
-      if (q_.empty()) return;  // stop requested and nothing left to run
-      std::function<void()> f = std::move(q_.front());
-      q_.pop_front();
-      lk.unlock();
-      f();
-      lk.lock();
-      done_++;
-      cv_.notify_all();
-    }
-  }
-  std::mutex mu_;
-  std::condition_variable cv_;
-  std::deque<std::function<void()>> q_;
-  uint64_t posted_ = 0, done_ = 0;
-  bool stop_ = false;
-  std::thread th_;  // last: the thread starts when every other member exists
-};
-
 // what a result slot of the multi-GPU object holds between launch and finish
 struct MgpuSlot {
   bool pending = false;
@@ -127,7 +77,7 @@ struct msm_hip_mgpu {
   DeviceWorker* worker[MGPU_MAX] = {};
   bool rccl = false;
   std::atomic<bool> broken{false};  // a device could not issue its call of a collective: the communicator is out of step, every later call fails
-  std::atomic<int> fault_device{-1};  // test hook (msm_hip_mgpu_inject_fault / MSM_HIP_FAULT_DEVICE): the next `fault_left` launches fail on this device
+  std::atomic<int> fault_device{-1};  // test hook (msm_hip_mgpu_inject_fault): the next `fault_left` launches fail on this device
   std::atomic<int> fault_left{0};
   bool endo = false;  // the resident bases carry their endomorphism images: window-sharded launches use the 8 half-length windows
   int wide_bits = 0;  // the resident bases are wide fixed-base tables of this digit width: window-sharded launches share their 2^(C-16) virtual windows
@@ -213,7 +163,13 @@ int mgpu_launch_on_device(msm_hip_mgpu* m, int d, int k, const void* scalars, bo
       hipStream_t gs = m->gather_stream[d];
       const size_t bytes = (size_t)rows * ctx->jb;
       if (launched) HIP_TRY(ctx, hipStreamWaitEvent(gs, ctx->slot[k].done, 0));
-      else if (e > b) HIP_TRY(ctx, hipMemsetAsync(ms.d_send[d], 0, bytes, gs));  // (a device without windows sends the zeros of its creation)
+      else if (e > b) {
+        // a failed launch sends zeros.  It may have failed AFTER queueing kernels that write the send block (on the context's main / reduce
+        // streams): the fill is ordered behind everything those streams hold, or a late kernel would overwrite it while the collective reads
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (hipStream_t r : ctx->reduce_stream) HIP_TRY(ctx, hipStreamSynchronize(r));
+        HIP_TRY(ctx, hipMemsetAsync(ms.d_send[d], 0, bytes, gs));  // (a device without windows sends the zeros of its creation)
+      }
       if (m->api.AllGather(ms.d_send[d], ms.d_gather[d], bytes, NCCL_UINT8, m->comm[d], gs) != 0) return MSM_HIP_ERR_HIP;
       if (d == 0) HIP_TRY(ctx, hipMemcpyAsync(ms.h_gather, ms.d_gather[0], (size_t)m->n * bytes, hipMemcpyDeviceToHost, gs));
       HIP_TRY(ctx, hipEventRecord(ms.gathered[d], gs));
@@ -359,13 +315,6 @@ int msm_hip_mgpu_create_curve(msm_hip_mgpu** out, const int* device_ids, int n_d
     }
     m->rccl = ok;  // AUTO: fall back to the pinned-buffer gather
   }
-  if (const char* e = getenv("MSM_HIP_FAULT_DEVICE")) {  // rehearsal of a failing device: its first launch fails (msm_hip_mgpu_inject_fault)
-    const int d = atoi(e);
-    if (d >= 0 && d < n_devices) {
-      m->fault_device = d;
-      m->fault_left = 1;
-    }
-  }
   *out = m;
   return MSM_HIP_OK;
 }
@@ -380,7 +329,7 @@ int msm_hip_mgpu_inject_fault(msm_hip_mgpu* m, int device_index, int launches) {
 int msm_hip_mgpu_device_count(const msm_hip_mgpu* m) { return m ? m->n : MSM_HIP_ERR_INVALID_ARG; }
 int msm_hip_mgpu_uses_rccl(const msm_hip_mgpu* m) { return m ? (m->rccl ? 1 : 0) : MSM_HIP_ERR_INVALID_ARG; }
 
-int msm_hip_mgpu_set_bases_bn254(msm_hip_mgpu* m, const uint8_t* xy_host, size_t n, uint32_t flags) {
+int msm_hip_mgpu_set_bases(msm_hip_mgpu* m, const uint8_t* xy_host, size_t n, uint32_t flags) {
   if (!m || (!xy_host && n)) return MSM_HIP_ERR_INVALID_ARG;
   for (const MgpuSlot& ms : m->slot)
     if (ms.pending) return MSM_HIP_ERR_SLOT_BUSY;
@@ -392,7 +341,7 @@ int msm_hip_mgpu_set_bases_bn254(msm_hip_mgpu* m, const uint8_t* xy_host, size_t
   if (!(flags & (MSM_HIP_BASES_PRECOMPUTE | MSM_HIP_BASES_PRECOMPUTE_WIDE | MSM_HIP_BASES_ENDOMORPHISM | MSM_HIP_BASES_PLAIN))) flags |= MSM_HIP_BASES_PLAIN;
   if (flags & MSM_HIP_BASES_PRECOMPUTE_WIDE)  // shares of virtual windows: 19-bit digits unless asked otherwise (a context alone picks 17 / 20 by n: 2 or 16 virtual windows)
     for (int d = 0; d < m->n; d++) m->ctx[d]->wide_bits_choice = m->wide_bits_choice ? m->wide_bits_choice : 19;
-  const int rc = mgpu_for_each(m, [&](int d) { return msm_hip_set_bases_bn254(m->ctx[d], xy_host, n, flags); });  // replicated
+  const int rc = mgpu_for_each(m, [&](int d) { return msm_hip_set_bases(m->ctx[d], xy_host, n, flags); });  // replicated
   m->endo = !rc && n && m->ctx[0]->endo;
   m->wide_bits = !rc && n ? m->ctx[0]->wide_bits : 0;
   return rc;
@@ -411,19 +360,19 @@ int msm_hip_mgpu_group_size(const msm_hip_mgpu* m) {
   return g < 1 ? 1 : g;
 }
 
-int msm_hip_mgpu_launch_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, int nvec, int slot) {
+int msm_hip_mgpu_launch_batch(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, int nvec, int slot) {
   if (!scalars_host && n) return MSM_HIP_ERR_INVALID_ARG;
   return mgpu_launch(m, nullptr, scalars_host, true, n, nvec, slot);
 }
 
-int msm_hip_mgpu_launch_batch_device_bn254(msm_hip_mgpu* m, const void* const* scalars_dev, size_t n, int nvec, int slot) {
+int msm_hip_mgpu_launch_batch_device(msm_hip_mgpu* m, const void* const* scalars_dev, size_t n, int nvec, int slot) {
   if (!m || !scalars_dev) return MSM_HIP_ERR_INVALID_ARG;
   for (int d = 0; d < m->n; d++)
     if (!scalars_dev[d] && n) return MSM_HIP_ERR_INVALID_ARG;
   return mgpu_launch(m, scalars_dev, nullptr, false, n, nvec, slot);
 }
 
-int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz) {
+int msm_hip_mgpu_finish_batch(msm_hip_mgpu* m, int slot, uint8_t* out_xyz) {
   if (!m || !out_xyz || slot < 0 || slot >= NSLOT) return MSM_HIP_ERR_INVALID_ARG;
   MgpuSlot& ms = m->slot[slot];
   if (!ms.pending) return MSM_HIP_ERR_INVALID_ARG;
@@ -502,18 +451,18 @@ int msm_hip_mgpu_finish_batch_bn254(msm_hip_mgpu* m, int slot, uint8_t* out_xyz)
   return ok ? MSM_HIP_OK : MSM_HIP_ERR_NONCANONICAL;
 }
 
-int msm_hip_mgpu_run_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
+int msm_hip_mgpu_run(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
   if (!m || !out_xyz || (!scalars_host && n)) return MSM_HIP_ERR_INVALID_ARG;
   if (n == 0) {
     memset(out_xyz, 0, m->ctx[0]->jb);
     return MSM_HIP_OK;
   }
-  int rc = msm_hip_mgpu_launch_batch_bn254(m, scalars_host, n, 1, 0);
+  int rc = msm_hip_mgpu_launch_batch(m, scalars_host, n, 1, 0);
   if (rc) return rc;
-  return msm_hip_mgpu_finish_batch_bn254(m, 0, out_xyz);
+  return msm_hip_mgpu_finish_batch(m, 0, out_xyz);
 }
 
-int msm_hip_mgpu_run_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz) {
+int msm_hip_mgpu_run_batch(msm_hip_mgpu* m, const uint8_t* scalars_host, size_t n, size_t batch, uint8_t* out_xyz) {
   if (!m || (!out_xyz && batch) || (!scalars_host && n && batch)) return MSM_HIP_ERR_INVALID_ARG;
   if (batch > (size_t)1 << 30) return MSM_HIP_ERR_INVALID_ARG;
   for (const MgpuSlot& ms : m->slot)
@@ -522,7 +471,7 @@ int msm_hip_mgpu_run_batch_bn254(msm_hip_mgpu* m, const uint8_t* scalars_host, s
     int b, e;
     (void)msm_hip_window_range(d, m->n, (int)batch, &b, &e);
     if (e == b) return (int)MSM_HIP_OK;
-    return msm_hip_run_batch_bn254(m->ctx[d], scalars_host + (size_t)b * n * 32, n, (size_t)(e - b), out_xyz + (size_t)b * m->ctx[d]->jb);
+    return msm_hip_run_batch(m->ctx[d], scalars_host + (size_t)b * n * 32, n, (size_t)(e - b), out_xyz + (size_t)b * m->ctx[d]->jb);
   });
 }
 

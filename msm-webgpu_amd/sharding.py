@@ -99,7 +99,7 @@ def sharded_batch_msm(ctx, scalars_dev, n, rank, world_size, group=None):
 def msms_per_launch(world_size, num_windows=NUM_WINDOWS):
     """How many MSMs a rank processes per launch in the window-sharded pipeline: as many as fit 16 local windows.  A rank's
     share of ONE MSM (2 windows at 8 GPUs) is too small to fill a GPU -- kernel latencies, not work, set its time -- so the
-    shares of several independent MSMs go through one kernel sequence (msm_hip_launch_windows_batch_device_bn254)."""
+    shares of several independent MSMs go through one kernel sequence (msm_hip_launch_windows_batch_device)."""
     return max(1, num_windows // max_windows_per_rank(world_size, num_windows))
 
 
@@ -146,7 +146,7 @@ class ShardedMsmPipeline:
     def __init__(self, ctx, rank, world_size, group=None, num_windows=None, depth=3, msms_per_issue=1, emulate_world=0, halves=False,
                  combine="all", wide=False):
         """halves: the context's bases carry their endomorphism images (set_bases(..., endomorphism=True)); the ranks then share the 8
-        HALF-length windows of the 2n-point problem (msm_hip_launch_half_windows_batch_device_bn254) instead of the 16 full-length ones.
+        HALF-length windows of the 2n-point problem (msm_hip_launch_half_windows_batch_device) instead of the 16 full-length ones.
         combine: who runs the host window combine (src/cuzk/msm.rs:411-416) of a launch's MSMs -- every rank holds all window sums after
         the all-gather.  "all": every rank combines every MSM (every rank returns every result; world x the host work).  "spread": vector v
         of a launch is combined ONCE, by rank v % world -- complete() returns None in the other ranks' places (the throughput form: each

@@ -4,6 +4,8 @@ an intermittent "Memory access fault by GPU".  The product build must contain no
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
@@ -131,3 +133,20 @@ def test_machine_verifier_fires_on_the_miscompiled_variant():
             os.environ["MSM_HIP_SLP"] = old
     assert found and all("k_smvp_stitch" in fn for fn, _ in found), found
     assert any("dead def" in msg for _, msg in found), found
+
+
+def test_library_on_disk_was_built_with_the_gated_flags(built, monkeypatch):
+    """The gates above inspect what the CURRENT flags and sources compile to; the stamp next to libmsm_hip.so says the library that is
+    loaded was built from exactly those (a library built once with MSM_HIP_SLP=1 or MSM_HIP_EXTRA_FLAGS must not be reused as the product)."""
+    import msm_webgpu_amd  # noqa: F401
+    import msm_webgpu_amd.build as b
+
+    assert b.stamp_is_current() and not b.needs_build()
+    plain = b.build_stamp()
+    monkeypatch.setenv("MSM_HIP_SLP", "1")
+    assert b.build_stamp() != plain and b.needs_build()  # variant flags: another build ...
+    with pytest.raises(RuntimeError):                    # ... which must name its own file: the product library is never overwritten by one
+        b.build()
+    monkeypatch.delenv("MSM_HIP_SLP")
+    monkeypatch.setenv("MSM_HIP_EXTRA_FLAGS", "-DX=1")
+    assert b.build_stamp() != plain

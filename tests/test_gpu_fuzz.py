@@ -29,3 +29,15 @@ def test_fuzz_against_oracle_other_curves(built, capsys, curve, cases):
     finally:
         sys.argv = argv
     assert "fuzz ok: %d cases" % cases in capsys.readouterr().out
+
+
+def test_fuzz_wide_tables_against_oracle(built, capsys, monkeypatch):
+    """the wide fixed-base tables only (whole MSMs, batches, shares of the virtual windows, the multi-GPU calls), at every digit width"""
+    monkeypatch.setenv("FUZZ_MODES", "wide,wide_batch,wide_shares,mgpu_wide")
+    argv = sys.argv
+    sys.argv = ["fuzz_gpu.py", "40", "20261006"]
+    try:
+        runpy.run_path(os.path.join(ROOT, "tools", "fuzz_gpu.py"), run_name="__main__")
+    finally:
+        sys.argv = argv
+    assert "fuzz ok: 40 cases" in capsys.readouterr().out

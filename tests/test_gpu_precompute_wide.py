@@ -113,9 +113,14 @@ def test_wide_tables_extreme_and_skewed_scalars(wctx):
     for v in ((1 << 254) - 1, (1 << 254) + 5):   # (at 17 bits the top digit is exactly 2^16 here: the largest bucket magnitude, beyond the 17-bit field)
         # (beyond the modulus, where the C oracle's Booth windows -- halo2curves' -- end: the big-integer model is the reference here)
         assert ctx.msm(v.to_bytes(32, "little")).to_affine_bytes() == ref.affine_to_bytes64(ref.mul(v % R, p0)), hex(v)
-    with pytest.raises(m.MsmHipError) as e:
-        ctx.msm(((1 << 254) + (1 << 253)).to_bytes(32, "little"))
-    assert e.value.code == -4
+    # further above the modulus: rejected (the top digit does not fit the bucket set) or still summed exactly -- never mis-added
+    for v in ((1 << 254) + (1 << 253), (1 << 255) + (1 << 254)):
+        try:
+            got = ctx.msm(v.to_bytes(32, "little"))
+        except m.MsmHipError as e:
+            assert e.code == -4, hex(v)
+        else:
+            assert got.to_affine_bytes() == ref.affine_to_bytes64(ref.mul(v % R, p0)), hex(v)
 
 
 def test_wide_tables_batches_and_flags(wctx):
@@ -157,28 +162,64 @@ def test_wide_tables_batches_and_flags(wctx):
 
 
 @pytest.mark.parametrize("n,bits", [(1 << 20, 17), ((1 << 20) + 8, 20)])
-def test_wide_tables_at_full_sizes_equal_the_other_modes(ctx, n, bits):
-    """BASELINE config 2's size (and just beyond it, where the policy gives 20-bit digits): the wide tables' result is the endomorphism mode's and the
-    16-bit tables' -- three independent paths through the sort and the finish -- for uniform and for skewed scalars; at 2^20 the endomorphism
-    mode itself is checked bit-exactly against the CPU oracle by bench.py and tests/test_gpu_baseline_configs.py."""
+def test_wide_tables_at_full_sizes_match_the_oracle(ctx, n, bits):
+    """BASELINE config 2's size (and just beyond it, where the policy gives 20-bit digits): the wide tables' result against the CPU ORACLE on the
+    same inputs (≙ src/lib.rs:166: GPU == cpu_msm), for uniform and for skewed scalars -- and the endomorphism mode's and the 16-bit tables'
+    beside it: three independent paths through the sort and the finish."""
+    import os
+
     import torch
 
+    threads = max(1, min(16, os.cpu_count() or 1))
     pts = ctx.sample_points(n, 1440)
     uniform = ctx.sample_scalars(n, 1441)
     skew = uniform.clone()
-    skew[: n // 2, 2:] = 0                       # half of the scalars below 2^16: one virtual window takes far more than its share
+    skew[: n // 2, 2:] = 0                       # half of the scalars below 2^16: the lowest digit position takes far more than its share
     skew[n // 2: n // 2 + n // 8] = uniform[7]   # and an eighth of them equal: giant buckets in every digit position
-    want = {}
-    for mode in ("endomorphism", "tables", "wide"):
+    pb = pts.cpu().numpy().tobytes()
+    want = {name: cpu.to_affine64(cpu.cpu_msm(pb, sc.cpu().numpy().tobytes(), threads)) for name, sc in (("uniform", uniform), ("skew", skew))}
+    for mode in ("wide", "endomorphism", "tables"):
         ctx.set_bases(pts, endomorphism=mode == "endomorphism", precompute="wide" if mode == "wide" else mode == "tables")
         if mode == "wide":
             assert ctx.wide_bits() == bits
         for name, sc in (("uniform", uniform), ("skew", skew)):
-            got = ctx.msm(sc).to_affine_bytes()
-            assert want.setdefault(name, got) == got, (mode, name)
+            assert ctx.msm(sc).to_affine_bytes() == want[name], (mode, name)
     del skew, uniform, pts
     torch.cuda.empty_cache()
     ctx.set_bases(ctx.sample_points(16, 1))      # give the tables' memory back
+
+
+def test_wide_tables_2p22_policy_width(ctx):
+    """2^22 points at the width the policy picks there (20 bits: 13 tables, 3.25 GiB): the whole MSM against the endomorphism mode, a 2^16 slice
+    of the same inputs against the CPU oracle (on the slice's own 16-bit tables AND forced to 20 bits), and split consistency over the tables"""
+    import os
+
+    import torch
+
+    n = 1 << 22
+    threads = max(1, min(16, os.cpu_count() or 1))
+    pts, sc = ctx.sample_points(n, 1450), ctx.sample_scalars(n, 1451)
+    ctx.set_bases(pts, precompute="wide")
+    assert ctx.wide_bits() == 20
+    whole = ctx.msm(sc)
+    h = n // 2 + 4321  # MSM(P, s) = MSM(P[:h], s[:h]) + the rest: the prefix runs over the same tables (table stride stays n)
+    first = ctx.msm(sc[:h].contiguous())
+    ctx.set_bases(pts, endomorphism=True)
+    assert ctx.msm(sc) == whole
+    ctx.set_bases(pts[h:].contiguous(), endomorphism=True)
+    second = ctx.msm(sc[h:].contiguous())
+    assert ref.add(first.to_affine(), second.to_affine()) == whole.to_affine()
+    k, off = 1 << 16, 3 << 20
+    sl_p, sl_s = pts[off:off + k].contiguous(), sc[off:off + k].contiguous()
+    want = cpu.to_affine64(cpu.cpu_msm(sl_p.cpu().numpy().tobytes(), sl_s.cpu().numpy().tobytes(), threads))
+    for bits in (0, 20):
+        ctx.set_wide_bits(bits)
+        ctx.set_bases(sl_p, precompute="wide")
+        assert ctx.msm(sl_s).to_affine_bytes() == want, bits
+    ctx.set_wide_bits(0)
+    del pts, sc
+    torch.cuda.empty_cache()
+    ctx.set_bases(ctx.sample_points(16, 1))
 
 
 def test_wide_tables_behind_the_multi_gpu_abi(built):

@@ -80,8 +80,11 @@ def test_2p20_skewed_scalars_through_shares(ctx, inputs_2p20):
     ctx.set_wide_bits(19)
     ctx.set_bases(pts, precompute="wide")
     for name, sc in (("all equal", eq), ("witness-like", wit), ("largest", top)):
-        got = _shares(ctx, sc, n, 1, 8)[0]
-        assert got.to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(pb, _host(sc), THREADS)), name
+        want = cpu.to_affine64(cpu.cpu_msm(pb, _host(sc), THREADS))
+        # 2 ranks: four virtual windows per share -- with equal scalars several digit positions' 2048 entries per block iteration land in one
+        # share, more than the scatter's LDS staging holds at once (WIDE_SHARE_CAP: the staging-window loop)
+        for world in (8, 2):
+            assert _shares(ctx, sc, n, 1, world)[0].to_affine_bytes() == want, (name, world)
 
 
 @pytest.mark.parametrize("bits", [16, 17, 18, 19, 20])

@@ -276,7 +276,7 @@ def _PAIRS(nvec, nwin):
 @pytest.mark.parametrize("world,nwin", [(2, 8), (3, 8), (2, 16)])
 def test_virtual_window_pairs_gather_and_finish_gloo(built, world, nwin):
     """the record shape of window-sharded launches over wide tables: every rank contributes (weighted sum, plain total) pairs of its virtual
-    windows; after ONE all-gather (gloo here) every rank finishes sum_hi W_hi + 2^15 sum_hi hi TC_hi (msm_hip_combine_vwindows_batch_curve)"""
+    windows; after ONE all-gather (gloo here) every rank finishes V sum_vw W_vw - sum_vw (V - 1 - vw) TC_vw (msm_hip_combine_vwindows_batch_curve)"""
     import msm_webgpu_amd as m
     from oracle import bn254_ref as ref
 
@@ -296,6 +296,6 @@ def test_virtual_window_pairs_gather_and_finish_gloo(built, world, nwin):
     assert all(g[1] == _PAIRS(nvec, nwin).tobytes() for g in got)  # every rank holds every pair, in virtual-window order
     res = m.MsmContext.combine_vwindows_batch(np.frombuffer(got[0][1], dtype=np.uint8), nwin)
     for v in range(nvec):
-        mult = sum(1000 * v + 7 * hi + 1 for hi in range(nwin)) + (1 << 15) * sum(hi * (13 * v + hi + 2) for hi in range(nwin))
+        mult = nwin * sum(1000 * v + 7 * hi + 1 for hi in range(nwin)) - sum((nwin - 1 - hi) * (13 * v + hi + 2) for hi in range(nwin))
         x, y = ref.mul(mult % ref.R, ref.G)
         assert res[v].to_affine_bytes() == x.to_bytes(32, "little") + y.to_bytes(32, "little"), v

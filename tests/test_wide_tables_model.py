@@ -2,8 +2,8 @@
 
 The MSM is linear in the points, so the additive group Z_r stands in for the curve: "point" i is an integer g_i, "sum_i s_i P_i" is
 sum_i s_i g_i mod r.  The model follows csrc/msm_kernels.h (k_count_wide / wide_digit: signed C-bit digits by one biased addition, the top
-digit shifted against a top table that is `shift` doublings short, magnitude m -> virtual window (m - 1) >> 15 and slot m & 0x7fff with
-value(slot 0) = 2^15) and csrc/host_g1.h (combine_wide: sum_hi W_hi + 2^15 sum_hi hi TC_hi), with the shape -- digit width, tables, virtual
+digit shifted against a top table that is `shift` doublings short -- 0 since round 5 --, magnitude m -> virtual window (m - 1) mod V and the slot of
+value (m - 1) / V + 1, slot 0 carrying 2^15) and csrc/host_g1.h (combine_wide: V sum_vw W_vw - sum_vw (V - 1 - vw) TC_vw), with the shape -- digit width, tables, virtual
 windows, top shift -- taken from the library's own host-only helper (msm_hip_wide_config), for every curve's scalar field and every width."""
 import ctypes as C
 import importlib
@@ -33,18 +33,18 @@ def wide_msm_model(r, scalars, points, bits, tables, vwin, shift):
                 mag, neg = d << shift, False
             if mag == 0:
                 continue
-            hi, slot = (mag - 1) >> 15, mag & 0x7FFF
+            hi, slot = (mag - 1) % vwin, ((mag - 1) // vwin + 1) & 0x7FFF               # msm_kernels.h: wide_key / wide_slot (interleaved)
             assert hi < vwin
             buckets[hi][slot] = (buckets[hi][slot] + (-table[w][i] if neg else table[w][i])) % r
-    total, run, weighted = 0, 0, 0
-    for hi in range(vwin - 1, -1, -1):                                                # host_g1.h: combine_wide
-        w_hi = sum((slot if slot else 1 << 15) * v for slot, v in enumerate(buckets[hi])) % r
-        tc_hi = sum(buckets[hi]) % r
-        total = (total + w_hi) % r
-        if hi >= 1:
-            run = (run + tc_hi) % r
-            weighted = (weighted + run) % r
-    return (total + (weighted << 15)) % r
+    total, run, minus = 0, 0, 0
+    for vw in range(vwin):                                                            # host_g1.h: combine_wide_strided
+        w_vw = sum((slot if slot else 1 << 15) * v for slot, v in enumerate(buckets[vw])) % r
+        tc_vw = sum(buckets[vw]) % r
+        total = (total + w_vw) % r
+        if vw < vwin - 1:
+            run = (run + tc_vw) % r
+            minus = (minus + run) % r
+    return (total * vwin - minus) % r
 
 
 @pytest.mark.parametrize("cid,name", CURVES)

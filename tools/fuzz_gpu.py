@@ -56,7 +56,7 @@ CBY = ctx.cb  # bytes per coordinate (48 on BLS12-381)
 # BLS12-381's cofactor is not 1: the samplers' points are outside the order-r subgroup, where the endomorphism modes are not exact (and the
 # R = 2^256 input format is the 4-limb curves')
 MODES = ["host", "device", "windows", "batch", "group", "hostbatch", "mont", "bits", "tables", "tables_batch", "hostpipe", "mgpu", "endo", "endo_batch",
-         "group_halves", "mgpu_batch", "mgpu_batch_endo", "auto", "wide", "wide_batch"]
+         "group_halves", "mgpu_batch", "mgpu_batch_endo", "auto", "wide", "wide_batch", "wide_shares", "mgpu_wide"]
 if curve == "bls12_381":
     MODES = [x for x in MODES if x not in ("mont", "endo", "endo_batch", "group_halves", "mgpu_batch_endo")]
 if curve.endswith("_g2"):  # (the "mont" case below writes G1 coordinates; the pool's points are multiples of G2's generator: the endomorphism modes are exact)
@@ -99,7 +99,13 @@ for case in range(cases):
     want = cpu.to_affine64(cpu.cpu_msm(points, sb))
     mode = rnd.choice(MODES)
     # ("auto": the C ABI's flags = 0 -- the curve's fastest mode on a curve of prime order, the plain shape otherwise)
+    wide_bits = 0
+    if mode.startswith("wide"):  # every digit width the curve's scalar field admits (0: by the number of bases); BLS12-381 cannot hold 15 x 17 bits
+        wide_bits = rnd.choice([0, 16, 17, 18, 19, 20] if curve not in ("bls12_381", "bls12_381_g2") else [0, 16, 18, 19, 20])
+        ctx.set_wide_bits(wide_bits)
     ctx.set_bases(points, precompute="wide" if mode.startswith("wide") else mode.startswith("tables"), endomorphism=None if mode == "auto" else (mode.startswith("endo") or mode == "group_halves"))
+    if mode.startswith("wide"):
+        ctx.set_wide_bits(0)
     if mode == "mont":
         # both inputs as R = 2^256 Montgomery words (MSM_HIP_BASES_MONT256, MSM_HIP_SCALARS_MONT256)
         PM, RM = ref.P, ref.R
@@ -136,6 +142,44 @@ for case in range(cases):
     elif mode in ("tables_batch", "wide_batch"):
         k = rnd.randrange(1, 7)
         got = ctx.msm_batch(sb * k, n)[k - 1]
+    elif mode == "wide_shares":
+        # shares of the wide tables' virtual windows (round 5): every rank's launch of a group, what the all-gather would deliver (pairs of
+        # records per virtual window) finished by msm_hip_combine_vwindows_batch_curve
+        nwin = ctx.virtual_windows()
+        world = rnd.choice([1, 2, 3, 5, 8, 16])
+        per = -(-nwin // world)
+        g = rnd.randrange(1, max(1, min(8, 64 // per)) + 1)
+        pos = rnd.randrange(g)
+        vecs = [bytes(len(sb)) if rnd.random() < 0.5 else sb for _ in range(g)]
+        vecs[pos] = sb
+        t = torch.frombuffer(bytearray(b"".join(vecs)), dtype=torch.uint8).cuda()
+        pairs = []
+        for r in range(world):
+            b, e = window_range(r, world, nwin)
+            if e == b:
+                continue
+            out = torch.empty((g * (e - b) * 2, 3 * CBY), dtype=torch.uint8, device="cuda")
+            ctx.launch_vwindows_batch(t, n, b, e, r % 4, out)
+            ctx.slot_sync(r % 4)
+            pairs.append(out[pos * (e - b) * 2:(pos + 1) * (e - b) * 2])
+        got = m.MsmContext.combine_vwindows_batch(torch.cat(pairs, dim=0).cpu(), nwin, curve)[0]
+    elif mode == "mgpu_wide":
+        # the same through msm_hip_mgpu_* (several contexts on this GPU, pinned-buffer gather), grouped launches and the synchronous call
+        world = rnd.choice([1, 2, 3, 8])
+        key = (world, "w")
+        if key not in mg:
+            mg[key] = m.MultiGpuMsm([0] * world, "host", curve=curve)
+        mg[key].set_wide_bits(rnd.choice([0, 16, 18, 19, 20] if curve in ("bls12_381", "bls12_381_g2") else [0, 16, 17, 18, 19, 20]))
+        mg[key].set_bases(points, precompute="wide")
+        if rnd.random() < 0.5:
+            got = mg[key].msm(sb)
+        else:
+            g = rnd.randrange(1, min(4, mg[key].group_size) + 1)
+            pos = rnd.randrange(g)
+            vecs = [bytes(len(sb)) if rnd.random() < 0.5 else sb for _ in range(g)]
+            vecs[pos] = sb
+            mg[key].launch_batch(b"".join(vecs), n, 1)
+            got = mg[key].finish_batch(1, g)[pos]
     elif mode == "hostpipe":
         # host scalars through the copy stream, three slots in flight
         for slot in range(3):
