@@ -199,6 +199,53 @@ FQ_HD fq fq_mul2(const fq& a, const fq& b, const fq& c_, const fq& d) {
   return r;
 }
 
+// (a*b + c*d + e*f + g*h)/R mod p with ONE Montgomery reduction -- a component of the Fq2 form of fq_mul2 (csrc/fq2.h: Y3 = R T + (-Y) PPP over
+// Fq2 is four prime-field products per component; round 5: 5 L^2 multiply-adds instead of the 6 L^2 of two fq_mul2).  EVERY operand exact (limbs
+// < 2^W + 64): a column then holds at most 4 L products and L reduction terms below 2^(2W), within 64 bits for both limb layouts (the generator
+// asserts it).  Sum of the four products <= R / p * p^2 (169 p^2 for BN254; the Fq2 formulas stay below 24 p^2).  Result exact, < 2p.
+FQ_HD fq fq_mul4(const fq& a, const fq& b, const fq& c_, const fq& d, const fq& e, const fq& f, const fq& g, const fq& h) {
+#if defined(FQ29_ASM) && !defined(FQ29_ASM_SMVP_ONLY)
+  return fq_mul4_asm(a, b, c_, d, e, f, g, h);
+#endif
+  uint64_t c[2 * FQ_L];
+#pragma unroll
+  for (int k = 0; k < 2 * FQ_L; k++) c[k] = 0;
+#pragma unroll
+  for (int i = 0; i < FQ_L; i++) {
+    FQ_ASSERT(a.v[i] <= (1u << FQ_W) + 64 && b.v[i] <= (1u << FQ_W) + 64 && c_.v[i] <= (1u << FQ_W) + 64 && d.v[i] <= (1u << FQ_W) + 64 &&
+                  e.v[i] <= (1u << FQ_W) + 64 && f.v[i] <= (1u << FQ_W) + 64 && g.v[i] <= (1u << FQ_W) + 64 && h.v[i] <= (1u << FQ_W) + 64,
+              "fq_mul4: operand limb too large");
+#pragma unroll
+    for (int j = 0; j < FQ_L; j++) c[i + j] += (uint64_t)a.v[j] * b.v[i];
+#pragma unroll
+    for (int j = 0; j < FQ_L; j++) c[i + j] += (uint64_t)c_.v[j] * d.v[i];
+#pragma unroll
+    for (int j = 0; j < FQ_L; j++) c[i + j] += (uint64_t)e.v[j] * f.v[i];
+#pragma unroll
+    for (int j = 0; j < FQ_L; j++) c[i + j] += (uint64_t)g.v[j] * h.v[i];
+    const uint32_t m = ((uint32_t)c[i] * FQ_N0_29) & FQ_MASK;
+#pragma unroll
+    for (int j = 0; j < FQ_L; j++) c[i + j] += (uint64_t)m * FQ_P29[j];
+    c[i + 1] += c[i] >> FQ_W;
+  }
+  fq r;
+#pragma unroll
+  for (int k = FQ_L; k < 2 * FQ_L - 1; k++) {
+    r.v[k - FQ_L] = (uint32_t)c[k] & FQ_MASK;
+    c[k + 1] += c[k] >> FQ_W;
+  }
+  r.v[FQ_L - 1] = (uint32_t)c[2 * FQ_L - 1];
+  FQ_ASSERT(fq_check_below_2p(r), "fq_mul4: result >= 2p (operand value bound violated)");
+  return r;
+}
+FQ_HD fq fq_mul4_fast(const fq& a, const fq& b, const fq& c_, const fq& d, const fq& e, const fq& f, const fq& g, const fq& h) {
+#if defined(FQ29_ASM)
+  return fq_mul4_asm(a, b, c_, d, e, f, g, h);
+#else
+  return fq_mul4(a, b, c_, d, e, f, g, h);
+#endif
+}
+
 // Montgomery square: 45 products instead of 81 (cross terms doubled once).
 FQ_HD fq fq_sqr(const fq& a) {
 #if defined(FQ29_ASM) && !defined(FQ29_ASM_SMVP_ONLY)

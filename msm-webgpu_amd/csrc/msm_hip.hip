@@ -560,6 +560,8 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     if (!others) rs = st;
   }
   // tiles of scalars for the two global sort passes: >= 2048 scalars each, at most MAX_TILES of them
+  // window shares (a few of a scalar's windows per vector): the first pass leaves digit planes, the second reads them (k_scatter_planes)
+  const bool planes = use_planes(ctx, mode, w_count_vec, wbits);
   // shares of at most WIDE_SHARE_VWIN_MAX virtual windows of wide tables: the first pass leaves compact lists of the share's entries per sub-tile of
   // LIST_SUB scalars (k_count_wide_list / k_scatter_list); tiles are then whole sub-tiles.  MSM_HIP_WIDE_SHARE_LISTS=0: the two-pass shape (A/B aid)
   static const bool share_lists = [] { const char* e = getenv("MSM_HIP_WIDE_SHARE_LISTS"); return !e || atoi(e) != 0; }();
@@ -576,8 +578,6 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   const size_t stride = stride_for(n_entries);
   ctx->last_stride = stride;
   uint16_t* digits = ctx->debug && !merge && !wide ? ctx->d_digits : nullptr;
-  // window shares (a few of a scalar's windows per vector): the first pass leaves digit planes, the second reads them (k_scatter_planes)
-  const bool planes = use_planes(ctx, mode, w_count_vec, wbits);
   uint32_t* d_err = reinterpret_cast<uint32_t*>(s.d_wsums + WSUM_BYTES);
   if (!wsums_out) wsums_out = reinterpret_cast<uint32_t*>(s.d_wsums);
   // the SMVP chunk length the device settles on for this launch (k_scatter_coarse -> fine sort, SMVP, stitch): a word of the slot
@@ -600,11 +600,12 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     AFTER_KERNEL(ctx, "k_scalars_from_mont256", st);
     d_scalars = ctx->d_scalar_conv;
   }
-#define LAUNCH_BY_WBITS_SW(KERNEL, SW, ...)                                              \
+  const unsigned gpos_bytes = (unsigned)(merge ? nvec : nvec * w_count_vec) * NCOARSE * 4;  // k_scatter_coarse's run cursors (dynamic LDS)
+#define LAUNCH_BY_WBITS_SW(KERNEL, LDS, SW, ...)                                         \
   do {                                                                                   \
-    if (wbits == 16) hipLaunchKernelGGL((KERNEL<16, SW>), dim3(tiles, nvec), dim3(256), 0, st, __VA_ARGS__); \
-    else if (wbits == 14) hipLaunchKernelGGL((KERNEL<14, SW>), dim3(tiles, nvec), dim3(256), 0, st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<12, SW>), dim3(tiles, nvec), dim3(256), 0, st, __VA_ARGS__); \
+    if (wbits == 16) hipLaunchKernelGGL((KERNEL<16, SW>), dim3(tiles, nvec), dim3(256), LDS, st, __VA_ARGS__); \
+    else if (wbits == 14) hipLaunchKernelGGL((KERNEL<14, SW>), dim3(tiles, nvec), dim3(256), LDS, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<12, SW>), dim3(tiles, nvec), dim3(256), LDS, st, __VA_ARGS__); \
   } while (0)
   // first pass: recode + coarse histogram (+ digit planes: 1 = debug read-back, 2 = the second pass reads them).  Endomorphism launches:
   // the same kernel splits every scalar k = k1 + k2 lambda itself and leaves the halves (interleaved: input 2 j = k1 of scalar j, 2 j + 1 =
@@ -635,7 +636,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
                        planes ? nullptr : ctx->d_halves, d_err, merge_nb);
     d_scalars = ctx->d_halves;
   } else {
-    LAUNCH_BY_WBITS_SW(k_count, 8, d_scalars, n_sc, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, plane_out, plane_mode,
+    LAUNCH_BY_WBITS_SW(k_count, 0, 8, d_scalars, n_sc, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, plane_out, plane_mode,
                        (uint64_t*)nullptr, (uint32_t*)nullptr, d_err, merge_nb);
   }
   AFTER_KERNEL(ctx, "k_count", st);
@@ -675,17 +676,21 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
                        tiles, w_count, w_count_vec, ctx->d_counts, ctx->d_bin_total, ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine,
                        (uint32_t)ctx->n_bases, chunks, chunk_len, d_chunk_len);
   } else if (halves) {
-    LAUNCH_BY_WBITS_SW(k_scatter_coarse, 4, d_scalars, n_sc, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
+    LAUNCH_BY_WBITS_SW(k_scatter_coarse, gpos_bytes, 4, d_scalars, n_sc, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
                        ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, (uint32_t)n, (uint32_t)ctx->n_bases, chunks, chunk_len, d_chunk_len);
   } else {
-    LAUNCH_BY_WBITS_SW(k_scatter_coarse, 8, d_scalars, n_sc, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
+    LAUNCH_BY_WBITS_SW(k_scatter_coarse, gpos_bytes, 8, d_scalars, n_sc, stride, tile_len, tiles, w_begin, w_count_vec, nvec, n * 8, ctx->d_counts, ctx->d_bin_total,
                        ctx->d_coarse_ptr, ctx->d_tmp_val, ctx->d_tmp_fine, merge_nb, (uint32_t)n, 0u, chunks, chunk_len, d_chunk_len);
   }
 #undef LAUNCH_BY_WBITS_SW
   AFTER_KERNEL(ctx, "k_scatter_coarse", st);
   HIP_TRY(ctx, mark(3, false));
   const uint32_t* part_hist = nullptr;
-  if (n_entries >= ctx->fine_hist_min_n) {  // large n: the sub-range histograms of huge coarse bins are made once, not by every sharer
+  // large n: the sub-range histograms of huge coarse bins are made once, not by every sharer.  (round 5) Not launched at all while uniform scalars
+  // cannot fill a coarse bin to three quarters of FINE_BIG -- 2^20 points and below: its 8192 workgroups found nothing to do and took 19 us of every
+  // launch's main stream; skewed scalars that make such a bin after all take the sharers' own histograms (k_sort_fine's fallback path)
+  const bool hist_useful = ctx->fine_hist_min_n != FINE_BIG + 1 || n_entries / ncoarse * 4 > (size_t)FINE_BIG * 3;
+  if (n_entries >= ctx->fine_hist_min_n && hist_useful) {
     hipLaunchKernelGGL(k_fine_hist, dim3(ncoarse, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
                        ctx->d_part_hist);
     AFTER_KERNEL(ctx, "k_fine_hist", st);
@@ -1168,7 +1173,7 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
     }
   } else if ((rc = ensure_work(ctx, merge ? n * (size_t)w_count : halves ? 2 * n : n, w_local, wbits,
                                merge ? 1 : halves ? nwin_of(wbits, true) : NWIN, s, use_planes(ctx, mode, w_count, wbits)))) return rc;
-  if (halves && (size_t)nvec * n > ctx->cap_halves) {
+  if (halves && !use_planes(ctx, mode, w_count, wbits) && (size_t)nvec * n > ctx->cap_halves) {  // (the halves as an array: only when the second pass reads them)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cap_halves = 0;
     if ((rc = dev_alloc(ctx, ctx->d_halves, (size_t)nvec * n * 8))) return rc;

@@ -583,8 +583,12 @@ __device__ __forceinline__ uint32_t smvp_chunk_len(uint32_t mx, uint32_t chunks,
 // addresses inside each (tile, bin) run instead of 64 unrelated 4-byte stores per wave instruction.
 constexpr int SCAT_SUB = 2048;  // scalars staged per block iteration (8 per thread)
 
+// (round 5) The run cursors (gpos) live in dynamic LDS, as many as the launch has local windows (512 B each): with the 32 KB of a 64-window launch
+// declared statically, three workgroups fitted a CU whatever the launch's size; the half-scalar form is held to 128 registers (four waves per SIMD):
+// 1290 -> 1148 us at 2^24.  (Tried and dropped: splitting the scalars again here instead of reading the halves the first pass wrote -- 1 GB less
+// traffic at 2^24, and 1522 us instead of 1148 with the first pass no faster: profiles/r05_sort.txt.)
 template <int C, int SW>
-__global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
+__global__ void __launch_bounds__(256, (SW == 4 ? 4 : 1)) k_scatter_coarse(const uint32_t* __restrict__ scalars, size_t n, size_t stride, uint32_t tile_len,
                                                         uint32_t tiles, int w_begin, int w_count, int nvec, size_t vec_stride,
                                                         const uint32_t* __restrict__ counts,
                                                         const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ coarse_ptr,
@@ -598,7 +602,7 @@ __global__ void __launch_bounds__(256) k_scatter_coarse(const uint32_t* __restri
   static_assert(SUB <= SCAT_SUB, "LDS staging arrays");
   // SW = 4 (endomorphism halves, interleaved by k_count<C, 4, true>): input 2 j is k1 of scalar j and multiplies base j; input 2 j + 1 is
   // k2 and multiplies phi(P_j), record half_shift = n_bases + j
-  __shared__ uint32_t gpos[MAXLW * NCOARSE];  // global write cursor of every (window, coarse bin) run of this tile
+  extern __shared__ uint32_t gpos[];  // [local windows of the launch][NCOARSE]: global write cursor of every (window, coarse bin) run of this tile
   __shared__ uint32_t hist[NCOARSE];
   __shared__ uint32_t lstart[NCOARSE];
   __shared__ uint32_t wave_tot[4];
@@ -1413,7 +1417,12 @@ __global__ void __launch_bounds__(256) k_scatter_planes(const uint16_t* __restri
   }
 }
 
-constexpr int FINE_CHUNK = 4096;  // entries staged per block iteration (16 per thread)
+#ifndef MSM_FINE_CHUNK
+#define MSM_FINE_CHUNK 4096
+#endif
+constexpr int FINE_CHUNK = MSM_FINE_CHUNK;  // entries staged per block iteration (16 per thread; 8192 -- runs of 32 entries per slot -- measured slower:
+                                            // 1.55 -> 1.69 ms at 2^24, 0.092 -> 0.106 at 2^20, profiles/r05_sort.txt)
+constexpr int FINE_PER = FINE_CHUNK / 256;  // entries per thread and iteration
 
 // counter[key] += 1 for every active lane, returning the lane's rank (old value).  All lanes that share the key of the
 // wave's first active lane are served by ONE LDS atomic (ballot + popcount): with heavily skewed scalars (many equal
@@ -1453,7 +1462,8 @@ __device__ __forceinline__ void lds_count_only(uint32_t* counter, uint32_t key, 
 // (the other FINE_SPLIT - 1 exit at once).
 constexpr int FINE_SPLIT = 8;
 
-constexpr uint32_t FINE_BIG = 8 * FINE_CHUNK;
+constexpr uint32_t FINE_BIG = 32768;  // (a multiple of FINE_CHUNK)
+static_assert(FINE_BIG % FINE_CHUNK == 0, "sub-ranges are whole chunks");
 
 // Histograms of the FINE_SPLIT sub-ranges of every coarse bin that exceeds FINE_BIG (part_hist[lw][bin][part][256]); launched
 // ahead of k_sort_fine when n is large enough for uniform scalars to produce such bins (the host decides), so that the
@@ -1472,14 +1482,14 @@ __global__ void __launch_bounds__(256) k_fine_hist(const uint8_t* __restrict__ t
   hist[tid] = 0;
   __syncthreads();
   for (uint32_t base = my_begin; base < my_end; base += FINE_CHUNK) {
-    uint32_t f[16];
+    uint32_t f[FINE_PER];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < FINE_PER; j++) {
       const uint32_t i = base + j * 256 + tid;
       f[j] = i < my_end ? tf[i] : 0xffffffffu;
     }
 #pragma unroll
-    for (int j = 0; j < 16; j++) lds_count_only(hist, f[j] & 0xffu, f[j] != 0xffffffffu);
+    for (int j = 0; j < FINE_PER; j++) lds_count_only(hist, f[j] & 0xffu, f[j] != 0xffffffffu);
   }
   __syncthreads();
   part_hist[(((size_t)lw * NCOARSE + bin) * FINE_SPLIT + part) * FINE + tid] = hist[tid];
@@ -1496,7 +1506,9 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
   __shared__ uint32_t gpos[FINE];
   __shared__ uint32_t wave_tot[4];
   __shared__ uint32_t st_val[FINE_CHUNK];
-  __shared__ uint32_t st_dst[FINE_CHUNK];
+  __shared__ uint8_t st_slot[FINE_CHUNK];  // (round 5: an entry's destination is its run's cursor + its place in the staged run -- recomputed at the
+                                           //  write-out from the slot, 1 B, instead of staged as 4 B: 24.6 KB instead of 36.9 -- six workgroups per CU, not four)
+  __shared__ uint32_t long_c0[FINE], long_c1[FINE], long_slot[FINE];  // (the chunk table's long runs: at most one per slot)
   __shared__ uint32_t skew_flag, long_count;
   const int bin = blockIdx.x, part = blockIdx.z, lw = blockIdx.y, tid = threadIdx.x;
   const uint32_t half = gridDim.x * FINE;  // bucket slots per window: the grid covers exactly the window's coarse bins
@@ -1524,14 +1536,14 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
   __syncthreads();
   if (!big) {
     for (uint32_t base = begin; base < end; base += FINE_CHUNK) {  // 16 independent byte loads in flight per thread
-      uint32_t f[16];
+      uint32_t f[FINE_PER];
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
+      for (int j = 0; j < FINE_PER; j++) {
         const uint32_t i = base + j * 256 + tid;
         f[j] = i < end ? tf[i] : 0xffffffffu;
       }
 #pragma unroll
-      for (int j = 0; j < 16; j++)
+      for (int j = 0; j < FINE_PER; j++)
         if (f[j] != 0xffffffffu) atomicAdd(&hist[f[j]], 1u);
     }
   } else if (part_hist) {
@@ -1549,23 +1561,23 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
   } else {
     // FINE_CHUNK entries per sweep step, 16 independent byte loads per thread in flight; a step lies wholly in front of
     // the sub-range or not (my_begin - begin is a multiple of FINE_CHUNK), so every entry is counted once
-    uint32_t f[16], g[16];  // double buffered: the loads of step k + 1 are in flight while step k is counted
+    uint32_t f[FINE_PER], g[FINE_PER];  // double buffered: the loads of step k + 1 are in flight while step k is counted
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < FINE_PER; j++) {
       const uint32_t i = begin + j * 256 + tid;
       f[j] = i < end ? tf[i] : 0xffffffffu;
     }
     for (uint32_t base = begin; base < end; base += FINE_CHUNK) {
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
+      for (int j = 0; j < FINE_PER; j++) {
         const uint32_t i = base + FINE_CHUNK + j * 256 + tid;
         g[j] = i < end ? tf[i] : 0xffffffffu;
       }
       uint32_t* counter = base < my_begin ? before : hist;
 #pragma unroll
-      for (int j = 0; j < 16; j++) lds_count_only(counter, f[j] & 0xffu, f[j] != 0xffffffffu);
+      for (int j = 0; j < FINE_PER; j++) lds_count_only(counter, f[j] & 0xffu, f[j] != 0xffffffffu);
 #pragma unroll
-      for (int j = 0; j < 16; j++) f[j] = g[j];
+      for (int j = 0; j < FINE_PER; j++) f[j] = g[j];
     }
     __syncthreads();
     hist[tid] += before[tid];
@@ -1592,16 +1604,16 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
       for (uint32_t c = c0; c < c1; c++) chunk_slot[(size_t)lw * chunks + c] = (uint32_t)(bin * FINE + tid);
     if (long_run) {
       const uint32_t k = atomicAdd(&long_count, 1u);
-      lstart[k] = c0;
-      st_dst[k] = c1;
-      st_val[k] = (uint32_t)(bin * FINE + tid);
+      long_c0[k] = c0;
+      long_c1[k] = c1;
+      long_slot[k] = (uint32_t)(bin * FINE + tid);
     }
   }
   __syncthreads();
   {
     const uint32_t nl = long_count, nparts = big ? FINE_SPLIT : 1;
     for (uint32_t k = 0; k < nl; k++)
-      for (uint32_t c = lstart[k] + part * 256 + tid; c < st_dst[k]; c += nparts * 256) chunk_slot[(size_t)lw * chunks + c] = st_val[k];
+      for (uint32_t c = long_c0[k] + part * 256 + tid; c < long_c1[k]; c += nparts * 256) chunk_slot[(size_t)lw * chunks + c] = long_slot[k];
   }
   __syncthreads();
   // pass 2: LDS-staged scatter of the sub-range, FINE_CHUNK entries at a time
@@ -1609,9 +1621,9 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
   for (uint32_t base = my_begin; base < my_end; base += FINE_CHUNK) {
     hist[tid] = 0;
     __syncthreads();
-    uint32_t v[16], fr[16];  // value; slot | rank << 8
+    uint32_t v[FINE_PER], fr[FINE_PER];  // value; slot | rank << 8
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < FINE_PER; j++) {
       const uint32_t i = base + j * 256 + tid;
       const bool valid = i < my_end;
       const uint32_t f = valid ? tf[i] : 0u;
@@ -1629,16 +1641,20 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
     __syncthreads();
     const uint32_t total = (my_end - base) < (uint32_t)FINE_CHUNK ? (my_end - base) : (uint32_t)FINE_CHUNK;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < FINE_PER; j++) {
       if (fr[j] != 0xffffffffu) {
         const uint32_t f = fr[j] & 0xffu, r = fr[j] >> 8;
         const uint32_t e = lstart[f] + r;
         st_val[e] = v[j];
-        st_dst[e] = gpos[f] + r;
+        st_slot[e] = (uint8_t)f;
       }
     }
     __syncthreads();
-    for (uint32_t e = tid; e < total; e += 256) out[st_dst[e]] = st_val[e];
+    for (uint32_t e = tid; e < total; e += 256) {
+      const uint32_t f = st_slot[e];
+      out[gpos[f] + (e - lstart[f])] = st_val[e];
+    }
+    __syncthreads();
     gpos[tid] += hist[tid];
     __syncthreads();
   }

@@ -138,8 +138,11 @@ def test_machine_verifier_fires_on_the_miscompiled_variant():
 def test_library_on_disk_was_built_with_the_gated_flags(built, monkeypatch):
     """The gates above inspect what the CURRENT flags and sources compile to; the stamp next to libmsm_hip.so says the library that is
     loaded was built from exactly those (a library built once with MSM_HIP_SLP=1 or MSM_HIP_EXTRA_FLAGS must not be reused as the product)."""
+    import importlib
+
     import msm_webgpu_amd  # noqa: F401
-    import msm_webgpu_amd.build as b
+
+    b = importlib.import_module("msm_webgpu_amd.build")  # (the package re-exports the FUNCTION build under the same name: take the module)
 
     assert b.stamp_is_current() and not b.needs_build()
     plain = b.build_stamp()

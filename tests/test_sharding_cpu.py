@@ -224,7 +224,7 @@ def test_pipeline_combines_every_msm_once_across_the_ranks(built, mode):
     owners = []
     for rank in range(world):
         p = ShardedMsmPipeline.__new__(ShardedMsmPipeline)
-        p.combine, p.emulate, p.world, p.rank, p.num_windows, p.ctx = mode, 0, world, rank, nw, Ctx()
+        p.combine, p.emulate, p.world, p.rank, p.num_windows, p.ctx, p.wide = mode, 0, world, rank, nw, Ctx(), False
         p.w_begin, p.w_end = window_range(rank, world, nw)
         p.host_np = [host]
         out = p._combine(0, nvec)

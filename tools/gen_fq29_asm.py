@@ -21,7 +21,8 @@ acc, acclo = "v[%d:%d]" % (ACC, ACC + 1), "v%d" % ACC
 
 
 def block(kind, inplace=None):
-    """kind: 'mul' (a*b), 'mul2' (a*b + c*d), 'sqr' (a*a; operand list a, a2 = 2a).
+    """kind: 'mul' (a*b), 'mul2' (a*b + c*d), 'mul4' (a*b + c*d + e*f + g*h: the component of an Fq2 fq_mul2, one reduction for four
+    products -- every operand exact, limbs < 2^LB + 64), 'sqr' (a*a; operand list a, a2 = 2a).
     inplace: name of the operand ('a' for mul, 'c' for mul2) whose registers receive the result: result limb j is column 9 + j, and
     limb j of the first factor of a product is last read in column j + 8, so the register is free by then; the m[k] are scratch."""
     L = []
@@ -34,12 +35,16 @@ def block(kind, inplace=None):
 
     for k in range(2 * NL):
         lo, hi = max(0, k - (NL - 1)), min(k, NL - 1)
-        if kind in ("mul", "mul2"):
+        if kind in ("mul", "mul2", "mul4"):
             for i in range(lo, hi + 1):
                 mad("%%[a%d]" % (k - i), "%%[b%d]" % i)
-            if kind == "mul2":
+            if kind in ("mul2", "mul4"):
                 for i in range(lo, hi + 1):
                     mad("%%[c%d]" % (k - i), "%%[d%d]" % i)
+            if kind == "mul4":
+                for x, y in (("e", "f"), ("g", "h")):
+                    for i in range(lo, hi + 1):
+                        mad("%%[%s%d]" % (x, k - i), "%%[%s%d]" % (y, i))
         else:
             if k % 2 == 0 and k // 2 < NL:
                 mad("%%[a%d]" % (k // 2), "%%[a%d]" % (k // 2))
@@ -75,6 +80,10 @@ def emit(name, kind):
     elif kind == "mul2":
         ins = ", ".join('[%s%d] "v"(%s.v[%d])' % (n, i, n if n != "c" else "c_", i) for n in "abcd" for i in range(NL))
         sig = "const fq& a, const fq& b, const fq& c_, const fq& d"
+        pre = ""
+    elif kind == "mul4":
+        ins = ", ".join('[%s%d] "v"(%s.v[%d])' % (n, i, n if n != "c" else "c_", i) for n in "abcdefgh" for i in range(NL))
+        sig = "const fq& a, const fq& b, const fq& c_, const fq& d, const fq& e, const fq& f, const fq& g, const fq& h"
         pre = ""
     else:
         ins = ", ".join('[a%d] "v"(a.v[%d])' % (i, i) for i in range(NL)) + ", " + ", ".join('[t%d] "v"(t[%d])' % (i, i) for i in range(1, NL))
@@ -130,6 +139,9 @@ print("namespace MSM_FIELD_NS {")
 emit("fq_mul_asm", "mul")
 emit("fq_sqr_asm", "sqr")
 emit("fq_mul2_asm", "mul2")
+# 4 x NL x (2^LB + 64)^2 product terms + NL x 2^(2 LB) reduction terms per column must fit the 64-bit accumulator
+assert 4 * NL * ((1 << LB) + 64) ** 2 + NL * (1 << (2 * LB)) < (1 << 64), "mul4 column overflow"
+emit("fq_mul4_asm", "mul4")
 emit_inplace("fq_mul_ip_asm", "mul")
 emit_inplace("fq_mul2_ip_asm", "mul2")
 print("}  // namespace MSM_FIELD_NS")
