@@ -93,8 +93,9 @@ def test_mgpu_grouped_asynchronous_launches(data, ids, gather, endo):
         mg.close()
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["windows", "virtual_windows"])
 @pytest.mark.parametrize("ids,gather,fault", [([0], "rccl", 0), ([0, 0, 0], "host", 1), ([0] * 8, "host", 7)])
-def test_mgpu_a_failing_device_is_reported_within_a_bound_and_the_next_launch_succeeds(data, ids, gather, fault):
+def test_mgpu_a_failing_device_is_reported_within_a_bound_and_the_next_launch_succeeds(data, ids, gather, fault, wide):
     """One device's launch fails (msm_hip_mgpu_inject_fault: before anything is queued there, as a busy slot, an allocation failure or a HIP
     error would).  RCCL gather: that device still issues its call of the launch's all-gather (zeroed block), so the collective completes,
     finish returns the error in bounded time, launches already in flight behind it are unaffected and the next launch succeeds.  (With one
@@ -104,7 +105,7 @@ def test_mgpu_a_failing_device_is_reported_within_a_bound_and_the_next_launch_su
     n, points, scalars, want = data
     mg = m.MultiGpuMsm(ids, gather)
     try:
-        mg.set_bases(points)
+        mg.set_bases(points, precompute="wide" if wide else False)   # (wide: the shares are virtual windows, the gathered records come in pairs)
         mg.launch_batch(scalars, n, 0)
         assert mg.finish_batch(0, 1)[0].to_affine_bytes() == want
         mg.inject_fault(fault, 1)
@@ -129,11 +130,11 @@ def test_mgpu_two_distinct_devices_over_rccl(data):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     n, points, scalars, want = data
-    for endo in (False, True):
+    for endo, wide in ((False, False), (True, False), (False, True)):   # 16 windows, 8 half-length windows, the virtual windows of wide tables (pairs of records)
         mg = m.MultiGpuMsm([0, 1], "rccl")
         try:
             assert mg.uses_rccl
-            mg.set_bases(points, endomorphism=endo)
+            mg.set_bases(points, endomorphism=endo, precompute="wide" if wide else False)
             assert mg.msm(scalars).to_affine_bytes() == want
             g = mg.group_size
             for k in range(3):
