@@ -387,7 +387,8 @@ int msm_hip_mgpu_inject_fault(msm_hip_mgpu* m, int device_index, int launches);
 
 const char* msm_hip_strerror(int code);
 int msm_hip_last_hip_error(msm_hip_ctx* ctx);
-/* ABI version; bumped on any signature change */
+/* ABI version; bumped on any signature change or addition (7 = round 5: curve-neutral names with the `_bn254` aliases kept, the virtual-window
+ * launches and their pair combine, msm_hip_msm_curve, msm_hip_mgpu_set_wide_bits) */
 int msm_hip_abi_version(void);
 
 /* ---- aliases: the names of rounds 1 - 4 (the reference instantiates its generic functions with halo2curves::bn256 only, src/lib.rs:91,154). Each is

@@ -971,7 +971,7 @@ int run_batch_groups(msm_hip_ctx* ctx, size_t n, size_t batch, uint8_t* out_xyz,
 
 extern "C" {
 
-int msm_hip_abi_version(void) { return 6; }
+int msm_hip_abi_version(void) { return 7; }  // 7 (round 5): curve-neutral names, virtual-window launches + pair combine, msm_hip_msm_curve, msm_hip_mgpu_set_wide_bits
 
 const char* msm_hip_strerror(int code) {
   switch (code) {

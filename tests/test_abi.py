@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported(built):
     assert len(names) >= 25
     for name in names:
         assert hasattr(L, name), name
-    assert L.msm_hip_abi_version() == 6
+    assert L.msm_hip_abi_version() == 7
     assert b"ok" == L.msm_hip_strerror(0)
 
 
@@ -216,7 +216,7 @@ def test_header_is_plain_c_and_links_from_c(built, tmp_path):
 int main(void) {
   int nw = 0, nb = 0, b = 0, e = 0;
   unsigned char sums[96 * 16], out[96];
-  if (msm_hip_abi_version() != 6) return 1;
+  if (msm_hip_abi_version() != 7) return 1;
   if (msm_hip_window_config(16, &nw, &nb) != MSM_HIP_OK || nw != 16 || nb != 32768) return 2;
   if (msm_hip_endomorphism_window_count(16) != 8) return 3;
   if (msm_hip_window_range(3, 8, 16, &b, &e) != MSM_HIP_OK || b != 6 || e != 8) return 4;
