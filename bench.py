@@ -814,11 +814,13 @@ def main():
         wrun.run(steady // 2 + max(args.warmup, 1), None)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        wrun.run(args.steps, None)
+        wide_stages = []
+        wrun.run(args.steps, wide_stages)
         torch.cuda.synchronize()
         wide_elapsed = time.perf_counter() - t1
         wide_line = {"value": args.steps / wide_elapsed, "unit": "MSM/s", "ms_per_step": wide_elapsed * 1e3 / args.steps, "digit_bits": ctx.wide_bits(),
                      "msms_per_launch": wrun.group, "table_setup_ms": setup_ms, "same_result_as_headline_mode": same,
+                     "roofline": wrun.roofline(wide_stages),  # this mode's SMVP launches over its own timed steps (fewer entries per point than the headline's)
                      "untimed_steps_before_timed_region": wrun.group * wrun.depth + steady // 2 + max(args.warmup, 1),
                      "note": "opt-in MSM_HIP_BASES_PRECOMPUTE_WIDE (fixed bases: 13 - 15 x the base memory); steady-state protocol (compare with value_steady_state), measured after the headline"}
         ctx.set_stage_timing(2)

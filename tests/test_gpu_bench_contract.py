@@ -38,6 +38,8 @@ def test_single_gpu_line_has_the_contract_keys(built):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1 and "traffic" in rf and "kernel_ms_rocprof" in rf
     # grouped small MSMs run 14-bit windows: the algorithmic bytes follow the engine's window size, not the 16-bit constants
     assert d["config"]["window_bits"] == 14 and d["config"]["msms_per_launch"] > 1
+    wl = d["fixed_base_tables_wide"]  # the opt-in mode's line carries its own SMVP roofline (its stage times explain a difference to the headline)
+    assert wl["same_result_as_headline_mode"] is True and wl["value"] > 0 and 0 < wl["roofline"]["frac"] < 1 and wl["roofline"]["kernel_ms"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "MSM/s" and cb["value"] > 0 and "sample" in cb
     # BASELINE.json's other configs on the same line, each verified in the run (round 5)
