@@ -189,7 +189,10 @@ int msm_hip_uses_endomorphism(const msm_hip_ctx* ctx); /* 1: the resident bases 
 int msm_hip_batch_group_size(msm_hip_ctx* ctx, size_t n);
 
 /* ---- run: sum_i scalars[i] * bases[i] over the first n bases (n <= number of bases set).
- *      ≙ compute_msm stages 1-5, src/cuzk/msm.rs:96-416 (decompose, transpose, SMVP, bucket reduce, Horner) ---- */
+ *      ≙ compute_msm stages 1-5, src/cuzk/msm.rs:96-416 (decompose, transpose, SMVP, bucket reduce, Horner).
+ *      Host scalars, from 2^20 points on (round 5; not with fixed-base tables, not while the caller has launches of its own in slots 1 - 2): the call is
+ *      the sum of 2 (from 2^22: 3) sub-MSMs over ranges of the points, one result slot each, so that a range's scalars cross the host link while
+ *      the previous range is accumulated; the results are added on the host.  Same group element. ---- */
 int msm_hip_run(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
 int msm_hip_run_device(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, uint8_t out_xyz[96]);
 /* asynchronous halves of run_device: `launch` enqueues all device work of one MSM into result slot `slot` (0 .. MSM_HIP_NUM_SLOTS-1)
@@ -317,7 +320,10 @@ int msm_hip_g1_to_affine_bn254(const uint8_t xyz[96], uint8_t out_xy[64]);
  *      creating and destroying one per call as the reference does with its wgpu device (creation, first-use allocations and the frees
  *      cost more than a 2^20 MSM); calls are serialised by a process-wide mutex, results do not depend on it.
  *      msm_hip_oneshot_release() frees the kept contexts (call it before unloading the library or to return the device memory);
- *      MSM_HIP_ONESHOT_KEEP=0 in the environment restores create / destroy per call. ---- */
+ *      MSM_HIP_ONESHOT_KEEP=0 in the environment restores create / destroy per call.
+ *      Round 5: the scalars are uploaded first and sorted while the points arrive in chunks, and from 2^19 points on the call runs as TWO sub-MSMs over
+ *      the two halves of the points (a context each, uploads one behind the other): the first half accumulates while the second is still arriving, and
+ *      only the second half's accumulation follows the upload; the two results are added on the host.  The result is the same group element. ---- */
 int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]);
 /* the same on any curve of this library (MSM_HIP_CURVE_*; record sizes as that curve's): msm_hip_msm_bn254_g1 is curve 0 */
 int msm_hip_msm_curve(int curve, const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t* out_xyz);
@@ -383,6 +389,10 @@ int msm_hip_test_g1_mul_u32(msm_hip_ctx* ctx, const uint8_t* a, const uint32_t* 
 /* test hook: the next `launches` window-sharded launches fail on device index `device_index` (MSM_HIP_ERR_HIP, before anything is queued
  * there) -- the rehearsal of one failing GPU.  Armed only through this call (round 5: no environment variable can make a deployment's launches fail). */
 int msm_hip_mgpu_inject_fault(msm_hip_mgpu* m, int device_index, int launches);
+
+/* test hook: the part policy of the one-shot call (msm_hip_msm_curve: `parts` sub-MSMs over ranges of the points when n >= min_points; 0, 0 restores
+ * the default of 2 parts from 2^19 points on) -- so that a test reaches the multi-part path with inputs the oracle finishes in seconds. */
+int msm_hip_test_oneshot_parts(int parts, size_t min_points);
 #endif /* MSM_HIP_TEST_HOOKS */
 
 const char* msm_hip_strerror(int code);

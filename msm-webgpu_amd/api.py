@@ -86,6 +86,8 @@ def lib():
         L.msm_hip_slot_sync.argtypes = [vp, i]
         L.msm_hip_combine_windows_bn254.argtypes = [u8p, i, u8p]
         L.msm_hip_msm_bn254_g1.argtypes = [u8p, u8p, sz, u8p]
+        L.msm_hip_msm_curve.argtypes = [i, u8p, u8p, sz, u8p]
+        L.msm_hip_test_oneshot_parts.argtypes = [i, sz]
         L.msm_hip_oneshot_release.argtypes = []
         L.msm_hip_oneshot_release.restype = None
         L.msm_hip_sample_scalars_device.argtypes = [vp, C.c_uint64, sz, vp]

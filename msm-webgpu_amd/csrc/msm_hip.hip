@@ -102,8 +102,27 @@ struct Slot {
   int timing_level = 0;
   int w_begin = 0, w_count = 0, nvec = 1;  // windows [w_begin, w_begin + w_count) of nvec scalar vectors
   size_t n = 0;
+  size_t base_off = 0;  // first base of this launch (records): point i of the launch is base base_off + i
 };
 
+}  // namespace
+
+namespace {
+// Part policy of the upload-bound call shapes (msm_hip_msm_curve: bases + scalars from the host; msm_hip_run: scalars from the host): 0 = the default
+// (MSM_HIP_ONESHOT_PARTS, else 2 parts from 2^19 points on); set by the test hook msm_hip_test_oneshot_parts
+std::atomic<int> g_oneshot_parts{0};
+std::atomic<size_t> g_oneshot_parts_min_n{0};
+// `two_from`, `three_from`: log2 of the point counts from which the call shape runs 2 / 3 parts (measured: profiles/r05_oneshot.txt)
+inline int upload_parts(size_t n, int cap, int two_from, int three_from) {
+  static const int env_parts = [] { const char* e = getenv("MSM_HIP_ONESHOT_PARTS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? v : 0; }();
+  const int hook = g_oneshot_parts.load();
+  const size_t hook_n = g_oneshot_parts_min_n.load();
+  int want = hook ? hook : env_parts;
+  if (!want) want = n >= ((size_t)1 << three_from) ? 3 : 2;
+  if (want > cap) want = cap;
+  const size_t min_n = hook_n ? hook_n : ((size_t)1 << two_from);
+  return n >= min_n && n >= (size_t)want ? want : 1;
+}
 }  // namespace
 
 struct msm_hip_ctx {
@@ -116,6 +135,7 @@ struct msm_hip_ctx {
   int last_hip_error = 0;
 
   uint32_t* d_bases = nullptr;  // n_bases x 16 words
+  size_t launch_base_off = 0;   // consumed by the next launch: it runs over the bases [off, off + n) (internal: the parts of msm_hip_run)
   size_t n_bases = 0, cap_bases = 0;  // points per table; capacity in point records (16 x n_bases with fixed-base tables)
   bool precomputed = false;           // d_bases holds the 16 tables 2^(16 w) P_i (MSM_HIP_BASES_PRECOMPUTE)
   int wide_bits_choice = 0;           // msm_hip_set_wide_bits: the digit width the next wide base set gets (0: by the number of bases)
@@ -716,7 +736,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   static const unsigned smvp_lds_pad = [] { const char* e = getenv("MSM_HIP_SMVP_LDS_PAD"); const long v = e ? atol(e) : 0; return v > 0 && v <= 65536 ? (unsigned)v : 0u; }();
   HIP_TRY(ctx, tl >= 2 ? hipEventRecord(s.ev[4], st) : hipSuccess);
   hipExtLaunchKernelGGL(ctx->ops->smvp_chunks, dim3((chunks + 255) / 256, w_count), dim3(256), smvp_lds_pad, st, tl == 1 ? s.ev[4] : nullptr,
-                        tl == 1 ? s.ev[5] : nullptr, 0, (const uint32_t*)ctx->d_bases, (const uint32_t*)s.d_col_ptr, (const uint32_t*)ctx->d_val, stride, chunks,
+                        tl == 1 ? s.ev[5] : nullptr, 0, (const uint32_t*)(ctx->d_bases + s.base_off * 2 * (size_t)ctx->ops->coord_words), (const uint32_t*)s.d_col_ptr, (const uint32_t*)ctx->d_val, stride, chunks,
                         (const uint32_t*)d_chunk_len, (const uint32_t*)ctx->d_chunk_slot, s.d_buckets, s.d_heads, s.d_tails, half);
   AFTER_KERNEL(ctx, "k_smvp_chunks", st);
   HIP_TRY(ctx, tl >= 2 ? hipEventRecord(s.ev[5], st) : hipSuccess);
@@ -1121,7 +1141,10 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
   const bool merge = mode == MODE_TABLES, halves = mode == MODE_HALVES, wide = mode == MODE_WIDE;
   const bool pairs = wide && v_count != 0;
   int rc = check_run_args(ctx, scalars_dev, n);
+  const size_t base_off = ctx ? ctx->launch_base_off : 0;
+  if (ctx && phase != 1) ctx->launch_base_off = 0;  // (a two-phase launch passes here twice)
   if (rc) return rc;
+  if (base_off + n > ctx->n_bases) return MSM_HIP_ERR_INVALID_ARG;
   if (slot < 0 || slot >= NSLOT || w_begin < 0 || w_end > nwin_of(wbits, halves) || w_begin >= w_end) return MSM_HIP_ERR_INVALID_ARG;
   if (wide && (nvec < 1 || w_begin != 0 || wbits != ctx->wide_bits || w_end != wide_tables_of(wbits))) return MSM_HIP_ERR_INVALID_ARG;
   if (wide && !pairs && (nvec * wide_vwin_of(ctx->wide_bits) > 24 || window_sums_dev)) return MSM_HIP_ERR_INVALID_ARG;
@@ -1137,6 +1160,7 @@ int launch_impl(msm_hip_ctx* ctx, const void* scalars_dev, size_t n, int nvec, i
   if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;  // its result was never collected (msm_hip_finish / msm_hip_slot_sync)
   if ((rc = setup_slot(ctx, s))) return rc;
   s.n = n;
+  s.base_off = base_off;
   s.w_begin = w_begin;
   s.w_count = w_count;
   s.nvec = nvec;
@@ -1338,6 +1362,29 @@ int msm_hip_launch(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, int 
 
 int msm_hip_run(msm_hip_ctx* ctx, const uint8_t* scalars_host, size_t n, uint8_t out_xyz[96]) {
   if (!out_xyz || !ctx) return MSM_HIP_ERR_INVALID_ARG;
+  // Parts (round 5): 32 n bytes over the host link come before anything can run.  From 2^19 points on the call is the sum of sub-MSMs over
+  // ranges of the points, one result slot each: part k + 1's scalars arrive while part k is sorted and accumulated, and the results are added
+  // on the host.  (Not with fixed-base tables: their launches are shaped by the table count.)
+  int parts = ctx->precomputed || ctx->wide_bits || !scalars_host ? 1 : upload_parts(n, NSLOT, 20, 22);  // (2^20: 2.44 -> 2.38 ms, 2^22: 8.61 -> 6.91; 2^19: slower)
+  for (int k = 0; k < parts; k++)
+    if (ctx->slot[k].pending) parts = 1;  // the caller has launches of its own in flight: the plain path (which reports a busy slot 0)
+  if (parts > 1 && n <= ctx->n_bases) {
+    uint8_t sums[NSLOT * MAX_JB];
+    int rc = MSM_HIP_OK, launched = 0;
+    for (int k = 0; k < parts && !rc; k++) {
+      const size_t first = n / parts * k + (n % parts < (size_t)k ? n % parts : (size_t)k), next = n / parts * (k + 1) + (n % parts < (size_t)(k + 1) ? n % parts : (size_t)(k + 1));
+      ctx->launch_base_off = first;
+      rc = msm_hip_launch(ctx, scalars_host + first * 32, next - first, k);
+      ctx->launch_base_off = 0;
+      if (!rc) launched++;
+    }
+    for (int k = 0; k < launched; k++) {
+      const int frc = msm_hip_finish(ctx, k, sums + (size_t)k * ctx->jb);
+      if (!rc) rc = frc;
+    }
+    if (!rc && !ctx->ops->combine_windows(sums, parts, 0, out_xyz)) rc = MSM_HIP_ERR_NONCANONICAL;  // (window_bits = 0: the plain sum)
+    return rc;
+  }
   ctx->sync_call = true;
   int rc = msm_hip_launch(ctx, scalars_host, n, 0);
   ctx->sync_call = false;
@@ -1448,8 +1495,9 @@ int msm_hip_g1_to_affine_curve(int curve, const uint8_t xyz[96], uint8_t out_xy[
 // msm_hip_oneshot_release() drops the kept contexts; MSM_HIP_ONESHOT_KEEP=0 restores create / destroy per call.
 namespace {
 constexpr int ONESHOT_MAX_DEVICES = 64;
+constexpr int ONESHOT_MAX_PARTS = 4;  // contexts per (curve, device): a large one-shot MSM runs as up to this many sub-MSMs over ranges of the points (below)
 std::mutex g_oneshot_mutex;
-msm_hip_ctx* g_oneshot_ctx[MSM_HIP_NUM_CURVES][ONESHOT_MAX_DEVICES] = {};
+msm_hip_ctx* g_oneshot_ctx[MSM_HIP_NUM_CURVES][ONESHOT_MAX_DEVICES][ONESHOT_MAX_PARTS] = {};
 inline bool oneshot_keep() {
   static const bool v = [] { const char* e = getenv("MSM_HIP_ONESHOT_KEEP"); return !(e && e[0] == '0'); }();
   return v;
@@ -1464,8 +1512,13 @@ namespace {
 // the 64 n bytes of points are still arriving -- in chunks on the copy stream, each converted to the device form (and its endomorphism image
 // made) as soon as it has landed --, and only the SMVP (launch phase 2) waits for the last chunk.  Hidden: the sort (~0.26 ms at 2^20), the
 // conversion kernels (~0.1 ms) and one host synchronisation.  MSM_HIP_ONESHOT_OVERLAP=0: upload, convert, then run (rounds 1 - 4).
-int oneshot_overlapped(msm_hip_ctx* ctx, const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, uint8_t* out_xyz) {
+// Two halves: oneshot_enqueue queues everything (copies on `cs` -- the copy stream of the call's FIRST part, so that the parts' uploads follow each
+// other instead of sharing the link -- and both launch phases), oneshot_collect waits for the result.  `he_out`: the first HIP error of the
+// chunk loop (the launch is completed regardless, its result discarded).
+int oneshot_enqueue(msm_hip_ctx* ctx, hipStream_t cs, const uint8_t* xy_host, const uint8_t* scalars_host, size_t n, hipError_t* he_out, bool* queued) {
   ON_DEVICE(ctx);
+  *he_out = hipSuccess;
+  *queued = false;  // true: the launch was taken to its second phase -- oneshot_collect has to follow, whatever this function returns
   const uint32_t flags = resolve_base_flags(ctx, n, 0);
   const bool endo = (flags & MSM_HIP_BASES_ENDOMORPHISM) != 0;
   int rc = reserve_bases(ctx, n, flags);  // (waits for the main stream: nothing is reading the old bases)
@@ -1473,7 +1526,6 @@ int oneshot_overlapped(msm_hip_ctx* ctx, const uint8_t* xy_host, const uint8_t* 
   Slot& s = ctx->slot[0];
   if (s.pending) return MSM_HIP_ERR_SLOT_BUSY;
   if ((rc = setup_slot(ctx, s))) return rc;
-  if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
   if (!ctx->bases_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->bases_ready, hipEventDisableTiming));
   if (n > s.cap_host_scalars) {
     s.cap_host_scalars = 0;
@@ -1481,10 +1533,10 @@ int oneshot_overlapped(msm_hip_ctx* ctx, const uint8_t* xy_host, const uint8_t* 
     s.cap_host_scalars = n;
   }
   // 1. the scalars, and their sort
-  HIP_TRY(ctx, hipMemcpyAsync(s.d_host_scalars, scalars_host, n * 32, hipMemcpyHostToDevice, ctx->copy_stream));
-  HIP_TRY(ctx, hipEventRecord(s.staged, ctx->copy_stream));
+  HIP_TRY(ctx, hipMemcpyAsync(s.d_host_scalars, scalars_host, n * 32, hipMemcpyHostToDevice, cs));
+  HIP_TRY(ctx, hipEventRecord(s.staged, cs));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.staged, 0));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0, 4, ctx->copy_stream));  // (ahead of every chunk's copy, hence of every conversion)
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0, 4, cs));  // (ahead of every chunk's copy, hence of every conversion)
   ctx->n_bases = n;  // (what the launch checks n against; the records themselves follow below)
   ctx->endo = endo;
   const LaunchMode mode = endo ? MODE_HALVES : MODE_PLAIN;
@@ -1512,8 +1564,8 @@ int oneshot_overlapped(msm_hip_ctx* ctx, const uint8_t* xy_host, const uint8_t* 
     uint32_t* dst = ctx->d_bases + first * 2 * (size_t)ctx->ops->coord_words;
     hipEvent_t& landed = ctx->chunk_landed[k & 7];
     if (!landed && (he = hipEventCreateWithFlags(&landed, hipEventDisableTiming)) != hipSuccess) break;
-    if ((he = hipMemcpyAsync(dst, xy_host + first * ctx->pb, count * ctx->pb, hipMemcpyHostToDevice, ctx->copy_stream)) != hipSuccess) break;
-    if ((he = hipEventRecord(landed, ctx->copy_stream)) != hipSuccess) break;
+    if ((he = hipMemcpyAsync(dst, xy_host + first * ctx->pb, count * ctx->pb, hipMemcpyHostToDevice, cs)) != hipSuccess) break;
+    if ((he = hipEventRecord(landed, cs)) != hipSuccess) break;
     if ((he = hipStreamWaitEvent(conv, landed, 0)) != hipSuccess) break;
     hipLaunchKernelGGL(ctx->ops->convert_points, dim3(blocks_for(count, 256)), dim3(256), 0, conv, dst, dst, count, flags, ctx->d_err);
     if (endo) hipLaunchKernelGGL(ctx->ops->endo_points, dim3(blocks_for(count, 256)), dim3(256), 0, conv, ctx->d_bases, n, first, count);
@@ -1523,8 +1575,17 @@ int oneshot_overlapped(msm_hip_ctx* ctx, const uint8_t* xy_host, const uint8_t* 
   if (he == hipSuccess) he = hipStreamWaitEvent(ctx->stream, ctx->bases_ready, 0);
   // 3. the rest of the launch (on failure above too: phase 1 left the slot's streams mid-launch -- the bases it then reads are whatever arrived,
   //    and the result is discarded)
+  *queued = true;
   rc = launch_impl(ctx, s.d_host_scalars, n, 1, 0, w_end, wbits, 0, nullptr, mode, 0, 0, 2);
   ctx->sync_call = false;
+  *he_out = he;
+  return rc;
+}
+
+// ... and the wait: the result of the part (discarded after a failure of its enqueue half), then the conversion's error word
+int oneshot_collect(msm_hip_ctx* ctx, int rc, hipError_t he, uint8_t* out_xyz) {
+  ON_DEVICE(ctx);
+  hipStream_t conv = ctx->reduce_stream[NREDUCE - 1];
   uint8_t scratch[MAX_JB];
   const int frc = rc ? rc : msm_hip_finish(ctx, 0, he == hipSuccess ? out_xyz : scratch);
   uint32_t base_bits = 0;  // the conversion's error word (read last: the launch was queued behind the copy stream before the host waits for anything)
@@ -1551,25 +1612,54 @@ int msm_hip_msm_curve(int curve, const uint8_t* xy_host, const uint8_t* scalars_
   if (hipGetDevice(&dev) != hipSuccess) return MSM_HIP_ERR_NO_DEVICE;  // the caller's current device (0 unless it chose another)
   if (!out_xyz || ((!xy_host || !scalars_host) && n)) return MSM_HIP_ERR_INVALID_ARG;
   const bool keep = oneshot_keep() && dev >= 0 && dev < ONESHOT_MAX_DEVICES;
-  std::unique_lock<std::mutex> lock(g_oneshot_mutex, std::defer_lock);
-  msm_hip_ctx* ctx = nullptr;
-  int rc = MSM_HIP_OK;
-  if (keep) {
-    lock.lock();
-    ctx = g_oneshot_ctx[curve][dev];
-  }
-  if (!ctx) {
-    if ((rc = msm_hip_ctx_create_curve(&ctx, dev, curve))) return rc;
-    if (keep) g_oneshot_ctx[curve][dev] = ctx;
-  }
+  std::lock_guard<std::mutex> lock(g_oneshot_mutex);  // (also without `keep`: the part policy below is process-wide state)
   static const bool overlap = [] { const char* e = getenv("MSM_HIP_ONESHOT_OVERLAP"); return !e || atoi(e) != 0; }();
-  if (overlap && n > 0 && n <= MAX_POINTS / 2) {
-    rc = oneshot_overlapped(ctx, xy_host, scalars_host, n, out_xyz);
-  } else {
-    rc = msm_hip_set_bases(ctx, xy_host, n, 0);
-    if (!rc) rc = msm_hip_run(ctx, scalars_host, n, out_xyz);
+  // Parts (round 5): a large one-shot MSM is upload-bound -- 96 n bytes over the host link against ~1 ms of SMVP at 2^20 --, and the SMVP cannot start
+  // before the last point has arrived.  Sum over the points is sum over RANGES of the points: the call runs as `parts` sub-MSMs, each on a context
+  // of its own, their uploads queued one behind the other on one copy stream, so that part k accumulates its buckets while part k + 1 is still
+  // arriving and only the LAST part's SMVP (n / parts points) follows the upload.  The results are added on the host (parts - 1 additions).
+  // 2 parts from 2^19 points on (MSM_HIP_ONESHOT_PARTS: tuning aid; more parts pay more per-part sorting, stitching and bucket reducing).
+  const bool overlapped = overlap && n > 0 && n <= MAX_POINTS / 2;
+  const int parts = overlapped ? upload_parts(n, ONESHOT_MAX_PARTS, 19, 30) : 1;  // (2^19: 2.00 -> 1.93 ms, 2^20: 3.55 -> 3.08, 2^22: 13.2 -> 11.1; three parts never better)
+  msm_hip_ctx* ctxs[ONESHOT_MAX_PARTS] = {};
+  int rc = MSM_HIP_OK;
+  for (int k = 0; k < parts && !rc; k++) {
+    if (keep) ctxs[k] = g_oneshot_ctx[curve][dev][k];
+    if (!ctxs[k]) {
+      rc = msm_hip_ctx_create_curve(&ctxs[k], dev, curve);
+      if (!rc && keep) g_oneshot_ctx[curve][dev][k] = ctxs[k];
+    }
   }
-  if (!keep) msm_hip_ctx_destroy(ctx);
+  if (!rc && !overlapped) {
+    rc = msm_hip_set_bases(ctxs[0], xy_host, n, 0);
+    if (!rc) rc = msm_hip_run(ctxs[0], scalars_host, n, out_xyz);
+  } else if (!rc) {
+    msm_hip_ctx* c0 = ctxs[0];
+    if (!c0->copy_stream) {
+      DeviceGuard guard(c0->device);
+      if (hipStreamCreateWithFlags(&c0->copy_stream, hipStreamNonBlocking) != hipSuccess) rc = MSM_HIP_ERR_HIP;
+    }
+    int prc[ONESHOT_MAX_PARTS] = {};
+    hipError_t phe[ONESHOT_MAX_PARTS] = {};
+    bool queued[ONESHOT_MAX_PARTS] = {};
+    uint8_t sums[ONESHOT_MAX_PARTS * MAX_JB];
+    const size_t pb = c0->pb, jb = c0->jb;
+    size_t first[ONESHOT_MAX_PARTS + 1];
+    for (int k = 0; k <= parts; k++) first[k] = n / parts * k + (n % parts < (size_t)k ? n % parts : (size_t)k);
+    for (int k = 0; k < parts && !rc; k++) {
+      prc[k] = oneshot_enqueue(ctxs[k], c0->copy_stream, xy_host + first[k] * pb, scalars_host + first[k] * 32, first[k + 1] - first[k], &phe[k], &queued[k]);
+      if (prc[k] && !queued[k]) rc = prc[k];  // nothing of this part is in flight: stop queueing, drain the earlier ones
+    }
+    for (int k = 0; k < parts; k++) {
+      if (!queued[k]) continue;
+      const int crc = oneshot_collect(ctxs[k], prc[k], phe[k], parts == 1 ? out_xyz : sums + (size_t)k * jb);
+      if (!rc) rc = crc;
+    }
+    if (!rc && parts > 1 && !c0->ops->combine_windows(sums, parts, 0, out_xyz)) rc = MSM_HIP_ERR_NONCANONICAL;  // (window_bits = 0: the plain sum of the records)
+  }
+  if (!keep)
+    for (msm_hip_ctx* c : ctxs)
+      if (c) msm_hip_ctx_destroy(c);
   return rc;
 }
 
@@ -1577,13 +1667,22 @@ int msm_hip_msm_bn254_g1(const uint8_t* xy_host, const uint8_t* scalars_host, si
   return msm_hip_msm_curve(MSM_HIP_CURVE_BN254_G1, xy_host, scalars_host, n, out_xyz);
 }
 
+// test hook: the one-shot call's part policy (0, 0 restores the default: 2 parts from 2^19 points on) -- lets a test run several parts on small inputs
+int msm_hip_test_oneshot_parts(int parts, size_t min_points) {
+  if (parts < 0 || parts > ONESHOT_MAX_PARTS) return MSM_HIP_ERR_INVALID_ARG;
+  g_oneshot_parts.store(parts);
+  g_oneshot_parts_min_n.store(min_points);
+  return MSM_HIP_OK;
+}
+
 void msm_hip_oneshot_release(void) {
   std::lock_guard<std::mutex> lock(g_oneshot_mutex);
   for (auto& per_curve : g_oneshot_ctx)
-    for (msm_hip_ctx*& c : per_curve) {
-      if (c) msm_hip_ctx_destroy(c);
-      c = nullptr;
-    }
+    for (auto& per_device : per_curve)
+      for (msm_hip_ctx*& c : per_device) {
+        if (c) msm_hip_ctx_destroy(c);
+        c = nullptr;
+      }
 }
 
 int msm_hip_sample_scalars_device(msm_hip_ctx* ctx, uint64_t seed, size_t n, void* scalars_dev) {

@@ -407,3 +407,96 @@ def test_one_shot_keeps_its_context_between_calls(built):
         assert L.msm_hip_msm_bn254_g1(cpu.sample_points(1, 2), bytes(64), 2, out) == 0 and cpu.to_affine64(out.raw) == bytes(64)
         L.msm_hip_oneshot_release()
     L.msm_hip_oneshot_release()  # nothing kept: a no-op
+
+
+def test_one_shot_in_parts(built):
+    """Round 5: from 2^19 points on the one-shot call (≙ compute_msm, src/cuzk/msm.rs:75-94) runs as sub-MSMs over ranges of the points, a context each,
+    their uploads one behind the other, and adds the results on the host.  The test hook lowers the threshold so that the oracle checks every
+    part count on small inputs: ragged ranges, fewer points than parts, an input error in a LATER part (the earlier ones are drained, the kept
+    contexts stay usable), another curve, and the real threshold at 2^19 + 3 against the persistent context's result."""
+    import ctypes as C
+
+    from oracle import cpu_grumpkin as gcpu
+
+    L = m.lib()
+    out = C.create_string_buffer(96)
+    try:
+        for parts in (2, 3, 4):
+            assert L.msm_hip_test_oneshot_parts(parts, 1) == 0
+            for n, seed in ((1, 1), (3, 2), (5, 3), (301, 4), (5000, 5), (70001, 6), (302, 7)):
+                points, scalars = cpu.sample_points(900 + seed, n), cpu.sample_scalars(950 + seed, n)
+                assert L.msm_hip_msm_bn254_g1(points, scalars, n, out) == 0
+                assert cpu.to_affine64(out.raw) == cpu.to_affine64(cpu.cpu_msm(points, scalars)), (parts, n)
+            # a non-canonical scalar in the last part, a non-canonical coordinate in the first: the call fails as a whole, the next one works
+            n = 1000
+            points, scalars = cpu.sample_points(31, n), cpu.sample_scalars(32, n)
+            bad_sc = scalars[:-32] + b"\xff" * 32
+            assert L.msm_hip_msm_bn254_g1(points, bad_sc, n, out) == -4
+            bad_pt = b"\xff" * 32 + points[32:]
+            assert L.msm_hip_msm_bn254_g1(bad_pt, scalars, n, out) == -4
+            assert L.msm_hip_msm_bn254_g1(points, scalars, n, out) == 0
+            assert cpu.to_affine64(out.raw) == cpu.to_affine64(cpu.cpu_msm(points, scalars))
+            # opposite halves: part 1 = -(part 0) gives the identity
+            half = cpu.sample_points(33, 500)
+            neg = b"".join(half[64 * k:64 * k + 32] + ((cpu.constants()["p"] - int.from_bytes(half[64 * k + 32:64 * k + 64], "little")) % cpu.constants()["p"]).to_bytes(32, "little") for k in range(500))
+            sc = cpu.sample_scalars(34, 500)
+            if parts == 2:
+                assert L.msm_hip_msm_bn254_g1(half + neg, sc + sc, 1000, out) == 0 and cpu.to_affine64(out.raw) == bytes(64)
+        # another curve through the curve-neutral entry point
+        assert L.msm_hip_test_oneshot_parts(3, 1) == 0
+        gp, gs = gcpu.sample_points(41, 2001), gcpu.sample_scalars(42, 2001)
+        assert L.msm_hip_msm_curve(1, gp, gs, 2001, out) == 0 and gcpu.to_affine64(out.raw) == gcpu.to_affine64(gcpu.cpu_msm(gp, gs))
+    finally:
+        assert L.msm_hip_test_oneshot_parts(0, 0) == 0
+        L.msm_hip_oneshot_release()
+    # the default policy: two parts at 2^19 + 3 points; compared with the same MSM on a persistent context (one part by construction)
+    n = (1 << 19) + 3
+    c = m.MsmContext(0)
+    try:
+        pts, sc = c.sample_points(n, 77), c.sample_scalars(n, 78)
+        c.set_bases(pts, endomorphism=None)
+        want = c.msm(sc).to_affine()
+        pb, sb = bytes(pts.cpu().numpy().tobytes()), bytes(sc.cpu().numpy().tobytes())
+    finally:
+        c.close()
+    assert L.msm_hip_msm_bn254_g1(pb, sb, n, out) == 0
+    assert m.G1(out.raw).to_affine() == want
+    L.msm_hip_oneshot_release()
+
+
+def test_host_scalar_run_in_parts(built):
+    """msm_hip_run with host scalars (scope B: resident bases, 32 n bytes over the host link per call) runs from 2^19 points on as sub-MSMs over ranges
+    of the points, one result slot each, so that a part's scalars arrive while the previous part is accumulated.  With the threshold lowered by the
+    test hook: every part count, ragged ranges, fewer scalars than bases, both base modes, a bad scalar in a later part, a busy slot (falls back to
+    the one-part path), and the default policy at 2^20 + 5 against the device-scalar path (one part by construction)."""
+    L = m.lib()
+    n = 6001
+    points, scalars = cpu.sample_points(61, n), cpu.sample_scalars(62, n)
+    c = m.MsmContext(0)
+    try:
+        for endo in (None, False):
+            c.set_bases(points, endomorphism=endo)
+            for parts in (2, 3, 4):
+                assert L.msm_hip_test_oneshot_parts(parts, 1) == 0
+                for k in (n, 4097, 7, 2):
+                    assert c.msm(scalars[:32 * k]).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points[:64 * k], scalars[:32 * k])), (endo, parts, k)
+                with pytest.raises(m.MsmHipError):
+                    c.msm(scalars[:-32] + b"\xff" * 32)
+                assert c.msm(scalars).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points, scalars))
+            # a launch of the caller's own in slot 1: the call takes the one-part path and leaves that launch alone
+            assert L.msm_hip_test_oneshot_parts(2, 1) == 0
+            c.launch_host(scalars[:32 * 100], 1)
+            assert c.msm(scalars).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points, scalars))
+            assert c.finish(1).to_affine_bytes() == cpu.to_affine64(cpu.cpu_msm(points[:64 * 100], scalars[:32 * 100]))
+    finally:
+        assert L.msm_hip_test_oneshot_parts(0, 0) == 0
+        c.close()
+    n = (1 << 20) + 5
+    c = m.MsmContext(0)
+    try:
+        pts, sc = c.sample_points(n, 81), c.sample_scalars(n, 82)
+        c.set_bases(pts, endomorphism=None)
+        want = c.msm(sc)                                   # device scalars: one launch
+        assert c.msm(bytes(sc.cpu().numpy().tobytes())) == want   # host scalars: two parts by the default policy
+    finally:
+        c.close()
