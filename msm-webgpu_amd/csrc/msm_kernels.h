@@ -1796,7 +1796,10 @@ __device__ __forceinline__ void smvp_assign(g1_xyzz& acc, const g1_xyzz& src) {
 #ifndef MSM_SMVP_WAVES_WIDE
 #define MSM_SMVP_WAVES_WIDE 1  // Fq2 on 14 limbs (BLS12-381 G2): 256 VGPRs + 130 AGPRs at one wave; two waves = a 256-register cap with scratch (A/B: profiles/r04_g2_two_waves.txt)
 #endif
-constexpr int SMVP_WAVES_PER_SIMD = FQ_L <= 9 ? 3 : FQ_L <= 18 ? 2 : MSM_SMVP_WAVES_WIDE;
+#ifndef MSM_SMVP_WAVES_9
+#define MSM_SMVP_WAVES_9 3  // (2: experiment -- a third of the register file and of the wave slots left to the kernels of another launch, profiles/r05_two_context_overlap.txt)
+#endif
+constexpr int SMVP_WAVES_PER_SIMD = FQ_L <= 9 ? MSM_SMVP_WAVES_9 : FQ_L <= 18 ? 2 : MSM_SMVP_WAVES_WIDE;
 // the stitch and the row / column sums (full additions: the widest kernels after the SMVP) in a unit with 18 limbs per coordinate: two waves per
 // SIMD as well (256 VGPRs + 0.26 KB of scratch instead of 309 - 317 + AGPRs: -1.5 % per MSM)
 #ifndef MSM_REDUCE_WAVES_FQ2
@@ -1809,6 +1812,9 @@ __global__ void __launch_bounds__(256, SMVP_WAVES_PER_SIMD) k_smvp_chunks(const 
                                                      uint32_t* __restrict__ buckets, uint32_t* __restrict__ heads,
                                                      uint32_t* __restrict__ tails, uint32_t half) {
   const uint32_t chunk_len = *chunk_len_dev;
+#if defined(__HIP_DEVICE_COMPILE__) && MSM_SMVP_WAVES_9 == 2
+  if constexpr (FQ_L <= 9) asm volatile("; two waves per SIMD" ::: "v175");  // 176 VGPRs allocated: 2 waves per SIMD whatever the loop needs
+#endif
   const int lw = blockIdx.y;
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;
   const uint32_t* cp = col_ptr + (size_t)lw * (half + 1);

@@ -41,3 +41,16 @@ def test_fuzz_wide_tables_against_oracle(built, capsys, monkeypatch):
     finally:
         sys.argv = argv
     assert "fuzz ok: 40 cases" in capsys.readouterr().out
+
+
+@pytest.mark.parametrize("curve,cases", [("bn254", 24), ("grumpkin", 10), ("bls12_381", 6), ("bn254_g2", 6)])
+def test_fuzz_upload_bound_calls_in_parts(built, capsys, monkeypatch, curve, cases):
+    """round 5: the one-shot call and msm_hip_run with host scalars as sums of 1 - 4 sub-MSMs over ranges of the points"""
+    monkeypatch.setenv("FUZZ_MODES", "oneshot_parts,run_parts")
+    argv = sys.argv
+    sys.argv = ["fuzz_gpu.py", str(cases), "20261007", curve]
+    try:
+        runpy.run_path(os.path.join(ROOT, "tools", "fuzz_gpu.py"), run_name="__main__")
+    finally:
+        sys.argv = argv
+    assert "fuzz ok: %d cases" % cases in capsys.readouterr().out

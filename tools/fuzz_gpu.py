@@ -56,7 +56,7 @@ CBY = ctx.cb  # bytes per coordinate (48 on BLS12-381)
 # BLS12-381's cofactor is not 1: the samplers' points are outside the order-r subgroup, where the endomorphism modes are not exact (and the
 # R = 2^256 input format is the 4-limb curves')
 MODES = ["host", "device", "windows", "batch", "group", "hostbatch", "mont", "bits", "tables", "tables_batch", "hostpipe", "mgpu", "endo", "endo_batch",
-         "group_halves", "mgpu_batch", "mgpu_batch_endo", "auto", "wide", "wide_batch", "wide_shares", "mgpu_wide"]
+         "group_halves", "mgpu_batch", "mgpu_batch_endo", "auto", "wide", "wide_batch", "wide_shares", "mgpu_wide", "oneshot_parts", "run_parts"]
 if curve == "bls12_381":
     MODES = [x for x in MODES if x not in ("mont", "endo", "endo_batch", "group_halves", "mgpu_batch_endo")]
 if curve.endswith("_g2"):  # (the "mont" case below writes G1 coordinates; the pool's points are multiples of G2's generator: the endomorphism modes are exact)
@@ -180,6 +180,24 @@ for case in range(cases):
             vecs[pos] = sb
             mg[key].launch_batch(b"".join(vecs), n, 1)
             got = mg[key].finish_batch(1, g)[pos]
+    elif mode in ("oneshot_parts", "run_parts"):
+        # the upload-bound call shapes as sums of sub-MSMs over ranges of the points (round 5): the one-shot call (a kept context per part) and
+        # msm_hip_run with host scalars (a result slot per part, launches on ranges of the resident bases); the test hook sets the part count
+        import ctypes
+        parts = rnd.randrange(1, 5)
+        assert m.lib().msm_hip_test_oneshot_parts(parts, 1) == 0
+        try:
+            if mode == "oneshot_parts":
+                out = ctypes.create_string_buffer(3 * CBY)
+                rc = m.lib().msm_hip_msm_curve(ctx.curve_id, points, sb, n, out)
+                assert rc == 0, rc
+                got = m.G1(out.raw, ctx.modulus)
+            else:
+                if rnd.random() < 0.5:
+                    ctx.set_bases(points, endomorphism=False)
+                got = ctx.msm(sb)
+        finally:
+            m.lib().msm_hip_test_oneshot_parts(0, 0)
     elif mode == "hostpipe":
         # host scalars through the copy stream, three slots in flight
         for slot in range(3):
@@ -269,4 +287,5 @@ for case in range(cases):
     if got.to_affine_bytes() != want:
         print("MISMATCH case", case, "n", n, "kind", kind, "mode", mode, "seeds", pseed, sseed)
         sys.exit(1)
+m.lib().msm_hip_oneshot_release()  # (the contexts the one-shot cases left behind)
 print("fuzz ok: %d cases in %.1f s (seed %d, %s)" % (cases, time.time() - t0, seed, curve))
