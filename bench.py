@@ -692,7 +692,9 @@ def main():
     # (msm_hip_launch: the copy of MSM i+1 runs on the copy stream under the device work of MSM i); C = one-shot incl.
     # base upload (≙ the reference's compute_msm call shape): the first call also creates the context the library then keeps
     scope_ms = None
-    if world == 1 and emulate <= 1 and args.logn <= 22:
+    # (not under rocprofv3: since round 5 these calls run as sub-MSMs over halves of the points -- half-size k_smvp_chunks launches that would mix into
+    #  the per-kernel averages and counter sums the profile of this command is read for)
+    if world == 1 and emulate <= 1 and args.logn <= 22 and "ROCP_TOOL_LIBRARIES" not in os.environ:
         sb_host = [s.cpu().numpy().tobytes() for s in scalar_sets]
         pb_host = points.cpu().numpy().tobytes()
         import ctypes
