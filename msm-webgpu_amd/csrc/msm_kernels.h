@@ -1946,6 +1946,11 @@ __global__ void __launch_bounds__(256, REDUCE_WAVES_PER_SIMD) k_smvp_stitch(cons
       }
     }
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // The queue pointer above is a scalar load issued inside a branch; in the units whose group addition is large (Fq2) the branches below are far
+  // ones, expanded through a scavenged SGPR pair -- which must not have that load still in flight (tools/check_long_branch_hazard.py)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #if MSM_STITCH_SORTED
   // Round 5: a slot's run spans 1 .. 5 chunks (64 entries per bucket against ~28 per chunk), and a wave walks as long as its longest run -- about 4.5
   // additions for a mean of 2.3.  The workgroup's 256 slots are therefore handed to its lanes in DESCENDING order of their addition count (a
