@@ -174,6 +174,7 @@ struct msm_hip_ctx {
   int window_bits = 0;                // 0: chosen from n for whole-MSM launches (pick_window_bits); else 12 / 14 / 16
   uint32_t* d_part_hist = nullptr;  // [MAXLW][128][FINE_SPLIT][256] sub-range histograms of huge coarse bins (k_fine_hist), on first use
   size_t fine_hist_min_n = FINE_BIG + 1;  // any n that can produce a coarse bin beyond FINE_BIG: run k_fine_hist (3 us when none does)
+  int skew_credit = 0;  // launches left for which k_fine_hist runs although uniform scalars could not fill a bin: set when a launch met a huge bin (wait_slot)
   uint32_t* d_err = nullptr;
   uint8_t* d_stage = nullptr;  // staging for host byte inputs of set_bases / test hooks
   size_t cap_stage = 0;
@@ -709,7 +710,11 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
   // large n: the sub-range histograms of huge coarse bins are made once, not by every sharer.  (round 5) Not launched at all while uniform scalars
   // cannot fill a coarse bin to three quarters of FINE_BIG -- 2^20 points and below: its 8192 workgroups found nothing to do and took 19 us of every
   // launch's main stream; skewed scalars that make such a bin after all take the sharers' own histograms (k_sort_fine's fallback path)
-  const bool hist_useful = ctx->fine_hist_min_n != FINE_BIG + 1 || n_entries / ncoarse * 4 > (size_t)FINE_BIG * 3;
+  // ... ADAPTIVELY (later in round 5): few distinct / small / equal scalars (witness vectors) fill huge bins at any size, and the fallback costs their
+  // fine sort 2 - 2.5 x (profiles/r05_skew_hist.txt): k_sort_fine reports a huge bin in the slot's status word, and the 64 launches after such a
+  // report run k_fine_hist (a prover's MSMs come in series of like inputs; the first of a series pays the fallback once)
+  const bool hist_useful = ctx->fine_hist_min_n != FINE_BIG + 1 || n_entries / ncoarse * 4 > (size_t)FINE_BIG * 3 || ctx->skew_credit > 0;
+  if (ctx->skew_credit > 0) ctx->skew_credit--;
   if (n_entries >= ctx->fine_hist_min_n && hist_useful) {
     hipLaunchKernelGGL(k_fine_hist, dim3(ncoarse, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
                        ctx->d_part_hist);
@@ -717,7 +722,7 @@ int enqueue(msm_hip_ctx* ctx, const uint32_t* d_scalars, size_t n, int w_begin, 
     part_hist = ctx->d_part_hist;
   }
   hipLaunchKernelGGL(k_sort_fine, dim3(ncoarse, w_count, FINE_SPLIT), dim3(256), 0, st, ctx->d_tmp_val, ctx->d_tmp_fine, stride, ctx->d_coarse_ptr,
-                     s.d_col_ptr, ctx->d_val, chunks, d_chunk_len, ctx->d_chunk_slot, part_hist);
+                     s.d_col_ptr, ctx->d_val, chunks, d_chunk_len, ctx->d_chunk_slot, part_hist, d_err);
   AFTER_KERNEL(ctx, "k_sort_fine", st);
   if (ctx->debug) {  // deterministic transpose for the stage read-back: every slot's run in ascending order
     hipLaunchKernelGGL(k_order_runs, dim3(blocks_for(n_entries, 256), w_count), dim3(256), 0, st, s.d_col_ptr, ctx->d_val, ctx->d_tmp_val, stride, half);
@@ -855,6 +860,7 @@ int wait_slot(msm_hip_ctx* ctx, Slot& s) {
   }
   uint32_t bits;
   memcpy(&bits, s.h_wsums + WSUM_BYTES, 4);
+  if (bits & INFOBIT_HUGE_BIN) ctx->skew_credit = 64;  // (see the launch of k_fine_hist)
   return err_from_bits(bits);
 }
 

@@ -184,6 +184,7 @@ __device__ __forceinline__ g1_xyzz ld_xyzz(PTR p) {
 constexpr uint32_t ERRBIT_NONCANONICAL = 1u;
 constexpr uint32_t ERRBIT_NOT_ON_CURVE = 2u;
 constexpr uint32_t ERRBIT_SCALAR_CARRY = 4u;
+constexpr uint32_t INFOBIT_HUGE_BIN = 0x100u;  // not an error: the fine sort met a coarse bin beyond FINE_BIG (skewed scalars, or large n) -- the host's cue to run k_fine_hist
 
 // ------------------------------------------------------------------------------------------------ stage 0: bases
 // canonical wire bytes -> packed Montgomery affine (≙ decompose_scalars.template.wgsl:41-70, the point half)
@@ -1498,7 +1499,7 @@ __global__ void __launch_bounds__(256) k_fine_hist(const uint8_t* __restrict__ t
 __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ tmp_val, const uint8_t* __restrict__ tmp_fine, size_t stride,
                                                    const uint32_t* __restrict__ coarse_ptr, uint32_t* __restrict__ col_ptr,
                                                    uint32_t* __restrict__ val_idxs, uint32_t chunks, const uint32_t* __restrict__ chunk_len_dev,
-                                                   uint32_t* __restrict__ chunk_slot, const uint32_t* __restrict__ part_hist) {
+                                                   uint32_t* __restrict__ chunk_slot, const uint32_t* __restrict__ part_hist, uint32_t* __restrict__ info) {
   const uint32_t chunk_len = *chunk_len_dev;
   __shared__ uint32_t hist[FINE];
   __shared__ uint32_t before[FINE];  // entries of every slot in front of this workgroup's sub-range
@@ -1548,6 +1549,7 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
     }
   } else if (part_hist) {
     // the sub-range histograms were made by k_fine_hist: sum them (and the ones in front of this workgroup's sub-range)
+    if (tid == 0 && part == 0) atomicOr(info, INFOBIT_HUGE_BIN);
     const uint32_t* ph = part_hist + ((size_t)lw * NCOARSE + bin) * FINE_SPLIT * FINE + tid;
     uint32_t all = 0, front = 0;
 #pragma unroll
@@ -1559,6 +1561,7 @@ __global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ 
     hist[tid] = all;
     before[tid] = front;
   } else {
+    if (tid == 0 && part == 0) atomicOr(info, INFOBIT_HUGE_BIN);  // (a huge bin without k_fine_hist's histograms: every sharer sweeps the bin up to its own end)
     // FINE_CHUNK entries per sweep step, 16 independent byte loads per thread in flight; a step lies wholly in front of
     // the sub-range or not (my_begin - begin is a multiple of FINE_CHUNK), so every entry is counted once
     uint32_t f[FINE_PER], g[FINE_PER];  // double buffered: the loads of step k + 1 are in flight while step k is counted

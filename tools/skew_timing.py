@@ -26,5 +26,6 @@ wit[sel < 0.7] = 0
 wit[(sel >= 0.4) & (sel < 0.7), 0] = 1
 for name, sc in (("uniform", uni), ("all equal", eq), ("half equal", half), ("2-bit scalars", small), ("3 distinct", three), ("64-bit scalars", w64),
                  ("top window only", top), ("witness-like", wit)):
+    ctx.msm(sc)  # (round 5: the first launch of a series that meets a huge bin takes k_sort_fine's fallback and arms k_fine_hist for the next 64 launches: timed is a repeat)
     torch.cuda.synchronize(); t0 = time.perf_counter(); r = ctx.msm(sc); dt = time.perf_counter() - t0
     print("%-14s %8.2f ms  %s" % (name, dt * 1e3, {k: round(v, 3) for k, v in ctx.stage_ms().items()}))
