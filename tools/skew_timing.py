@@ -4,12 +4,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import msm_webgpu_amd as m
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-endo = len(sys.argv) > 2 and sys.argv[2] == "endomorphism"   # bases with their endomorphism images (8 windows over 2n points)
+mode = sys.argv[2] if len(sys.argv) > 2 else "plain"   # endomorphism: bases with their images (8 windows over 2n points); tables / tables_wide: fixed-base tables
+endo = mode == "endomorphism"
 n = 1 << logn
 ctx = m.MsmContext(0)
 pts = ctx.sample_points(n, 1)
-ctx.set_bases(pts, endomorphism=endo)
-print("bases:", "endomorphism" if endo else "plain")
+ctx.set_bases(pts, endomorphism=endo, precompute="wide" if mode == "tables_wide" else mode == "tables")
+print("bases:", mode)
 uni = ctx.sample_scalars(n, 2)
 ctx.msm(uni)
 s = 0x123456789ABCDEF013579BDF2468ACE0FEDCBA9876543210
