@@ -4,7 +4,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 count = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("msmk::", ""), r.get("Queue_Id", "?")) for r in rows))
+ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("msmk::", ""), r.get("Queue_Id", "?")) for r in rows))
 starts = [i for i, k in enumerate(ks) if k[2].startswith("k_count")]
 i0, i1 = starts[first], starts[first + count]
 t0 = ks[i0][0]
